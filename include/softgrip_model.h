@@ -1,0 +1,58 @@
+/* softgrip_model.h -- binary layout of a compiled soft-gripper model ("blob").
+ *
+ * The blob is what the Python MJCF compiler (soft-grip_amd/mjcf.py, the
+ * counterpart of mujoco_py.load_model_from_path, reference
+ * environment/manenv.py:27,36) hands to the C-ABI library (softgrip.h) and to
+ * the CPU oracle (oracle/sg_oracle.c).  It is a tagged-array container:
+ *
+ *   sg_blob_header
+ *   nrec x { sg_blob_record ; payload (count * elemsize bytes) ; pad to 8 }
+ *
+ * Field names and enum values follow MuJoCo's mjModel where a counterpart
+ * exists (body_pos, jnt_axis, geom_size, ...), all reals are IEEE fp64, all
+ * integers int32, little endian.  Arrays that mjModel stores per quaternion of
+ * inertia are replaced by body_imat (3x3 inertia about the COM, body frame).
+ */
+#ifndef SOFTGRIP_MODEL_H
+#define SOFTGRIP_MODEL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_BLOB_MAGIC 0x4D474753u /* 'SGGM' */
+#define SG_BLOB_VERSION 1u
+
+enum { SG_DT_F64 = 1, SG_DT_I32 = 2, SG_DT_U8 = 3 };
+
+typedef struct sg_blob_header {
+  uint32_t magic;
+  uint32_t version;
+  uint32_t nrec;
+  uint32_t reserved;
+  int64_t total_bytes; /* header + all records */
+} sg_blob_header;
+
+typedef struct sg_blob_record {
+  char name[24]; /* NUL padded */
+  uint32_t dtype; /* SG_DT_* */
+  uint32_t reserved;
+  int64_t count; /* number of elements */
+} sg_blob_record;
+
+/* enums (MuJoCo numbering) */
+enum { SG_JNT_SLIDE = 2, SG_JNT_HINGE = 3 };
+enum { SG_GEOM_PLANE = 0, SG_GEOM_SPHERE = 2, SG_GEOM_CAPSULE = 3, SG_GEOM_BOX = 6 };
+enum { SG_EQ_JOINT = 2, SG_EQ_TENDON = 3 };
+enum { SG_WRAP_JOINT = 1, SG_WRAP_SITE = 3 };
+enum { SG_SENS_ACCELEROMETER = 1, SG_SENS_GYRO = 3 };
+
+/* opt_d = { timestep, gravity[3], tolerance, impratio, meaninertia }
+ * opt_i = { iterations, nconmax, njmax } */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOFTGRIP_MODEL_H */
