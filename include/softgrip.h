@@ -1,0 +1,116 @@
+/* softgrip.h -- C ABI of the MI355X-native batched soft-gripper simulator.
+ *
+ * This is the boundary the reference crosses through mujoco_py; every
+ * entry point names the mujoco_py call it replaces in reference environment/manenv.py.
+ * All functions return 0 on success or a negative sg_status; sg_last_error() gives the
+ * message of the last failure on the calling thread.  Per-env numeric failure is DATA
+ * (the `flags` output), not an error code.
+ *
+ * Memory: the library owns models and batch state (device memory).  Callers own every
+ * output buffer and pass raw pointers (device pointers unless stated otherwise; with
+ * PyTorch-ROCm: tensor.data_ptr()).  `stream` is a hipStream_t (NULL = default stream);
+ * no function synchronises the host unless it says so.
+ *
+ * A batch is externally synchronised (one caller thread at a time); different batches,
+ * e.g. one per GPU, are fully independent.  No CPU fallback exists: creating a batch on
+ * a machine without a HIP device fails with SG_ERR_NO_DEVICE.
+ */
+#ifndef SOFTGRIP_H
+#define SOFTGRIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sg_model sg_model;
+typedef struct sg_batch sg_batch;
+
+typedef enum sg_status {
+  SG_OK = 0,
+  SG_ERR_INVALID = -1,     /* bad argument */
+  SG_ERR_MODEL = -2,       /* blob malformed or model outside the supported class */
+  SG_ERR_NO_DEVICE = -3,   /* no HIP device / device index out of range */
+  SG_ERR_HIP = -4,         /* a HIP runtime call failed */
+  SG_ERR_NOMEM = -5
+} sg_status;
+
+/* per-env flag bits written by sg_step/sg_reset (any of 1|2|4|8|16|32 is what mujoco_py
+ * would have turned into MujocoException, reference environment/manenv.py:50) */
+enum {
+  SG_FLAG_BADQPOS = 1, SG_FLAG_BADQVEL = 2, SG_FLAG_BADQACC = 4,
+  SG_FLAG_CONTACTFULL = 8, SG_FLAG_CNSTRFULL = 16, SG_FLAG_UNSUPPORTED_PAIR = 32
+};
+
+const char* sg_last_error(void);
+const char* sg_version(void);
+
+/* ---- model: replaces mujoco_py.load_model_from_path (manenv.py:27,36).  The MJCF is
+ * compiled by the Python host (soft-grip_amd/mjcf.py) into the blob of softgrip_model.h;
+ * this call validates it and derives the kernel plan.  Host pointers. */
+int sg_model_create(const void* blob, size_t nbytes, sg_model** out);
+void sg_model_destroy(sg_model* m);
+int sg_model_nq(const sg_model* m);           /* == nv */
+int sg_model_nu(const sg_model* m);           /* == na */
+int sg_model_nsensordata(const sg_model* m);
+int sg_model_ntendon(const sg_model* m);
+int sg_model_nelem(const sg_model* m);
+
+/* ---- batch of n_envs independent simulations: replaces mujoco_py.MjSim(model)
+ * (manenv.py:28,37), one MjSim per env.  State starts as after mj_resetData. */
+int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out);
+void sg_batch_destroy(sg_batch* b);
+int sg_batch_nenvs(const sg_batch* b);
+int sg_batch_device(const sg_batch* b);
+
+/* replaces `model.jnt_stiffness[i] = k` / `model.tendon_stiffness[i] = k`
+ * (manenv.py:105-108): env e uses k[e] on the listed joint and tendon ids and the model's
+ * own stiffness everywhere else.  k: device or host pointer to n_envs doubles
+ * (k_on_host selects); ids: host pointers.  The id sets replace those of earlier calls. */
+int sg_set_stiffness(sg_batch* b, const double* k, int k_on_host, const int* jnt_ids, int nj, const int* ten_ids, int nt,
+                     void* stream);
+
+/* replaces `data.ctrl[i] = v` (manenv.py:95,100).  ctrl: HOST pointer to nu doubles when
+ * broadcast != 0 (same control for every env), else device pointer to [n_envs][nu]. */
+int sg_set_ctrl(sg_batch* b, const double* ctrl, int broadcast, void* stream);
+
+/* replaces sim.reset(); sim.forward(); then `sim_start` x sim.step()  (manenv.py:57-61)
+ * for the envs whose mask byte is non-zero (mask == NULL: all).  mask: device pointer to
+ * n_envs bytes.  ctrl of the reset envs is zeroed (mj_resetData).  Outputs as sg_step. */
+int sg_reset(sg_batch* b, const uint8_t* mask, int sim_start, double* sens_out, int32_t* flags_out, int32_t* touch_out,
+             void* stream);
+
+/* replaces n_substeps x sim.step() followed by reading data.sensordata / data.contact
+ * (manenv.py:48-49,65-85).  Device pointers, any may be NULL:
+ *   sens_out  [n_envs][nsensordata] f64, the sensordata after the last substep
+ *   flags_out [n_envs] int32, OR of SG_FLAG_* raised during the call; an env that raised
+ *             BADQPOS/BADQVEL/BADQACC stops integrating for the rest of the call
+ *   touch_out [n_envs] int32, bit (2*chain + box) set when that finger box is in contact
+ *             with an object geom in the final contact list (data.contact at read time)
+ * sens_stride: element stride between envs in sens_out (0 = nsensordata); lets the caller
+ * write step t of a [n_envs][T][nsensordata] block directly. */
+int sg_step(sg_batch* b, int n_substeps, double* sens_out, long long sens_stride, int32_t* flags_out, int32_t* touch_out,
+            void* stream);
+
+/* state access for tests and checkpointing: [n_envs][nq] (qpos, qvel, qacc_warmstart) and
+ * [n_envs][nu] (act, ctrl); device pointers, any may be NULL. */
+int sg_get_state(sg_batch* b, double* qpos, double* qvel, double* act, double* qacc_warmstart, double* ctrl, void* stream);
+int sg_set_state(sg_batch* b, const double* qpos, const double* qvel, const double* act, const double* qacc_warmstart,
+                 const double* ctrl, void* stream);
+
+/* diagnostics of the last sg_step/sg_reset: [n_envs] int32 each, device pointers, may be NULL:
+ * number of contacts, constraint rows and PGS sweeps of the final substep */
+int sg_get_solver_stats(sg_batch* b, int32_t* ncon, int32_t* nefc, int32_t* iters, void* stream);
+
+/* kernel timing hook for bench.py: average device time (ms) of the step kernel over the
+ * launches since the last call with reset != 0, measured with HIP events on the launch
+ * stream.  Synchronises the host. */
+int sg_profile_enable(sg_batch* b, int enable);
+int sg_profile_read(sg_batch* b, int reset, double* avg_ms, long long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOFTGRIP_H */

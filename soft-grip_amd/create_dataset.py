@@ -1,0 +1,130 @@
+"""Dataset generation host: the reference's create_dataset.py (reference create_dataset.py:1-93)
+driving batched envs.  Same constants, same schedule, same pickle schema
+(``{"data": [ (200,12) float64 ...], "stiffness": [float ...]}``).
+
+Multi-GPU: launched with torch.distributed.run, every rank simulates its own stiffness bin on
+its own GPU and writes its own shard file -- no collective.
+"""
+import os
+import pickle
+from argparse import ArgumentParser
+
+import numpy as np
+
+from .manenv import ManEnv
+
+NUM_EPISODES = 1
+MAX_ITER_PER_EP = 160
+OPEN_CLOSE_DIV = 80
+START_STEP = 40
+
+
+def episode_schedule():
+    """ctrl applied before each of the 200 env steps (reference create_dataset.py:41-56):
+    40 idle, close (-0.2), toggle to +0.2 at i == 80."""
+    sched = [None] * (START_STEP + MAX_ITER_PER_EP)
+    sched[START_STEP] = -0.2
+    for i in range(MAX_ITER_PER_EP):
+        if i % OPEN_CLOSE_DIV == 0 and i > 0:
+            sched[START_STEP + i] = 0.2 if sched[START_STEP + i - OPEN_CLOSE_DIV] == -0.2 else -0.2
+    return sched
+
+
+def stiffness_bin(rank, world, lo=300.0, hi=1400.0):
+    w = (hi - lo) / world
+    return lo + w * rank, lo + w * (rank + 1)
+
+
+def log_into_file(args):
+    assert type(args.mujoco_model_paths) is list
+    num_envs = len(args.mujoco_model_paths)
+    current_env = 0
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+
+    env_spec = ManEnv.get_std_spec(args)
+    env_spec["device"] = int(os.environ.get("LOCAL_RANK", getattr(args, "device", 0)))
+    env = ManEnv(**env_spec)
+    n = env.n_envs
+
+    os.makedirs(args.data_folder, exist_ok=True)
+    name = args.data_name if world == 1 else "%s.rank%d" % (args.data_name, rank)
+    path = os.path.join(args.data_folder, "{}.pickle".format(name))
+    data, stiffness = list(), list()
+
+    for ep in range(NUM_EPISODES * num_envs):
+        if world > 1:  # stiffness sweep sharded by bin (BASELINE.json configs[3])
+            lo, hi = stiffness_bin(rank, world)
+            env.set_new_stiffness(lo, hi)
+            env.env.reset(max(env.sim_start, 0), sens=env._sens, flags=env._flags, touch=env._touch)
+            current_stiffness = env.stiffness.copy()
+        else:
+            current_stiffness = env.reset()
+
+        samples = list()
+        for _ in range(START_STEP):
+            readings, contact = env.step()
+            readings = _mask(args, readings, contact)
+            samples.append(readings)
+        env.close_hand()
+        for i in range(MAX_ITER_PER_EP):
+            env.render()
+            if i % OPEN_CLOSE_DIV == 0 and i > 0:
+                env.toggle_grip()
+            readings, contact = env.step()
+            readings = _mask(args, readings, contact)
+            samples.append(readings)
+
+        if n == 1:
+            data.append(np.array(samples))
+            stiffness.append(float(np.asarray(current_stiffness).reshape(-1)[0]))
+        else:
+            import torch
+            block = torch.stack(samples, dim=1).cpu().numpy()  # [n, 200, 12]
+            data.extend(np.array(block[e]) for e in range(n))
+            stiffness.extend(float(k) for k in np.asarray(env.stiffness))
+
+        if (ep + 1) % NUM_EPISODES == 0 and num_envs > 1:
+            current_env += 1
+            if current_env >= num_envs:
+                current_env = 0
+            env.load_env(current_env)
+
+    with open(path, "wb") as file:
+        pickle.dump({"data": data, "stiffness": stiffness}, file)
+    print("Total number of samples: {0}".format(len(data)))
+    return path
+
+
+def _mask(args, readings, contact):
+    if not args.mask_contact:
+        return readings
+    if isinstance(contact, (bool, np.bool_)):
+        return readings if contact else np.zeros_like(readings)
+    return readings * contact.to(readings.dtype).unsqueeze(-1)
+
+
+def make_parser():
+    parser = ArgumentParser()
+    parser.add_argument('--sim-step', type=int, default=7)
+    parser.add_argument('--vis', action='store_true', default=False)          # real booleans (reference uses type=bool)
+    parser.add_argument('--mask-contact', action='store_true', default=False)
+    parser.add_argument('--sim-start', type=int, default=1)
+    parser.add_argument('--data-folder', type=str, default="./data/dataset/testing_datasets")
+    parser.add_argument('--data-name', type=str, default="dataset_all_shapes")
+    parser.add_argument('--mujoco-model-paths', nargs="+", required=True)
+    parser.add_argument('--n-envs', type=int, default=1)
+    parser.add_argument('--device', type=int, default=0)
+    parser.add_argument('--seed', type=int, default=None)
+    return parser
+
+
+def main(argv=None):
+    args, _ = make_parser().parse_known_args(argv)
+    if args.seed is not None:
+        np.random.seed(args.seed + int(os.environ.get("RANK", 0)) * 1000)
+    log_into_file(args)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,283 @@
+// sg_api.hip -- C ABI (include/softgrip.h) over the gfx950 kernels.  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sg_kernels.hip"
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(x)                                                                              \
+  do {                                                                                         \
+    hipError_t e_ = (x);                                                                       \
+    if (e_ != hipSuccess) return fail(SG_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+__global__ void sg_fill_rows_kernel(double* dst, const double* row, int n, int w) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * w) dst[i] = row[i % w];
+}
+}  // namespace
+
+struct sg_model {
+  SgPlan plan;
+  int rounds;  // ceil(nelem / 64)
+};
+
+struct sg_batch {
+  const sg_model* m;
+  int n, device;
+  SgPlanHeader* dH;
+  double *delem, *qpos, *qvel, *warm, *act, *ctrl, *kenv, *ctrl_row;
+  int *kmask_jnt, *kmask_ten, *flags, *touch, *ncon, *nefc, *iters;
+  // profiling
+  bool prof;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  double prof_ms;
+  long long prof_n;
+};
+
+extern "C" {
+
+const char* sg_last_error(void) { return g_err.c_str(); }
+const char* sg_version(void) { return "softgrip-mi355x 0.1 (gfx950)"; }
+
+int sg_model_create(const void* blob, size_t nbytes, sg_model** out) {
+  if (!blob || !out) return fail(SG_ERR_INVALID, "sg_model_create: null argument");
+  sg_model* m = new sg_model();
+  std::string err;
+  if (!sg_plan_build(blob, nbytes, &m->plan, &err)) {
+    delete m;
+    return fail(SG_ERR_MODEL, "sg_model_create: " + err);
+  }
+  m->rounds = (m->plan.h.nelem + 63) / 64;
+  if (m->rounds > 4) {
+    delete m;
+    return fail(SG_ERR_MODEL, "sg_model_create: more than 256 composite elements");
+  }
+  *out = m;
+  return SG_OK;
+}
+void sg_model_destroy(sg_model* m) { delete m; }
+int sg_model_nq(const sg_model* m) { return m->plan.h.nv; }
+int sg_model_nu(const sg_model* m) { return m->plan.h.nu; }
+int sg_model_nsensordata(const sg_model* m) { return m->plan.h.nsensordata; }
+int sg_model_ntendon(const sg_model* m) { return m->plan.h.ntendon; }
+int sg_model_nelem(const sg_model* m) { return m->plan.h.nelem; }
+
+void sg_batch_destroy(sg_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  void* ptrs[] = {b->dH, b->delem, b->qpos, b->qvel, b->warm, b->act, b->ctrl, b->kenv, b->ctrl_row, b->kmask_jnt, b->kmask_ten,
+                  b->flags, b->touch, b->ncon, b->nefc, b->iters};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& e : b->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  delete b;
+}
+
+int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
+  if (!m || !out || n_envs <= 0) return fail(SG_ERR_INVALID, "sg_batch_create: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SG_ERR_NO_DEVICE, "sg_batch_create: no HIP device (there is no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(SG_ERR_NO_DEVICE, "sg_batch_create: device index out of range");
+  HIPCHK(hipSetDevice(device));
+  sg_batch* b = new sg_batch();
+  memset((void*)b, 0, sizeof(void*) * 0);
+  b->m = m; b->n = n_envs; b->device = device; b->prof = false; b->prof_ms = 0; b->prof_n = 0;
+  b->dH = nullptr; b->delem = b->qpos = b->qvel = b->warm = b->act = b->ctrl = b->kenv = b->ctrl_row = nullptr;
+  b->kmask_jnt = b->kmask_ten = b->flags = b->touch = b->ncon = b->nefc = b->iters = nullptr;
+  const SgPlanHeader& H = m->plan.h;
+  const size_t n = n_envs, nv = H.nv, nu = H.nu > 0 ? H.nu : 1, nt = H.ntendon;
+#define ALLOC(p, bytes)                                   \
+  do {                                                    \
+    hipError_t e_ = hipMalloc((void**)&(p), (bytes));     \
+    if (e_ != hipSuccess) {                               \
+      sg_batch_destroy(b);                                \
+      return fail(SG_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e_)); \
+    }                                                     \
+  } while (0)
+  ALLOC(b->dH, sizeof(SgPlanHeader));
+  ALLOC(b->delem, sizeof(double) * m->plan.elem.size());
+  ALLOC(b->qpos, sizeof(double) * n * nv); ALLOC(b->qvel, sizeof(double) * n * nv); ALLOC(b->warm, sizeof(double) * n * nv);
+  ALLOC(b->act, sizeof(double) * n * nu); ALLOC(b->ctrl, sizeof(double) * n * nu); ALLOC(b->kenv, sizeof(double) * n);
+  ALLOC(b->ctrl_row, sizeof(double) * nu);
+  ALLOC(b->kmask_jnt, sizeof(int) * nv); ALLOC(b->kmask_ten, sizeof(int) * nt);
+  ALLOC(b->flags, sizeof(int) * n); ALLOC(b->touch, sizeof(int) * n); ALLOC(b->ncon, sizeof(int) * n); ALLOC(b->nefc, sizeof(int) * n);
+  ALLOC(b->iters, sizeof(int) * n);
+#undef ALLOC
+  HIPCHK(hipMemcpy(b->dH, &H, sizeof H, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->delem, m->plan.elem.data(), sizeof(double) * m->plan.elem.size(), hipMemcpyHostToDevice));
+  // state as after mj_resetData
+  std::vector<double> q0(nv, 0.0);
+  for (int c = 0; c < H.nchain; c++)
+    for (int d = 0; d < H.chain[c].ndof; d++) q0[H.chain[c].dof0 + d] = H.chain[c].qpos0[d];
+  for (int e = 0; e < H.nelem; e++) q0[H.elem_dof0 + e] = m->plan.elem[(size_t)SGE_QPOS0 * H.nelem + e];
+  std::vector<double> qall(n * nv);
+  for (size_t i = 0; i < n; i++) memcpy(&qall[i * nv], q0.data(), sizeof(double) * nv);
+  HIPCHK(hipMemcpy(b->qpos, qall.data(), sizeof(double) * n * nv, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(b->qvel, 0, sizeof(double) * n * nv)); HIPCHK(hipMemset(b->warm, 0, sizeof(double) * n * nv));
+  HIPCHK(hipMemset(b->act, 0, sizeof(double) * n * nu)); HIPCHK(hipMemset(b->ctrl, 0, sizeof(double) * n * nu));
+  HIPCHK(hipMemset(b->kenv, 0, sizeof(double) * n));
+  HIPCHK(hipMemset(b->kmask_jnt, 0, sizeof(int) * nv)); HIPCHK(hipMemset(b->kmask_ten, 0, sizeof(int) * nt));
+  HIPCHK(hipMemset(b->flags, 0, sizeof(int) * n)); HIPCHK(hipMemset(b->touch, 0, sizeof(int) * n));
+  HIPCHK(hipMemset(b->ncon, 0, sizeof(int) * n)); HIPCHK(hipMemset(b->nefc, 0, sizeof(int) * n)); HIPCHK(hipMemset(b->iters, 0, sizeof(int) * n));
+  *out = b;
+  return SG_OK;
+}
+int sg_batch_nenvs(const sg_batch* b) { return b->n; }
+int sg_batch_device(const sg_batch* b) { return b->device; }
+
+int sg_set_stiffness(sg_batch* b, const double* k, int k_on_host, const int* jnt_ids, int nj, const int* ten_ids, int nt, void* stream) {
+  if (!b || !k || nj < 0 || nt < 0 || (nj && !jnt_ids) || (nt && !ten_ids)) return fail(SG_ERR_INVALID, "sg_set_stiffness: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  const SgPlanHeader& H = b->m->plan.h;
+  std::vector<int> mj(H.nv, 0), mt(H.ntendon, 0);
+  for (int i = 0; i < nj; i++) {
+    if (jnt_ids[i] < 0 || jnt_ids[i] >= H.nv) return fail(SG_ERR_INVALID, "sg_set_stiffness: joint id out of range");
+    mj[jnt_ids[i]] = 1;
+  }
+  for (int i = 0; i < nt; i++) {
+    if (ten_ids[i] < 0 || ten_ids[i] >= H.ntendon) return fail(SG_ERR_INVALID, "sg_set_stiffness: tendon id out of range");
+    mt[ten_ids[i]] = 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  // the masks are tiny; a synchronous copy keeps the host vectors' lifetime trivial
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipMemcpy(b->kmask_jnt, mj.data(), sizeof(int) * H.nv, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->kmask_ten, mt.data(), sizeof(int) * H.ntendon, hipMemcpyHostToDevice));
+  if (k_on_host) HIPCHK(hipMemcpy(b->kenv, k, sizeof(double) * b->n, hipMemcpyHostToDevice));
+  else HIPCHK(hipMemcpyAsync(b->kenv, k, sizeof(double) * b->n, hipMemcpyDeviceToDevice, s));
+  return SG_OK;
+}
+
+int sg_set_ctrl(sg_batch* b, const double* ctrl, int broadcast, void* stream) {
+  if (!b || !ctrl) return fail(SG_ERR_INVALID, "sg_set_ctrl: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int nu = b->m->plan.h.nu;
+  if (nu == 0) return SG_OK;
+  if (broadcast) {
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpy(b->ctrl_row, ctrl, sizeof(double) * nu, hipMemcpyHostToDevice));
+    int total = b->n * nu;
+    hipLaunchKernelGGL(sg_fill_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, s, b->ctrl, b->ctrl_row, b->n, nu);
+    HIPCHK(hipGetLastError());
+  } else {
+    HIPCHK(hipMemcpyAsync(b->ctrl, ctrl, sizeof(double) * b->n * nu, hipMemcpyDeviceToDevice, s));
+  }
+  return SG_OK;
+}
+
+static int launch(sg_batch* b, int mode, const uint8_t* mask, int nsub, double* sens, long long stride, int32_t* flags, int32_t* touch,
+                  hipStream_t s) {
+  const SgPlanHeader& H = b->m->plan.h;
+  SgKArgs a;
+  a.H = b->dH; a.elem = b->delem;
+  a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.act = b->act; a.ctrl = b->ctrl;
+  a.kenv = b->kenv; a.kmask_jnt = b->kmask_jnt; a.kmask_ten = b->kmask_ten;
+  a.mask = mask;
+  a.sens = sens; a.sens_stride = stride > 0 ? stride : H.nsensordata;
+  a.flags = flags ? flags : b->flags; a.touch = touch ? touch : b->touch;
+  a.ncon = b->ncon; a.nefc = b->nefc; a.iters = b->iters;
+  a.nenv = b->n; a.nsub = nsub; a.mode = mode;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (b->prof) {
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, s));
+  }
+  dim3 grid(b->n), block(64);
+  switch (b->m->rounds) {
+    case 1: hipLaunchKernelGGL((sg_step_kernel<1, 2>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((sg_step_kernel<2, 2>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((sg_step_kernel<3, 2>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((sg_step_kernel<4, 2>), grid, block, 0, s, a); break;
+  }
+  HIPCHK(hipGetLastError());
+  if (b->prof) {
+    HIPCHK(hipEventRecord(e1, s));
+    b->ev.emplace_back(e0, e1);
+  }
+  return SG_OK;
+}
+
+int sg_reset(sg_batch* b, const uint8_t* mask, int sim_start, double* sens_out, int32_t* flags_out, int32_t* touch_out, void* stream) {
+  if (!b || sim_start < 0) return fail(SG_ERR_INVALID, "sg_reset: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  return launch(b, 1, mask, sim_start, sens_out, 0, flags_out, touch_out, (hipStream_t)stream);
+}
+
+int sg_step(sg_batch* b, int n_substeps, double* sens_out, long long sens_stride, int32_t* flags_out, int32_t* touch_out, void* stream) {
+  if (!b || n_substeps < 0) return fail(SG_ERR_INVALID, "sg_step: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  return launch(b, 0, nullptr, n_substeps, sens_out, sens_stride, flags_out, touch_out, (hipStream_t)stream);
+}
+
+int sg_get_state(sg_batch* b, double* qpos, double* qvel, double* act, double* warm, double* ctrl, void* stream) {
+  if (!b) return fail(SG_ERR_INVALID, "sg_get_state: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = b->n, nv = b->m->plan.h.nv, nu = b->m->plan.h.nu;
+  if (qpos) HIPCHK(hipMemcpyAsync(qpos, b->qpos, sizeof(double) * n * nv, hipMemcpyDeviceToDevice, s));
+  if (qvel) HIPCHK(hipMemcpyAsync(qvel, b->qvel, sizeof(double) * n * nv, hipMemcpyDeviceToDevice, s));
+  if (warm) HIPCHK(hipMemcpyAsync(warm, b->warm, sizeof(double) * n * nv, hipMemcpyDeviceToDevice, s));
+  if (act && nu) HIPCHK(hipMemcpyAsync(act, b->act, sizeof(double) * n * nu, hipMemcpyDeviceToDevice, s));
+  if (ctrl && nu) HIPCHK(hipMemcpyAsync(ctrl, b->ctrl, sizeof(double) * n * nu, hipMemcpyDeviceToDevice, s));
+  return SG_OK;
+}
+
+int sg_set_state(sg_batch* b, const double* qpos, const double* qvel, const double* act, const double* warm, const double* ctrl, void* stream) {
+  if (!b) return fail(SG_ERR_INVALID, "sg_set_state: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = b->n, nv = b->m->plan.h.nv, nu = b->m->plan.h.nu;
+  if (qpos) HIPCHK(hipMemcpyAsync(b->qpos, qpos, sizeof(double) * n * nv, hipMemcpyDeviceToDevice, s));
+  if (qvel) HIPCHK(hipMemcpyAsync(b->qvel, qvel, sizeof(double) * n * nv, hipMemcpyDeviceToDevice, s));
+  if (warm) HIPCHK(hipMemcpyAsync(b->warm, warm, sizeof(double) * n * nv, hipMemcpyDeviceToDevice, s));
+  if (act && nu) HIPCHK(hipMemcpyAsync(b->act, act, sizeof(double) * n * nu, hipMemcpyDeviceToDevice, s));
+  if (ctrl && nu) HIPCHK(hipMemcpyAsync(b->ctrl, ctrl, sizeof(double) * n * nu, hipMemcpyDeviceToDevice, s));
+  return SG_OK;
+}
+
+int sg_get_solver_stats(sg_batch* b, int32_t* ncon, int32_t* nefc, int32_t* iters, void* stream) {
+  if (!b) return fail(SG_ERR_INVALID, "sg_get_solver_stats: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = b->n;
+  if (ncon) HIPCHK(hipMemcpyAsync(ncon, b->ncon, sizeof(int) * n, hipMemcpyDeviceToDevice, s));
+  if (nefc) HIPCHK(hipMemcpyAsync(nefc, b->nefc, sizeof(int) * n, hipMemcpyDeviceToDevice, s));
+  if (iters) HIPCHK(hipMemcpyAsync(iters, b->iters, sizeof(int) * n, hipMemcpyDeviceToDevice, s));
+  return SG_OK;
+}
+
+int sg_profile_enable(sg_batch* b, int enable) {
+  if (!b) return fail(SG_ERR_INVALID, "sg_profile_enable: bad argument");
+  b->prof = enable != 0;
+  return SG_OK;
+}
+
+int sg_profile_read(sg_batch* b, int reset, double* avg_ms, long long* launches) {
+  if (!b) return fail(SG_ERR_INVALID, "sg_profile_read: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  for (auto& e : b->ev) {
+    HIPCHK(hipEventSynchronize(e.second));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+    b->prof_ms += ms; b->prof_n++;
+    (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+  }
+  b->ev.clear();
+  if (avg_ms) *avg_ms = b->prof_n ? b->prof_ms / b->prof_n : 0.0;
+  if (launches) *launches = b->prof_n;
+  if (reset) { b->prof_ms = 0; b->prof_n = 0; }
+  return SG_OK;
+}
+
+}  // extern "C"

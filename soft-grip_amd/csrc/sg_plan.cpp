@@ -1,0 +1,471 @@
+// sg_plan.cpp -- builds the kernel plan from a generic model blob (host side, once per model).
+// Counterpart of the part of mujoco_py.load_model_from_path (reference
+// environment/manenv.py:27) that turns a parsed model into solver-ready constants.
+#include "sg_plan.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+
+#include "../../include/softgrip_model.h"
+
+namespace {
+
+struct Blob {
+  const char* base;
+  size_t n;
+  const void* find(const char* name, int dtype, long long* cnt) const {
+    const sg_blob_header* h = (const sg_blob_header*)base;
+    const char* p = base + sizeof(sg_blob_header);
+    for (uint32_t r = 0; r < h->nrec; r++) {
+      const sg_blob_record* rec = (const sg_blob_record*)p;
+      size_t es = rec->dtype == SG_DT_F64 ? 8 : rec->dtype == SG_DT_I32 ? 4 : 1;
+      size_t nb = (size_t)rec->count * es;
+      nb += (8 - nb % 8) % 8;
+      if (strncmp(rec->name, name, 24) == 0 && (int)rec->dtype == dtype) {
+        if (cnt) *cnt = rec->count;
+        return p + sizeof(sg_blob_record);
+      }
+      p += sizeof(sg_blob_record) + nb;
+    }
+    return nullptr;
+  }
+};
+
+void quat2mat(double* M, const double* q) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  M[0] = w * w + x * x - y * y - z * z; M[1] = 2 * (x * y - w * z); M[2] = 2 * (x * z + w * y);
+  M[3] = 2 * (x * y + w * z); M[4] = w * w - x * x + y * y - z * z; M[5] = 2 * (y * z - w * x);
+  M[6] = 2 * (x * z - w * y); M[7] = 2 * (y * z + w * x); M[8] = w * w - x * x - y * y + z * z;
+}
+void mulmat33(double* r, const double* A, const double* B) {
+  double t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+  memcpy(r, t, sizeof t);
+}
+void mulmat3(double* r, const double* M, const double* v) {
+  double x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2], y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2], z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+
+}  // namespace
+
+#define FAIL(msg)                  \
+  do {                             \
+    if (err) *err = (msg);         \
+    return false;                  \
+  } while (0)
+#define NEEDF(var, name)                                                         \
+  const double* var = (const double*)B.find(name, SG_DT_F64, &cnt);              \
+  if (!var) FAIL(std::string("model blob lacks ") + name)
+#define NEEDI(var, name)                                                         \
+  const int* var = (const int*)B.find(name, SG_DT_I32, &cnt);                    \
+  if (!var) FAIL(std::string("model blob lacks ") + name)
+
+bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* err) {
+  const sg_blob_header* hd = (const sg_blob_header*)blob;
+  if (nbytes < sizeof *hd || hd->magic != SG_BLOB_MAGIC || hd->version != SG_BLOB_VERSION || (size_t)hd->total_bytes != nbytes)
+    FAIL("not a softgrip model blob");
+  Blob B{(const char*)blob, nbytes};
+  long long cnt = 0;
+  NEEDF(opt_d, "opt_d");
+  NEEDI(opt_i, "opt_i");
+  NEEDF(body_pos, "body_pos");
+  const int nbody = (int)(cnt / 3);
+  NEEDF(body_quat, "body_quat"); NEEDF(body_ipos, "body_ipos"); NEEDF(body_imat, "body_imat"); NEEDF(body_mass, "body_mass");
+  NEEDF(body_invweight0, "body_invweight0");
+  NEEDF(jnt_pos, "jnt_pos");
+  const int nv = (int)(cnt / 3);
+  NEEDF(jnt_axis, "jnt_axis"); NEEDF(jnt_range, "jnt_range"); NEEDF(jnt_stiffness, "jnt_stiffness"); NEEDF(jnt_margin, "jnt_margin");
+  NEEDF(jnt_solref, "jnt_solref"); NEEDF(jnt_solimp, "jnt_solimp"); NEEDF(qpos0, "qpos0"); NEEDF(qpos_spring, "qpos_spring");
+  NEEDF(dof_damping, "dof_damping"); NEEDF(dof_armature, "dof_armature"); NEEDF(dof_invweight0, "dof_invweight0");
+  NEEDF(geom_size, "geom_size");
+  const int ngeom = (int)(cnt / 3);
+  NEEDF(geom_pos, "geom_pos"); NEEDF(geom_quat, "geom_quat"); NEEDF(geom_friction, "geom_friction"); NEEDF(geom_solref, "geom_solref");
+  NEEDF(geom_solimp, "geom_solimp"); NEEDF(geom_solmix, "geom_solmix"); NEEDF(geom_margin, "geom_margin"); NEEDF(geom_gap, "geom_gap");
+  NEEDF(geom_rbound, "geom_rbound");
+  NEEDF(site_pos, "site_pos");
+  const int nsite = (int)(cnt / 3);
+  NEEDF(site_quat, "site_quat");
+  NEEDF(tendon_stiffness, "tendon_stiffness");
+  const int ntendon = (int)cnt;
+  NEEDF(tendon_damping, "tendon_damping"); NEEDF(tendon_lengthspring, "tendon_lengthspring"); NEEDF(tendon_length0, "tendon_length0");
+  NEEDF(tendon_invweight0, "tendon_invweight0"); NEEDF(wrap_prm, "wrap_prm");
+  NEEDF(eq_solref, "eq_solref");
+  const int neq = (int)(cnt / 2);
+  NEEDF(eq_solimp, "eq_solimp"); NEEDF(eq_data, "eq_data");
+  NEEDF(actuator_timeconst, "actuator_timeconst");
+  const int nu = (int)cnt;
+  NEEDF(actuator_gain, "actuator_gain"); NEEDF(actuator_bias, "actuator_bias"); NEEDF(actuator_gear, "actuator_gear");
+  NEEDI(body_parentid, "body_parentid"); NEEDI(body_weldid, "body_weldid"); NEEDI(body_jntadr, "body_jntadr"); NEEDI(body_jntnum, "body_jntnum");
+  NEEDI(body_geomadr, "body_geomadr"); NEEDI(body_geomnum, "body_geomnum"); NEEDI(jnt_type, "jnt_type"); NEEDI(jnt_limited, "jnt_limited");
+  NEEDI(geom_type, "geom_type"); NEEDI(geom_bodyid, "geom_bodyid"); NEEDI(geom_contype, "geom_contype"); NEEDI(geom_conaffinity, "geom_conaffinity");
+  NEEDI(geom_condim, "geom_condim"); NEEDI(geom_priority, "geom_priority"); NEEDI(site_bodyid, "site_bodyid");
+  NEEDI(tendon_adr, "tendon_adr"); NEEDI(tendon_num, "tendon_num"); NEEDI(wrap_type, "wrap_type"); NEEDI(wrap_objid, "wrap_objid");
+  NEEDI(eq_type, "eq_type"); NEEDI(eq_obj1id, "eq_obj1id"); NEEDI(actuator_trnid, "actuator_trnid");
+  NEEDI(sensor_type, "sensor_type");
+  const int nsensor = (int)cnt;
+  NEEDI(sensor_objid, "sensor_objid"); NEEDI(sensor_adr, "sensor_adr");
+  (void)nsite; (void)geom_quat; (void)geom_priority;
+
+  SgPlan& P = *out;
+  P = SgPlan();
+  SgPlanHeader& H = P.h;
+  memset(&H, 0, sizeof H);
+  H.nv = nv; H.nu = nu; H.nsensordata = 3 * nsensor; H.ntendon = ntendon;
+  H.timestep = opt_d[0]; memcpy(H.gravity, opt_d + 1, 24); H.tolerance = opt_d[4]; H.impratio = opt_d[5]; H.meaninertia = opt_d[6];
+  H.iterations = opt_i[0];
+  H.pgs_scale = 1.0 / (H.meaninertia * (nv > 1 ? nv : 1));
+  if (H.impratio != 1.0) FAIL("impratio != 1 is not supported by the kernels");
+
+  // world poses of world-welded (static) bodies
+  std::vector<double> wpos(3 * nbody, 0.0), wmat(9 * nbody, 0.0), wquat(4 * nbody, 0.0);
+  wquat[0] = 1; wmat[0] = wmat[4] = wmat[8] = 1;
+  auto qmul = [](double* r, const double* a, const double* b) {
+    double t[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                   a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
+    memcpy(r, t, sizeof t);
+  };
+  for (int b = 1; b < nbody; b++) {
+    if (body_weldid[b] != 0) continue;
+    int p = body_parentid[b];
+    double t[3];
+    mulmat3(t, &wmat[9 * p], body_pos + 3 * b);
+    for (int c = 0; c < 3; c++) wpos[3 * b + c] = wpos[3 * p + c] + t[c];
+    qmul(&wquat[4 * b], &wquat[4 * p], body_quat + 4 * b);
+    quat2mat(&wmat[9 * b], &wquat[4 * b]);
+  }
+  std::vector<int> nchild(nbody, 0);
+  for (int b = 1; b < nbody; b++) nchild[body_parentid[b]]++;
+
+  // ---- classify moving bodies: elements vs chain bodies ----
+  std::vector<int> is_elem(nbody, 0), chain_of(nbody, -1), cbidx(nbody, -1);
+  int first_elem = -1, nelem = 0;
+  for (int b = 1; b < nbody; b++) {
+    if (body_weldid[b] == 0) continue;
+    bool slider = body_jntnum[b] == 1 && jnt_type[body_jntadr[b]] == SG_JNT_SLIDE;
+    if (slider) {
+      if (body_weldid[body_parentid[b]] != 0 || nchild[b] != 0) FAIL("slide joints are only supported on leaf bodies with a static parent");
+      if (body_geomnum[b] != 1 || geom_type[body_geomadr[b]] != SG_GEOM_CAPSULE) FAIL("element bodies must carry exactly one capsule");
+      if (first_elem < 0) first_elem = b;
+      if (b != first_elem + nelem) FAIL("element bodies must be contiguous");
+      if (body_jntadr[b] != body_jntadr[first_elem] + nelem) FAIL("element dofs must be contiguous");
+      is_elem[b] = 1;
+      nelem++;
+    }
+  }
+  if (nelem == 0) FAIL("model has no composite elements");
+  H.nelem = nelem;
+  H.elem_dof0 = body_jntadr[first_elem];
+  if (H.elem_dof0 + nelem != nv) FAIL("element dofs must be the last dofs of the model");
+
+  int nchain = 0;
+  for (int b = 1; b < nbody; b++) {
+    if (body_weldid[b] == 0 || is_elem[b]) continue;
+    if (b >= first_elem) FAIL("chain bodies must precede the composite elements");
+    for (int k = 0; k < body_jntnum[b]; k++)
+      if (jnt_type[body_jntadr[b] + k] != SG_JNT_HINGE) FAIL("chain bodies may only have hinge joints");
+    if (body_jntnum[b] < 1 || body_jntnum[b] > 2) FAIL("chain bodies need 1 or 2 hinge joints");
+    int p = body_parentid[b];
+    if (body_weldid[p] == 0) {  // new chain
+      if (nchain == SG_MAXCH) FAIL("more than 2 finger chains");
+      chain_of[b] = nchain; cbidx[b] = 0;
+      SgChain& C = H.chain[nchain++];
+      C.nbody = 1;
+      memcpy(C.root_pos, &wpos[3 * p], 24);
+      memcpy(C.root_mat, &wmat[9 * p], 72);
+      C.dof0 = body_jntadr[b];
+    } else {
+      int c = chain_of[p];
+      if (c < 0 || cbidx[p] != H.chain[c].nbody - 1) FAIL("finger chains must be serial (no branching)");
+      if (H.chain[c].nbody == SG_CB) FAIL("finger chain longer than 2 bodies");
+      chain_of[b] = c; cbidx[b] = H.chain[c].nbody++;
+    }
+    SgChain& C = H.chain[chain_of[b]];
+    int bi = cbidx[b];
+    memcpy(C.b_pos[bi], body_pos + 3 * b, 24); memcpy(C.b_quat[bi], body_quat + 4 * b, 32);
+    memcpy(C.b_ipos[bi], body_ipos + 3 * b, 24); memcpy(C.b_imat[bi], body_imat + 9 * b, 72);
+    C.b_mass[bi] = body_mass[b]; C.b_invw_tran[bi] = body_invweight0[2 * b];
+    C.b_njnt[bi] = body_jntnum[b]; C.b_dof0[bi] = C.ndof;
+    for (int k = 0; k < body_jntnum[b]; k++) {
+      int j = body_jntadr[b] + k, d = C.ndof++;
+      if (d >= SG_CD) FAIL("finger chain has more than 4 dofs");
+      if (j != C.dof0 + d) FAIL("chain dofs must be contiguous");
+      memcpy(C.j_axis[d], jnt_axis + 3 * j, 24); memcpy(C.j_pos[d], jnt_pos + 3 * j, 24);
+      C.qpos0[d] = qpos0[j]; C.range[d][0] = jnt_range[2 * j]; C.range[d][1] = jnt_range[2 * j + 1]; C.jmargin[d] = jnt_margin[j];
+      C.damping[d] = dof_damping[j]; C.armature[d] = dof_armature[j]; C.stiffness[d] = jnt_stiffness[j]; C.springref[d] = qpos_spring[j];
+      C.invw[d] = dof_invweight0[j]; C.limited[d] = jnt_limited[j]; C.d_body[d] = bi;
+      const double *sr = jnt_solref + 2 * j, *si = jnt_solimp + 5 * j;
+      double dmax = fmin(0.9999, fmax(1e-4, si[1]));
+      if (sr[0] > 0 && sr[1] > 0) {
+        double tc = fmax(sr[0], 2 * H.timestep);
+        C.lim_K[d] = 1 / fmax(1e-15, dmax * dmax * tc * tc * sr[1] * sr[1]);
+        C.lim_B[d] = 2 / fmax(1e-15, dmax * tc);
+      } else {
+        C.lim_K[d] = -sr[0] / fmax(1e-15, dmax * dmax);
+        C.lim_B[d] = -sr[1] / fmax(1e-15, dmax);
+      }
+      memcpy(C.lim_solimp[d], si, 40);
+    }
+    for (int k = 0; k < body_geomnum[b]; k++) {
+      int g = body_geomadr[b] + k;
+      if (geom_type[g] != SG_GEOM_BOX) FAIL("chain bodies may only carry box geoms");
+      if (C.ngeom == SG_CG) FAIL("more than 2 box geoms on a finger chain");
+      int gi = C.ngeom++;
+      C.g_body[gi] = bi; C.g_id[gi] = g;
+      memcpy(C.g_pos[gi], geom_pos + 3 * g, 24);
+      quat2mat(C.g_mat[gi], geom_quat + 4 * g);
+      memcpy(C.g_size[gi], geom_size + 3 * g, 24);
+      C.g_rbound[gi] = geom_rbound[g];
+    }
+  }
+  H.nchain = nchain;
+  if (nchain == 0) FAIL("model has no finger chain");
+  // the kernels are compiled for one chain topology: SG_CB bodies with SG_CJ hinges each
+  for (int c = 0; c < nchain; c++) {
+    if (H.chain[c].nbody != SG_CB) FAIL("finger chains must have exactly 2 moving bodies");
+    for (int bi = 0; bi < SG_CB; bi++)
+      if (H.chain[c].b_njnt[bi] != SG_CJ) FAIL("finger chain bodies must have exactly 2 hinge joints");
+  }
+
+  // ---- elements ----
+  P.elem.assign((size_t)SGE_NFIELD * nelem, 0.0);
+  P.elem_geom.resize(nelem);
+  P.elem_dofmap.resize(nelem);
+  auto E = [&](int f, int e) -> double& { return P.elem[(size_t)f * nelem + e]; };
+  for (int e = 0; e < nelem; e++) {
+    int b = first_elem + e, j = H.elem_dof0 + e, g = body_geomadr[b], p = body_parentid[b];
+    P.elem_geom[e] = g; P.elem_dofmap[e] = j;
+    // body frame in the world at q = qpos0
+    double bp[3], bq[4], bm[9], t[3];
+    mulmat3(t, &wmat[9 * p], body_pos + 3 * b);
+    for (int c = 0; c < 3; c++) bp[c] = wpos[3 * p + c] + t[c];
+    qmul(bq, &wquat[4 * p], body_quat + 4 * b);
+    quat2mat(bm, bq);
+    double ax[3], gp[3], gm[9], gl[9];
+    mulmat3(ax, bm, jnt_axis + 3 * j);
+    mulmat3(t, bm, geom_pos + 3 * g);
+    for (int c = 0; c < 3; c++) gp[c] = bp[c] + t[c];
+    quat2mat(gl, geom_quat + 4 * g);
+    mulmat33(gm, bm, gl);
+    E(SGE_AX, e) = ax[0]; E(SGE_AY, e) = ax[1]; E(SGE_AZ, e) = ax[2];
+    E(SGE_GX, e) = gp[0]; E(SGE_GY, e) = gp[1]; E(SGE_GZ, e) = gp[2];
+    E(SGE_CX, e) = gm[2]; E(SGE_CY, e) = gm[5]; E(SGE_CZ, e) = gm[8];
+    E(SGE_MASS, e) = body_mass[b]; E(SGE_ARMATURE, e) = dof_armature[j]; E(SGE_DAMPING, e) = dof_damping[j];
+    E(SGE_K0, e) = jnt_stiffness[j]; E(SGE_SPRINGREF, e) = qpos_spring[j]; E(SGE_QPOS0, e) = qpos0[j];
+    E(SGE_INVW, e) = dof_invweight0[j]; E(SGE_BINVW, e) = body_invweight0[2 * b];
+    if (jnt_limited[j]) FAIL("limited element sliders are not supported");
+    if (e == 0) { H.cap_radius = geom_size[3 * g]; H.cap_hl = geom_size[3 * g + 1]; H.cap_rbound = geom_rbound[g]; }
+    else if (geom_size[3 * g] != H.cap_radius || geom_size[3 * g + 1] != H.cap_hl) FAIL("element capsules must share one size");
+    if (body_mass[b] <= 0) FAIL("element without mass");
+  }
+
+  // ---- tendons ----
+  H.t0_id = -1;
+  std::vector<int> site_used_by_chain(ntendon, -1);
+  for (int t = 0; t < ntendon; t++) {
+    int a = tendon_adr[t], n = tendon_num[t];
+    if (wrap_type[a] == SG_WRAP_JOINT) {
+      if (H.t0_id >= 0) FAIL("more than one fixed tendon");
+      if (n != nelem) FAIL("the fixed tendon must wrap every element slider exactly once");
+      for (int w = 0; w < n; w++) {
+        if (wrap_objid[a + w] != H.elem_dof0 + w) FAIL("the fixed tendon must list the element sliders in order");
+        E(SGE_COEF, w) = wrap_prm[a + w];
+      }
+      H.t0_id = t; H.t0_k0 = tendon_stiffness[t]; H.t0_damping = tendon_damping[t]; H.t0_lspring = tendon_lengthspring[t];
+      H.t0_L0 = tendon_length0[t]; H.eqt_invw = tendon_invweight0[t];
+    } else {
+      if (n != 2) FAIL("spatial tendons must have exactly two sites");
+      int s0 = wrap_objid[a], s1 = wrap_objid[a + 1], b0 = site_bodyid[s0], b1 = site_bodyid[s1];
+      int sfix = -1, smov = -1;
+      if (body_weldid[b0] == 0 && chain_of[b1] >= 0) { sfix = s0; smov = s1; }
+      else if (body_weldid[b1] == 0 && chain_of[b0] >= 0) { sfix = s1; smov = s0; }
+      else FAIL("spatial tendons must join a static site and a finger site");
+      int bm_ = site_bodyid[smov], bf = site_bodyid[sfix];
+      SgChain& C = H.chain[chain_of[bm_]];
+      if (C.has_ten) FAIL("more than one spatial tendon on a finger chain");
+      C.has_ten = 1; C.ten_id = t; C.ten_body = cbidx[bm_];
+      memcpy(C.ten_site, site_pos + 3 * smov, 24);
+      double tt[3];
+      mulmat3(tt, &wmat[9 * bf], site_pos + 3 * sfix);
+      for (int c = 0; c < 3; c++) C.ten_fixed[c] = wpos[3 * bf + c] + tt[c];
+      C.ten_k0 = tendon_stiffness[t]; C.ten_damping = tendon_damping[t]; C.ten_lspring = tendon_lengthspring[t];
+    }
+  }
+  if (H.t0_id < 0) FAIL("model has no fixed tendon over the elements");
+
+  // ---- equality rows: [joint-fix per element in order][tendon-fix] ----
+  if (neq != nelem + 1) FAIL("expected one joint equality per element plus one tendon equality");
+  auto kb = [&](const double* sr, const double* si, double* K, double* Bd) {
+    double dmax = fmin(0.9999, fmax(1e-4, si[1]));
+    if (sr[0] > 0 && sr[1] > 0) {
+      double tc = fmax(sr[0], 2 * H.timestep);
+      *K = 1 / fmax(1e-15, dmax * dmax * tc * tc * sr[1] * sr[1]);
+      *Bd = 2 / fmax(1e-15, dmax * tc);
+    } else {
+      *K = -sr[0] / fmax(1e-15, dmax * dmax);
+      *Bd = -sr[1] / fmax(1e-15, dmax);
+    }
+  };
+  for (int e = 0; e < nelem; e++) {
+    if (eq_type[e] != SG_EQ_JOINT || eq_obj1id[e] != H.elem_dof0 + e) FAIL("equality e must fix element slider e");
+    if (eq_data[5 * e] != 0) FAIL("joint equality offsets are not supported");
+    if (memcmp(eq_solref + 2 * e, eq_solref, 16) || memcmp(eq_solimp + 5 * e, eq_solimp, 40)) FAIL("joint equalities must share solref/solimp");
+  }
+  kb(eq_solref, eq_solimp, &H.eqj_K, &H.eqj_B);
+  memcpy(H.eqj_solimp, eq_solimp, 40);
+  if (eq_type[nelem] != SG_EQ_TENDON || eq_obj1id[nelem] != H.t0_id || eq_data[5 * nelem] != 0) FAIL("the last equality must fix the element tendon");
+  kb(eq_solref + 2 * nelem, eq_solimp + 5 * nelem, &H.eqt_K, &H.eqt_B);
+  memcpy(H.eqt_solimp, eq_solimp + 5 * nelem, 40);
+
+  // ---- actuators and sensors ----
+  for (int u = 0; u < nu; u++) {
+    int t = actuator_trnid[u], found = -1;
+    for (int c = 0; c < nchain; c++)
+      if (H.chain[c].has_ten && H.chain[c].ten_id == t) found = c;
+    if (found < 0) FAIL("actuators must act on a finger tendon");
+    SgChain& C = H.chain[found];
+    if (C.has_act) FAIL("more than one actuator on a finger tendon");
+    C.has_act = 1; C.act_id = u; C.act_gain = actuator_gain[u]; C.act_tc = actuator_timeconst[u]; C.act_gear = actuator_gear[u];
+    memcpy(C.act_bias, actuator_bias + 3 * u, 24);
+  }
+  std::map<int, std::pair<int, int>> site_slot;  // site id -> (chain, slot)
+  for (int s = 0; s < nsensor; s++) {
+    int site = sensor_objid[s], b = site_bodyid[site];
+    if (chain_of[b] < 0) FAIL("sensors must sit on finger bodies");
+    auto it = site_slot.find(site);
+    if (it == site_slot.end()) {
+      SgChain& C = H.chain[chain_of[b]];
+      if (C.nsite == SG_CS) FAIL("more than 2 sensor sites on a finger chain");
+      int sl = C.nsite++;
+      C.s_body[sl] = cbidx[b]; C.s_acc_adr[sl] = -1; C.s_gyro_adr[sl] = -1;
+      memcpy(C.s_pos[sl], site_pos + 3 * site, 24);
+      quat2mat(C.s_mat[sl], site_quat + 4 * site);
+      it = site_slot.emplace(site, std::make_pair(chain_of[b], sl)).first;
+    }
+    SgChain& C = H.chain[it->second.first];
+    if (sensor_type[s] == SG_SENS_ACCELEROMETER) C.s_acc_adr[it->second.second] = sensor_adr[s];
+    else if (sensor_type[s] == SG_SENS_GYRO) C.s_gyro_adr[it->second.second] = sensor_adr[s];
+    else FAIL("unsupported sensor type");
+  }
+
+  // ---- static geoms and contact-parameter uniformity ----
+  H.center_geom = H.plane_geom = -1;
+  int ref_g1 = -1, ref_g2 = -1;
+  auto allowed = [&](int g1, int g2) {
+    return (geom_contype[g1] & geom_conaffinity[g2]) || (geom_contype[g2] & geom_conaffinity[g1]);
+  };
+  auto check_pair = [&](int g1, int g2) -> bool {  // same mixed parameters as the reference pair?
+    if (ref_g1 < 0) { ref_g1 = g1; ref_g2 = g2; return true; }
+    auto mx = [&](const double* a, int k, int x, int y) { return fmax(a[k * x], a[k * y]); };
+    (void)mx;
+    for (int k = 0; k < 3; k++)
+      if (fmax(geom_friction[3 * g1 + k], geom_friction[3 * g2 + k]) != fmax(geom_friction[3 * ref_g1 + k], geom_friction[3 * ref_g2 + k])) return false;
+    for (int g : {g1, g2})
+      if (memcmp(geom_solref + 2 * g, geom_solref + 2 * ref_g1, 16) || memcmp(geom_solimp + 5 * g, geom_solimp + 5 * ref_g1, 40) ||
+          geom_solmix[g] != geom_solmix[ref_g1] || geom_margin[g] != 0 || geom_gap[g] != 0)
+        return false;
+    return std::max(geom_condim[g1], geom_condim[g2]) == 3;
+  };
+  std::vector<int> chain_geoms;
+  for (int c = 0; c < nchain; c++)
+    for (int k = 0; k < H.chain[c].ngeom; k++) chain_geoms.push_back(H.chain[c].g_id[k]);
+  if (chain_geoms.empty()) FAIL("finger chains carry no geoms");
+  for (int g : chain_geoms) {
+    if (!allowed(g, P.elem_geom[0])) FAIL("finger boxes must be able to collide with the element capsules");
+    if (!check_pair(P.elem_geom[0], g)) FAIL("contact parameters must be uniform over all finger/object pairs");
+  }
+  if (std::max(geom_condim[ref_g1], geom_condim[ref_g2]) != 3) FAIL("only condim 3 contacts are supported");
+  for (int e = 1; e < nelem; e++) {
+    int g = P.elem_geom[e], g0 = P.elem_geom[0];
+    if (geom_contype[g] != geom_contype[g0] || geom_conaffinity[g] != geom_conaffinity[g0] || geom_condim[g] != geom_condim[g0] ||
+        memcmp(geom_friction + 3 * g, geom_friction + 3 * g0, 24) || memcmp(geom_solref + 2 * g, geom_solref + 2 * g0, 16) ||
+        memcmp(geom_solimp + 5 * g, geom_solimp + 5 * g0, 40) || geom_solmix[g] != geom_solmix[g0] || geom_margin[g] != 0 || geom_gap[g] != 0)
+      FAIL("element capsules must share contact parameters");
+    if (allowed(g, g0)) FAIL("element capsules must not collide with each other");
+  }
+  for (int g = 0; g < ngeom; g++) {
+    int b = geom_bodyid[g];
+    if (body_weldid[b] != 0) continue;
+    bool hits_chain = false, hits_elem = allowed(g, P.elem_geom[0]);
+    for (int cg : chain_geoms) hits_chain |= allowed(g, cg);
+    if (!hits_chain && !hits_elem) continue;
+    double gp[3], gm[9], gl[9], t[3];
+    mulmat3(t, &wmat[9 * b], geom_pos + 3 * g);
+    for (int c = 0; c < 3; c++) gp[c] = wpos[3 * b + c] + t[c];
+    quat2mat(gl, geom_quat + 4 * g);
+    mulmat33(gm, &wmat[9 * b], gl);
+    if (geom_type[g] == SG_GEOM_PLANE) {
+      if (H.has_plane) FAIL("more than one static plane");
+      H.has_plane = 1; H.plane_geom = g;
+      memcpy(H.plane_pos, gp, 24);
+      H.plane_normal[0] = gm[2]; H.plane_normal[1] = gm[5]; H.plane_normal[2] = gm[8];
+    } else if (geom_type[g] == SG_GEOM_SPHERE) {
+      if (hits_elem) FAIL("static spheres colliding with elements are not supported");
+      if (H.has_center) FAIL("more than one static sphere");
+      if (!check_pair(g, chain_geoms[0])) FAIL("contact parameters must be uniform over all finger/object pairs");
+      H.has_center = 1; H.center_geom = g; H.center_radius = geom_size[3 * g];
+      memcpy(H.center_pos, gp, 24);
+    } else if (geom_type[g] == SG_GEOM_BOX) {
+      if (H.nstatic == SG_MAXSTATIC) FAIL("too many static boxes");
+      int k = H.nstatic++;
+      memcpy(H.st_pos[k], gp, 24); memcpy(H.st_mat[k], gm, 72); memcpy(H.st_size[k], geom_size + 3 * g, 24);
+      H.st_rbound[k] = geom_rbound[g];
+    } else {
+      FAIL("unsupported static geom type");
+    }
+  }
+  // Safe slider range per element: while q stays inside (QLO, QHI) the capsule's bounding sphere cannot touch a static box or the
+  // plane, so those pairs (legal in the model, never active in the reference scenes) need no narrowphase; outside it the kernels
+  // raise the "unsupported pair" flag.  The distance to a convex static geom is convex in q, so the unsafe set is one interval.
+  for (int e = 0; e < nelem; e++) {
+    double ax[3] = {E(SGE_AX, e), E(SGE_AY, e), E(SGE_AZ, e)}, g0[3] = {E(SGE_GX, e), E(SGE_GY, e), E(SGE_GZ, e)}, q0 = E(SGE_QPOS0, e);
+    double qlo = -1e30, qhi = 1e30;
+    auto clearance = [&](int kind, int k, double q) {  // >0: bounding sphere clear of static geom k
+      double c[3] = {g0[0] + ax[0] * (q - q0), g0[1] + ax[1] * (q - q0), g0[2] + ax[2] * (q - q0)};
+      if (kind == 0) return (c[0] - H.plane_pos[0]) * H.plane_normal[0] + (c[1] - H.plane_pos[1]) * H.plane_normal[1] + (c[2] - H.plane_pos[2]) * H.plane_normal[2] - H.cap_rbound;
+      double t[3] = {c[0] - H.st_pos[k][0], c[1] - H.st_pos[k][1], c[2] - H.st_pos[k][2]}, o2 = 0, in = -1e300;
+      for (int a = 0; a < 3; a++) {
+        double l = t[0] * H.st_mat[k][a] + t[1] * H.st_mat[k][3 + a] + t[2] * H.st_mat[k][6 + a], ex = fabs(l) - H.st_size[k][a];
+        if (ex > 0) o2 += ex * ex;
+        if (ex > in) in = ex;
+      }
+      return (o2 > 0 ? sqrt(o2) : in) - H.cap_rbound;
+    };
+    for (int kind = 0; kind < 2; kind++)
+      for (int k = 0; k < (kind == 0 ? H.has_plane : H.nstatic); k++) {
+        if (clearance(kind, k, q0) <= 0) FAIL("an element capsule touches a static geom in the reference pose");
+        for (int dir = -1; dir <= 1; dir += 2) {  // march outwards from q0 to bracket the first unsafe q, then bisect
+          double lo = q0, hi = q0, step = 0.01;
+          bool found = false;
+          for (int it = 0; it < 40 && fabs(hi - q0) < 100; it++) {
+            hi = q0 + dir * step;
+            if (clearance(kind, k, hi) <= 0) { found = true; break; }
+            lo = hi; step *= 2;
+          }
+          if (!found) continue;
+          for (int it = 0; it < 60; it++) {
+            double mid = 0.5 * (lo + hi);
+            if (clearance(kind, k, mid) <= 0) hi = mid; else lo = mid;
+          }
+          if (dir < 0) qlo = fmax(qlo, lo); else qhi = fmin(qhi, lo);
+        }
+      }
+    E(SGE_QLO, e) = qlo; E(SGE_QHI, e) = qhi;
+  }
+  // mixed contact parameters of the reference pair
+  {
+    int g1 = ref_g1, g2 = ref_g2;
+    double fr0 = fmax(geom_friction[3 * g1], geom_friction[3 * g2]);
+    H.con_mu[0] = H.con_mu[1] = fr0;
+    double sr[2], si[5];
+    for (int k = 0; k < 2; k++) sr[k] = 0.5 * geom_solref[2 * g1 + k] + 0.5 * geom_solref[2 * g2 + k];
+    for (int k = 0; k < 5; k++) si[k] = 0.5 * geom_solimp[5 * g1 + k] + 0.5 * geom_solimp[5 * g2 + k];
+    if (!(geom_solref[2 * g1] > 0 && geom_solref[2 * g2] > 0)) FAIL("direct-format contact solref is not supported");
+    kb(sr, si, &H.con_K, &H.con_B);
+    memcpy(H.con_solimp, si, 40);
+    H.con_margin = 0;
+  }
+  return true;
+}

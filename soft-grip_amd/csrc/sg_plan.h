@@ -1,0 +1,88 @@
+// sg_plan.h -- the "plan": model constants re-laid-out for the CDNA4 kernels.
+//
+// The generic model blob (include/softgrip_model.h) describes a kinematic tree.  The
+// kernels exploit the structure every soft-gripper scene has:
+//   * <=2 independent finger CHAINS: serial hinge chains (<=2 bodies, <=4 dofs) hanging
+//     off world-welded bodies, carrying the box geoms, the actuated spatial tendon and
+//     the accelerometer/gyro sites;
+//   * N ELEMENTS: leaf bodies of a <composite> shell -- one slide joint each, static
+//     parent, one capsule -- so their mass-matrix blocks are 1x1 and constant;
+//   * constraints: one joint-fix equality per element, one tendon-fix equality over
+//     all elements, hinge limits, box-capsule / box-sphere contacts.
+// sg_plan_build() verifies a model has exactly this structure and refuses it otherwise.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#define SG_MAXCH 2  // chains
+#define SG_CB 2     // bodies per chain (exactly)
+#define SG_CJ 2     // hinge joints per chain body (exactly)
+#define SG_CD 4     // dofs per chain = SG_CB * SG_CJ
+#define SG_CG 2     // box geoms per chain
+#define SG_CS 2     // sensor sites per chain
+#define SG_MAXSTATIC 8
+
+struct SgChain {
+  int nbody, ndof, ngeom, nsite, dof0, pad0[3];
+  double root_pos[3], root_mat[9];
+  // bodies (pose relative to previous chain body / chain root)
+  double b_pos[SG_CB][3], b_quat[SG_CB][4], b_ipos[SG_CB][3], b_imat[SG_CB][9], b_mass[SG_CB], b_invw_tran[SG_CB];
+  int b_njnt[SG_CB], b_dof0[SG_CB];
+  // dofs (hinges), local index
+  double j_axis[SG_CD][3], j_pos[SG_CD][3], qpos0[SG_CD], range[SG_CD][2], jmargin[SG_CD], damping[SG_CD], armature[SG_CD],
+      stiffness[SG_CD], springref[SG_CD], invw[SG_CD], lim_K[SG_CD], lim_B[SG_CD], lim_solimp[SG_CD][5];
+  int limited[SG_CD], d_body[SG_CD];
+  // box geoms
+  int g_body[SG_CG], g_id[SG_CG];
+  double g_pos[SG_CG][3], g_mat[SG_CG][9], g_size[SG_CG][3], g_rbound[SG_CG];
+  // spatial tendon (static site <-> chain site) and its cylinder actuator
+  int has_ten, ten_id, ten_body, has_act, act_id, pad1[3];
+  double ten_site[3], ten_fixed[3], ten_k0, ten_damping, ten_lspring;
+  double act_gain, act_tc, act_bias[3], act_gear;
+  // sensor sites
+  int s_body[SG_CS], s_acc_adr[SG_CS], s_gyro_adr[SG_CS];
+  double s_pos[SG_CS][3], s_mat[SG_CS][9];
+};
+
+// per-element SoA field indices into SgPlan::elem (each field is nelem doubles)
+enum {
+  SGE_AX = 0, SGE_AY, SGE_AZ,        // slider axis (world, constant because the parent is static)
+  SGE_GX, SGE_GY, SGE_GZ,            // capsule centre at q = qpos0
+  SGE_CX, SGE_CY, SGE_CZ,            // capsule axis (world)
+  SGE_MASS, SGE_ARMATURE, SGE_DAMPING, SGE_K0, SGE_SPRINGREF, SGE_QPOS0,
+  SGE_INVW,                          // dof_invweight0
+  SGE_BINVW,                         // body_invweight0 (translational)
+  SGE_COEF,                          // coefficient in the fixed tendon
+  SGE_QLO, SGE_QHI,                  // slider range inside which the capsule cannot reach any static geom
+  SGE_NFIELD
+};
+
+struct SgPlanHeader {
+  int nv, nu, nsensordata, ntendon, nchain, nelem, elem_dof0, iterations, nstatic, has_center, has_plane, center_geom, plane_geom, pad[3];
+  double timestep, gravity[3], tolerance, impratio, meaninertia, pgs_scale;
+  // element-uniform parameters
+  double cap_radius, cap_hl, cap_rbound;
+  double eqj_K, eqj_B, eqj_solimp[5];            // joint-fix equality rows
+  double eqt_K, eqt_B, eqt_solimp[5], eqt_invw;  // tendon-fix equality row
+  double t0_k0, t0_damping, t0_lspring, t0_L0;   // the fixed tendon's own spring/damper
+  int t0_id, pad2;
+  // contact parameters (identical for every candidate pair, checked at build)
+  double con_K, con_B, con_solimp[5], con_mu[2], con_margin;
+  // static geoms
+  double center_pos[3], center_radius;
+  double plane_pos[3], plane_normal[3];
+  double st_pos[SG_MAXSTATIC][3], st_mat[SG_MAXSTATIC][9], st_size[SG_MAXSTATIC][3], st_rbound[SG_MAXSTATIC];
+  SgChain chain[SG_MAXCH];
+};
+
+struct SgPlan {
+  SgPlanHeader h;
+  std::vector<double> elem;        // SGE_NFIELD x nelem
+  std::vector<int> elem_geom;      // geom id of each element's capsule
+  std::vector<int> elem_dofmap;    // (informational) global dof of element e = elem_dof0 + e
+};
+
+// Parses a model blob and fills the plan.  Returns false and sets err if the model is
+// outside the supported class.
+bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* err);

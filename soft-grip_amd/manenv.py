@@ -1,0 +1,238 @@
+"""Batched ``ManEnv``: the reference's env API (reference environment/manenv.py:8-126,
+environment/interface/environment.py:1-10) over the MI355X-native simulator.
+
+Same constructor, methods, class attributes and defaults as the reference; the one
+extension is ``n_envs`` (default 1).  With ``n_envs == 1`` every method returns what the
+reference returns (``step() -> (ndarray(12,), bool)``, ``reset() -> float``); with
+``n_envs > 1`` the same calls act on all envs in lockstep and return device tensors
+(``[n,12]`` float64, ``[n]`` bool) / an ``ndarray[n]`` of stiffnesses.
+"""
+import numpy as np
+
+from . import native
+from .mjcf import load_model
+
+
+class Env(object):
+    """reference environment/interface/environment.py:1-10"""
+
+    def __init__(self, sim_start, sim_step):
+        self.sim_start = sim_start
+        self.sim_step = sim_step
+
+    def step(self, *args):
+        raise NotImplementedError("Not implemented")
+
+    def reset(self):
+        raise NotImplementedError("Not implemented")
+
+
+class SimulationError(Exception):
+    """Counterpart of mujoco_py.builder.MujocoException (reference manenv.py:50)."""
+
+
+class ManEnv(Env):
+    # ids / names exactly as the reference (environment/manenv.py:12-18)
+    joint_ids = list(range(11, 64))
+    tendon_ids = list(range(1))
+    finger_names = ['g12', 'g2']
+    obj_name = 'OBJ'
+
+    def __init__(self, sim_start, sim_step, env_paths, is_vis=True, n_envs=1, device=0, contact_flag_mode="intent"):
+        super().__init__(sim_start, sim_step)
+        assert len(env_paths) > 0
+        assert contact_flag_mode in ("intent", "reference")
+        self.is_vis = is_vis  # no viewer exists; kept for signature parity (render() is a no-op)
+        self.env_paths = env_paths
+        self.n_envs = int(n_envs)
+        self.device_index = device
+        self.contact_flag_mode = contact_flag_mode
+        self.rng = np.random  # the reference draws from the global NumPy RNG (manenv.py:104)
+        self._load(env_paths[0])
+        self.is_closing = True
+
+    # ---- model / batch management (reference manenv.py:27-41) ----
+    def _load(self, path):
+        import torch
+        self.model = load_model(path)
+        self.nmodel = native.NativeModel(self.model)
+        self.env = native.NativeBatch(self.nmodel, self.n_envs, self.device_index)
+        dev = self.env.device
+        self._sens = torch.zeros(self.n_envs, self.nmodel.nsensordata, dtype=torch.float64, device=dev)
+        self._flags = torch.zeros(self.n_envs, dtype=torch.int32, device=dev)
+        self._touch = torch.zeros(self.n_envs, dtype=torch.int32, device=dev)
+        self._ctrl = np.zeros(self.nmodel.nu)
+        self.stiffness = np.full(self.n_envs, np.nan)
+        # which finger boxes (bit 2*chain+box of `touch`) match each name in finger_names
+        self._finger_bits = []
+        bits = self._chain_geom_bits()
+        for name in type(self).finger_names if self.contact_flag_mode == "reference" else self.finger_names:
+            self._finger_bits.append(sum(1 << b for b, gname in bits.items() if name in gname))
+        self._finger_bits_names = list(self.finger_names)
+        self._fingers_left = [list(self.finger_names) for _ in range(self.n_envs)]  # "reference" mode state
+
+    def _chain_geom_bits(self):
+        """bit index -> geom name for the moving finger boxes, in the kernels' (chain, box) order"""
+        m = self.model
+        moving = [g for g in range(m.ngeom) if m.body_weldid[m.geom_bodyid[g]] != 0 and m.geom_type[g] == 6]
+        chains = {}
+        for g in moving:  # chain = root moving body of the finger
+            b = m.geom_bodyid[g]
+            while m.body_weldid[m.body_parentid[b]] != 0:
+                b = m.body_parentid[b]
+            chains.setdefault(b, []).append(g)
+        bits = {}
+        for c, root in enumerate(sorted(chains)):
+            for k, g in enumerate(chains[root]):
+                bits[2 * c + k] = m.geom_names[g]
+        return bits
+
+    def load_env(self, num):
+        if num < len(self.env_paths):
+            self._load(self.env_paths[num])
+        else:
+            print("Wrong number,")
+
+    # ---- main methods ----
+    def step(self, num_steps=-1, actions=None, min_dist=0.1):
+        """reference manenv.py:44-53 (``actions`` / ``min_dist`` are unused there too)"""
+        if num_steps < 1:
+            num_steps = self.sim_step
+        self.env.step(num_steps, sens=self._sens, flags=self._flags, touch=self._touch)
+        bad = (self._flags != 0)
+        if bool(bad.any()):  # mujoco_py raised -> the reference resets (re-drawing the stiffness) and carries on
+            self._reset_envs(bad)
+        return self._result()
+
+    def reset(self):
+        """reference manenv.py:55-63"""
+        current_stiffness = self.set_new_stiffness()
+        self.env.reset(max(self.sim_start, 0), sens=self._sens, flags=self._flags, touch=self._touch)
+        self._ctrl[:] = 0  # mj_resetData clears ctrl
+        bad = (self._flags != 0)
+        if bool(bad.any()):
+            self._reset_envs(bad)
+        return current_stiffness
+
+    def _reset_envs(self, bad_mask, max_tries=5):
+        import torch
+        for _ in range(max_tries):
+            idx = torch.nonzero(bad_mask).flatten().cpu().numpy()
+            if idx.size == 0:
+                return
+            self.stiffness[idx] = self.rng.uniform(300, 1400, size=idx.size) if idx.size > 1 else self.rng.uniform(300, 1400)
+            self.env.set_stiffness(self.stiffness, self.joint_ids, self.tendon_ids)
+            mask = bad_mask.to(torch.uint8).contiguous()
+            flags = torch.zeros_like(self._flags)
+            self.env.reset(max(self.sim_start, 0), sens=self._sens, flags=flags, touch=self._touch, mask=mask)
+            self.env.set_ctrl_broadcast(self._ctrl)  # the reference's ctrl survives only via is_closing; keep the schedule's ctrl
+            bad_mask = bad_mask & (flags != 0)
+        raise SimulationError("envs keep failing after %d resets: %s" % (max_tries, idx))
+
+    def _contact_flags(self):
+        import torch
+        touch = self._touch
+        if self.contact_flag_mode == "intent":
+            ok = torch.ones(self.n_envs, dtype=torch.bool, device=touch.device)
+            for bits in self._finger_bits:
+                ok &= (touch & bits) != 0
+            return ok
+        # "reference": reproduce the aliased, never-refilled list of manenv.py:70-83 per env
+        t = touch.cpu().numpy()
+        ncon = self.env.solver_stats()["ncon"].cpu().numpy()
+        out = np.zeros(self.n_envs, dtype=bool)
+        for e in range(self.n_envs):
+            left = self._fingers_left[e]
+            for name, bits in zip(self._finger_bits_names, self._finger_bits):
+                if name in left and (t[e] & bits):
+                    left.remove(name)
+            out[e] = len(left) == 0 and ncon[e] > 0
+        return torch.from_numpy(out).to(touch.device)
+
+    def _result(self):
+        flag = self._contact_flags()
+        if self.n_envs == 1:
+            return self._sens[0].cpu().numpy().copy(), bool(flag[0])
+        return self._sens.clone(), flag
+
+    def get_sensor_sensordata(self):
+        """reference manenv.py:65-85"""
+        return self._result()
+
+    def toggle_grip(self):
+        if self.is_closing:
+            self.loose_hand()
+        else:
+            self.close_hand()
+
+    def close_hand(self):
+        self._ctrl[:2] = -0.2
+        self.env.set_ctrl_broadcast(self._ctrl)
+        self.is_closing = True
+
+    def loose_hand(self):
+        self._ctrl[:2] = 0.2
+        self.env.set_ctrl_broadcast(self._ctrl)
+        self.is_closing = False
+
+    def set_new_stiffness(self, range_min=300, range_max=1400):
+        """reference manenv.py:103-109: one draw per env from the global NumPy RNG, written to
+        jnt_stiffness[joint_ids] and tendon_stiffness[tendon_ids]"""
+        if self.n_envs == 1:
+            new_value = self.rng.uniform(range_min, range_max)
+            self.stiffness[0] = new_value
+        else:
+            new_value = self.rng.uniform(range_min, range_max, size=self.n_envs)
+            self.stiffness[:] = new_value
+        self.env.set_stiffness(self.stiffness, self.joint_ids, self.tendon_ids)
+        return new_value
+
+    def set_stiffness_values(self, values):
+        """batched extension: explicit per-env stiffness (e.g. a stiffness-bin sweep)"""
+        self.stiffness[:] = np.asarray(values, dtype=np.float64).reshape(self.n_envs)
+        self.env.set_stiffness(self.stiffness, self.joint_ids, self.tendon_ids)
+
+    def get_env(self):
+        return self.env
+
+    def render(self):
+        pass  # viewer is out of scope
+
+    # ---- fused episode: the create_dataset.py schedule without a host round trip per step ----
+    def rollout(self, schedule, out=None, reset=True):
+        """Runs ``len(schedule)`` env steps; ``schedule[t]`` is the broadcast ctrl (or None = unchanged) applied
+        before step t.  Writes sensordata into ``out[n, T, 12]`` (allocated when None) and returns
+        ``(out, flags_or[n])``.  Envs that fail are NOT reset here (their flags are returned)."""
+        import torch
+        T = len(schedule)
+        dev = self.env.device
+        nsd = self.nmodel.nsensordata
+        if out is None:
+            out = torch.empty(self.n_envs, T, nsd, dtype=torch.float64, device=dev)
+        assert out.shape == (self.n_envs, T, nsd) and out.is_contiguous()
+        flags_or = torch.zeros(self.n_envs, dtype=torch.int32, device=dev)
+        if reset:
+            self.env.reset(max(self.sim_start, 0), sens=self._sens, flags=self._flags, touch=self._touch)
+            self._ctrl[:] = 0
+            flags_or |= self._flags
+        for t in range(T):
+            if schedule[t] is not None:
+                self._ctrl[:] = schedule[t]
+                self.env.set_ctrl_broadcast(self._ctrl)
+            self.env.step(self.sim_step, sens=out[:, t], sens_stride=T * nsd, flags=self._flags, touch=self._touch)
+            flags_or |= self._flags
+        return out, flags_or
+
+    # specs
+    @staticmethod
+    def get_std_spec(args):
+        spec = {
+            "sim_start": args.sim_start,
+            "sim_step": args.sim_step,
+            "env_paths": args.mujoco_model_paths,
+            "is_vis": args.vis,
+        }
+        for extra in ("n_envs", "device"):
+            if hasattr(args, extra):
+                spec[extra] = getattr(args, extra)
+        return spec
