@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched soft-gripper simulator (BASELINE.json metric).
+
+A "step" is one ManEnv.step() (7 mj_step substeps + 12-channel sensor read-out, reference
+environment/manenv.py:44-53) for every env of the batch.  Workload at N GPUs: 4096 envs per
+GPU of the softbox scene, stiffness drawn from U(300,1400) (BASELINE.json configs[2]; with
+N > 1 each rank draws from its own stiffness bin, configs[3]), following the reference's
+200-step squeeze schedule (create_dataset.py:41-60) from a fresh reset, state resident in HBM.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_env_step(nq, nv, na, nu, nsens):
+    """state {qpos, qvel, qacc_warmstart, act} read + written once per ManEnv.step(),
+    plus ctrl, the stiffness scalar and the sensor outputs, in fp64 words."""
+    return 8 * (2 * (nq + 2 * nv + na) + nu + 1 + nsens)
+
+
+def cpu_baseline(model, ks, sim_step, sched, budget_envs, threads):
+    """The CPU oracle (oracle/sg_oracle.c, a port -- not MuJoCo) on the host cores: `budget_envs`
+    envs x one full 200-step episode, OpenMP over envs."""
+    from oracle import oracle as O
+    om = O.OracleModel(model.to_blob())
+    sims = [O.OracleSim(om) for _ in range(budget_envs)]
+    jids, tids = list(range(11, 64)), [0]
+    for s, k in zip(sims, ks):
+        s.jnt_stiffness[jids] = k
+        s.tendon_stiffness[tids] = k
+        s.reset()
+        s.forward()
+        s.step()
+    t0 = time.perf_counter()
+    for t in range(len(sched)):
+        if sched[t] is not None:
+            for s in sims:
+                s.ctrl[:] = sched[t]
+        O.step_many(om, sims, sim_step, threads)
+    dt = time.perf_counter() - t0
+    return budget_envs * len(sched) / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--scene", default="softbox")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import softgrip_amd as sg
+    from softgrip_amd import native
+    from softgrip_amd.create_dataset import episode_schedule, stiffness_bin
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+
+    model = sg.load_model(os.path.join(ROOT, "models", args.scene + ".sgmodel"))
+    nm = native.NativeModel(model)
+    n = args.envs
+    batch = native.NativeBatch(nm, n, local)
+    dev = batch.device
+    # stiffness: full paper range on one GPU, one bin per rank on several (no collective on the data path)
+    if world == 1:
+        ks = np.random.RandomState(0).uniform(300, 1400, n)
+    else:
+        lo, hi = stiffness_bin(rank, world)
+        ks = np.random.RandomState(1000 + rank).uniform(lo, hi, n)
+    jids, tids = list(range(11, 64)), [0]
+    batch.set_stiffness(ks, jids, tids)
+    sched = episode_schedule()
+    T = len(sched)
+    sim_step, sim_start = 7, 1
+    nsd = nm.nsensordata
+    out = torch.zeros(n, T, nsd, dtype=torch.float64, device=dev)
+    flags = torch.zeros(n, dtype=torch.int32, device=dev)
+    flags_or = torch.zeros(n, dtype=torch.int32, device=dev)
+    ctrl = np.zeros(nm.nu)
+
+    def run(nsteps, t_begin):
+        """nsteps env steps following the episode schedule from position t_begin (reset at every episode start)"""
+        t = t_begin
+        for _ in range(nsteps):
+            if t % T == 0:
+                batch.reset(sim_start, flags=flags)
+                ctrl[:] = 0
+            if sched[t % T] is not None:
+                ctrl[:] = sched[t % T]
+                batch.set_ctrl_broadcast(ctrl)
+            batch.step(sim_step, sens=out[:, t % T], sens_stride=T * nsd, flags=flags)
+            flags_or.bitwise_or_(flags)
+            t += 1
+        return t
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # warmup: first W steps of an episode, then start the timed region at a fresh episode
+    run(args.warmup, 0)
+    barrier()
+    flags_or.zero_()
+    batch.profile_enable(True)
+    batch.profile_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, 0)
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = batch.profile_read(reset=True)
+    batch.profile_enable(False)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    nbad = int((flags_or != 0).sum().item())
+
+    if rank == 0:
+        value = world * n * args.steps / dt
+        abytes = algorithmic_bytes_per_env_step(nm.nq, nm.nq, nm.nu, nm.nu, nsd)
+        ach = abytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        res = {
+            "metric": "env steps/sec (whole node) at batch=4096",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[2]: %d envs/GPU, %s scene (nv=%d), stiffness ~ U(300,1400)%s, reference 200-step squeeze "
+                                   "schedule from reset, 7 substeps per env step" % (n, args.scene, nm.nq, " split in per-rank bins" if world > 1 else ""),
+                       "envs_per_gpu": n, "substeps_per_step": sim_step, "physics_substeps_per_s": value * sim_step,
+                       "envs_flagged_bad": nbad, "launches_timed": launches},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "sg_step_kernel", "avg_kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_env_step": abytes,
+                         "note": "state stays on chip across the 7 substeps; the path is issue/latency-bound, not HBM-bound (DESIGN.md)"},
+        }
+        if not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            envs = max(cores, 2 * cores)
+            v, cdt = cpu_baseline(model, ks, sim_step, sched, envs, cores)
+            res["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                                   "sample": "%d envs x one 200-step episode (same scene/schedule/stiffness draws) on the fp64 C oracle, "
+                                             "OpenMP over envs, %.1f s" % (envs, cdt)}
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
