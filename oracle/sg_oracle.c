@@ -971,11 +971,14 @@ static void rne_bias(const sgo_model* m, sgo_data* d) {
 }
 
 /* ------------------------------------------------------------------ PGS (mj_solPGS) */
+long long sgo_dbg_counters[8];
 static int qcqp2(double* res, const double* Ain, const double* bin, const double* dd, double r) {
   double b1 = bin[0] * dd[0], b2 = bin[1] * dd[1];
   double A11 = Ain[0] * dd[0] * dd[0], A22 = Ain[3] * dd[1] * dd[1], A12 = Ain[1] * dd[0] * dd[1];
   double la = 0, v1 = 0, v2 = 0;
+  sgo_dbg_counters[0]++;
   for (int it = 0; it < 20; it++) {
+    sgo_dbg_counters[1]++;
     double det = (A11 + la) * (A22 + la) - A12 * A12;
     if (det < 1e-10) { res[0] = res[1] = 0; return 0; }
     double di = 1 / det, P11 = (A22 + la) * di, P22 = (A11 + la) * di, P12 = -A12 * di;
@@ -1033,7 +1036,9 @@ static void sol_pgs(const sgo_model* m, sgo_data* d) {
         for (int j = 0; j < 3; j++)
           for (int k = 0; k < 3; k++) Athis[3 * j + k] = d->AR[(size_t)(i + j) * ne + i + k];
         /* normal or ray update */
+        sgo_dbg_counters[2]++;
         if (f[i] < MINVAL) {
+          sgo_dbg_counters[3]++;
           f[i] -= res[0] / Athis[0];
           if (f[i] < 0) f[i] = 0;
           f[i + 1] = f[i + 2] = 0;

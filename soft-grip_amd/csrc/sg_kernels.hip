@@ -4,7 +4,8 @@
 // mj_step's (reference environment/manenv.py:48-49), keeping the whole state on chip
 // between substeps.  Work split inside the wave:
 //   * lanes 0 / 32 own finger chain 0 / 1: kinematics, 4x4 mass matrix, bias, tendon,
-//     actuator, joint limits, accelerometer + gyro (sg_math.h chain_*);
+//     actuator, joint limits, accelerometer + gyro (sg_math.h chain_*); their state is
+//     parked in LDS so that it does not occupy registers in the other 62 lanes;
 //   * every lane owns R elements (e = r*64 + lane): slider dynamics, the joint-fix rows,
 //     capsule-vs-finger-box narrowphase;
 //   * contacts are compacted in MuJoCo's order into two streams (one per chain); the i-th
@@ -41,17 +42,20 @@ struct StageRec {
   int sl, box;
 };
 
+struct ChainLds {  // everything only the chain lane needs between phases
+  double q[SG_CD], v[SG_CD], w[SG_CD], k[SG_CD], act, ctrl, kten, act_dot;
+  double qfrc_smooth[SG_CD], qacc_smooth[SG_CD], M[16], Minv[16];
+  int lim_active, pad;
+  double lim_sign[SG_MAXLIM], lim_R[SG_MAXLIM], lim_b[SG_MAXLIM], lim_f[SG_MAXLIM];
+};
+
 template <int R, int CPL>
 struct Smem {
   ChainKin K[SG_MAXCH];
-  double Minv[SG_MAXCH][16];
-  double vc[SG_MAXCH][SG_CD], asmc[SG_MAXCH][SG_CD], wc[SG_MAXCH][SG_CD];
+  ChainLds cs[SG_MAXCH];
   double boxp[SG_MAXCH * SG_CG][3], boxm[SG_MAXCH * SG_CG][9];
   double ve[R * 64], asme[R * 64], we[R * 64], as[R * 64];
   StageRec stage[SG_MAXCH][32 * CPL];
-  // joint-limit rows per chain
-  int lim_active[SG_MAXCH];  // bit k: slot k = 2*dof + side is an active row
-  double lim_sign[SG_MAXCH][SG_MAXLIM], lim_R[SG_MAXCH][SG_MAXLIM], lim_b[SG_MAXCH][SG_MAXLIM], lim_f[SG_MAXCH][SG_MAXLIM];
   int owner[R * 64];  // stream that touched slider e in this step (-1 none, 2 both)
 };
 
@@ -63,9 +67,16 @@ __device__ __forceinline__ double wave_sum(double x) {
 __device__ __forceinline__ int lanes_below(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
+// value of x in lane `src` (low half) / lane `src + 32` (high half), src wave-uniform: two v_readlane pairs + a select
+__device__ __forceinline__ double bcast_half(double x, int src, bool high) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  int lo0 = __builtin_amdgcn_readlane(lo, src), hi0 = __builtin_amdgcn_readlane(hi, src);
+  int lo1 = __builtin_amdgcn_readlane(lo, src + 32), hi1 = __builtin_amdgcn_readlane(hi, src + 32);
+  return __hiloint2double(high ? hi1 : hi0, high ? lo1 : lo0);
+}
 
 template <int R, int CPL>
-__global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
+__global__ __launch_bounds__(64, 2) void sg_step_kernel(SgKArgs a) {
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= a.nenv) return;
   if (a.mode == 1 && a.mask && !a.mask[env]) return;
@@ -76,33 +87,33 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
   auto EL = [&](int f, int e) { return a.elem[(size_t)f * N + e]; };
 
   const int half = lane >> 5;
+  const bool high = half != 0;
   const bool is_chain_lane = (lane & 31) == 0 && half < nchain;
   const SgChain& C = H.chain[half < nchain ? half : 0];
+  ChainLds& CS = S.cs[half];
 
   // ---------------- load state ----------------
-  double qc[SG_CD], vc[SG_CD], wc[SG_CD], kc[SG_CD], act = 0, ctrl = 0, kten = 0;
   double qe[R], ve[R], we[R], ke[R];
   const double kenv = a.kenv[env];
   const double kt0 = a.kmask_ten[H.t0_id] ? kenv : H.t0_k0;
   double* gq = a.qpos + (size_t)env * nv;
   double* gv = a.qvel + (size_t)env * nv;
   double* gw = a.warm + (size_t)env * nv;
-#pragma unroll
-  for (int d = 0; d < SG_CD; d++) { qc[d] = vc[d] = wc[d] = kc[d] = 0; }
   if (is_chain_lane) {
 #pragma unroll
-    for (int d = 0; d < SG_CD; d++)
-      if (d < C.ndof) {
-        int j = C.dof0 + d;
-        if (a.mode == 1) { qc[d] = C.qpos0[d]; vc[d] = 0; wc[d] = 0; }
-        else { qc[d] = gq[j]; vc[d] = gv[j]; wc[d] = gw[j]; }
-        kc[d] = a.kmask_jnt[j] ? kenv : C.stiffness[d];
-      }
+    for (int d = 0; d < SG_CD; d++) {
+      int j = C.dof0 + d;
+      if (a.mode == 1) { CS.q[d] = C.qpos0[d]; CS.v[d] = 0; CS.w[d] = 0; }
+      else { CS.q[d] = gq[j]; CS.v[d] = gv[j]; CS.w[d] = gw[j]; }
+      CS.k[d] = a.kmask_jnt[j] ? kenv : C.stiffness[d];
+    }
+    double act = 0, ctrl = 0;
     if (C.has_act) {
-      if (a.mode == 1) { act = 0; ctrl = 0; a.ctrl[(size_t)env * nu + C.act_id] = 0; }
+      if (a.mode == 1) a.ctrl[(size_t)env * nu + C.act_id] = 0;
       else { act = a.act[(size_t)env * nu + C.act_id]; ctrl = a.ctrl[(size_t)env * nu + C.act_id]; }
     }
-    if (C.has_ten) kten = a.kmask_ten[C.ten_id] ? kenv : C.ten_k0;
+    CS.act = act; CS.ctrl = ctrl; CS.act_dot = 0;
+    CS.kten = C.has_ten ? (a.kmask_ten[C.ten_id] ? kenv : C.ten_k0) : 0.0;
   }
 #pragma unroll
   for (int r = 0; r < R; r++) {
@@ -120,31 +131,36 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
 
   for (int step = -pre; step < a.nsub; step++) {
     const bool integrate = step >= 0;
+    __syncthreads();
     // ---- mj_checkPos / mj_checkVel ----
     {
       int bad = 0;
 #pragma unroll
       for (int r = 0; r < R; r++) bad |= (isbad(qe[r]) ? SG_FLAG_BADQPOS : 0) | (isbad(ve[r]) ? SG_FLAG_BADQVEL : 0);
+      if (is_chain_lane) {
 #pragma unroll
-      for (int d = 0; d < SG_CD; d++) bad |= (isbad(qc[d]) ? SG_FLAG_BADQPOS : 0) | (isbad(vc[d]) ? SG_FLAG_BADQVEL : 0);
-      unsigned long long anybad = __ballot(bad != 0);
-      if (anybad) {
+        for (int d = 0; d < SG_CD; d++) bad |= (isbad(CS.q[d]) ? SG_FLAG_BADQPOS : 0) | (isbad(CS.v[d]) ? SG_FLAG_BADQVEL : 0);
+      }
+      if (__ballot(bad != 0)) {
         flags |= (__ballot(bad & 1) ? 1 : 0) | (__ballot(bad & 2) ? 2 : 0);
         break;
       }
     }
-    __syncthreads();
-    // ---- chains: kinematics + smooth dynamics (lanes 0, 32) ----
-    ChainDyn D;
+    // ---- chains: kinematics + smooth dynamics + limit rows (lanes 0, 32) ----
     if (is_chain_lane) {
+      double qc[SG_CD], vc[SG_CD], wc[SG_CD], kc[SG_CD];
+#pragma unroll
+      for (int d = 0; d < SG_CD; d++) { qc[d] = CS.q[d]; vc[d] = CS.v[d]; wc[d] = CS.w[d]; kc[d] = CS.k[d]; }
       ChainKin K;
+      ChainDyn D;
       chain_kinematics(C, qc, K);
-      chain_dynamics(C, K, qc, vc, act, ctrl, kc, kten, H.gravity, D);
+      chain_dynamics(C, K, qc, vc, CS.act, CS.ctrl, kc, CS.kten, H.gravity, D);
       S.K[half] = K;
 #pragma unroll
-      for (int i = 0; i < 16; i++) S.Minv[half][i] = D.Minv[i];
+      for (int i = 0; i < 16; i++) { CS.Minv[i] = D.Minv[i]; CS.M[i] = D.M[i]; }
 #pragma unroll
-      for (int d = 0; d < SG_CD; d++) { S.vc[half][d] = vc[d]; S.asmc[half][d] = D.qacc_smooth[d]; S.wc[half][d] = wc[d]; }
+      for (int d = 0; d < SG_CD; d++) { CS.qfrc_smooth[d] = D.qfrc_smooth[d]; CS.qacc_smooth[d] = D.qacc_smooth[d]; }
+      CS.act_dot = D.act_dot;
 #pragma unroll
       for (int g = 0; g < SG_CG; g++)
         if (g < C.ngeom) {
@@ -157,14 +173,11 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
 #pragma unroll
           for (int k = 0; k < 9; k++) S.boxm[half * SG_CG + g][k] = bm2[k];
         }
-      // joint limit rows
       LimitRows L;
       limits_build(C, qc, vc, D.qacc_smooth, wc, L);
-      S.lim_active[half] = L.active;
+      CS.lim_active = L.active;
 #pragma unroll
-      for (int k = 0; k < SG_MAXLIM; k++) {
-        S.lim_sign[half][k] = L.sign[k]; S.lim_R[half][k] = L.R[k]; S.lim_b[half][k] = L.b[k]; S.lim_f[half][k] = L.f[k];
-      }
+      for (int k = 0; k < SG_MAXLIM; k++) { CS.lim_sign[k] = L.sign[k]; CS.lim_R[k] = L.R[k]; CS.lim_b[k] = L.b[k]; CS.lim_f[k] = L.f[k]; }
     }
     // ---- elements: smooth dynamics ----
     double invm[R], fsm[R], asme[R], coef[R];
@@ -177,100 +190,102 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
     }
     const double L0 = wave_sum(L0p), Ld = wave_sum(Ldp);
     const double frc_t0 = -kt0 * (L0 - H.t0_lspring) - H.t0_damping * Ld;
-    double cpos[R][3];
     int unsupported = 0;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      int e = r * 64 + lane;
-      invm[r] = fsm[r] = asme[r] = 0;
-      cpos[r][0] = cpos[r][1] = cpos[r][2] = 1e30;
-      if (e < N) {
-        double ax[3] = {EL(SGE_AX, e), EL(SGE_AY, e), EL(SGE_AZ, e)}, m = EL(SGE_MASS, e);
-        double bias = -m * dot3(H.gravity, ax);
-        double f = -ke[r] * (qe[r] - EL(SGE_SPRINGREF, e)) - EL(SGE_DAMPING, e) * ve[r] + coef[r] * frc_t0 - bias;
-        invm[r] = 1.0 / (m + EL(SGE_ARMATURE, e));
-        fsm[r] = f; asme[r] = f * invm[r];
-        double dq = qe[r] - EL(SGE_QPOS0, e);
-        cpos[r][0] = EL(SGE_GX, e) + ax[0] * dq; cpos[r][1] = EL(SGE_GY, e) + ax[1] * dq; cpos[r][2] = EL(SGE_GZ, e) + ax[2] * dq;
-        if (!(qe[r] > EL(SGE_QLO, e) && qe[r] < EL(SGE_QHI, e))) unsupported = 1;
-        S.ve[e] = ve[r]; S.asme[e] = asme[r]; S.we[e] = we[r];
-        S.owner[e] = -1;
-      }
-    }
-    __syncthreads();
-    // ---- collision: per chain, per box: centre sphere, then elements in index order ----
     int ns0 = 0, ns1 = 0;  // contacts staged per stream
-    int overflow = 0;
-    touch = 0;
+    {
+      double cpos[R][3];
 #pragma unroll
-    for (int c = 0; c < SG_MAXCH; c++) {
-      if (c >= nchain) break;
-      const SgChain& Cc = H.chain[c];
-      int nsc = 0;
-#pragma unroll
-      for (int g = 0; g < SG_CG; g++) {
-        if (g >= Cc.ngeom) break;
-        const int b = c * SG_CG + g;
-        double bp[3], bm[9], sz[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { bp[k] = S.boxp[b][k]; sz[k] = Cc.g_size[g][k]; }
-#pragma unroll
-        for (int k = 0; k < 9; k++) bm[k] = S.boxm[b][k];
-        const double rb = Cc.g_rbound[g];
-        if (H.has_center) {  // uniform: every lane computes the same test
-          double dif[3] = {bp[0] - H.center_pos[0], bp[1] - H.center_pos[1], bp[2] - H.center_pos[2]}, bound = H.center_radius + rb + H.con_margin;
-          ConRec rc;
-          if (dot3(dif, dif) <= bound * bound && sphere_box(H.center_pos, H.center_radius, bp, bm, sz, H.con_margin, rc) && rc.dist < H.con_margin) {
-            int slot = nsc;
-            if (slot < 32 * CPL) {
-              if (lane == 0) {
-                StageRec& s = S.stage[c][slot];
-                s.dist = rc.dist; s.sl = -1; s.box = g;
-                for (int k = 0; k < 3; k++) { s.pos[k] = rc.pos[k]; s.n[k] = rc.n[k]; }
-              }
-              nsc = slot + 1;
-              touch |= 1 << b;
-            } else overflow = 1;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          int e = r * 64 + lane, n = 0;
-          ConRec r0, r1;
-          bool v0 = false, v1 = false;
-          double dif[3] = {bp[0] - cpos[r][0], bp[1] - cpos[r][1], bp[2] - cpos[r][2]}, bound = H.cap_rbound + rb + H.con_margin;
-          if (e < N && dot3(dif, dif) <= bound * bound) {
-            double cax[3] = {EL(SGE_CX, e), EL(SGE_CY, e), EL(SGE_CZ, e)};
-            int mk = capsule_box(cpos[r], cax, H.cap_radius, H.cap_hl, bp, bm, sz, H.con_margin, r0, r1);
-            v0 = (mk & 1) && r0.dist < H.con_margin;
-            v1 = (mk & 2) && r1.dist < H.con_margin;
-            n = (int)v0 + (int)v1;
-          }
-          unsigned long long m1 = __ballot(n >= 1), m2 = __ballot(n >= 2);
-          int base = nsc + lanes_below(m1) + lanes_below(m2);
-          int total = __popcll(m1) + __popcll(m2);
-          if (v0 && base < 32 * CPL) {
-            StageRec& s = S.stage[c][base];
-            s.dist = r0.dist; s.sl = e; s.box = g;
-            for (int q = 0; q < 3; q++) { s.pos[q] = r0.pos[q]; s.n[q] = r0.n[q]; }
-          }
-          if (v1 && base + (int)v0 < 32 * CPL) {
-            StageRec& s = S.stage[c][base + (int)v0];
-            s.dist = r1.dist; s.sl = e; s.box = g;
-            for (int q = 0; q < 3; q++) { s.pos[q] = r1.pos[q]; s.n[q] = r1.n[q]; }
-          }
-          if (n > 0) {  // which streams touch this slider (streams may only run together when they share none)
-            int o = S.owner[e];
-            S.owner[e] = (o < 0 || o == c) ? c : 2;
-          }
-          if (total) touch |= 1 << b;
-          nsc += total;
-          if (nsc > 32 * CPL) { nsc = 32 * CPL; overflow = 1; }
+      for (int r = 0; r < R; r++) {
+        int e = r * 64 + lane;
+        invm[r] = fsm[r] = asme[r] = 0;
+        cpos[r][0] = cpos[r][1] = cpos[r][2] = 1e30;
+        if (e < N) {
+          double ax[3] = {EL(SGE_AX, e), EL(SGE_AY, e), EL(SGE_AZ, e)}, m = EL(SGE_MASS, e);
+          double bias = -m * dot3(H.gravity, ax);
+          double f = -ke[r] * (qe[r] - EL(SGE_SPRINGREF, e)) - EL(SGE_DAMPING, e) * ve[r] + coef[r] * frc_t0 - bias;
+          invm[r] = 1.0 / (m + EL(SGE_ARMATURE, e));
+          fsm[r] = f; asme[r] = f * invm[r];
+          double dq = qe[r] - EL(SGE_QPOS0, e);
+          cpos[r][0] = EL(SGE_GX, e) + ax[0] * dq; cpos[r][1] = EL(SGE_GY, e) + ax[1] * dq; cpos[r][2] = EL(SGE_GZ, e) + ax[2] * dq;
+          if (!(qe[r] > EL(SGE_QLO, e) && qe[r] < EL(SGE_QHI, e))) unsupported = 1;
+          S.ve[e] = ve[r]; S.asme[e] = asme[r]; S.we[e] = we[r];
+          S.owner[e] = -1;
         }
       }
-      if (c == 0) ns0 = nsc; else ns1 = nsc;
+      __syncthreads();
+      // ---- collision: per chain, per box: centre sphere, then elements in index order ----
+      int overflow = 0;
+      touch = 0;
+#pragma unroll
+      for (int c = 0; c < SG_MAXCH; c++) {
+        if (c >= nchain) break;
+        const SgChain& Cc = H.chain[c];
+        int nsc = 0;
+#pragma unroll
+        for (int g = 0; g < SG_CG; g++) {
+          if (g >= Cc.ngeom) break;
+          const int b = c * SG_CG + g;
+          double bp[3], bm[9], sz[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) { bp[k] = S.boxp[b][k]; sz[k] = Cc.g_size[g][k]; }
+#pragma unroll
+          for (int k = 0; k < 9; k++) bm[k] = S.boxm[b][k];
+          const double rb = Cc.g_rbound[g];
+          if (H.has_center) {  // uniform: every lane computes the same test
+            double dif[3] = {bp[0] - H.center_pos[0], bp[1] - H.center_pos[1], bp[2] - H.center_pos[2]}, bound = H.center_radius + rb + H.con_margin;
+            ConRec rc;
+            if (dot3(dif, dif) <= bound * bound && sphere_box(H.center_pos, H.center_radius, bp, bm, sz, H.con_margin, rc) && rc.dist < H.con_margin) {
+              int slot = nsc;
+              if (slot < 32 * CPL) {
+                if (lane == 0) {
+                  StageRec& s = S.stage[c][slot];
+                  s.dist = rc.dist; s.sl = -1; s.box = g;
+                  for (int k = 0; k < 3; k++) { s.pos[k] = rc.pos[k]; s.n[k] = rc.n[k]; }
+                }
+                nsc = slot + 1;
+                touch |= 1 << b;
+              } else overflow = 1;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            int e = r * 64 + lane, n = 0;
+            ConRec r0, r1;
+            bool v0 = false, v1 = false;
+            double dif[3] = {bp[0] - cpos[r][0], bp[1] - cpos[r][1], bp[2] - cpos[r][2]}, bound = H.cap_rbound + rb + H.con_margin;
+            if (e < N && dot3(dif, dif) <= bound * bound) {
+              double cax[3] = {EL(SGE_CX, e), EL(SGE_CY, e), EL(SGE_CZ, e)};
+              int mk = capsule_box(cpos[r], cax, H.cap_radius, H.cap_hl, bp, bm, sz, H.con_margin, r0, r1);
+              v0 = (mk & 1) && r0.dist < H.con_margin;
+              v1 = (mk & 2) && r1.dist < H.con_margin;
+              n = (int)v0 + (int)v1;
+            }
+            unsigned long long m1 = __ballot(n >= 1), m2 = __ballot(n >= 2);
+            int base = nsc + lanes_below(m1) + lanes_below(m2);
+            int total = __popcll(m1) + __popcll(m2);
+            if (v0 && base < 32 * CPL) {
+              StageRec& s = S.stage[c][base];
+              s.dist = r0.dist; s.sl = e; s.box = g;
+              for (int q = 0; q < 3; q++) { s.pos[q] = r0.pos[q]; s.n[q] = r0.n[q]; }
+            }
+            if (v1 && base + (int)v0 < 32 * CPL) {
+              StageRec& s = S.stage[c][base + (int)v0];
+              s.dist = r1.dist; s.sl = e; s.box = g;
+              for (int q = 0; q < 3; q++) { s.pos[q] = r1.pos[q]; s.n[q] = r1.n[q]; }
+            }
+            if (n > 0) {  // which streams touch this slider (streams may only run together when they share none)
+              int o = S.owner[e];
+              S.owner[e] = (o < 0 || o == c) ? c : 2;
+            }
+            if (total) touch |= 1 << b;
+            nsc += total;
+            if (nsc > 32 * CPL) { nsc = 32 * CPL; overflow = 1; }
+          }
+        }
+        if (c == 0) ns0 = nsc; else ns1 = nsc;
+      }
+      if (overflow) flags |= SG_FLAG_CONTACTFULL;
     }
-    if (overflow) flags |= SG_FLAG_CONTACTFULL;
     // envelope checks: pairs that are legal in the model but outside the supported class
     {
       int nb = nchain * SG_CG, npairs = nb * H.nstatic;
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
 
     // ---- contact rows: owner lanes build their contacts from the staged geometry ----
     Contact ct[CPL];
-    const int myn = half == 0 ? ns0 : ns1;
+    const int myn = high ? ns1 : ns0;
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
       int i = (lane & 31) + 32 * k;
@@ -336,8 +351,7 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
           ve_ = S.ve[sl]; as_ = S.asme[sl]; we_ = S.we[sl];
           im = 1.0 / (EL(SGE_MASS, sl) + EL(SGE_ARMATURE, sl)); bw = EL(SGE_BINVW, sl);
         }
-        contact_build(ct[k], rec, S.K[half], nd, S.Minv[half], S.vc[half], S.asmc[half], S.wc[half], C.b_invw_tran[bi], sl, ax, ve_, as_, we_, im,
-                      bw, H);
+        contact_build(ct[k], rec, S.K[half], nd, CS.Minv, CS.v, CS.qacc_smooth, CS.w, C.b_invw_tran[bi], sl, ax, ve_, as_, we_, im, bw, H);
       }
     }
     // ---- equality rows ----
@@ -361,9 +375,10 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
     const double tb = wave_sum(tbp) - taref, tjar = wave_sum(tjp) - taref, tA = wave_sum(tAp) + tR;
     double tf = -tjar / tR;
 
-    const int limact = S.lim_active[0] | (nchain > 1 ? S.lim_active[1] : 0);
+    const int limact = S.cs[0].lim_active | (nchain > 1 ? S.cs[1].lim_active : 0);
     st_ncon = ns0 + ns1;
-    st_nefc = N + 1 + 3 * st_ncon + __popc(S.lim_active[0]) + (nchain > 1 ? __popc(S.lim_active[1]) : 0);
+    st_nefc = N + 1 + 3 * st_ncon + __popc(S.cs[0].lim_active) + (nchain > 1 ? __popc(S.cs[1].lim_active) : 0);
+    const int nmaxs = ns0 > ns1 ? ns0 : ns1;
 
     // ---- M^-1 J' f from scratch: sliders into S.as, chains into aF (replicated per half) ----
     double aF[SG_CD];
@@ -376,13 +391,12 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
       __syncthreads();
       // contact contributions to the sliders, in contact order (deterministic)
       double g[SG_CD] = {0, 0, 0, 0};
-      const int nmax = ns0 > ns1 ? ns0 : ns1;
       for (int pass = 0; pass < (shared_slider ? 2 : 1); pass++)
 #pragma unroll
         for (int k = 0; k < CPL; k++)
           for (int ii = 0; ii < 32; ii++) {
             int i = 32 * k + ii;
-            if (i >= nmax) break;
+            if (i >= nmaxs) break;
             bool mine = (lane & 31) == ii && i < myn && (!shared_slider || half == pass);
             if (mine && ct[k].sl >= 0) S.as[ct[k].sl] += ct[k].invm * (ct[k].Js[0] * ct[k].f[0] + ct[k].Js[1] * ct[k].f[1] + ct[k].Js[2] * ct[k].f[2]);
           }
@@ -392,10 +406,10 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
 #pragma unroll
           for (int d = 0; d < SG_CD; d++) g[d] += ct[k].Jf[0][d] * ct[k].f[0] + ct[k].Jf[1][d] * ct[k].f[1] + ct[k].Jf[2][d] * ct[k].f[2];
       if (is_chain_lane) {
-        const int la = S.lim_active[half];
+        const int la = CS.lim_active;
 #pragma unroll
         for (int k = 0; k < SG_MAXLIM; k++)
-          if (la >> k & 1) g[k / 2] += S.lim_sign[half][k] * S.lim_f[half][k];
+          if (la >> k & 1) g[k / 2] += CS.lim_sign[k] * CS.lim_f[k];
       }
       // sum g over the half (32 lanes), then aF = Minv g
 #pragma unroll
@@ -409,7 +423,7 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
       for (int a2 = 0; a2 < SG_CD; a2++) {
         double s = 0;
 #pragma unroll
-        for (int b2 = 0; b2 < SG_CD; b2++) s += S.Minv[half][4 * a2 + b2] * g[b2];
+        for (int b2 = 0; b2 < SG_CD; b2++) s += CS.Minv[4 * a2 + b2] * g[b2];
         aF[a2] = s;
       }
       __syncthreads();
@@ -426,10 +440,10 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
       double tJa = wave_sum(tJap);
       if (lane == 0) cp += tf * (0.5 * (tJa + tR * tf) + tb);
       if (is_chain_lane) {
-        const int la = S.lim_active[half];
+        const int la = CS.lim_active;
 #pragma unroll
         for (int k = 0; k < SG_MAXLIM; k++)
-          if (la >> k & 1) cp += S.lim_f[half][k] * (0.5 * (S.lim_sign[half][k] * aF[k / 2] + S.lim_R[half][k] * S.lim_f[half][k]) + S.lim_b[half][k]);
+          if (la >> k & 1) cp += CS.lim_f[k] * (0.5 * (CS.lim_sign[k] * aF[k / 2] + CS.lim_R[k] * CS.lim_f[k]) + CS.lim_b[k]);
       }
 #pragma unroll
       for (int k = 0; k < CPL; k++)
@@ -450,7 +464,7 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
         tf = 0;
         if (is_chain_lane) {
 #pragma unroll
-          for (int k = 0; k < SG_MAXLIM; k++) S.lim_f[half][k] = 0;
+          for (int k = 0; k < SG_MAXLIM; k++) CS.lim_f[k] = 0;
         }
 #pragma unroll
         for (int k = 0; k < CPL; k++) ct[k].f[0] = ct[k].f[1] = ct[k].f[2] = 0;
@@ -460,7 +474,6 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
     }
     // ---- PGS sweeps ----
     st_iters = 0;
-    const int nmaxs = ns0 > ns1 ? ns0 : ns1;
     for (int it = 0; it < H.iterations; it++) {
       double imp_acc = 0;
       // joint-fix rows (mutually independent) then the tendon row
@@ -499,16 +512,16 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
           if (!(limact >> k & 1)) continue;  // uniform
           const int d = k / 2;
           double dA[SG_CD] = {0, 0, 0, 0};
-          if (is_chain_lane && act_half && (S.lim_active[half] >> k & 1)) {
-            double f = S.lim_f[half][k], old = f, sg = S.lim_sign[half][k], Rr = S.lim_R[half][k];
-            imp_acc -= scalar_update(f, S.lim_b[half][k], sg * aF[d], Rr, S.Minv[half][5 * d] + Rr, true);
-            S.lim_f[half][k] = f;
+          if (is_chain_lane && act_half && (CS.lim_active >> k & 1)) {
+            double f = CS.lim_f[k], old = f, sg = CS.lim_sign[k], Rr = CS.lim_R[k];
+            imp_acc -= scalar_update(f, CS.lim_b[k], sg * aF[d], Rr, CS.Minv[5 * d] + Rr, true);
+            CS.lim_f[k] = f;
             double df = sg * (f - old);
 #pragma unroll
-            for (int q = 0; q < SG_CD; q++) dA[q] = S.Minv[half][4 * q + d] * df;
+            for (int q = 0; q < SG_CD; q++) dA[q] = CS.Minv[4 * q + d] * df;
           }
 #pragma unroll
-          for (int q = 0; q < SG_CD; q++) aF[q] += __shfl(dA[q], lane & 32);
+          for (int q = 0; q < SG_CD; q++) aF[q] += bcast_half(dA[q], 0, high);
         }
 #pragma unroll
         for (int k = 0; k < CPL; k++)
@@ -528,12 +541,12 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
               for (int q = 0; q < SG_CD; q++) {
                 double s = 0;
 #pragma unroll
-                for (int d = 0; d < SG_CD; d++) s += S.Minv[half][4 * q + d] * g[d];
+                for (int d = 0; d < SG_CD; d++) s += CS.Minv[4 * q + d] * g[d];
                 dA[q] = s;
               }
             }
 #pragma unroll
-            for (int q = 0; q < SG_CD; q++) aF[q] += __shfl(dA[q], (lane & 32) | ii);
+            for (int q = 0; q < SG_CD; q++) aF[q] += bcast_half(dA[q], ii, high);
           }
         __syncthreads();
       }
@@ -543,87 +556,95 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
     }
     recompute_a();
     // ---- accelerations, sensors (stage 11), warmstart for the next solve ----
-    double qacc_c[SG_CD], qacc_e[R];
+    double qacc_e[R];
     int badacc = 0;
-#pragma unroll
-    for (int d = 0; d < SG_CD; d++) { qacc_c[d] = 0; }
-    if (is_chain_lane) {
-#pragma unroll
-      for (int d = 0; d < SG_CD; d++) {
-        qacc_c[d] = D.qacc_smooth[d] + aF[d];
-        if (d < C.ndof && isbad(qacc_c[d])) badacc = 1;
-      }
-    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
       int e = r * 64 + lane;
       qacc_e[r] = 0;
       if (e < N) { qacc_e[r] = asme[r] + S.as[e]; if (isbad(qacc_e[r])) badacc = 1; }
     }
-    if (is_chain_lane && a.sens) {
-      ChainMotion Mo;
-      chain_motion(C, S.K[half], vc, qacc_c, H.gravity, Mo);
-      double* so = a.sens + (size_t)env * a.sens_stride;
-      for (int s = 0; s < C.nsite; s++) {
-        int bi = C.s_body[s];
-        double r3[3], sm[9], t[3], t2[3], acc[3], out[3], sbp[3], sbm[9], bw[3], bal[3];
-        chain_body_pose(S.K[half], bi, sbp, sbm);
-        mulmat3(r3, sbm, C.s_pos[s]);
-        mulmat33(sm, sbm, C.s_mat[s]);
-        for (int k = 0; k < 3; k++) { bw[k] = bi == 0 ? Mo.w[0][k] : Mo.w[SG_CB - 1][k]; bal[k] = bi == 0 ? Mo.al[0][k] : Mo.al[SG_CB - 1][k]; }
-        if (C.s_gyro_adr[s] >= 0) {
-          mulmatT3(out, sm, bw);
-          for (int k = 0; k < 3; k++) so[C.s_gyro_adr[s] + k] = out[k];
+    if (is_chain_lane) {
+#pragma unroll
+      for (int d = 0; d < SG_CD; d++)
+        if (isbad(CS.qacc_smooth[d] + aF[d])) badacc = 1;
+    }
+    // mj_checkAcc: a bad acceleration anywhere stops the env before anything is integrated (uniform through the ballot)
+    const bool anybadacc = __ballot(badacc) != 0;
+    if (is_chain_lane) {
+      double qacc_c[SG_CD], vc[SG_CD];
+#pragma unroll
+      for (int d = 0; d < SG_CD; d++) {
+        qacc_c[d] = CS.qacc_smooth[d] + aF[d];
+        vc[d] = CS.v[d];
+      }
+      if (a.sens) {
+        ChainMotion Mo;
+        chain_motion(C, S.K[half], vc, qacc_c, H.gravity, Mo);
+        double* so = a.sens + (size_t)env * a.sens_stride;
+        for (int s = 0; s < C.nsite; s++) {
+          int bi = C.s_body[s];
+          double r3[3], sm[9], t[3], t2[3], acc[3], out[3], sbp[3], sbm[9], bw[3], bal[3];
+          chain_body_pose(S.K[half], bi, sbp, sbm);
+          mulmat3(r3, sbm, C.s_pos[s]);
+          mulmat33(sm, sbm, C.s_mat[s]);
+          for (int k = 0; k < 3; k++) { bw[k] = bi == 0 ? Mo.w[0][k] : Mo.w[SG_CB - 1][k]; bal[k] = bi == 0 ? Mo.al[0][k] : Mo.al[SG_CB - 1][k]; }
+          if (C.s_gyro_adr[s] >= 0) {
+            mulmatT3(out, sm, bw);
+            for (int k = 0; k < 3; k++) so[C.s_gyro_adr[s] + k] = out[k];
+          }
+          if (C.s_acc_adr[s] >= 0) {
+            for (int k = 0; k < 3; k++) acc[k] = bi == 0 ? Mo.a[0][k] : Mo.a[SG_CB - 1][k];
+            cross3(t, bal, r3); addscl3(acc, t, 1);
+            cross3(t, bw, r3); cross3(t2, bw, t); addscl3(acc, t2, 1);
+            mulmatT3(out, sm, acc);
+            for (int k = 0; k < 3; k++) so[C.s_acc_adr[s] + k] = out[k];
+          }
         }
-        if (C.s_acc_adr[s] >= 0) {
-          for (int k = 0; k < 3; k++) acc[k] = bi == 0 ? Mo.a[0][k] : Mo.a[SG_CB - 1][k];
-          cross3(t, bal, r3); addscl3(acc, t, 1);
-          cross3(t, bw, r3); cross3(t2, bw, t); addscl3(acc, t2, 1);
-          mulmatT3(out, sm, acc);
-          for (int k = 0; k < 3; k++) so[C.s_acc_adr[s] + k] = out[k];
+      }
+      if (!anybadacc) {
+#pragma unroll
+        for (int d = 0; d < SG_CD; d++) CS.w[d] = qacc_c[d];
+        if (integrate) {  // Euler with implicit joint damping (stage 12), chain part
+          bool damp = false;
+#pragma unroll
+          for (int d = 0; d < SG_CD; d++) damp |= C.damping[d] > 0;
+          double qa[SG_CD];
+          if (damp) {
+            double MhB[16], MhBinv[16], rhs[SG_CD];
+#pragma unroll
+            for (int i = 0; i < 16; i++) MhB[i] = CS.M[i];
+#pragma unroll
+            for (int d = 0; d < SG_CD; d++) MhB[5 * d] += h * C.damping[d];
+            spd_inverse4(MhB, MhBinv);
+#pragma unroll
+            for (int a2 = 0; a2 < SG_CD; a2++) {
+              double s = CS.qfrc_smooth[a2];
+#pragma unroll
+              for (int b2 = 0; b2 < SG_CD; b2++) s += CS.M[4 * a2 + b2] * aF[b2];
+              rhs[a2] = s;
+            }
+#pragma unroll
+            for (int a2 = 0; a2 < SG_CD; a2++) {
+              double s = 0;
+#pragma unroll
+              for (int b2 = 0; b2 < SG_CD; b2++) s += MhBinv[4 * a2 + b2] * rhs[b2];
+              qa[a2] = s;
+            }
+          } else {
+#pragma unroll
+            for (int d = 0; d < SG_CD; d++) qa[d] = qacc_c[d];
+          }
+          CS.act += h * CS.act_dot;
+#pragma unroll
+          for (int d = 0; d < SG_CD; d++) { double vn = CS.v[d] + h * qa[d]; CS.v[d] = vn; CS.q[d] += h * vn; }
         }
       }
     }
-    if (__ballot(badacc)) { flags |= SG_FLAG_BADQACC; break; }
-#pragma unroll
-    for (int d = 0; d < SG_CD; d++) wc[d] = qacc_c[d];
+    if (anybadacc) { flags |= SG_FLAG_BADQACC; break; }
 #pragma unroll
     for (int r = 0; r < R; r++) we[r] = qacc_e[r];
     if (!integrate) continue;
-    // ---- Euler with implicit joint damping (stage 12) ----
-    if (is_chain_lane) {
-      bool damp = false;
-      for (int d = 0; d < C.ndof; d++) damp |= C.damping[d] > 0;
-      double qa[SG_CD];
-      if (damp) {
-        double MhB[16], MhBinv[16], rhs[SG_CD];
-#pragma unroll
-        for (int i = 0; i < 16; i++) MhB[i] = D.M[i];
-        for (int d = 0; d < C.ndof; d++) MhB[5 * d] += h * C.damping[d];
-        spd_inverse4(MhB, MhBinv);
-#pragma unroll
-        for (int a2 = 0; a2 < SG_CD; a2++) {
-          double s = D.qfrc_smooth[a2];
-#pragma unroll
-          for (int b2 = 0; b2 < SG_CD; b2++) s += D.M[4 * a2 + b2] * aF[b2];
-          rhs[a2] = s;
-        }
-#pragma unroll
-        for (int a2 = 0; a2 < SG_CD; a2++) {
-          double s = 0;
-#pragma unroll
-          for (int b2 = 0; b2 < SG_CD; b2++) s += MhBinv[4 * a2 + b2] * rhs[b2];
-          qa[a2] = s;
-        }
-      } else {
-#pragma unroll
-        for (int d = 0; d < SG_CD; d++) qa[d] = qacc_c[d];
-      }
-      act += h * D.act_dot;
-#pragma unroll
-      for (int d = 0; d < SG_CD; d++)
-        if (d < C.ndof) { vc[d] += h * qa[d]; qc[d] += h * vc[d]; }
-    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
       int e = r * 64 + lane;
@@ -637,11 +658,11 @@ __global__ __launch_bounds__(64) void sg_step_kernel(SgKArgs a) {
   }
 
   // ---------------- store state ----------------
+  __syncthreads();
   if (is_chain_lane) {
 #pragma unroll
-    for (int d = 0; d < SG_CD; d++)
-      if (d < C.ndof) { int j = C.dof0 + d; gq[j] = qc[d]; gv[j] = vc[d]; gw[j] = wc[d]; }
-    if (C.has_act) a.act[(size_t)env * nu + C.act_id] = act;
+    for (int d = 0; d < SG_CD; d++) { int j = C.dof0 + d; gq[j] = CS.q[d]; gv[j] = CS.v[d]; gw[j] = CS.w[d]; }
+    if (C.has_act) a.act[(size_t)env * nu + C.act_id] = CS.act;
   }
 #pragma unroll
   for (int r = 0; r < R; r++) {

@@ -1,0 +1,166 @@
+"""Host logic (ManEnv mirror + dataset rollout) against the fixture captured from the REFERENCE's own Python
+(scripts/gen_harness_fixture.py -> tests/golden/harness_fixture.json).  A fake native batch records the calls,
+so no GPU is needed."""
+import json
+import os
+import pickle
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import softgrip_amd as sg
+from helpers import ROOT, model_path
+from softgrip_amd import create_dataset as cd
+from softgrip_amd import manenv, native
+
+FX = json.load(open(os.path.join(ROOT, "tests", "golden", "harness_fixture.json")))
+
+
+class FakeModel:
+    def __init__(self, model):
+        self.model, self.nq, self.nu, self.nsensordata, self.ntendon, self.nelem = model, model.nv, model.nu, 12, 3, 110
+
+
+class FakeBatch:
+    """records every physics call; sensordata = running substep count (like the stub simulator of the fixture)"""
+    log = []
+
+    def __init__(self, nmodel, n_envs, device=0):
+        self.n, self.nmodel, self.device = n_envs, nmodel, torch.device("cpu")
+        self.ctrl = np.zeros(2)
+        self.nsub = 0
+        self.k = None
+
+    def set_stiffness(self, k, jids, tids):
+        self.k = np.array(k, copy=True)
+        FakeBatch.log.append(("stiffness", list(jids), list(tids), self.k.copy()))
+
+    def set_ctrl_broadcast(self, c):
+        self.ctrl[:] = c
+
+    def reset(self, sim_start, sens=None, flags=None, touch=None, mask=None):
+        FakeBatch.log.append(("reset", sim_start))
+        self.ctrl[:] = 0
+        self.nsub = 0
+        self._advance(sim_start, sens, flags, touch)
+
+    def step(self, n, sens=None, sens_stride=0, flags=None, touch=None):
+        self._advance(n, sens, flags, touch)
+
+    def _advance(self, n, sens, flags, touch):
+        for _ in range(n):
+            self.nsub += 1
+            FakeBatch.log.append(("substep", float(self.ctrl[0]), float(self.ctrl[1])))
+        if sens is not None:
+            sens[:] = self.nsub
+        if flags is not None:
+            flags.zero_()
+        if touch is not None:
+            touch.zero_()
+
+    def solver_stats(self):
+        return dict(ncon=torch.zeros(self.n, dtype=torch.int32))
+
+
+@pytest.fixture
+def fake_native(monkeypatch):
+    FakeBatch.log = []
+    monkeypatch.setattr(native, "NativeModel", FakeModel)
+    monkeypatch.setattr(native, "NativeBatch", FakeBatch)
+    return FakeBatch
+
+
+def _args(tmp, n_envs=1):
+    return types.SimpleNamespace(mujoco_model_paths=[model_path("softbox")], sim_start=1, sim_step=7, vis=False, mask_contact=False,
+                                 data_folder=str(tmp), data_name="fx", n_envs=n_envs, device=0)
+
+
+def test_constants_and_class_attrs():
+    assert {k: getattr(cd, k) for k in FX["constants"]} == FX["constants"]
+    s = FX["set_new_stiffness"]
+    assert manenv.ManEnv.joint_ids == s["joint_ids_attr"] and manenv.ManEnv.tendon_ids == s["tendon_ids_attr"]
+    assert manenv.ManEnv.finger_names == s["finger_names"] and manenv.ManEnv.obj_name == s["obj_name"]
+    assert s["joint_ids_changed"] == s["joint_ids_attr"]          # exactly ids 11..63
+
+
+def test_rng_draws_match_reference():
+    for seed in (0, 1, 1234):
+        np.random.seed(seed)
+        assert [float(np.random.uniform(300, 1400)) for _ in range(4)] == FX["uniform_300_1400_seed%d" % seed]
+        np.random.seed(seed)   # a batch draw consumes the stream exactly like successive scalar draws
+        assert np.random.uniform(300, 1400, size=4).tolist() == FX["uniform_300_1400_seed%d" % seed]
+
+
+def test_episode_schedule_matches_reference_step_log(fake_native, tmp_path):
+    np.random.seed(0)
+    path = cd.log_into_file(_args(tmp_path))
+    sub = [e for e in fake_native.log if e[0] == "substep"]
+    runs = []
+    for _, c0, c1 in sub:
+        if runs and runs[-1][0] == [c0, c1]:
+            runs[-1][1] += 1
+        else:
+            runs.append([[c0, c1], 1])
+    assert runs == FX["mj_step_ctrl_runs"] and len(sub) == FX["n_mj_step"]
+    st = [e for e in fake_native.log if e[0] == "stiffness"]
+    assert st[0][1] == FX["set_new_stiffness"]["joint_ids_attr"] and st[0][2] == FX["set_new_stiffness"]["tendon_ids_attr"]
+    d = pickle.load(open(path, "rb"))
+    assert sorted(d.keys()) == FX["pickle_keys"]
+    x = np.array(d["data"][0])
+    assert list(x.shape) == FX["sample_shape"] and str(x.dtype) == FX["sample_dtype"]
+    assert d["stiffness"] == FX["stiffness_seed0"]
+    # the fake sensors count substeps: sample t holds 1 + 7 (t + 1), as with the reference against the stub simulator
+    np.testing.assert_array_equal(x[:, 0], 1 + 7 * (np.arange(200) + 1))
+    # fused schedule used by rollout()/bench.py is the same control sequence
+    sched = cd.episode_schedule()
+    ctrl, seq = 0.0, []
+    for c in sched:
+        ctrl = ctrl if c is None else c
+        seq += [ctrl] * 7
+    assert [c0 for _, c0, _ in sub[1:]] == seq
+
+
+def test_batched_dataset_schema(fake_native, tmp_path):
+    np.random.seed(0)
+    path = cd.log_into_file(_args(tmp_path, n_envs=4))
+    d = pickle.load(open(path, "rb"))
+    assert len(d["data"]) == 4 and len(d["stiffness"]) == 4
+    assert d["stiffness"] == FX["uniform_300_1400_seed0"]          # env e gets the e-th draw of the reference's stream
+    assert all(np.array(x).shape == (200, 12) and np.array(x).dtype == np.float64 for x in d["data"])
+
+
+def test_manenv_single_env_return_types(fake_native):
+    np.random.seed(0)
+    env = manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False)
+    k = env.reset()
+    assert isinstance(k, float) and k == FX["stiffness_seed0"][0]
+    r, c = env.step()
+    assert isinstance(r, np.ndarray) and r.shape == (12,) and r.dtype == np.float64 and isinstance(c, bool)
+    assert sorted(manenv.ManEnv.get_std_spec(types.SimpleNamespace(sim_start=1, sim_step=7, mujoco_model_paths=["a"], vis=False)).keys()) == FX["std_spec_keys"]
+    env.close_hand(); assert env.is_closing and env.env.ctrl.tolist() == [-0.2, -0.2]
+    env.toggle_grip(); assert not env.is_closing and env.env.ctrl.tolist() == [0.2, 0.2]
+    env.toggle_grip(); assert env.is_closing
+    env.load_env(5)   # out of range: prints, like the reference
+
+
+def test_contact_flag_modes(fake_native):
+    env = manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=3)
+    bits = env._chain_geom_bits()
+    assert bits == {0: "g122", 1: "g123", 2: "g22", 3: "g23"}
+    assert env._finger_bits == [0b0011, 0b1100]                    # 'g12' -> left boxes, 'g2' -> right boxes
+    env._touch[:] = torch.tensor([0b0001, 0b0101, 0], dtype=torch.int32)
+    assert env._contact_flags().tolist() == [False, True, False]
+    # reference mode: the per-env list is never refilled (manenv.py:70-83 aliasing) -> after both fingers touched once,
+    # the flag follows ncon > 0
+    env2 = manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=1, contact_flag_mode="reference")
+    env2.env.solver_stats = lambda: dict(ncon=torch.tensor([3], dtype=torch.int32))
+    env2._touch[:] = 0b0001
+    assert env2._contact_flags().tolist() == [False]
+    env2._touch[:] = 0b0100
+    assert env2._contact_flags().tolist() == [True]
+    env2._touch[:] = 0
+    assert env2._contact_flags().tolist() == [True]                # ncon > 0 is enough from now on
+    env2.env.solver_stats = lambda: dict(ncon=torch.tensor([0], dtype=torch.int32))
+    assert env2._contact_flags().tolist() == [False]
