@@ -158,8 +158,8 @@ def main():
                          "note": "state stays on chip across the 7 substeps; the path is issue/latency-bound, not HBM-bound (DESIGN.md)"},
         }
         if not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
-            envs = max(cores, 2 * cores)
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            envs = 2 * cores
             v, cdt = cpu_baseline(model, ks, sim_step, sched, envs, cores)
             res["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
                                    "sample": "%d envs x one 200-step episode (same scene/schedule/stiffness draws) on the fp64 C oracle, "

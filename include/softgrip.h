@@ -104,8 +104,13 @@ int sg_set_state(sg_batch* b, const double* qpos, const double* qvel, const doub
  * number of contacts, constraint rows and PGS sweeps of the final substep */
 int sg_get_solver_stats(sg_batch* b, int32_t* ncon, int32_t* nefc, int32_t* iters, void* stream);
 
-/* kernel timing hook for bench.py: average device time (ms) of the step kernel over the
- * launches since the last call with reset != 0, measured with HIP events on the launch
+/* kernel pipeline: 1 = split (default; phase / PGS kernel chain, one lane per finger stream in the solver),
+ * 0 = fused (one kernel per call, everything on chip).  Same results; the env var SG_PIPELINE=fused|split sets
+ * the default of new batches. */
+int sg_set_pipeline(sg_batch* b, int pipeline);
+
+/* kernel timing hook for bench.py: average device time (ms) of one sg_step/sg_reset call's kernels over the
+ * calls since the last call with reset != 0, measured with HIP events on the launch
  * stream.  Synchronises the host. */
 int sg_profile_enable(sg_batch* b, int enable);
 int sg_profile_read(sg_batch* b, int reset, double* avg_ms, long long* launches);

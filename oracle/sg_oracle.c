@@ -91,6 +91,8 @@ struct sgo_data {
   size_t AR_cap;
   int *AR_rownnz, *AR_rowadr, *AR_col, AR_colcap; /* nonzero pattern of AR rows */
   int *dofrow_adr, *dofrow, dofrow_cap, *stamp;
+  int *scr_cols, *scr_fill, *scr_rowJk, scr_rowJk_cap;
+  double* scr_vals;
   int solver_iter, warnings;
 };
 
@@ -304,6 +306,7 @@ sgo_data* sgo_data_new(const sgo_model* m) {
   d->act_dot = dalloc(m->nu); d->actuator_force = dalloc(m->nu); d->sensordata = dalloc(3 * m->nsensor);
   d->contact = (contact_t*)calloc(MAXCON, sizeof(contact_t));
   d->dofrow_adr = ialloc(nv + 1);
+  d->scr_cols = ialloc(nv + 2 * MAXCHAIN); d->scr_vals = dalloc(nv + 2 * MAXCHAIN); d->scr_fill = ialloc(nv);
   sgo_reset(m, d);
   return d;
 }
@@ -317,7 +320,9 @@ void sgo_data_free(sgo_data* d) {
                   d->act_dot, d->actuator_force, d->sensordata, d->J_val, d->efc_pos, d->efc_margin, d->efc_diagApprox, d->efc_R,
                   d->efc_D, d->efc_KBIP, d->efc_vel, d->efc_aref, d->efc_b, d->efc_force, d->efc_jar, d->AR};
   for (size_t i = 0; i < sizeof ds / sizeof ds[0]; i++) free(ds[i]);
-  int* is[] = {d->efc_type, d->efc_id, d->J_rowadr, d->J_col, d->AR_rownnz, d->AR_rowadr, d->AR_col, d->dofrow_adr, d->dofrow, d->stamp};
+  int* is[] = {d->efc_type, d->efc_id, d->J_rowadr, d->J_col, d->AR_rownnz, d->AR_rowadr, d->AR_col, d->dofrow_adr, d->dofrow, d->stamp,
+               d->scr_cols, d->scr_fill, d->scr_rowJk};
+  free(d->scr_vals);
   for (size_t i = 0; i < sizeof is / sizeof is[0]; i++) free(is[i]);
   free(d->contact);
   free(d);
@@ -766,8 +771,8 @@ static void make_constraint(const sgo_model* m, sgo_data* d) {
   int nv = m->nv;
   efc_reserve(d, 8, 8);
   d->nefc = 0; d->J_rowadr[0] = 0;
-  int* cols = (int*)malloc(sizeof(int) * (nv + 2 * MAXCHAIN));
-  double* vals = (double*)malloc(sizeof(double) * (nv + 2 * MAXCHAIN));
+  int* cols = d->scr_cols;
+  double* vals = d->scr_vals;
   /* equality rows, by id */
   for (int e = 0; e < m->neq; e++) {
     if (m->eq_type[e] == SG_EQ_JOINT) {
@@ -807,7 +812,6 @@ static void make_constraint(const sgo_model* m, sgo_data* d) {
               r == 0 ? con->includemargin : 0.0, n, cols, vals);
     }
   }
-  free(cols); free(vals);
   /* diagApprox, impedance, R, D, KBIP (mj_makeImpedance) */
   for (int i = 0; i < d->nefc; i++) {
     const double *solref, *solimp;
@@ -872,14 +876,15 @@ static void project_constraint(const sgo_model* m, sgo_data* d) {
   memset(d->dofrow_adr, 0, sizeof(int) * (nv + 1));
   for (int k = 0; k < nnz; k++) d->dofrow_adr[d->J_col[k] + 1]++;
   for (int i = 0; i < nv; i++) d->dofrow_adr[i + 1] += d->dofrow_adr[i];
-  int* fill = (int*)calloc((size_t)(nv > 0 ? nv : 1), sizeof(int));
-  int* rowJk = (int*)malloc(sizeof(int) * (nnz ? nnz : 1)); /* index into J_val for (dof,row) */
+  int* fill = d->scr_fill;
+  memset(fill, 0, sizeof(int) * nv);
+  if (nnz > d->scr_rowJk_cap) { d->scr_rowJk_cap = nnz * 2; d->scr_rowJk = (int*)realloc(d->scr_rowJk, sizeof(int) * d->scr_rowJk_cap); }
+  int* rowJk = d->scr_rowJk; /* index into J_val for (dof,row) */
   for (int r = 0; r < ne; r++)
     for (int k = d->J_rowadr[r]; k < d->J_rowadr[r + 1]; k++) {
       int c = d->J_col[k], slot = d->dofrow_adr[c] + fill[c]++;
       d->dofrow[slot] = r; rowJk[slot] = k;
     }
-  free(fill);
   /* column j of A: w = M^-1 J_j', then scatter J_i . w over the rows i that touch supp(w) */
   size_t colcap = 0;
   int* colcount = d->AR_rownnz;
@@ -895,7 +900,6 @@ static void project_constraint(const sgo_model* m, sgo_data* d) {
       for (int s = d->dofrow_adr[c]; s < d->dofrow_adr[c + 1]; s++) d->AR[(size_t)d->dofrow[s] * ne + j] += d->J_val[rowJk[s]] * w[c];
     }
   }
-  free(rowJk);
   for (int i = 0; i < ne; i++) d->AR[(size_t)i * ne + i] += d->efc_R[i];
   for (int i = 0; i < ne; i++) {
     int n = 0;

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "sg_kernels.hip"
+#include "sg_split.hip"
 
 namespace {
 thread_local std::string g_err;
@@ -24,6 +25,11 @@ __global__ void sg_fill_rows_kernel(double* dst, const double* row, int n, int w
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n * w) dst[i] = row[i % w];
 }
+__global__ void sg_masked_copy_kernel(const unsigned char* mask, int n, const int* s0, int* d0, const int* s1, int* d1, const int* s2, int* d2,
+                                      const int* s3, int* d3, const int* s4, int* d4) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && mask[i]) { d0[i] = s0[i]; d1[i] = s1[i]; d2[i] = s2[i]; d3[i] = s3[i]; d4[i] = s4[i]; }
+}
 }  // namespace
 
 struct sg_model {
@@ -37,6 +43,9 @@ struct sg_batch {
   SgPlanHeader* dH;
   double *delem, *qpos, *qvel, *warm, *act, *ctrl, *kenv, *ctrl_row;
   int *kmask_jnt, *kmask_ten, *flags, *touch, *ncon, *nefc, *iters;
+  int pipeline;  // 0 fused (one kernel per call), 1 split (phase / pgs kernel chain)
+  SgWork w;
+  std::vector<void*> wbufs;
   // profiling
   bool prof;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -79,6 +88,8 @@ void sg_batch_destroy(sg_batch* b) {
                   b->flags, b->touch, b->ncon, b->nefc, b->iters};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (void* p : b->wbufs)
+    if (p) (void)hipFree(p);
   for (auto& e : b->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete b;
 }
@@ -112,6 +123,30 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   ALLOC(b->kmask_jnt, sizeof(int) * nv); ALLOC(b->kmask_ten, sizeof(int) * nt);
   ALLOC(b->flags, sizeof(int) * n); ALLOC(b->touch, sizeof(int) * n); ALLOC(b->ncon, sizeof(int) * n); ALLOC(b->nefc, sizeof(int) * n);
   ALLOC(b->iters, sizeof(int) * n);
+  {  // workspace of the split pipeline
+    const size_t S = 2 * n, N = H.nelem;
+    memset(&b->w, 0, sizeof b->w);
+    auto walloc = [&](void** p, size_t bytes) -> bool {
+      if (hipMalloc(p, bytes) != hipSuccess) return false;
+      b->wbufs.push_back(*p);
+      return hipMemset(*p, 0, bytes) == hipSuccess;
+    };
+    bool ok = walloc((void**)&b->w.crec, sizeof(double) * SG_CAP * SG_NF * S) && walloc((void**)&b->w.cf, sizeof(double) * SG_CAP * 3 * S) &&
+              walloc((void**)&b->w.csl, sizeof(int) * SG_CAP * S) && walloc((void**)&b->w.ns, sizeof(int) * S) &&
+              walloc((void**)&b->w.envh, sizeof(double) * 4 * n) && walloc((void**)&b->w.shared, sizeof(int) * n) &&
+              walloc((void**)&b->w.pending, sizeof(int) * n) && walloc((void**)&b->w.status, sizeof(int) * n) &&
+              walloc((void**)&b->w.iters, sizeof(int) * n) && walloc((void**)&b->w.ncon, sizeof(int) * n) &&
+              walloc((void**)&b->w.nefc, sizeof(int) * n) && walloc((void**)&b->w.touch, sizeof(int) * n) &&
+              walloc((void**)&b->w.sMinv, sizeof(double) * 16 * S) && walloc((void**)&b->w.saF, sizeof(double) * 4 * S) &&
+              walloc((void**)&b->w.lim_active, sizeof(int) * S) && walloc((void**)&b->w.lim, sizeof(double) * 4 * SG_MAXLIM * S) &&
+              walloc((void**)&b->w.as, sizeof(double) * n * N) && walloc((void**)&b->w.eqf, sizeof(double) * n * N) &&
+              walloc((void**)&b->w.eqb, sizeof(double) * n * N) && walloc((void**)&b->w.eqR, sizeof(double) * n * N) &&
+              walloc((void**)&b->w.asme, sizeof(double) * n * N) && walloc((void**)&b->w.fsm, sizeof(double) * n * N) &&
+              walloc((void**)&b->w.chh, sizeof(double) * n * 2 * SG_CHW);
+    if (!ok) { sg_batch_destroy(b); return fail(SG_ERR_NOMEM, "hipMalloc (split-pipeline workspace)"); }
+    const char* pm = getenv("SG_PIPELINE");
+    b->pipeline = (pm && strcmp(pm, "fused") == 0) ? 0 : 1;
+  }
 #undef ALLOC
   HIPCHK(hipMemcpy(b->dH, &H, sizeof H, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->delem, m->plan.elem.data(), sizeof(double) * m->plan.elem.size(), hipMemcpyHostToDevice));
@@ -176,8 +211,78 @@ int sg_set_ctrl(sg_batch* b, const double* ctrl, int broadcast, void* stream) {
   return SG_OK;
 }
 
+// split pipeline: phase(begin) -> pgs -> [phase(finish+begin) -> pgs]* -> phase(finish)
+static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, double* sens, long long stride, int32_t* flags, int32_t* touch,
+                        hipStream_t s) {
+  const SgPlanHeader& H = b->m->plan.h;
+  SgPhaseArgs pa;
+  pa.H = b->dH; pa.elem = b->delem;
+  pa.qpos = b->qpos; pa.qvel = b->qvel; pa.warm = b->warm; pa.act = b->act; pa.ctrl = b->ctrl;
+  pa.kenv = b->kenv; pa.kmask_jnt = b->kmask_jnt; pa.kmask_ten = b->kmask_ten;
+  pa.mask = mask; pa.sens = nullptr; pa.sens_stride = stride > 0 ? stride : H.nsensordata;
+  pa.w = b->w; pa.nenv = b->n;
+  SgPgsArgs ga;
+  ga.H = b->dH; ga.elem = b->delem; ga.w = b->w; ga.nenv = b->n;
+  const size_t lds = sizeof(double) * ((size_t)34 * H.nelem + 8 * 2 * 4 * SG_MAXLIM);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  // forward passes to run: (mode 1: one non-integrating forward first) + nsub integrating ones
+  const int nfwd = nsub + (mode == 1 ? 1 : 0);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (b->prof) {
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, s));
+  }
+  auto phase = [&](const SgPhaseArgs& p) {
+    switch (b->m->rounds) {
+      case 1: hipLaunchKernelGGL((sg_phase_kernel<1, 2>), dim3(b->n), dim3(64), 0, s, p); break;
+      case 2: hipLaunchKernelGGL((sg_phase_kernel<2, 2>), dim3(b->n), dim3(64), 0, s, p); break;
+      case 3: hipLaunchKernelGGL((sg_phase_kernel<3, 2>), dim3(b->n), dim3(64), 0, s, p); break;
+      default: hipLaunchKernelGGL((sg_phase_kernel<4, 2>), dim3(b->n), dim3(64), 0, s, p); break;
+    }
+  };
+  for (int k = 0; k <= nfwd; k++) {
+    SgPhaseArgs p = pa;
+    p.first = k == 0;
+    p.do_reset = (mode == 1 && k == 0);
+    p.do_finish = k > 0;
+    p.finish_integrate = (mode == 1) ? (k > 1) : 1;  // forward k-1 was the non-integrating one iff mode 1 and k == 1
+    p.do_begin = k < nfwd;
+    p.sens = (k == nfwd) ? sens : nullptr;
+    if (nfwd == 0) { p.do_begin = 0; p.do_finish = 0; }
+    phase(p);
+    HIPCHK(hipGetLastError());
+    if (k < nfwd) {
+      hipLaunchKernelGGL(sg_pgs_kernel, dim3((b->n + 7) / 8), dim3(64), lds, s, ga);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  if (b->prof) {
+    HIPCHK(hipEventRecord(e1, s));
+    b->ev.emplace_back(e0, e1);
+  }
+  // outputs of the call
+  const size_t nb = sizeof(int) * (size_t)b->n;
+  if (mask == nullptr) {
+    HIPCHK(hipMemcpyAsync(flags ? flags : b->flags, b->w.status, nb, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(touch ? touch : b->touch, b->w.touch, nb, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->ncon, b->w.ncon, nb, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->nefc, b->w.nefc, nb, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->iters, b->w.iters, nb, hipMemcpyDeviceToDevice, s));
+  } else {  // masked reset: only the selected envs' entries may change
+    hipLaunchKernelGGL(sg_masked_copy_kernel, dim3((b->n + 255) / 256), dim3(256), 0, s, mask, b->n, b->w.status, flags ? flags : b->flags,
+                       b->w.touch, touch ? touch : b->touch, b->w.ncon, b->ncon, b->w.nefc, b->nefc, b->w.iters, b->iters);
+    HIPCHK(hipGetLastError());
+  }
+  return SG_OK;
+}
+
 static int launch(sg_batch* b, int mode, const uint8_t* mask, int nsub, double* sens, long long stride, int32_t* flags, int32_t* touch,
                   hipStream_t s) {
+  if (b->pipeline == 1) return launch_split(b, mode, mask, nsub, sens, stride, flags, touch, s);
   const SgPlanHeader& H = b->m->plan.h;
   SgKArgs a;
   a.H = b->dH; a.elem = b->delem;
@@ -254,6 +359,12 @@ int sg_get_solver_stats(sg_batch* b, int32_t* ncon, int32_t* nefc, int32_t* iter
   if (ncon) HIPCHK(hipMemcpyAsync(ncon, b->ncon, sizeof(int) * n, hipMemcpyDeviceToDevice, s));
   if (nefc) HIPCHK(hipMemcpyAsync(nefc, b->nefc, sizeof(int) * n, hipMemcpyDeviceToDevice, s));
   if (iters) HIPCHK(hipMemcpyAsync(iters, b->iters, sizeof(int) * n, hipMemcpyDeviceToDevice, s));
+  return SG_OK;
+}
+
+int sg_set_pipeline(sg_batch* b, int pipeline) {
+  if (!b || pipeline < 0 || pipeline > 1) return fail(SG_ERR_INVALID, "sg_set_pipeline: bad argument");
+  b->pipeline = pipeline;
   return SG_OK;
 }
 

@@ -1,0 +1,863 @@
+// sg_split.hip -- "split" pipeline: the same substep as sg_kernels.hip, cut at the constraint solve.
+//
+//   sg_phase_kernel<R,CPL>  one wavefront per env.  FINISH part: takes the solver's result for the previous
+//                           substep (slider and chain constraint accelerations), produces qacc, the sensors,
+//                           the warmstart and integrates.  BEGIN part: smooth dynamics, collision, constraint
+//                           rows, warmstart test, and EXPORTS the constraint problem to the workspace.
+//   sg_pgs_kernel           the PGS sweeps.  8 lanes per env / 8 envs per wavefront: the joint-fix rows of an env
+//                           are spread over its 8 lanes (slider arrays in LDS), and each of the two finger streams
+//                           gets ITS OWN LANE that walks its contacts sequentially, streaming the contact records
+//                           from memory (layout [slot][field][stream]: the stream lanes of consecutive envs read
+//                           consecutive addresses).  In the fused kernel 2 of 64 lanes carry the serial contact
+//                           sweep; here 16 of 64 do, and the records no longer pin 116 VGPRs per lane.
+//
+// Row order, update formulas and therefore results are the same Gauss-Seidel sweep as the fused kernel and the
+// oracle (checked by the same parity tests).  A launch of n_substeps is the chain
+//   phase(begin) -> pgs -> phase(finish+begin) -> pgs -> ... -> phase(finish).
+#include <hip/hip_runtime.h>
+
+#include "../../include/softgrip.h"
+#include "sg_math.h"
+
+using namespace sgm;
+
+#define SG_CAP 64        // contact capacity per stream in the split pipeline
+#define SG_NF 26         // constant fields of a contact record
+#define SG_G 8           // lanes per env in the PGS kernel
+#define SG_CHW 80        // doubles of chain hand-off per chain
+
+struct SgWork {          // device workspace of one batch (all pointers device memory)
+  double *crec, *cf;     // [SG_CAP][SG_NF][S], [SG_CAP][3][S]      S = 2 * nenv streams
+  int* csl;              // [SG_CAP][S]
+  int* ns;               // [S]
+  double* envh;          // [4][nenv]: tb, tR, tA, tf
+  int *shared, *pending, *status, *iters, *ncon, *nefc, *touch;  // [nenv]
+  double *sMinv, *saF;   // [16][S], [4][S]
+  int* lim_active;       // [S]
+  double* lim;           // [4][SG_MAXLIM][S]: sign, R, b, f
+  double *as, *eqf, *eqb, *eqR;  // [nenv][N]
+  double *asme, *fsm;    // [nenv][N]  begin -> finish hand-off
+  double* chh;           // [nenv][2][SG_CHW]  chain hand-off: qacc_smooth, qfrc_smooth, act_dot, M, K
+};
+
+struct SgPhaseArgs {
+  const SgPlanHeader* H;
+  const double* elem;
+  double *qpos, *qvel, *warm, *act, *ctrl;
+  const double* kenv;
+  const int *kmask_jnt, *kmask_ten;
+  const unsigned char* mask;
+  double* sens;
+  long long sens_stride;
+  SgWork w;
+  int nenv;
+  int do_reset, do_finish, finish_integrate, do_begin, first;
+};
+
+struct StageRec2 {
+  double dist, pos[3], n[3];
+  int sl, box;
+};
+
+struct ChainLds2 {
+  double q[SG_CD], v[SG_CD], w[SG_CD], k[SG_CD], act, ctrl, kten, act_dot;
+  double qfrc_smooth[SG_CD], qacc_smooth[SG_CD], M[16], Minv[16];
+  int lim_active, pad;
+  double lim_sign[SG_MAXLIM], lim_R[SG_MAXLIM], lim_b[SG_MAXLIM], lim_f[SG_MAXLIM];
+};
+
+template <int R, int CPL>
+struct Smem2 {
+  ChainKin K[SG_MAXCH];
+  ChainLds2 cs[SG_MAXCH];
+  double boxp[SG_MAXCH * SG_CG][3], boxm[SG_MAXCH * SG_CG][9];
+  double ve[R * 64], asme[R * 64], we[R * 64], as[R * 64];
+  StageRec2 stage[SG_MAXCH][32 * CPL];
+  int owner[R * 64];
+};
+
+__device__ __forceinline__ double wave_sum2(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+__device__ __forceinline__ int lanes_below2(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase kernel: [finish previous substep] [begin next substep]
+// ------------------------------------------------------------------------------------------------
+template <int R, int CPL>
+__global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= a.nenv) return;
+  if (a.mask && !a.mask[env]) return;
+  const SgPlanHeader& H = *a.H;
+  const int N = H.nelem, nv = H.nv, nu = H.nu, e0 = H.elem_dof0, nchain = H.nchain;
+  const size_t S = 2 * (size_t)a.nenv;
+  const double h = H.timestep;
+  __shared__ Smem2<R, CPL> Sm;
+  auto EL = [&](int f, int e) { return a.elem[(size_t)f * N + e]; };
+  const int half = lane >> 5;
+  const bool high = half != 0;
+  const bool is_chain_lane = (lane & 31) == 0 && half < nchain;
+  const SgChain& C = H.chain[half < nchain ? half : 0];
+  ChainLds2& CS = Sm.cs[half];
+  SgWork& W = a.w;
+
+  int status = a.first ? 0 : W.status[env];
+  if (a.first && lane == 0) { W.status[env] = 0; if (!a.do_finish) W.pending[env] = 0; }
+  const bool dead = (status & (SG_FLAG_BADQPOS | SG_FLAG_BADQVEL | SG_FLAG_BADQACC)) != 0;
+  if (dead) return;  // the env stopped integrating earlier in this call
+
+  double* gq = a.qpos + (size_t)env * nv;
+  double* gv = a.qvel + (size_t)env * nv;
+  double* gw = a.warm + (size_t)env * nv;
+  const double kenv = a.kenv[env];
+  const double kt0 = a.kmask_ten[H.t0_id] ? kenv : H.t0_k0;
+
+  // ---------------- load state ----------------
+  double qe[R], ve[R], we[R], ke[R];
+  if (is_chain_lane) {
+#pragma unroll
+    for (int d = 0; d < SG_CD; d++) {
+      int j = C.dof0 + d;
+      if (a.do_reset) { CS.q[d] = C.qpos0[d]; CS.v[d] = 0; CS.w[d] = 0; }
+      else { CS.q[d] = gq[j]; CS.v[d] = gv[j]; CS.w[d] = gw[j]; }
+      CS.k[d] = a.kmask_jnt[j] ? kenv : C.stiffness[d];
+    }
+    double act = 0, ctrl = 0;
+    if (C.has_act) {
+      if (a.do_reset) a.ctrl[(size_t)env * nu + C.act_id] = 0;
+      else { act = a.act[(size_t)env * nu + C.act_id]; ctrl = a.ctrl[(size_t)env * nu + C.act_id]; }
+    }
+    CS.act = act; CS.ctrl = ctrl; CS.act_dot = 0;
+    CS.kten = C.has_ten ? (a.kmask_ten[C.ten_id] ? kenv : C.ten_k0) : 0.0;
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    int e = r * 64 + lane;
+    qe[r] = ve[r] = we[r] = ke[r] = 0;
+    if (e < N) {
+      if (a.do_reset) { qe[r] = EL(SGE_QPOS0, e); }
+      else { qe[r] = gq[e0 + e]; ve[r] = gv[e0 + e]; we[r] = gw[e0 + e]; }
+      ke[r] = a.kmask_jnt[e0 + e] ? kenv : EL(SGE_K0, e);
+    }
+  }
+  __syncthreads();
+
+  // =============================== FINISH the previous substep ===============================
+  if (a.do_finish && W.pending[env]) {
+    int badacc = 0;
+    double qacc_e[R], ase[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int e = r * 64 + lane;
+      qacc_e[r] = ase[r] = 0;
+      if (e < N) {
+        ase[r] = W.as[(size_t)env * N + e];
+        qacc_e[r] = W.asme[(size_t)env * N + e] + ase[r];
+        if (isbad(qacc_e[r])) badacc = 1;
+      }
+    }
+    double aF[SG_CD] = {0, 0, 0, 0}, qsm[SG_CD] = {0, 0, 0, 0};
+    const double* ch = W.chh + ((size_t)env * 2 + half) * SG_CHW;
+    if (is_chain_lane) {
+#pragma unroll
+      for (int d = 0; d < SG_CD; d++) {
+        aF[d] = W.saF[(size_t)d * S + 2 * env + half];
+        qsm[d] = ch[d];
+        if (isbad(qsm[d] + aF[d])) badacc = 1;
+      }
+    }
+    const bool anybadacc = __ballot(badacc) != 0;
+    if (is_chain_lane) {
+      double qacc_c[SG_CD], vc[SG_CD];
+#pragma unroll
+      for (int d = 0; d < SG_CD; d++) { qacc_c[d] = qsm[d] + aF[d]; vc[d] = CS.v[d]; }
+      if (a.sens) {
+        ChainKin K;
+        {
+          const double* kk = ch + 25;
+          double* kd = (double*)&K;
+#pragma unroll
+          for (int i = 0; i < 48; i++) kd[i] = kk[i];
+        }
+        ChainMotion Mo;
+        chain_motion(C, K, vc, qacc_c, H.gravity, Mo);
+        double* so = a.sens + (size_t)env * a.sens_stride;
+        for (int s = 0; s < C.nsite; s++) {
+          int bi = C.s_body[s];
+          double r3[3], sm[9], t[3], t2[3], acc[3], out[3], sbp[3], sbm[9], bw[3], bal[3];
+          chain_body_pose(K, bi, sbp, sbm);
+          mulmat3(r3, sbm, C.s_pos[s]);
+          mulmat33(sm, sbm, C.s_mat[s]);
+          for (int k = 0; k < 3; k++) { bw[k] = bi == 0 ? Mo.w[0][k] : Mo.w[SG_CB - 1][k]; bal[k] = bi == 0 ? Mo.al[0][k] : Mo.al[SG_CB - 1][k]; }
+          if (C.s_gyro_adr[s] >= 0) {
+            mulmatT3(out, sm, bw);
+            for (int k = 0; k < 3; k++) so[C.s_gyro_adr[s] + k] = out[k];
+          }
+          if (C.s_acc_adr[s] >= 0) {
+            for (int k = 0; k < 3; k++) acc[k] = bi == 0 ? Mo.a[0][k] : Mo.a[SG_CB - 1][k];
+            cross3(t, bal, r3); addscl3(acc, t, 1);
+            cross3(t, bw, r3); cross3(t2, bw, t); addscl3(acc, t2, 1);
+            mulmatT3(out, sm, acc);
+            for (int k = 0; k < 3; k++) so[C.s_acc_adr[s] + k] = out[k];
+          }
+        }
+      }
+      if (!anybadacc) {
+#pragma unroll
+        for (int d = 0; d < SG_CD; d++) CS.w[d] = qacc_c[d];
+        if (a.finish_integrate) {
+          bool damp = false;
+#pragma unroll
+          for (int d = 0; d < SG_CD; d++) damp |= C.damping[d] > 0;
+          double qa[SG_CD];
+          if (damp) {
+            double MhB[16], MhBinv[16], rhs[SG_CD], Mm[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) { Mm[i] = ch[9 + i]; MhB[i] = Mm[i]; }
+#pragma unroll
+            for (int d = 0; d < SG_CD; d++) MhB[5 * d] += h * C.damping[d];
+            spd_inverse4(MhB, MhBinv);
+#pragma unroll
+            for (int a2 = 0; a2 < SG_CD; a2++) {
+              double s = ch[4 + a2];
+#pragma unroll
+              for (int b2 = 0; b2 < SG_CD; b2++) s += Mm[4 * a2 + b2] * aF[b2];
+              rhs[a2] = s;
+            }
+#pragma unroll
+            for (int a2 = 0; a2 < SG_CD; a2++) {
+              double s = 0;
+#pragma unroll
+              for (int b2 = 0; b2 < SG_CD; b2++) s += MhBinv[4 * a2 + b2] * rhs[b2];
+              qa[a2] = s;
+            }
+          } else {
+#pragma unroll
+            for (int d = 0; d < SG_CD; d++) qa[d] = qacc_c[d];
+          }
+          CS.act += h * ch[8];
+#pragma unroll
+          for (int d = 0; d < SG_CD; d++) { double vn = CS.v[d] + h * qa[d]; CS.v[d] = vn; CS.q[d] += h * vn; }
+        }
+      }
+    }
+    if (anybadacc) {
+      status |= SG_FLAG_BADQACC;
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        int e = r * 64 + lane;
+        we[r] = qacc_e[r];
+        if (e < N && a.finish_integrate) {
+          double m = EL(SGE_MASS, e) + EL(SGE_ARMATURE, e);
+          double qa = (W.fsm[(size_t)env * N + e] + m * ase[r]) / (m + h * EL(SGE_DAMPING, e));
+          ve[r] += h * qa;
+          qe[r] += h * ve[r];
+        }
+      }
+    }
+    if (lane == 0) W.pending[env] = 0;
+  }
+  __syncthreads();
+
+  // =============================== BEGIN the next substep ===============================
+  int flags = 0;
+  if (a.do_begin && !(status & SG_FLAG_BADQACC)) {
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) bad |= (isbad(qe[r]) ? SG_FLAG_BADQPOS : 0) | (isbad(ve[r]) ? SG_FLAG_BADQVEL : 0);
+    if (is_chain_lane) {
+#pragma unroll
+      for (int d = 0; d < SG_CD; d++) bad |= (isbad(CS.q[d]) ? SG_FLAG_BADQPOS : 0) | (isbad(CS.v[d]) ? SG_FLAG_BADQVEL : 0);
+    }
+    if (__ballot(bad != 0)) {
+      flags |= (__ballot(bad & 1) ? 1 : 0) | (__ballot(bad & 2) ? 2 : 0);
+    } else {
+      // ---- chains ----
+      if (is_chain_lane) {
+        double qc[SG_CD], vc[SG_CD], wc[SG_CD], kc[SG_CD];
+#pragma unroll
+        for (int d = 0; d < SG_CD; d++) { qc[d] = CS.q[d]; vc[d] = CS.v[d]; wc[d] = CS.w[d]; kc[d] = CS.k[d]; }
+        ChainKin K;
+        ChainDyn D;
+        chain_kinematics(C, qc, K);
+        chain_dynamics(C, K, qc, vc, CS.act, CS.ctrl, kc, CS.kten, H.gravity, D);
+        Sm.K[half] = K;
+        double* ch = W.chh + ((size_t)env * 2 + half) * SG_CHW;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { CS.Minv[i] = D.Minv[i]; ch[9 + i] = D.M[i]; W.sMinv[(size_t)i * S + 2 * env + half] = D.Minv[i]; }
+#pragma unroll
+        for (int d = 0; d < SG_CD; d++) { CS.qacc_smooth[d] = D.qacc_smooth[d]; ch[d] = D.qacc_smooth[d]; ch[4 + d] = D.qfrc_smooth[d]; }
+        ch[8] = D.act_dot;
+        {
+          const double* kd = (const double*)&K;
+#pragma unroll
+          for (int i = 0; i < 48; i++) ch[25 + i] = kd[i];
+        }
+#pragma unroll
+        for (int g = 0; g < SG_CG; g++)
+          if (g < C.ngeom) {
+            double t[3], bp_[3], bm_[9], bm2[9];
+            chain_body_pose(K, C.g_body[g], bp_, bm_);
+            mulmat3(t, bm_, C.g_pos[g]);
+            mulmat33(bm2, bm_, C.g_mat[g]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) Sm.boxp[half * SG_CG + g][k] = bp_[k] + t[k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) Sm.boxm[half * SG_CG + g][k] = bm2[k];
+          }
+        LimitRows L;
+        limits_build(C, qc, vc, D.qacc_smooth, wc, L);
+        CS.lim_active = L.active;
+#pragma unroll
+        for (int k = 0; k < SG_MAXLIM; k++) { CS.lim_sign[k] = L.sign[k]; CS.lim_R[k] = L.R[k]; CS.lim_b[k] = L.b[k]; CS.lim_f[k] = L.f[k]; }
+      }
+      // ---- elements ----
+      double invm[R], asme[R], coef[R];
+      double L0p = 0, Ldp = 0;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        int e = r * 64 + lane;
+        coef[r] = e < N ? EL(SGE_COEF, e) : 0.0;
+        L0p += coef[r] * qe[r]; Ldp += coef[r] * ve[r];
+      }
+      const double L0 = wave_sum2(L0p), Ld = wave_sum2(Ldp);
+      const double frc_t0 = -kt0 * (L0 - H.t0_lspring) - H.t0_damping * Ld;
+      int unsupported = 0, ns0 = 0, ns1 = 0, touch = 0;
+      {
+        double cpos[R][3];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          int e = r * 64 + lane;
+          invm[r] = asme[r] = 0;
+          cpos[r][0] = cpos[r][1] = cpos[r][2] = 1e30;
+          if (e < N) {
+            double ax[3] = {EL(SGE_AX, e), EL(SGE_AY, e), EL(SGE_AZ, e)}, m = EL(SGE_MASS, e);
+            double bias = -m * dot3(H.gravity, ax);
+            double f = -ke[r] * (qe[r] - EL(SGE_SPRINGREF, e)) - EL(SGE_DAMPING, e) * ve[r] + coef[r] * frc_t0 - bias;
+            invm[r] = 1.0 / (m + EL(SGE_ARMATURE, e));
+            asme[r] = f * invm[r];
+            W.fsm[(size_t)env * N + e] = f; W.asme[(size_t)env * N + e] = asme[r];
+            double dq = qe[r] - EL(SGE_QPOS0, e);
+            cpos[r][0] = EL(SGE_GX, e) + ax[0] * dq; cpos[r][1] = EL(SGE_GY, e) + ax[1] * dq; cpos[r][2] = EL(SGE_GZ, e) + ax[2] * dq;
+            if (!(qe[r] > EL(SGE_QLO, e) && qe[r] < EL(SGE_QHI, e))) unsupported = 1;
+            Sm.ve[e] = ve[r]; Sm.asme[e] = asme[r]; Sm.we[e] = we[r];
+            Sm.owner[e] = -1;
+          }
+        }
+        __syncthreads();
+        int overflow = 0;
+#pragma unroll
+        for (int c = 0; c < SG_MAXCH; c++) {
+          if (c >= nchain) break;
+          const SgChain& Cc = H.chain[c];
+          int nsc = 0;
+#pragma unroll
+          for (int g = 0; g < SG_CG; g++) {
+            if (g >= Cc.ngeom) break;
+            const int b = c * SG_CG + g;
+            double bp[3], bm[9], sz[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { bp[k] = Sm.boxp[b][k]; sz[k] = Cc.g_size[g][k]; }
+#pragma unroll
+            for (int k = 0; k < 9; k++) bm[k] = Sm.boxm[b][k];
+            const double rb = Cc.g_rbound[g];
+            if (H.has_center) {
+              double dif[3] = {bp[0] - H.center_pos[0], bp[1] - H.center_pos[1], bp[2] - H.center_pos[2]}, bound = H.center_radius + rb + H.con_margin;
+              ConRec rc;
+              if (dot3(dif, dif) <= bound * bound && sphere_box(H.center_pos, H.center_radius, bp, bm, sz, H.con_margin, rc) && rc.dist < H.con_margin) {
+                int slot = nsc;
+                if (slot < 32 * CPL) {
+                  if (lane == 0) {
+                    StageRec2& s = Sm.stage[c][slot];
+                    s.dist = rc.dist; s.sl = -1; s.box = g;
+                    for (int k = 0; k < 3; k++) { s.pos[k] = rc.pos[k]; s.n[k] = rc.n[k]; }
+                  }
+                  nsc = slot + 1;
+                  touch |= 1 << b;
+                } else overflow = 1;
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+              int e = r * 64 + lane, n = 0;
+              ConRec r0, r1;
+              bool v0 = false, v1 = false;
+              double dif[3] = {bp[0] - cpos[r][0], bp[1] - cpos[r][1], bp[2] - cpos[r][2]}, bound = H.cap_rbound + rb + H.con_margin;
+              if (e < N && dot3(dif, dif) <= bound * bound) {
+                double cax[3] = {EL(SGE_CX, e), EL(SGE_CY, e), EL(SGE_CZ, e)};
+                int mk = capsule_box(cpos[r], cax, H.cap_radius, H.cap_hl, bp, bm, sz, H.con_margin, r0, r1);
+                v0 = (mk & 1) && r0.dist < H.con_margin;
+                v1 = (mk & 2) && r1.dist < H.con_margin;
+                n = (int)v0 + (int)v1;
+              }
+              unsigned long long m1 = __ballot(n >= 1), m2 = __ballot(n >= 2);
+              int base = nsc + lanes_below2(m1) + lanes_below2(m2);
+              int total = __popcll(m1) + __popcll(m2);
+              if (v0 && base < 32 * CPL) {
+                StageRec2& s = Sm.stage[c][base];
+                s.dist = r0.dist; s.sl = e; s.box = g;
+                for (int q = 0; q < 3; q++) { s.pos[q] = r0.pos[q]; s.n[q] = r0.n[q]; }
+              }
+              if (v1 && base + (int)v0 < 32 * CPL) {
+                StageRec2& s = Sm.stage[c][base + (int)v0];
+                s.dist = r1.dist; s.sl = e; s.box = g;
+                for (int q = 0; q < 3; q++) { s.pos[q] = r1.pos[q]; s.n[q] = r1.n[q]; }
+              }
+              if (n > 0) {
+                int o = Sm.owner[e];
+                Sm.owner[e] = (o < 0 || o == c) ? c : 2;
+              }
+              if (total) touch |= 1 << b;
+              nsc += total;
+              if (nsc > 32 * CPL) { nsc = 32 * CPL; overflow = 1; }
+            }
+          }
+          if (c == 0) ns0 = nsc; else ns1 = nsc;
+        }
+        if (overflow) flags |= SG_FLAG_CONTACTFULL;
+      }
+      {  // envelope checks (same as the fused kernel)
+        int nb = nchain * SG_CG, npairs = nb * H.nstatic;
+        if (lane < npairs) {
+          int b = lane / H.nstatic, s = lane % H.nstatic, c = b / SG_CG, g = b % SG_CG;
+          if (g < H.chain[c].ngeom) {
+            const SgChain& Cc = H.chain[c];
+            double dif[3] = {Sm.boxp[b][0] - H.st_pos[s][0], Sm.boxp[b][1] - H.st_pos[s][1], Sm.boxp[b][2] - H.st_pos[s][2]}, bd = Cc.g_rbound[g] + H.st_rbound[s];
+            if (dot3(dif, dif) <= bd * bd && box_box_overlap(Sm.boxp[b], Sm.boxm[b], Cc.g_size[g], H.st_pos[s], H.st_mat[s], H.st_size[s], 0)) unsupported = 1;
+          }
+        } else if (lane >= 32 && lane < 32 + SG_CG * SG_CG && nchain == 2) {
+          int g = (lane - 32) / SG_CG, g2 = (lane - 32) % SG_CG;
+          if (g < H.chain[0].ngeom && g2 < H.chain[1].ngeom) {
+            int b = g, b2 = SG_CG + g2;
+            double dif[3] = {Sm.boxp[b][0] - Sm.boxp[b2][0], Sm.boxp[b][1] - Sm.boxp[b2][1], Sm.boxp[b][2] - Sm.boxp[b2][2]}, bd = H.chain[0].g_rbound[g] + H.chain[1].g_rbound[g2];
+            if (dot3(dif, dif) <= bd * bd && box_box_overlap(Sm.boxp[b], Sm.boxm[b], H.chain[0].g_size[g], Sm.boxp[b2], Sm.boxm[b2], H.chain[1].g_size[g2], 0)) unsupported = 1;
+          }
+        } else if (lane >= 48 && lane < 48 + SG_MAXCH * SG_CG && H.has_plane) {
+          int b = lane - 48, c = b / SG_CG, g = b % SG_CG;
+          if (c < nchain && g < H.chain[c].ngeom) {
+            double dif[3] = {Sm.boxp[b][0] - H.plane_pos[0], Sm.boxp[b][1] - H.plane_pos[1], Sm.boxp[b][2] - H.plane_pos[2]}, ext = 0;
+            for (int k = 0; k < 3; k++)
+              ext += H.chain[c].g_size[g][k] * fabs(H.plane_normal[0] * Sm.boxm[b][k] + H.plane_normal[1] * Sm.boxm[b][3 + k] + H.plane_normal[2] * Sm.boxm[b][6 + k]);
+            if (dot3(dif, H.plane_normal) - ext <= 0) unsupported = 1;
+          }
+        }
+        if (__ballot(unsupported)) flags |= SG_FLAG_UNSUPPORTED_PAIR;
+      }
+      __syncthreads();
+      int shared_slider = 0;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        int e = r * 64 + lane;
+        if (e < N && Sm.owner[e] == 2) shared_slider = 1;
+      }
+      shared_slider = __ballot(shared_slider) != 0;
+
+      // ---- contact rows (kept in registers only for the warmstart test, then exported) ----
+      Contact ct[CPL];
+      const int myn = high ? ns1 : ns0;
+#pragma unroll
+      for (int k = 0; k < CPL; k++) {
+        int i = (lane & 31) + 32 * k;
+        ct[k].sl = -1; ct[k].invm = 0; ct[k].R = 1;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          ct[k].f[r] = ct[k].b[r] = ct[k].Js[r] = 0;
+#pragma unroll
+          for (int d = 0; d < SG_CD; d++) ct[k].Jf[r][d] = 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) ct[k].A[q] = (q == 0 || q == 3 || q == 5) ? 1.0 : 0.0;
+        if (i < myn) {
+          const StageRec2& s = Sm.stage[half][i];
+          ConRec rec;
+          rec.dist = s.dist;
+          for (int q = 0; q < 3; q++) { rec.pos[q] = s.pos[q]; rec.n[q] = s.n[q]; }
+          int sl = s.sl, g = s.box, bi = C.g_body[g], nd = chain_ndof_of_body(bi);
+          double ax[3] = {0, 0, 0}, ve_ = 0, as_ = 0, we_ = 0, im = 0, bw = 0;
+          if (sl >= 0) {
+            ax[0] = EL(SGE_AX, sl); ax[1] = EL(SGE_AY, sl); ax[2] = EL(SGE_AZ, sl);
+            ve_ = Sm.ve[sl]; as_ = Sm.asme[sl]; we_ = Sm.we[sl];
+            im = 1.0 / (EL(SGE_MASS, sl) + EL(SGE_ARMATURE, sl)); bw = EL(SGE_BINVW, sl);
+          }
+          contact_build(ct[k], rec, Sm.K[half], nd, CS.Minv, CS.v, CS.qacc_smooth, CS.w, C.b_invw_tran[bi], sl, ax, ve_, as_, we_, im, bw, H);
+        }
+      }
+      // ---- equality rows ----
+      double eqR[R], eqb[R], eqf[R];
+      double tbp = 0, tjp = 0, tAp = 0;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        int e = r * 64 + lane;
+        eqR[r] = 1; eqb[r] = 0; eqf[r] = 0;
+        if (e < N) {
+          double pos = qe[r] - EL(SGE_QPOS0, e), imp = impedance(H.eqj_solimp, pos, 0);
+          eqR[r] = fmax(SG_MINVAL, (1 - imp) / imp * EL(SGE_INVW, e));
+          double aref = -H.eqj_B * ve[r] - H.eqj_K * imp * pos;
+          eqb[r] = asme[r] - aref;
+          eqf[r] = -(we[r] - aref) / eqR[r];
+          tbp += coef[r] * asme[r]; tjp += coef[r] * we[r]; tAp += coef[r] * coef[r] * invm[r];
+        }
+      }
+      const double tpos = L0 - H.t0_L0, timp = impedance(H.eqt_solimp, tpos, 0), tR = fmax(SG_MINVAL, (1 - timp) / timp * H.eqt_invw);
+      const double taref = -H.eqt_B * Ld - H.eqt_K * timp * tpos;
+      const double tb = wave_sum2(tbp) - taref, tjar = wave_sum2(tjp) - taref, tA = wave_sum2(tAp) + tR;
+      double tf = -tjar / tR;
+      const int nmaxs = ns0 > ns1 ? ns0 : ns1;
+
+      double aF[SG_CD];
+      auto recompute_a = [&]() {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          int e = r * 64 + lane;
+          if (e < N) Sm.as[e] = invm[r] * (eqf[r] + coef[r] * tf);
+        }
+        __syncthreads();
+        double g[SG_CD] = {0, 0, 0, 0};
+        for (int pass = 0; pass < (shared_slider ? 2 : 1); pass++)
+#pragma unroll
+          for (int k = 0; k < CPL; k++)
+            for (int ii = 0; ii < 32; ii++) {
+              int i = 32 * k + ii;
+              if (i >= nmaxs) break;
+              bool mine = (lane & 31) == ii && i < myn && (!shared_slider || half == pass);
+              if (mine && ct[k].sl >= 0) Sm.as[ct[k].sl] += ct[k].invm * (ct[k].Js[0] * ct[k].f[0] + ct[k].Js[1] * ct[k].f[1] + ct[k].Js[2] * ct[k].f[2]);
+            }
+#pragma unroll
+        for (int k = 0; k < CPL; k++)
+          if ((lane & 31) + 32 * k < myn)
+#pragma unroll
+            for (int d = 0; d < SG_CD; d++) g[d] += ct[k].Jf[0][d] * ct[k].f[0] + ct[k].Jf[1][d] * ct[k].f[1] + ct[k].Jf[2][d] * ct[k].f[2];
+        if (is_chain_lane) {
+          const int la = CS.lim_active;
+#pragma unroll
+          for (int k = 0; k < SG_MAXLIM; k++)
+            if (la >> k & 1) g[k / 2] += CS.lim_sign[k] * CS.lim_f[k];
+        }
+#pragma unroll
+        for (int d = 0; d < SG_CD; d++) {
+          double x = g[d];
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o);
+          g[d] = x;
+        }
+#pragma unroll
+        for (int a2 = 0; a2 < SG_CD; a2++) {
+          double s = 0;
+#pragma unroll
+          for (int b2 = 0; b2 < SG_CD; b2++) s += CS.Minv[4 * a2 + b2] * g[b2];
+          aF[a2] = s;
+        }
+        __syncthreads();
+      };
+      recompute_a();
+      {
+        double cp = 0, tJap = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          int e = r * 64 + lane;
+          if (e < N) { double ae = Sm.as[e]; cp += eqf[r] * (0.5 * (ae + eqR[r] * eqf[r]) + eqb[r]); tJap += coef[r] * ae; }
+        }
+        double tJa = wave_sum2(tJap);
+        if (lane == 0) cp += tf * (0.5 * (tJa + tR * tf) + tb);
+        if (is_chain_lane) {
+          const int la = CS.lim_active;
+#pragma unroll
+          for (int k = 0; k < SG_MAXLIM; k++)
+            if (la >> k & 1) cp += CS.lim_f[k] * (0.5 * (CS.lim_sign[k] * aF[k / 2] + CS.lim_R[k] * CS.lim_f[k]) + CS.lim_b[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < CPL; k++)
+          if ((lane & 31) + 32 * k < myn) {
+            double as_ = ct[k].sl >= 0 ? Sm.as[ct[k].sl] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+              double Ja = ct[k].Js[r] * as_;
+#pragma unroll
+              for (int d = 0; d < SG_CD; d++) Ja += ct[k].Jf[r][d] * aF[d];
+              cp += ct[k].f[r] * (0.5 * (Ja + ct[k].R * ct[k].f[r]) + ct[k].b[r]);
+            }
+          }
+        double cost = wave_sum2(cp);
+        if (cost > 0) {
+#pragma unroll
+          for (int r = 0; r < R; r++) eqf[r] = 0;
+          tf = 0;
+          if (is_chain_lane) {
+#pragma unroll
+            for (int k = 0; k < SG_MAXLIM; k++) CS.lim_f[k] = 0;
+          }
+#pragma unroll
+          for (int k = 0; k < CPL; k++) ct[k].f[0] = ct[k].f[1] = ct[k].f[2] = 0;
+          __syncthreads();
+          recompute_a();
+        }
+      }
+      // ---- export the constraint problem ----
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        int e = r * 64 + lane;
+        if (e < N) {
+          size_t o = (size_t)env * N + e;
+          W.as[o] = Sm.as[e]; W.eqf[o] = eqf[r]; W.eqb[o] = eqb[r]; W.eqR[o] = eqR[r];
+        }
+      }
+      const size_t st = 2 * (size_t)env + half;
+#pragma unroll
+      for (int k = 0; k < CPL; k++) {
+        int i = (lane & 31) + 32 * k;
+        if (i < myn && i < SG_CAP) {
+          double* rec = W.crec + (size_t)i * SG_NF * S + st;
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int d = 0; d < SG_CD; d++) rec[(size_t)(4 * r + d) * S] = ct[k].Jf[r][d];
+#pragma unroll
+          for (int r = 0; r < 3; r++) rec[(size_t)(12 + r) * S] = ct[k].Js[r];
+#pragma unroll
+          for (int q = 0; q < 6; q++) rec[(size_t)(15 + q) * S] = ct[k].A[q];
+#pragma unroll
+          for (int r = 0; r < 3; r++) rec[(size_t)(21 + r) * S] = ct[k].b[r];
+          rec[(size_t)24 * S] = ct[k].R;
+          rec[(size_t)25 * S] = ct[k].invm;
+#pragma unroll
+          for (int r = 0; r < 3; r++) W.cf[((size_t)i * 3 + r) * S + st] = ct[k].f[r];
+          W.csl[(size_t)i * S + st] = ct[k].sl;
+        }
+      }
+      if (is_chain_lane) {
+        W.ns[st] = myn < SG_CAP ? myn : SG_CAP;
+        W.lim_active[st] = CS.lim_active;
+#pragma unroll
+        for (int k = 0; k < SG_MAXLIM; k++) {
+          W.lim[((size_t)0 * SG_MAXLIM + k) * S + st] = CS.lim_sign[k]; W.lim[((size_t)1 * SG_MAXLIM + k) * S + st] = CS.lim_R[k];
+          W.lim[((size_t)2 * SG_MAXLIM + k) * S + st] = CS.lim_b[k]; W.lim[((size_t)3 * SG_MAXLIM + k) * S + st] = CS.lim_f[k];
+        }
+#pragma unroll
+        for (int d = 0; d < SG_CD; d++) W.saF[(size_t)d * S + st] = aF[d];
+      }
+      if (lane == 0) {
+        W.envh[(size_t)0 * a.nenv + env] = tb; W.envh[(size_t)1 * a.nenv + env] = tR;
+        W.envh[(size_t)2 * a.nenv + env] = tA; W.envh[(size_t)3 * a.nenv + env] = tf;
+        W.shared[env] = shared_slider;
+        W.pending[env] = 1;
+        W.ncon[env] = ns0 + ns1;
+        W.nefc[env] = N + 1 + 3 * (ns0 + ns1) + __popc(Sm.cs[0].lim_active) + (nchain > 1 ? __popc(Sm.cs[1].lim_active) : 0);
+        W.touch[env] = touch;
+      }
+    }
+  }
+
+  // ---------------- store state ----------------
+  __syncthreads();
+  if (is_chain_lane) {
+#pragma unroll
+    for (int d = 0; d < SG_CD; d++) { int j = C.dof0 + d; gq[j] = CS.q[d]; gv[j] = CS.v[d]; gw[j] = CS.w[d]; }
+    if (C.has_act) a.act[(size_t)env * nu + C.act_id] = CS.act;
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    int e = r * 64 + lane;
+    if (e < N) { gq[e0 + e] = qe[r]; gv[e0 + e] = ve[r]; gw[e0 + e] = we[r]; }
+  }
+  if (lane == 0) W.status[env] = status | flags;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PGS kernel: 8 lanes per env, 8 envs per wavefront
+// ------------------------------------------------------------------------------------------------
+struct SgPgsArgs {
+  const SgPlanHeader* H;
+  const double* elem;
+  SgWork w;
+  int nenv;
+};
+
+__global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
+  extern __shared__ double lds[];  // [8 envs][4 arrays][N] + invm[N] + coef[N] + limits
+  const int lane = threadIdx.x, le = lane >> 3, g = lane & 7;
+  const int env = blockIdx.x * 8 + le;
+  const SgPlanHeader& H = *a.H;
+  const int N = H.nelem;
+  const size_t S = 2 * (size_t)a.nenv;
+  const SgWork& W = a.w;
+  const bool valid = env < a.nenv && W.pending[env] != 0;
+  if (!__ballot(valid)) return;
+  double* Las = lds + (size_t)le * 4 * N;
+  double *Lf = Las + N, *Lb = Lf + N, *LR = Lb + N;
+  double* Linvm = lds + (size_t)8 * 4 * N;
+  double* Lcoef = Linvm + N;
+  double* Llim = Lcoef + N + (size_t)(le * 2) * 4 * SG_MAXLIM;  // per stream: sign, R, b, f x 8
+  for (int j = lane; j < N; j += 64) { Linvm[j] = 1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]); Lcoef[j] = a.elem[(size_t)SGE_COEF * N + j]; }
+  if (valid)
+    for (int j = g; j < N; j += SG_G) {
+      size_t o = (size_t)env * N + j;
+      Las[j] = W.as[o]; Lf[j] = W.eqf[o]; Lb[j] = W.eqb[o]; LR[j] = W.eqR[o];
+    }
+  const bool is_stream = valid && g < 2;
+  const size_t st = 2 * (size_t)(valid ? env : 0) + (g & 1);
+  int ns = 0, lim_active = 0, shared = 0;
+  double Minv[16], aF[SG_CD] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 16; i++) Minv[i] = 0;
+  double tb = 0, tR = 1, tA = 1, tf = 0;
+  if (valid) {
+    tb = W.envh[(size_t)0 * a.nenv + env]; tR = W.envh[(size_t)1 * a.nenv + env];
+    tA = W.envh[(size_t)2 * a.nenv + env]; tf = W.envh[(size_t)3 * a.nenv + env];
+    shared = W.shared[env];
+  }
+  double* mylim = Llim + (size_t)(g & 1) * 4 * SG_MAXLIM;
+  if (is_stream) {
+    ns = W.ns[st];
+    lim_active = W.lim_active[st];
+#pragma unroll
+    for (int i = 0; i < 16; i++) Minv[i] = W.sMinv[(size_t)i * S + st];
+#pragma unroll
+    for (int d = 0; d < SG_CD; d++) aF[d] = W.saF[(size_t)d * S + st];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int k = 0; k < SG_MAXLIM; k++) mylim[q * SG_MAXLIM + k] = W.lim[((size_t)q * SG_MAXLIM + k) * S + st];
+  }
+  __syncthreads();
+  int nsmax = ns;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(nsmax, o); nsmax = t > nsmax ? t : nsmax; }
+  const unsigned long long any_lim = __ballot(lim_active != 0);
+
+  bool running = valid;
+  int iters = 0;
+  const double* __restrict__ crec = W.crec;
+  double* cf = W.cf;
+  const int* __restrict__ csl = W.csl;
+
+  for (int it = 0; it < H.iterations; it++) {
+    if (!__ballot(running)) break;
+    double imp_acc = 0, tJap = 0;
+    if (running) {
+      for (int j = g; j < N; j += SG_G) {
+        double ae = Las[j], f = Lf[j], old = f, im = Linvm[j];
+        double Rr = LR[j];
+        imp_acc -= scalar_update(f, Lb[j], ae, Rr, im + Rr, false);
+        ae += im * (f - old);
+        Lf[j] = f; Las[j] = ae;
+        tJap += Lcoef[j] * ae;
+      }
+    }
+    {  // tendon row: sum over the env's 8 lanes
+      double Ja = tJap;
+      Ja += __shfl_xor(Ja, 1); Ja += __shfl_xor(Ja, 2); Ja += __shfl_xor(Ja, 4);
+      if (running) {
+        double old = tf, tfn = tf;
+        double ch = scalar_update(tfn, tb, Ja, tR, tA, false);
+        if (g == 0) imp_acc -= ch;
+        tf = tfn;
+        double dft = tf - old;
+        for (int j = g; j < N; j += SG_G) Las[j] += Linvm[j] * Lcoef[j] * dft;
+      }
+    }
+    __syncthreads();
+    // limits + contacts.  pass 0: stream 0 everywhere and stream 1 where the streams share no slider; pass 1: the rest
+    for (int pass = 0; pass < 2; pass++) {
+      const bool mine = is_stream && running && ((g == 0 || !shared) ? pass == 0 : pass == 1);
+      if (!__ballot(mine)) continue;
+      if (any_lim) {
+#pragma unroll
+        for (int k = 0; k < SG_MAXLIM; k++) {
+          if (mine && (lim_active >> k & 1)) {
+            const int d = k / 2;
+            double f = mylim[3 * SG_MAXLIM + k], old = f, sg = mylim[k], Rr = mylim[SG_MAXLIM + k];
+            imp_acc -= scalar_update(f, mylim[2 * SG_MAXLIM + k], sg * aF[d], Rr, Minv[5 * d] + Rr, true);
+            mylim[3 * SG_MAXLIM + k] = f;
+            double df = sg * (f - old);
+#pragma unroll
+            for (int q = 0; q < SG_CD; q++) aF[q] += Minv[4 * q + d] * df;
+          }
+        }
+      }
+      for (int i = 0; i < nsmax; i++) {
+        if (mine && i < ns) {
+          Contact c;
+          const double* rec = crec + (size_t)i * SG_NF * S + st;
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int d = 0; d < SG_CD; d++) c.Jf[r][d] = rec[(size_t)(4 * r + d) * S];
+#pragma unroll
+          for (int r = 0; r < 3; r++) c.Js[r] = rec[(size_t)(12 + r) * S];
+#pragma unroll
+          for (int q = 0; q < 6; q++) c.A[q] = rec[(size_t)(15 + q) * S];
+#pragma unroll
+          for (int r = 0; r < 3; r++) c.b[r] = rec[(size_t)(21 + r) * S];
+          c.R = rec[(size_t)24 * S];
+          c.invm = rec[(size_t)25 * S];
+#pragma unroll
+          for (int r = 0; r < 3; r++) c.f[r] = cf[((size_t)i * 3 + r) * S + st];
+          c.sl = csl[(size_t)i * S + st];
+          double as_ = c.sl >= 0 ? Las[c.sl] : 0.0, df[3];
+          imp_acc -= contact_update(c, aF, as_, H.con_mu, df);
+          if (c.sl >= 0) Las[c.sl] = as_ + c.invm * (c.Js[0] * df[0] + c.Js[1] * df[1] + c.Js[2] * df[2]);
+          double gg[SG_CD];
+#pragma unroll
+          for (int d = 0; d < SG_CD; d++) gg[d] = c.Jf[0][d] * df[0] + c.Jf[1][d] * df[1] + c.Jf[2][d] * df[2];
+#pragma unroll
+          for (int q = 0; q < SG_CD; q++) {
+            double s = 0;
+#pragma unroll
+            for (int d = 0; d < SG_CD; d++) s += Minv[4 * q + d] * gg[d];
+            aF[q] += s;
+          }
+#pragma unroll
+          for (int r = 0; r < 3; r++) cf[((size_t)i * 3 + r) * S + st] = c.f[r];
+        }
+      }
+      __syncthreads();
+    }
+    double imp = imp_acc;
+    imp += __shfl_xor(imp, 1); imp += __shfl_xor(imp, 2); imp += __shfl_xor(imp, 4);
+    if (running) {
+      iters = it + 1;
+      if (imp * H.pgs_scale < H.tolerance) running = false;
+    }
+  }
+  __syncthreads();
+  // ---- fresh M^-1 J' f from the final forces (same as the fused kernel's recompute) ----
+  if (valid)
+    for (int j = g; j < N; j += SG_G) Las[j] = Linvm[j] * (Lf[j] + Lcoef[j] * tf);
+  __syncthreads();
+  double gF[SG_CD] = {0, 0, 0, 0};
+  for (int pass = 0; pass < 2; pass++) {  // stream 0 then stream 1: deterministic when they share a slider
+    if (is_stream && g == pass) {
+#pragma unroll
+      for (int k = 0; k < SG_MAXLIM; k++)
+        if (lim_active >> k & 1) gF[k / 2] += mylim[k] * mylim[3 * SG_MAXLIM + k];
+      for (int i = 0; i < ns; i++) {
+        const double* rec = crec + (size_t)i * SG_NF * S + st;
+        double f0 = cf[((size_t)i * 3 + 0) * S + st], f1 = cf[((size_t)i * 3 + 1) * S + st], f2 = cf[((size_t)i * 3 + 2) * S + st];
+        int sl = csl[(size_t)i * S + st];
+        if (sl >= 0) Las[sl] += rec[(size_t)25 * S] * (rec[(size_t)12 * S] * f0 + rec[(size_t)13 * S] * f1 + rec[(size_t)14 * S] * f2);
+#pragma unroll
+        for (int d = 0; d < SG_CD; d++) gF[d] += rec[(size_t)d * S] * f0 + rec[(size_t)(4 + d) * S] * f1 + rec[(size_t)(8 + d) * S] * f2;
+      }
+    }
+    __syncthreads();
+  }
+  if (is_stream) {
+#pragma unroll
+    for (int q = 0; q < SG_CD; q++) {
+      double s = 0;
+#pragma unroll
+      for (int d = 0; d < SG_CD; d++) s += Minv[4 * q + d] * gF[d];
+      W.saF[(size_t)q * S + st] = s;
+    }
+  }
+  if (valid) {
+    for (int j = g; j < N; j += SG_G) W.as[(size_t)env * N + j] = Las[j];
+    if (g == 0) W.iters[env] = iters;
+  }
+}

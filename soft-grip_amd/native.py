@@ -17,7 +17,7 @@ SYMBOLS = [
     "sg_last_error", "sg_version", "sg_model_create", "sg_model_destroy", "sg_model_nq", "sg_model_nu",
     "sg_model_nsensordata", "sg_model_ntendon", "sg_model_nelem", "sg_batch_create", "sg_batch_destroy",
     "sg_batch_nenvs", "sg_batch_device", "sg_set_stiffness", "sg_set_ctrl", "sg_reset", "sg_step", "sg_get_state",
-    "sg_set_state", "sg_get_solver_stats", "sg_profile_enable", "sg_profile_read",
+    "sg_set_state", "sg_get_solver_stats", "sg_set_pipeline", "sg_profile_enable", "sg_profile_read",
 ]
 
 
@@ -56,6 +56,7 @@ def lib():
     L.sg_get_state.argtypes = [vp, dp, dp, dp, dp, dp, vp]
     L.sg_set_state.argtypes = [vp, dp, dp, dp, dp, dp, vp]
     L.sg_get_solver_stats.argtypes = [vp, ip, ip, ip, vp]
+    L.sg_set_pipeline.argtypes = [vp, C.c_int]
     L.sg_profile_enable.argtypes = [vp, C.c_int]
     L.sg_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     _LIB = L
@@ -152,6 +153,9 @@ class NativeBatch:
         out = [t.empty(self.n, dtype=t.int32, device=self.device) for _ in range(3)]
         check(lib().sg_get_solver_stats(self.ptr, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), self._stream()))
         return dict(ncon=out[0], nefc=out[1], iters=out[2])
+
+    def set_pipeline(self, name):
+        check(lib().sg_set_pipeline(self.ptr, {"fused": 0, "split": 1}[name]))
 
     def profile_enable(self, on=True):
         check(lib().sg_profile_enable(self.ptr, int(on)))
