@@ -570,8 +570,8 @@ static int sphere_box(const sgo_model* m, sgo_data* d, int g1, int g2, const dou
   if (dist <= MINVAL) { /* centre inside the box: leave through the nearest face */
     double closest = 1e300; int ka = 0; double sg = 1;
     for (int k = 0; k < 3; k++) {
-      if (sz[k] - cen[k] < closest) { closest = sz[k] - cen[k]; ka = k; sg = 1; }
-      if (sz[k] + cen[k] < closest) { closest = sz[k] + cen[k]; ka = k; sg = -1; }
+      if (sz[k] - cen[k] < closest - 1e-12) { closest = sz[k] - cen[k]; ka = k; sg = 1; }
+      if (sz[k] + cen[k] < closest - 1e-12) { closest = sz[k] + cen[k]; ka = k; sg = -1; }
     }
     nl[0] = nl[1] = nl[2] = 0; nl[ka] = -sg;
     for (int k = 0; k < 3; k++) pl[k] = cen[k] + nl[k] * (r - closest) * 0.5;
@@ -650,7 +650,7 @@ static double seg_box_param(const double* p, const double* h, const double* sz) 
   for (int i = 0; i < nc; i++) {
     double f = -1e300;
     for (int k = 0; k < 6; k++) { double v = a[k] * cand[i] + b[k]; if (v > f) f = v; }
-    if (f < best) { best = f; tb = cand[i]; }
+    if (f < best - 1e-12) { best = f; tb = cand[i]; } /* ties: first candidate wins in every implementation */
   }
   return tb;
 }

@@ -1,0 +1,23 @@
+"""Summarise a rocprofv3 --kernel-trace CSV of a bench.py run of the split pipeline: per-kernel time by episode phase."""
+import csv
+import glob
+import sys
+
+import numpy as np
+
+d = sys.argv[1]
+f = glob.glob(d + "/*/*_kernel_trace.csv")[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+ph = [r for r in rows if 'sg_phase' in r['Kernel_Name']]
+pg = [r for r in rows if 'sg_pgs' in r['Kernel_Name']]
+print(len(ph), len(pg), "phase VGPR", ph[0]['VGPR_Count'], ph[0].get('Accum_VGPR_Count'), "pgs VGPR", pg[0]['VGPR_Count'], pg[0].get('Accum_VGPR_Count'), "LDS", pg[0]['LDS_Block_Size'])
+php = np.array([dur(r) for r in ph][-1600:]).reshape(200, 8)
+pgp = np.array([dur(r) for r in pg][-1400:]).reshape(200, 7)
+for a, b in [(0, 40), (40, 50), (50, 80), (80, 120), (120, 140), (140, 200)]:
+    print(a, b, "phase us/kernel %.0f  pgs us/kernel %.0f   step ms %.2f (phase %.2f pgs %.2f)" % (
+        php[a:b].mean(), pgp[a:b].mean(), (php[a:b].sum(1) + pgp[a:b].sum(1)).mean() / 1e3, php[a:b].sum(1).mean() / 1e3, pgp[a:b].sum(1).mean() / 1e3))
+print("sum kernels per episode ms %.1f  (phase %.1f, pgs %.1f)" % ((php.sum() + pgp.sum()) / 1e3, php.sum() / 1e3, pgp.sum() / 1e3))
+t0 = int(ph[-1600]['Start_Timestamp']); t1 = int(ph[-1]['End_Timestamp'])
+print("wall of timed region ms %.1f" % ((t1 - t0) / 1e6))

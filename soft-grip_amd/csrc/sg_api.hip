@@ -131,8 +131,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
       b->wbufs.push_back(*p);
       return hipMemset(*p, 0, bytes) == hipSuccess;
     };
-    bool ok = walloc((void**)&b->w.crec, sizeof(double) * SG_CAP * SG_NF * S) && walloc((void**)&b->w.cf, sizeof(double) * SG_CAP * 3 * S) &&
-              walloc((void**)&b->w.csl, sizeof(int) * SG_CAP * S) && walloc((void**)&b->w.ns, sizeof(int) * S) &&
+    bool ok = walloc((void**)&b->w.crec, sizeof(double) * SG_CAP * ((n + 7) / 8 + 1) * SG_RF * 16) && walloc((void**)&b->w.ns, sizeof(int) * S) &&
               walloc((void**)&b->w.envh, sizeof(double) * 4 * n) && walloc((void**)&b->w.shared, sizeof(int) * n) &&
               walloc((void**)&b->w.pending, sizeof(int) * n) && walloc((void**)&b->w.status, sizeof(int) * n) &&
               walloc((void**)&b->w.iters, sizeof(int) * n) && walloc((void**)&b->w.ncon, sizeof(int) * n) &&
@@ -221,6 +220,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   pa.kenv = b->kenv; pa.kmask_jnt = b->kmask_jnt; pa.kmask_ten = b->kmask_ten;
   pa.mask = mask; pa.sens = nullptr; pa.sens_stride = stride > 0 ? stride : H.nsensordata;
   pa.w = b->w; pa.nenv = b->n;
+  { const char* ds = getenv("SG_DBG_SKIP"); pa.dbg_skip = ds ? atoi(ds) : 0; }
   SgPgsArgs ga;
   ga.H = b->dH; ga.elem = b->delem; ga.w = b->w; ga.nenv = b->n;
   const size_t lds = sizeof(double) * ((size_t)34 * H.nelem + 8 * 2 * 4 * SG_MAXLIM);

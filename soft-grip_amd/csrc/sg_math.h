@@ -120,7 +120,9 @@ SG_HD void chain_kinematics(const SgChain& C, const double* q, ChainKin& K) {
 #pragma unroll
       for (int c = 0; c < 3; c++) K.xanchor[d][c] = pos[c] + t[c];
       mulmat3(K.xaxis[d], mat, C.j_axis[d]);
-      double dq = q[d] - C.qpos0[d], s = sin(0.5 * dq), ql[4] = {cos(0.5 * dq), C.j_axis[d][0] * s, C.j_axis[d][1] * s, C.j_axis[d][2] * s};
+      double dq = q[d] - C.qpos0[d], s, cs;
+      sincos(0.5 * dq, &s, &cs);
+      double ql[4] = {cs, C.j_axis[d][0] * s, C.j_axis[d][1] * s, C.j_axis[d][2] * s};
       quatmul(quat, quat, ql);
       quat2mat(lm, quat);
       mulmat33(mat, rootmat, lm);
@@ -349,8 +351,8 @@ SG_HD int sphere_box(const double* c, double r, const double* bp, const double* 
     double closest = 1e300, sg = 1;
     int ka = 0;
     for (int k = 0; k < 3; k++) {
-      if (sz[k] - cen[k] < closest) { closest = sz[k] - cen[k]; ka = k; sg = 1; }
-      if (sz[k] + cen[k] < closest) { closest = sz[k] + cen[k]; ka = k; sg = -1; }
+      if (sz[k] - cen[k] < closest - 1e-12) { closest = sz[k] - cen[k]; ka = k; sg = 1; }
+      if (sz[k] + cen[k] < closest - 1e-12) { closest = sz[k] + cen[k]; ka = k; sg = -1; }
     }
     for (int k = 0; k < 3; k++) nl[k] = (k == ka) ? -sg : 0.0;
     for (int k = 0; k < 3; k++) pl[k] = cen[k] + nl[k] * (r - closest) * 0.5;
@@ -433,7 +435,7 @@ SG_HD double seg_box_param(const double* p, const double* h, const double* sz) {
     }
     double f = -1e300;
     for (int k = 0; k < 6; k++) { double v = a[k] * t + b[k]; if (v > f) f = v; }
-    if (f < best) { best = f; tb = t; }
+    if (f < best - 1e-12) { best = f; tb = t; }  // ties: first candidate wins in every implementation
   }
   return tb;
 }
@@ -596,12 +598,8 @@ SG_HD double contact_update(Contact& c, const double* aF, double as_, const doub
   double res[3], old[3] = {c.f[0], c.f[1], c.f[2]}, f[3] = {c.f[0], c.f[1], c.f[2]};
   const double A00 = c.A[0], A01 = c.A[1], A02 = c.A[2], A11 = c.A[3], A12 = c.A[4], A22 = c.A[5];
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
-    double s = c.b[r] + c.Js[r] * as_ + c.R * c.f[r];
-#pragma unroll
-    for (int d = 0; d < SG_CD; d++) s += c.Jf[r][d] * aF[d];
-    res[r] = s;
-  }
+  for (int r = 0; r < 3; r++)  // two independent partial sums: half the dependency depth of a serial accumulation
+    res[r] = ((c.b[r] + c.Js[r] * as_) + (c.Jf[r][0] * aF[0] + c.Jf[r][1] * aF[1])) + ((c.R * c.f[r] + c.Jf[r][2] * aF[2]) + c.Jf[r][3] * aF[3]);
   if (f[0] < SG_MINVAL) {
     f[0] -= sg_div(res[0], A00);
     if (f[0] < 0) f[0] = 0;

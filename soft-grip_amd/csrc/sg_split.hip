@@ -23,12 +23,17 @@ using namespace sgm;
 
 #define SG_CAP 64        // contact capacity per stream in the split pipeline
 #define SG_NF 26         // constant fields of a contact record
+#define SG_RF 30         // record fields: 26 constants, 3 force components, slider index (as an int in a double slot)
+// Contact records are blocked for the PGS kernel: one block per (slot, PGS wavefront) holds SG_RF fields x 16 streams,
+// so a wavefront reads a whole record with ONE vector address plus immediate offsets (field stride 128 B), and its 16
+// stream lanes use every byte of the 128-B lines they touch.  Block index nwb (one past the last wave) is a dummy
+// target for the unconditional stores of idle lanes.
+#define SG_REC_INDEX(slot, wave, field, pos, nwb) (((((size_t)(slot)) * ((nwb) + 1) + (wave)) * SG_RF + (field)) * 16 + (pos))
 #define SG_G 8           // lanes per env in the PGS kernel
 #define SG_CHW 80        // doubles of chain hand-off per chain
 
 struct SgWork {          // device workspace of one batch (all pointers device memory)
-  double *crec, *cf;     // [SG_CAP][SG_NF][S], [SG_CAP][3][S]      S = 2 * nenv streams
-  int* csl;              // [SG_CAP][S]
+  double* crec;          // [SG_CAP][nwb + 1][SG_RF][16]   nwb = ceil(nenv / 8) PGS wavefronts (+1 dummy block)
   int* ns;               // [S]
   double* envh;          // [4][nenv]: tb, tR, tA, tf
   int *shared, *pending, *status, *iters, *ncon, *nefc, *touch;  // [nenv]
@@ -52,6 +57,7 @@ struct SgPhaseArgs {
   SgWork w;
   int nenv;
   int do_reset, do_finish, finish_integrate, do_begin, first;
+  int dbg_skip;  // timing experiments only (SG_DBG_SKIP): bit0 chain stage, bit1 collision, bit2 warmstart test, bit3 finish
 };
 
 struct StageRec2 {
@@ -68,6 +74,7 @@ struct ChainLds2 {
 
 template <int R, int CPL>
 struct Smem2 {
+  SgChain chain[SG_MAXCH];  // the chains' model constants, staged once per kernel (the chain lanes read them hundreds of times)
   ChainKin K[SG_MAXCH];
   ChainLds2 cs[SG_MAXCH];
   double boxp[SG_MAXCH * SG_CG][3], boxm[SG_MAXCH * SG_CG][9];
@@ -102,7 +109,14 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   const int half = lane >> 5;
   const bool high = half != 0;
   const bool is_chain_lane = (lane & 31) == 0 && half < nchain;
-  const SgChain& C = H.chain[half < nchain ? half : 0];
+  {
+    static_assert(sizeof(SgChain) % 8 == 0, "SgChain must be a whole number of doubles");
+    const double* src = (const double*)&H.chain[0];
+    double* dst = (double*)&Sm.chain[0];
+    for (int i = lane; i < (int)(SG_MAXCH * sizeof(SgChain) / 8); i += 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  const SgChain& C = Sm.chain[half < nchain ? half : 0];
   ChainLds2& CS = Sm.cs[half];
   SgWork& W = a.w;
 
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   __syncthreads();
 
   // =============================== FINISH the previous substep ===============================
-  if (a.do_finish && W.pending[env]) {
+  if (a.do_finish && W.pending[env] && !(a.dbg_skip & 8)) {
     int badacc = 0;
     double qacc_e[R], ase[R];
 #pragma unroll
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
       flags |= (__ballot(bad & 1) ? 1 : 0) | (__ballot(bad & 2) ? 2 : 0);
     } else {
       // ---- chains ----
-      if (is_chain_lane) {
+      if (is_chain_lane && !(a.dbg_skip & 1)) {
         double qc[SG_CD], vc[SG_CD], wc[SG_CD], kc[SG_CD];
 #pragma unroll
         for (int d = 0; d < SG_CD; d++) { qc[d] = CS.q[d]; vc[d] = CS.v[d]; wc[d] = CS.w[d]; kc[d] = CS.k[d]; }
@@ -354,8 +368,8 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         int overflow = 0;
 #pragma unroll
         for (int c = 0; c < SG_MAXCH; c++) {
-          if (c >= nchain) break;
-          const SgChain& Cc = H.chain[c];
+          if (c >= nchain || (a.dbg_skip & 2)) break;
+          const SgChain& Cc = Sm.chain[c];
           int nsc = 0;
 #pragma unroll
           for (int g = 0; g < SG_CG; g++) {
@@ -388,8 +402,16 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
               int e = r * 64 + lane, n = 0;
               ConRec r0, r1;
               bool v0 = false, v1 = false;
-              double dif[3] = {bp[0] - cpos[r][0], bp[1] - cpos[r][1], bp[2] - cpos[r][2]}, bound = H.cap_rbound + rb + H.con_margin;
-              if (e < N && dot3(dif, dif) <= bound * bound) {
+              // broadphase: bounding spheres (MuJoCo's filter), then the capsule centre against the box grown by the capsule's
+              // bounding radius in the box frame -- still conservative, so the contact set is unchanged
+              double dif[3] = {cpos[r][0] - bp[0], cpos[r][1] - bp[1], cpos[r][2] - bp[2]}, bound = H.cap_rbound + rb + H.con_margin;
+              bool near = e < N && dot3(dif, dif) <= bound * bound;
+              if (near) {
+                double lc[3], grow = H.cap_rbound + H.con_margin;
+                mulmatT3(lc, bm, dif);
+                near = fabs(lc[0]) <= sz[0] + grow && fabs(lc[1]) <= sz[1] + grow && fabs(lc[2]) <= sz[2] + grow;
+              }
+              if (near) {
                 double cax[3] = {EL(SGE_CX, e), EL(SGE_CY, e), EL(SGE_CZ, e)};
                 int mk = capsule_box(cpos[r], cax, H.cap_radius, H.cap_hl, bp, bm, sz, H.con_margin, r0, r1);
                 v0 = (mk & 1) && r0.dist < H.con_margin;
@@ -458,34 +480,54 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
       }
       shared_slider = __ballot(shared_slider) != 0;
 
-      // ---- contact rows (kept in registers only for the warmstart test, then exported) ----
-      Contact ct[CPL];
+      // ---- contact rows: built one slot at a time and exported at once; only a 7-double summary per slot stays
+      //      in registers for the warmstart test (g = Jf' f, Js.f, invm, f.(R f/2 + b), slider index)
       const int myn = high ? ns1 : ns0;
+      const size_t st = 2 * (size_t)env + half;
+      const int nwb = (a.nenv + 7) / 8;
+      double cg[CPL][SG_CD], cjsf[CPL], cinvm[CPL], ccost0[CPL];
+      int csl_[CPL];
 #pragma unroll
       for (int k = 0; k < CPL; k++) {
         int i = (lane & 31) + 32 * k;
-        ct[k].sl = -1; ct[k].invm = 0; ct[k].R = 1;
+        csl_[k] = -1; cjsf[k] = cinvm[k] = ccost0[k] = 0;
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-          ct[k].f[r] = ct[k].b[r] = ct[k].Js[r] = 0;
-#pragma unroll
-          for (int d = 0; d < SG_CD; d++) ct[k].Jf[r][d] = 0;
-        }
-#pragma unroll
-        for (int q = 0; q < 6; q++) ct[k].A[q] = (q == 0 || q == 3 || q == 5) ? 1.0 : 0.0;
+        for (int d = 0; d < SG_CD; d++) cg[k][d] = 0;
         if (i < myn) {
-          const StageRec2& s = Sm.stage[half][i];
+          Contact c;
+          const StageRec2& sr = Sm.stage[half][i];
           ConRec rec;
-          rec.dist = s.dist;
-          for (int q = 0; q < 3; q++) { rec.pos[q] = s.pos[q]; rec.n[q] = s.n[q]; }
-          int sl = s.sl, g = s.box, bi = C.g_body[g], nd = chain_ndof_of_body(bi);
+          rec.dist = sr.dist;
+          for (int q = 0; q < 3; q++) { rec.pos[q] = sr.pos[q]; rec.n[q] = sr.n[q]; }
+          int sl = sr.sl, g = sr.box, bi = C.g_body[g], nd = chain_ndof_of_body(bi);
           double ax[3] = {0, 0, 0}, ve_ = 0, as_ = 0, we_ = 0, im = 0, bw = 0;
           if (sl >= 0) {
             ax[0] = EL(SGE_AX, sl); ax[1] = EL(SGE_AY, sl); ax[2] = EL(SGE_AZ, sl);
             ve_ = Sm.ve[sl]; as_ = Sm.asme[sl]; we_ = Sm.we[sl];
             im = 1.0 / (EL(SGE_MASS, sl) + EL(SGE_ARMATURE, sl)); bw = EL(SGE_BINVW, sl);
           }
-          contact_build(ct[k], rec, Sm.K[half], nd, CS.Minv, CS.v, CS.qacc_smooth, CS.w, C.b_invw_tran[bi], sl, ax, ve_, as_, we_, im, bw, H);
+          contact_build(c, rec, Sm.K[half], nd, CS.Minv, CS.v, CS.qacc_smooth, CS.w, C.b_invw_tran[bi], sl, ax, ve_, as_, we_, im, bw, H);
+          csl_[k] = sl; cinvm[k] = c.invm;
+          cjsf[k] = c.Js[0] * c.f[0] + c.Js[1] * c.f[1] + c.Js[2] * c.f[2];
+          ccost0[k] = c.f[0] * (0.5 * c.R * c.f[0] + c.b[0]) + c.f[1] * (0.5 * c.R * c.f[1] + c.b[1]) + c.f[2] * (0.5 * c.R * c.f[2] + c.b[2]);
+#pragma unroll
+          for (int d = 0; d < SG_CD; d++) cg[k][d] = c.Jf[0][d] * c.f[0] + c.Jf[1][d] * c.f[1] + c.Jf[2][d] * c.f[2];
+          double* ro = W.crec + SG_REC_INDEX(i, env >> 3, 0, 2 * (env & 7) + half, nwb);
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int d = 0; d < SG_CD; d++) ro[(4 * r + d) * 16] = c.Jf[r][d];
+#pragma unroll
+          for (int r = 0; r < 3; r++) ro[(12 + r) * 16] = c.Js[r];
+#pragma unroll
+          for (int q = 0; q < 6; q++) ro[(15 + q) * 16] = c.A[q];
+#pragma unroll
+          for (int r = 0; r < 3; r++) ro[(21 + r) * 16] = c.b[r];
+          ro[24 * 16] = c.R;
+          ro[25 * 16] = c.invm;
+#pragma unroll
+          for (int r = 0; r < 3; r++) ro[(26 + r) * 16] = c.f[r];
+          ((int*)(ro + 29 * 16))[0] = sl;
         }
       }
       // ---- equality rows ----
@@ -526,13 +568,12 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
               int i = 32 * k + ii;
               if (i >= nmaxs) break;
               bool mine = (lane & 31) == ii && i < myn && (!shared_slider || half == pass);
-              if (mine && ct[k].sl >= 0) Sm.as[ct[k].sl] += ct[k].invm * (ct[k].Js[0] * ct[k].f[0] + ct[k].Js[1] * ct[k].f[1] + ct[k].Js[2] * ct[k].f[2]);
+              if (mine && csl_[k] >= 0) Sm.as[csl_[k]] += cinvm[k] * cjsf[k];
             }
 #pragma unroll
         for (int k = 0; k < CPL; k++)
-          if ((lane & 31) + 32 * k < myn)
 #pragma unroll
-            for (int d = 0; d < SG_CD; d++) g[d] += ct[k].Jf[0][d] * ct[k].f[0] + ct[k].Jf[1][d] * ct[k].f[1] + ct[k].Jf[2][d] * ct[k].f[2];
+          for (int d = 0; d < SG_CD; d++) g[d] += cg[k][d];
         if (is_chain_lane) {
           const int la = CS.lim_active;
 #pragma unroll
@@ -548,15 +589,15 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         }
 #pragma unroll
         for (int a2 = 0; a2 < SG_CD; a2++) {
-          double s = 0;
+          double s2 = 0;
 #pragma unroll
-          for (int b2 = 0; b2 < SG_CD; b2++) s += CS.Minv[4 * a2 + b2] * g[b2];
-          aF[a2] = s;
+          for (int b2 = 0; b2 < SG_CD; b2++) s2 += CS.Minv[4 * a2 + b2] * g[b2];
+          aF[a2] = s2;
         }
         __syncthreads();
       };
       recompute_a();
-      {
+      if (!(a.dbg_skip & 4)) {
         double cp = 0, tJap = 0;
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -574,14 +615,11 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 #pragma unroll
         for (int k = 0; k < CPL; k++)
           if ((lane & 31) + 32 * k < myn) {
-            double as_ = ct[k].sl >= 0 ? Sm.as[ct[k].sl] : 0.0;
+            // sum_r f_r (J_r a / 2 + R f_r / 2 + b_r) = (g.aF + (Js.f) a_s) / 2 + f.(R f / 2 + b)
+            double as_ = csl_[k] >= 0 ? Sm.as[csl_[k]] : 0.0, ga = 0;
 #pragma unroll
-            for (int r = 0; r < 3; r++) {
-              double Ja = ct[k].Js[r] * as_;
-#pragma unroll
-              for (int d = 0; d < SG_CD; d++) Ja += ct[k].Jf[r][d] * aF[d];
-              cp += ct[k].f[r] * (0.5 * (Ja + ct[k].R * ct[k].f[r]) + ct[k].b[r]);
-            }
+            for (int d = 0; d < SG_CD; d++) ga += cg[k][d] * aF[d];
+            cp += 0.5 * (ga + cjsf[k] * as_) + ccost0[k];
           }
         double cost = wave_sum2(cp);
         if (cost > 0) {
@@ -593,41 +631,28 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             for (int k = 0; k < SG_MAXLIM; k++) CS.lim_f[k] = 0;
           }
 #pragma unroll
-          for (int k = 0; k < CPL; k++) ct[k].f[0] = ct[k].f[1] = ct[k].f[2] = 0;
+          for (int k = 0; k < CPL; k++) {
+            int i = (lane & 31) + 32 * k;
+            cjsf[k] = 0;
+#pragma unroll
+            for (int d = 0; d < SG_CD; d++) cg[k][d] = 0;
+            if (i < myn) {
+              double* ro = W.crec + SG_REC_INDEX(i, env >> 3, 0, 2 * (env & 7) + half, nwb);
+#pragma unroll
+              for (int r = 0; r < 3; r++) ro[(26 + r) * 16] = 0.0;
+            }
+          }
           __syncthreads();
           recompute_a();
         }
       }
-      // ---- export the constraint problem ----
+      // ---- export the rest of the constraint problem ----
 #pragma unroll
       for (int r = 0; r < R; r++) {
         int e = r * 64 + lane;
         if (e < N) {
           size_t o = (size_t)env * N + e;
           W.as[o] = Sm.as[e]; W.eqf[o] = eqf[r]; W.eqb[o] = eqb[r]; W.eqR[o] = eqR[r];
-        }
-      }
-      const size_t st = 2 * (size_t)env + half;
-#pragma unroll
-      for (int k = 0; k < CPL; k++) {
-        int i = (lane & 31) + 32 * k;
-        if (i < myn && i < SG_CAP) {
-          double* rec = W.crec + (size_t)i * SG_NF * S + st;
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int d = 0; d < SG_CD; d++) rec[(size_t)(4 * r + d) * S] = ct[k].Jf[r][d];
-#pragma unroll
-          for (int r = 0; r < 3; r++) rec[(size_t)(12 + r) * S] = ct[k].Js[r];
-#pragma unroll
-          for (int q = 0; q < 6; q++) rec[(size_t)(15 + q) * S] = ct[k].A[q];
-#pragma unroll
-          for (int r = 0; r < 3; r++) rec[(size_t)(21 + r) * S] = ct[k].b[r];
-          rec[(size_t)24 * S] = ct[k].R;
-          rec[(size_t)25 * S] = ct[k].invm;
-#pragma unroll
-          for (int r = 0; r < 3; r++) W.cf[((size_t)i * 3 + r) * S + st] = ct[k].f[r];
-          W.csl[(size_t)i * S + st] = ct[k].sl;
         }
       }
       if (is_chain_lane) {
@@ -685,7 +710,10 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
   const SgPlanHeader& H = *a.H;
   const int N = H.nelem;
   const size_t S = 2 * (size_t)a.nenv;
+  const int nwb = (a.nenv + 7) / 8;
   const SgWork& W = a.w;
+  const double mu[2] = {H.con_mu[0], H.con_mu[1]}, pgs_scale = H.pgs_scale, tolerance = H.tolerance;
+  const int max_iter = H.iterations;
   const bool valid = env < a.nenv && W.pending[env] != 0;
   if (!__ballot(valid)) return;
   double* Las = lds + (size_t)le * 4 * N;
@@ -700,7 +728,7 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
       Las[j] = W.as[o]; Lf[j] = W.eqf[o]; Lb[j] = W.eqb[o]; LR[j] = W.eqR[o];
     }
   const bool is_stream = valid && g < 2;
-  const size_t st = 2 * (size_t)(valid ? env : 0) + (g & 1);
+  const size_t st = 2 * (size_t)(env < a.nenv ? env : 0) + (g & 1);
   int ns = 0, lim_active = 0, shared = 0;
   double Minv[16], aF[SG_CD] = {0, 0, 0, 0};
 #pragma unroll
@@ -732,11 +760,13 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
 
   bool running = valid;
   int iters = 0;
-  const double* __restrict__ crec = W.crec;
-  double* cf = W.cf;
-  const int* __restrict__ csl = W.csl;
+  // my record column inside the wave's block; idle lanes read their env's stream (same address as its stream lane)
+  // and store to the dummy block
+  double* const rec0 = W.crec + SG_REC_INDEX(0, blockIdx.x, 0, 2 * le + (g & 1), nwb);
+  double* const rec0_store = (valid && g < 2) ? rec0 : W.crec + SG_REC_INDEX(0, nwb, 0, lane & 15, nwb);
+  const size_t slot_stride = (size_t)(nwb + 1) * SG_RF * 16;
 
-  for (int it = 0; it < H.iterations; it++) {
+  for (int it = 0; it < max_iter; it++) {
     if (!__ballot(running)) break;
     double imp_acc = 0, tJap = 0;
     if (running) {
@@ -780,41 +810,52 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
           }
         }
       }
-      for (int i = 0; i < nsmax; i++) {
-        if (mine && i < ns) {
-          Contact c;
-          const double* rec = crec + (size_t)i * SG_NF * S + st;
+      // Software pipeline: the record of contact i+1 is requested before contact i is updated, so the L2 / Infinity
+      // Cache latency overlaps the update arithmetic.  Every lane issues the same loads and stores unconditionally
+      // (idle lanes read their env's stream -- same addresses as the active lane -- and write to the dummy block), so
+      // the compiler can count vmcnt and only waits for the previous batch of loads.
+      const int nsl = mine ? ns : 0;
+      auto load_rec = [&](Contact& c, int i) {
+        const double* rec = rec0 + (size_t)i * slot_stride;
 #pragma unroll
-          for (int r = 0; r < 3; r++)
+        for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int d = 0; d < SG_CD; d++) c.Jf[r][d] = rec[(size_t)(4 * r + d) * S];
+          for (int d = 0; d < SG_CD; d++) c.Jf[r][d] = rec[(4 * r + d) * 16];
 #pragma unroll
-          for (int r = 0; r < 3; r++) c.Js[r] = rec[(size_t)(12 + r) * S];
+        for (int r = 0; r < 3; r++) c.Js[r] = rec[(12 + r) * 16];
 #pragma unroll
-          for (int q = 0; q < 6; q++) c.A[q] = rec[(size_t)(15 + q) * S];
+        for (int q = 0; q < 6; q++) c.A[q] = rec[(15 + q) * 16];
 #pragma unroll
-          for (int r = 0; r < 3; r++) c.b[r] = rec[(size_t)(21 + r) * S];
-          c.R = rec[(size_t)24 * S];
-          c.invm = rec[(size_t)25 * S];
+        for (int r = 0; r < 3; r++) c.b[r] = rec[(21 + r) * 16];
+        c.R = rec[24 * 16];
+        c.invm = rec[25 * 16];
 #pragma unroll
-          for (int r = 0; r < 3; r++) c.f[r] = cf[((size_t)i * 3 + r) * S + st];
-          c.sl = csl[(size_t)i * S + st];
+        for (int r = 0; r < 3; r++) c.f[r] = rec[(26 + r) * 16];
+        c.sl = ((const int*)(rec + 29 * 16))[0];
+      };
+      auto update_rec = [&](Contact& c, int i) {
+        if (i < nsl) {
           double as_ = c.sl >= 0 ? Las[c.sl] : 0.0, df[3];
-          imp_acc -= contact_update(c, aF, as_, H.con_mu, df);
+          imp_acc -= contact_update(c, aF, as_, mu, df);
           if (c.sl >= 0) Las[c.sl] = as_ + c.invm * (c.Js[0] * df[0] + c.Js[1] * df[1] + c.Js[2] * df[2]);
           double gg[SG_CD];
 #pragma unroll
           for (int d = 0; d < SG_CD; d++) gg[d] = c.Jf[0][d] * df[0] + c.Jf[1][d] * df[1] + c.Jf[2][d] * df[2];
 #pragma unroll
-          for (int q = 0; q < SG_CD; q++) {
-            double s = 0;
-#pragma unroll
-            for (int d = 0; d < SG_CD; d++) s += Minv[4 * q + d] * gg[d];
-            aF[q] += s;
-          }
-#pragma unroll
-          for (int r = 0; r < 3; r++) cf[((size_t)i * 3 + r) * S + st] = c.f[r];
+          for (int q = 0; q < SG_CD; q++) aF[q] += (Minv[4 * q] * gg[0] + Minv[4 * q + 1] * gg[1]) + (Minv[4 * q + 2] * gg[2] + Minv[4 * q + 3] * gg[3]);
         }
+        double* recs = rec0_store + (size_t)i * slot_stride;
+#pragma unroll
+        for (int r = 0; r < 3; r++) recs[(26 + r) * 16] = c.f[r];
+      };
+      // two contacts per trip with the buffers swapping roles (no register copies)
+      Contact ca, cb;
+      load_rec(ca, 0);
+      for (int i = 0; i < nsmax; i += 2) {
+        load_rec(cb, i + 1 < SG_CAP ? i + 1 : i);
+        update_rec(ca, i);
+        load_rec(ca, i + 2 < SG_CAP ? i + 2 : i);
+        update_rec(cb, i + 1);
       }
       __syncthreads();
     }
@@ -822,7 +863,7 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
     imp += __shfl_xor(imp, 1); imp += __shfl_xor(imp, 2); imp += __shfl_xor(imp, 4);
     if (running) {
       iters = it + 1;
-      if (imp * H.pgs_scale < H.tolerance) running = false;
+      if (imp * pgs_scale < tolerance) running = false;
     }
   }
   __syncthreads();
@@ -837,12 +878,12 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
       for (int k = 0; k < SG_MAXLIM; k++)
         if (lim_active >> k & 1) gF[k / 2] += mylim[k] * mylim[3 * SG_MAXLIM + k];
       for (int i = 0; i < ns; i++) {
-        const double* rec = crec + (size_t)i * SG_NF * S + st;
-        double f0 = cf[((size_t)i * 3 + 0) * S + st], f1 = cf[((size_t)i * 3 + 1) * S + st], f2 = cf[((size_t)i * 3 + 2) * S + st];
-        int sl = csl[(size_t)i * S + st];
-        if (sl >= 0) Las[sl] += rec[(size_t)25 * S] * (rec[(size_t)12 * S] * f0 + rec[(size_t)13 * S] * f1 + rec[(size_t)14 * S] * f2);
+        const double* rec = rec0 + (size_t)i * slot_stride;
+        double f0 = rec[26 * 16], f1 = rec[27 * 16], f2 = rec[28 * 16];
+        int sl = ((const int*)(rec + 29 * 16))[0];
+        if (sl >= 0) Las[sl] += rec[25 * 16] * (rec[12 * 16] * f0 + rec[13 * 16] * f1 + rec[14 * 16] * f2);
 #pragma unroll
-        for (int d = 0; d < SG_CD; d++) gF[d] += rec[(size_t)d * S] * f0 + rec[(size_t)(4 + d) * S] * f1 + rec[(size_t)(8 + d) * S] * f2;
+        for (int d = 0; d < SG_CD; d++) gF[d] += rec[d * 16] * f0 + rec[(4 + d) * 16] * f1 + rec[(8 + d) * 16] * f2;
       }
     }
     __syncthreads();
