@@ -594,47 +594,83 @@ SG_HD int qcqp2(double* res, const double* Ain, const double* bin, const double*
 
 // One Gauss-Seidel block update of an elliptic contact (mj_solPGS).  aF = current M^-1 J' f of the chain dofs, as_ = same for
 // the slider.  Writes the force change df and returns the cost change (<= 0).
+//
+// Same operations as the textbook sequence (normal-or-ray update, friction QCQP with the normal fixed, cost check); the
+// common case -- active normal force, friction inside the cone after one Newton evaluation -- runs without a data-dependent
+// branch (selects), because on the GPU every branch drains the wave's pipeline; the uncommon cases share one fallback.
 SG_HD double contact_update(Contact& c, const double* aF, double as_, const double* mu, double* df) {
-  double res[3], old[3] = {c.f[0], c.f[1], c.f[2]}, f[3] = {c.f[0], c.f[1], c.f[2]};
+  const double o0 = c.f[0], o1 = c.f[1], o2 = c.f[2];
   const double A00 = c.A[0], A01 = c.A[1], A02 = c.A[2], A11 = c.A[3], A12 = c.A[4], A22 = c.A[5];
+  double res[3];
 #pragma unroll
   for (int r = 0; r < 3; r++)  // two independent partial sums: half the dependency depth of a serial accumulation
     res[r] = ((c.b[r] + c.Js[r] * as_) + (c.Jf[r][0] * aF[0] + c.Jf[r][1] * aF[1])) + ((c.R * c.f[r] + c.Jf[r][2] * aF[2]) + c.Jf[r][3] * aF[3]);
-  if (f[0] < SG_MINVAL) {
-    f[0] -= sg_div(res[0], A00);
-    if (f[0] < 0) f[0] = 0;
-    f[1] = f[2] = 0;
-  } else {
-    double v0 = f[0], v1 = f[1], v2 = f[2];
-    double w0 = A00 * v0 + A01 * v1 + A02 * v2, w1 = A01 * v0 + A11 * v1 + A12 * v2, w2 = A02 * v0 + A12 * v1 + A22 * v2;
-    double denom = v0 * w0 + v1 * w1 + v2 * w2;
-    if (denom >= SG_MINVAL) {
-      double x = sg_div(-(v0 * res[0] + v1 * res[1] + v2 * res[2]), denom);
-      if (f[0] + x * v0 < 0) x = -1.0;  /* = -f[0] / v0 */
-      f[0] += x * v0; f[1] += x * v1; f[2] += x * v2;
+  // ---- normal (f0 ~ 0) or ray update ----
+  double g0, g1, g2;
+  {
+    double w0 = A00 * o0 + A01 * o1 + A02 * o2, w1 = A01 * o0 + A11 * o1 + A12 * o2, w2 = A02 * o0 + A12 * o1 + A22 * o2;
+    double denom = o0 * w0 + o1 * w1 + o2 * w2;
+    double x = denom >= SG_MINVAL ? sg_div(-(o0 * res[0] + o1 * res[1] + o2 * res[2]), denom) : 0.0;
+    x = (o0 + x * o0 < 0) ? -1.0 : x;
+    g0 = o0 + x * o0; g1 = o1 + x * o1; g2 = o2 + x * o2;
+  }
+  if (o0 < SG_MINVAL) {  // uncommon: no normal force yet
+    g0 = o0 - sg_div(res[0], A00);
+    g0 = g0 < 0 ? 0.0 : g0;
+    g1 = g2 = 0;
+  }
+  // ---- friction update with the normal force fixed: min 1/2 v'Ac v + v'bc  s.t. |v/mu| <= g0 (mju_QCQP2) ----
+  double v0 = 0, v1 = 0;
+  {
+    const double bc0 = res[1] - (A11 * o1 + A12 * o2) + A01 * (g0 - o0), bc1 = res[2] - (A12 * o1 + A22 * o2) + A02 * (g0 - o0);
+    const double b1 = bc0 * mu[0], b2 = bc1 * mu[1];
+    const double S11 = A11 * mu[0] * mu[0], S22 = A22 * mu[1] * mu[1], S12 = A12 * mu[0] * mu[1];
+    const double r = g0;
+    double la = 0, u1 = 0, u2 = 0;
+    bool zero = false, more;
+    {  // Newton evaluation at la = 0
+      double det = S11 * S22 - S12 * S12;
+      zero = det < 1e-10;
+      double di = sg_div(1.0, zero ? 1.0 : det), P11 = S22 * di, P22 = S11 * di, P12 = -S12 * di;
+      u1 = -P11 * b1 - P12 * b2; u2 = -P12 * b1 - P22 * b2;
+      double val = u1 * u1 + u2 * u2 - r * r;
+      double deriv = -2 * (P11 * u1 * u1 + 2 * P12 * u1 * u2 + P22 * u2 * u2);
+      more = !zero && !(val < 1e-10) && !(g0 < SG_MINVAL);
+      double delta = more ? sg_div(-val, deriv) : 0.0;
+      more = more && !(delta < 1e-10);
+      la = more ? delta : 0.0;
+    }
+    if (more) {  // uncommon: the unconstrained minimiser leaves the cone -- continue Newton on the multiplier
+      for (int it = 1; it < 20; it++) {
+        double det = (S11 + la) * (S22 + la) - S12 * S12;
+        if (det < 1e-10) { zero = true; break; }
+        double di = sg_div(1.0, det), P11 = (S22 + la) * di, P22 = (S11 + la) * di, P12 = -S12 * di;
+        u1 = -P11 * b1 - P12 * b2; u2 = -P12 * b1 - P22 * b2;
+        double val = u1 * u1 + u2 * u2 - r * r;
+        if (val < 1e-10) break;
+        double deriv = -2 * (P11 * u1 * u1 + 2 * P12 * u1 * u2 + P22 * u2 * u2), delta = sg_div(-val, deriv);
+        if (delta < 1e-10) break;
+        la += delta;
+      }
+    }
+    v0 = zero ? 0.0 : u1 * mu[0];
+    v1 = zero ? 0.0 : u2 * mu[1];
+    if (!zero && la != 0) {  // on the cone: put v exactly on the ellipse
+      double s = v0 * v0 / (mu[0] * mu[0]) + v1 * v1 / (mu[1] * mu[1]);
+      s = sqrt(g0 * g0 / fmax(SG_MINVAL, s));
+      v0 *= s; v1 *= s;
     }
   }
-  if (f[0] < SG_MINVAL) {
-    f[1] = f[2] = 0;
-  } else {
-    double Ac[4] = {A11, A12, A12, A22}, bc[2], v[2];
-    bc[0] = res[1] - (A11 * old[1] + A12 * old[2]) + A01 * (f[0] - old[0]);
-    bc[1] = res[2] - (A12 * old[1] + A22 * old[2]) + A02 * (f[0] - old[0]);
-    int active = qcqp2(v, Ac, bc, mu, f[0]);
-    if (active) {
-      double s = v[0] * v[0] / (mu[0] * mu[0]) + v[1] * v[1] / (mu[1] * mu[1]);
-      s = sqrt(f[0] * f[0] / fmax(SG_MINVAL, s));
-      v[0] *= s; v[1] *= s;
-    }
-    f[1] = v[0]; f[2] = v[1];
-  }
-  double d0 = f[0] - old[0], d1 = f[1] - old[1], d2 = f[2] - old[2];
+  const bool nofric = g0 < SG_MINVAL;
+  g1 = nofric ? 0.0 : v0;
+  g2 = nofric ? 0.0 : v1;
+  double d0 = g0 - o0, d1 = g1 - o1, d2 = g2 - o2;
   double change = 0.5 * (d0 * (A00 * d0 + A01 * d1 + A02 * d2) + d1 * (A01 * d0 + A11 * d1 + A12 * d2) + d2 * (A02 * d0 + A12 * d1 + A22 * d2)) +
                   d0 * res[0] + d1 * res[1] + d2 * res[2];
-  if (change > 1e-10) { d0 = d1 = d2 = 0; change = 0; f[0] = old[0]; f[1] = old[1]; f[2] = old[2]; }
-  c.f[0] = f[0]; c.f[1] = f[1]; c.f[2] = f[2];
-  df[0] = d0; df[1] = d1; df[2] = d2;
-  return change;
+  const bool reject = change > 1e-10;  // the update must not increase the cost
+  c.f[0] = reject ? o0 : g0; c.f[1] = reject ? o1 : g1; c.f[2] = reject ? o2 : g2;
+  df[0] = reject ? 0.0 : d0; df[1] = reject ? 0.0 : d1; df[2] = reject ? 0.0 : d2;
+  return reject ? 0.0 : change;
 }
 
 // scalar row update (equality: free, limit: f >= 0); returns cost change, writes new force

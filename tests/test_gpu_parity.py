@@ -11,13 +11,15 @@ pytestmark = pytest.mark.gpu
 TOL_SENSOR = 1e-7   # abs, fp64 path; north_star allows 1e-4 against MuJoCo-CPU
 
 
-def _gpu_batch(scene, ks):
+def _gpu_batch(scene, ks, pipeline=None):
     import torch
     from softgrip_amd import native
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     m = sg.load_model(model_path(scene))
     nm = native.NativeModel(m)
     b = native.NativeBatch(nm, len(ks), 0)
+    if pipeline is not None:
+        b.set_pipeline(pipeline)
     b.set_stiffness(np.asarray(ks, dtype=np.float64), JOINT_IDS, TENDON_IDS)
     return m, nm, b
 
@@ -28,9 +30,12 @@ def _bufs(b, n):
             torch.zeros(n, dtype=torch.int32, device=b.device))
 
 
-def test_softbox_episode_matches_oracle():
-    ks = [700.0, 903.6948543200572, 300.0, 1400.0, 512.25]
-    m, nm, b = _gpu_batch("softbox", ks)
+@pytest.mark.parametrize("pipeline", ["split", "fused"])
+def test_softbox_episode_matches_oracle(pipeline):
+    """both kernel pipelines (the default split chain and the single fused kernel) against the oracle, 9 envs so that the
+    PGS kernel runs a full and a partial wavefront"""
+    ks = [700.0, 903.6948543200572, 300.0, 1400.0, 512.25, 350.0, 1000.0, 1250.0, 640.0]
+    m, nm, b = _gpu_batch("softbox", ks, pipeline)
     sens, flags, touch = _bufs(b, len(ks))
     sims = [oracle_sim(m, k) for k in ks]
     for s in sims:
@@ -65,12 +70,13 @@ def test_softbox_episode_matches_oracle():
         np.testing.assert_allclose(st["act"][e].cpu().numpy(), s.act, atol=1e-13)
 
 
+@pytest.mark.parametrize("pipeline", ["split", "fused"])
 @pytest.mark.parametrize("scene", ["softcylinder", "softball"])
-def test_other_scenes_first_substeps(scene):
+def test_other_scenes_first_substeps(scene, pipeline):
     """R = 3 / 4 kernel instantiations; these scenes start in deep penetration (chaotic), so only the first substeps
     are compared point-wise"""
     ks = [700.0, 400.0]
-    m, nm, b = _gpu_batch(scene, ks)
+    m, nm, b = _gpu_batch(scene, ks, pipeline)
     sens, flags, touch = _bufs(b, len(ks))
     sims = [oracle_sim(m, k) for k in ks]
     for s in sims:
@@ -113,6 +119,14 @@ def test_full_size_properties():
     s2, q2 = outs[1]
     assert np.array_equal(s1[0::2], s1[1::2]) and np.array_equal(q1[0::2], q1[1::2])
     assert np.array_equal(s1[perm], s2) and np.array_equal(q1[perm], q2)
+    # the two pipelines run the same Gauss-Seidel sweep: they agree to round-off on every env of the big batch
+    _, _, b3 = _gpu_batch("softbox", ks, "fused")
+    sens, flags, touch = _bufs(b3, n)
+    b3.reset(1, sens=sens, flags=flags, touch=touch)
+    b3.set_ctrl_broadcast(np.array([-0.2, -0.2]))
+    for _ in range(60):
+        b3.step(7, sens=sens, flags=flags, touch=touch)
+    assert np.abs(sens.cpu().numpy() - s1).max() < 1e-8
     assert np.isfinite(s1).all() and np.abs(s1[:, 2] - 9.81).max() < 5.0       # accelerometer z stays near gravity
 
 
