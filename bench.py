@@ -14,6 +14,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # the CPU baseline's OpenMP threads must not spin between steps
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,6 +28,25 @@ def algorithmic_bytes_per_env_step(nq, nv, na, nu, nsens):
     """state {qpos, qvel, qacc_warmstart, act} read + written once per ManEnv.step(),
     plus ctrl, the stiffness scalar and the sensor outputs, in fp64 words."""
     return 8 * (2 * (nq + 2 * nv + na) + nu + 1 + nsens)
+
+
+def usable_cores():
+    """host cores this process may really use: affinity mask capped by the cgroup CPU quota (containers)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
 
 
 def cpu_baseline(model, ks, sim_step, sched, budget_envs, threads):
@@ -153,13 +174,14 @@ def main():
                        "envs_per_gpu": n, "substeps_per_step": sim_step, "physics_substeps_per_s": value * sim_step,
                        "envs_flagged_bad": nbad, "launches_timed": launches},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "sg_step_kernel", "avg_kernel_ms": kernel_ms,
+                         "traffic": None, "kernel": "sg_phase_kernel + sg_pgs_kernel chain of one sg_step call (split pipeline)" if os.environ.get("SG_PIPELINE", "split") != "fused" else "sg_step_kernel",
+                         "avg_kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": abytes,
                          "note": "state stays on chip across the 7 substeps; the path is issue/latency-bound, not HBM-bound (DESIGN.md)"},
         }
         if not args.no_cpu_baseline:
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            envs = 2 * cores
+            cores = usable_cores()
+            envs = 16 * cores  # 16 full episodes per core: about 10-20 s of wall time
             v, cdt = cpu_baseline(model, ks, sim_step, sched, envs, cores)
             res["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
                                    "sample": "%d envs x one 200-step episode (same scene/schedule/stiffness draws) on the fp64 C oracle, "
