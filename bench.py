@@ -179,7 +179,7 @@ def main():
                          "algorithmic_bytes_per_env_step": abytes,
                          "note": "state stays on chip across the 7 substeps; the path is issue/latency-bound, not HBM-bound (DESIGN.md)"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             cores = usable_cores()
             envs = 16 * cores  # 16 full episodes per core: about 10-20 s of wall time
             v, cdt = cpu_baseline(model, ks, sim_step, sched, envs, cores)

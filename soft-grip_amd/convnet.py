@@ -1,0 +1,79 @@
+"""ConvNet stiffness regressor of the reference (net/NeuralNets.py:6-27, net/layers.py:13-52) in PyTorch-ROCm,
+for BASELINE.json configs[4]: it consumes the simulator's on-device ``[n, 200, 12]`` observation block directly.
+
+Layer by layer: Conv1D(128,3,s2,SAME)+BN+ReLU, Conv1D(256,3,s2,SAME)+BN+ReLU, Conv1D(512,3,s2,SAME),
+GlobalAveragePooling1D, Dense 512/256/128 (+BN+ReLU each), Dense 64, Dense 1.  Keras defaults are mirrored:
+Glorot-uniform kernels, zero bias, BatchNorm momentum 0.99 (torch momentum 0.01) and eps 1e-3; TF's SAME padding for
+kernel 3 / stride 2 on an even length pads (0, 1).  Head: ``1100 * sigmoid(y) + 300`` (functions/optimization.py:17-19).
+Input normalisation ``(x - mean) / std`` over axes (0, 1) (functions/utils.py:40-41); noise augmentation sigma 0.7 on the
+accelerometer channels 0:6 and 0.06 on the gyro channels 6:12 (functions/optimization.py:6-14).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class ConvNet(nn.Module):
+    def __init__(self, in_channels=12):
+        super().__init__()
+        bn = dict(momentum=0.01, eps=1e-3)
+        self.conv1, self.bn1 = nn.Conv1d(in_channels, 128, 3, stride=2), nn.BatchNorm1d(128, **bn)
+        self.conv2, self.bn2 = nn.Conv1d(128, 256, 3, stride=2), nn.BatchNorm1d(256, **bn)
+        self.conv3 = nn.Conv1d(256, 512, 3, stride=2)
+        self.fc1, self.fbn1 = nn.Linear(512, 512), nn.BatchNorm1d(512, **bn)
+        self.fc2, self.fbn2 = nn.Linear(512, 256), nn.BatchNorm1d(256, **bn)
+        self.fc3, self.fbn3 = nn.Linear(256, 128), nn.BatchNorm1d(128, **bn)
+        self.fc4 = nn.Linear(128, 64)
+        self.out = nn.Linear(64, 1)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv1d, nn.Linear)):
+                nn.init.xavier_uniform_(m.weight)   # Glorot uniform, as Keras
+                nn.init.zeros_(m.bias)
+
+    @staticmethod
+    def _same(x):  # TF "SAME" for kernel 3, stride 2: total padding 1 when the length is even, all of it on the right
+        return F.pad(x, (0, 1)) if x.shape[-1] % 2 == 0 else F.pad(x, (1, 1))
+
+    def forward(self, x):
+        """x: [B, T, 12] (channels last, any float dtype) -> raw output [B, 1]"""
+        x = x.to(torch.float32).transpose(1, 2)            # tf.cast(inputs, tf.float32) (NeuralNets.py:22)
+        x = F.relu(self.bn1(self.conv1(self._same(x))))
+        x = F.relu(self.bn2(self.conv2(self._same(x))))
+        x = self.conv3(self._same(x))                       # no BN / activation on the last conv (layers.py:26)
+        x = x.mean(dim=-1)                                  # GlobalAveragePooling1D
+        x = F.relu(self.fbn1(self.fc1(x)))
+        x = F.relu(self.fbn2(self.fc2(x)))
+        x = F.relu(self.fbn3(self.fc3(x)))
+        x = self.fc4(x)                                     # no BN / activation (layers.py:44)
+        return self.out(x)
+
+
+def normalize_predictions(preds):
+    """functions/optimization.py:17-19"""
+    return (1100.0 * torch.sigmoid(preds) + 300.0).squeeze(-1)
+
+
+def channel_stats(x):
+    """per-channel mean / std over axes (0, 1), keepdims (functions/utils.py:40-41; np.std = population std)"""
+    return x.mean(dim=(0, 1), keepdim=True), x.std(dim=(0, 1), keepdim=True, unbiased=False)
+
+
+def noised_modality(x, generator=None):
+    """functions/optimization.py:6-14"""
+    noise = torch.randn(x.shape, dtype=x.dtype, device=x.device, generator=generator)
+    scale = torch.cat([torch.full((6,), 0.7), torch.full((x.shape[-1] - 6,), 0.06)]).to(x)
+    return x + noise * scale
+
+
+def train_step(model, optimizer, x, y, mean, std, add_noise=False):
+    """one eager step of functions/optimization.py:31-51: MAE on the rescaled sigmoid head (the L2 term there is computed
+    and then overwritten, so the gradients carry no weight decay)"""
+    model.train()
+    if add_noise:
+        x = noised_modality(x)
+    pred = normalize_predictions(model((x - mean) / std))
+    loss = (pred - y.to(pred.dtype)).abs().mean()
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), pred.detach()
