@@ -238,10 +238,10 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   }
   auto phase = [&](const SgPhaseArgs& p) {
     switch (b->m->rounds) {
-      case 1: hipLaunchKernelGGL((sg_phase_kernel<1, 2>), dim3(b->n), dim3(64), 0, s, p); break;
-      case 2: hipLaunchKernelGGL((sg_phase_kernel<2, 2>), dim3(b->n), dim3(64), 0, s, p); break;
-      case 3: hipLaunchKernelGGL((sg_phase_kernel<3, 2>), dim3(b->n), dim3(64), 0, s, p); break;
-      default: hipLaunchKernelGGL((sg_phase_kernel<4, 2>), dim3(b->n), dim3(64), 0, s, p); break;
+      case 1: hipLaunchKernelGGL((sg_phase_kernel<1, 2, true>), dim3(b->n), dim3(64), 0, s, p); break;
+      case 2: hipLaunchKernelGGL((sg_phase_kernel<2, 2, true>), dim3(b->n), dim3(64), 0, s, p); break;
+      case 3: hipLaunchKernelGGL((sg_phase_kernel<3, 2, true>), dim3(b->n), dim3(64), 0, s, p); break;
+      default: hipLaunchKernelGGL((sg_phase_kernel<4, 2, true>), dim3(b->n), dim3(64), 0, s, p); break;
     }
   };
   for (int k = 0; k <= nfwd; k++) {
@@ -253,6 +253,9 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     p.do_begin = k < nfwd;
     p.sens = (k == nfwd) ? sens : nullptr;
     if (nfwd == 0) { p.do_begin = 0; p.do_finish = 0; }
+    hipLaunchKernelGGL(sg_chain_kernel, dim3((2 * b->n + 63) / 64), dim3(64), 0, s, p);
+    HIPCHK(hipGetLastError());
+    p.sens = nullptr;  // the chain kernel writes the sensors (they all sit on finger sites)
     phase(p);
     HIPCHK(hipGetLastError());
     if (k < nfwd) {

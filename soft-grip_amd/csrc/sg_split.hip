@@ -30,7 +30,7 @@ using namespace sgm;
 // target for the unconditional stores of idle lanes.
 #define SG_REC_INDEX(slot, wave, field, pos, nwb) (((((size_t)(slot)) * ((nwb) + 1) + (wave)) * SG_RF + (field)) * 16 + (pos))
 #define SG_G 8           // lanes per env in the PGS kernel
-#define SG_CHW 80        // doubles of chain hand-off per chain
+#define SG_CHW 160       // doubles of chain hand-off per stream (layout: see sg_chain_kernel)
 
 struct SgWork {          // device workspace of one batch (all pointers device memory)
   double* crec;          // [SG_CAP][nwb + 1][SG_RF][16]   nwb = ceil(nenv / 8) PGS wavefronts (+1 dummy block)
@@ -42,7 +42,7 @@ struct SgWork {          // device workspace of one batch (all pointers device m
   double* lim;           // [4][SG_MAXLIM][S]: sign, R, b, f
   double *as, *eqf, *eqb, *eqR;  // [nenv][N]
   double *asme, *fsm;    // [nenv][N]  begin -> finish hand-off
-  double* chh;           // [nenv][2][SG_CHW]  chain hand-off: qacc_smooth, qfrc_smooth, act_dot, M, K
+  double* chh;           // [nenv][2][SG_CHW]  chain hand-off (enum SGH_*)
 };
 
 struct SgPhaseArgs {
@@ -59,6 +59,10 @@ struct SgPhaseArgs {
   int do_reset, do_finish, finish_integrate, do_begin, first;
   int dbg_skip;  // timing experiments only (SG_DBG_SKIP): bit0 chain stage, bit1 collision, bit2 warmstart test, bit3 finish
 };
+
+// chain hand-off record (doubles): written by the chain stage (phase kernel or sg_chain_kernel), read by FINISH and by BEGIN
+enum { SGH_QSM = 0, SGH_QFRC = 4, SGH_ACTDOT = 8, SGH_M = 9, SGH_K = 25, SGH_MINV = 73, SGH_V = 89, SGH_W = 93, SGH_BOX = 97,
+       SGH_LIMACT = 121, SGH_LIMSIGN = 122, SGH_LIMR = 130, SGH_LIMB = 138, SGH_LIMF = 146 };
 
 struct StageRec2 {
   double dist, pos[3], n[3];
@@ -95,7 +99,7 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
 // ------------------------------------------------------------------------------------------------
 // phase kernel: [finish previous substep] [begin next substep]
 // ------------------------------------------------------------------------------------------------
-template <int R, int CPL>
+template <int R, int CPL, bool CHAINK>
 __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= a.nenv) return;
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   ChainLds2& CS = Sm.cs[half];
   SgWork& W = a.w;
 
-  int status = a.first ? 0 : W.status[env];
-  if (a.first && lane == 0) { W.status[env] = 0; if (!a.do_finish) W.pending[env] = 0; }
+  int status = (a.first && !CHAINK) ? 0 : W.status[env];
+  if (!CHAINK && a.first && lane == 0) { W.status[env] = 0; if (!a.do_finish) W.pending[env] = 0; }
   const bool dead = (status & (SG_FLAG_BADQPOS | SG_FLAG_BADQVEL | SG_FLAG_BADQACC)) != 0;
   if (dead) return;  // the env stopped integrating earlier in this call
 
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 
   // ---------------- load state ----------------
   double qe[R], ve[R], we[R], ke[R];
-  if (is_chain_lane) {
+  if (is_chain_lane && !CHAINK) {
 #pragma unroll
     for (int d = 0; d < SG_CD; d++) {
       int j = C.dof0 + d;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
     }
     double aF[SG_CD] = {0, 0, 0, 0}, qsm[SG_CD] = {0, 0, 0, 0};
     const double* ch = W.chh + ((size_t)env * 2 + half) * SG_CHW;
-    if (is_chain_lane) {
+    if (is_chain_lane && !CHAINK) {
 #pragma unroll
       for (int d = 0; d < SG_CD; d++) {
         aF[d] = W.saF[(size_t)d * S + 2 * env + half];
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
       }
     }
     const bool anybadacc = __ballot(badacc) != 0;
-    if (is_chain_lane) {
+    if (is_chain_lane && !CHAINK) {
       double qacc_c[SG_CD], vc[SG_CD];
 #pragma unroll
       for (int d = 0; d < SG_CD; d++) { qacc_c[d] = qsm[d] + aF[d]; vc[d] = CS.v[d]; }
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
     int bad = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) bad |= (isbad(qe[r]) ? SG_FLAG_BADQPOS : 0) | (isbad(ve[r]) ? SG_FLAG_BADQVEL : 0);
-    if (is_chain_lane) {
+    if (is_chain_lane && !CHAINK) {
 #pragma unroll
       for (int d = 0; d < SG_CD; d++) bad |= (isbad(CS.q[d]) ? SG_FLAG_BADQPOS : 0) | (isbad(CS.v[d]) ? SG_FLAG_BADQVEL : 0);
     }
@@ -293,7 +297,23 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
       flags |= (__ballot(bad & 1) ? 1 : 0) | (__ballot(bad & 2) ? 2 : 0);
     } else {
       // ---- chains ----
-      if (is_chain_lane && !(a.dbg_skip & 1)) {
+      if (CHAINK) {  // the chain stage ran in sg_chain_kernel: import its hand-off record
+        if (is_chain_lane) {
+          const double* ch = W.chh + ((size_t)env * 2 + half) * SG_CHW;
+          double* kd = (double*)&Sm.K[half];
+          for (int i = 0; i < 48; i++) kd[i] = ch[SGH_K + i];
+          for (int i = 0; i < 16; i++) CS.Minv[i] = ch[SGH_MINV + i];
+          for (int d = 0; d < SG_CD; d++) { CS.qacc_smooth[d] = ch[SGH_QSM + d]; CS.v[d] = ch[SGH_V + d]; CS.w[d] = ch[SGH_W + d]; }
+          for (int g = 0; g < SG_CG; g++) {
+            for (int k = 0; k < 3; k++) Sm.boxp[half * SG_CG + g][k] = ch[SGH_BOX + 12 * g + k];
+            for (int k = 0; k < 9; k++) Sm.boxm[half * SG_CG + g][k] = ch[SGH_BOX + 12 * g + 3 + k];
+          }
+          CS.lim_active = (int)ch[SGH_LIMACT];
+          for (int k = 0; k < SG_MAXLIM; k++) {
+            CS.lim_sign[k] = ch[SGH_LIMSIGN + k]; CS.lim_R[k] = ch[SGH_LIMR + k]; CS.lim_b[k] = ch[SGH_LIMB + k]; CS.lim_f[k] = ch[SGH_LIMF + k];
+          }
+        }
+      } else if (is_chain_lane && !(a.dbg_skip & 1)) {
         double qc[SG_CD], vc[SG_CD], wc[SG_CD], kc[SG_CD];
 #pragma unroll
         for (int d = 0; d < SG_CD; d++) { qc[d] = CS.q[d]; vc[d] = CS.v[d]; wc[d] = CS.w[d]; kc[d] = CS.k[d]; }
@@ -680,7 +700,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 
   // ---------------- store state ----------------
   __syncthreads();
-  if (is_chain_lane) {
+  if (is_chain_lane && !CHAINK) {
 #pragma unroll
     for (int d = 0; d < SG_CD; d++) { int j = C.dof0 + d; gq[j] = CS.q[d]; gv[j] = CS.v[d]; gw[j] = CS.w[d]; }
     if (C.has_act) a.act[(size_t)env * nu + C.act_id] = CS.act;
@@ -690,7 +710,181 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
     int e = r * 64 + lane;
     if (e < N) { gq[e0 + e] = qe[r]; gv[e0 + e] = ve[r]; gw[e0 + e] = we[r]; }
   }
-  if (lane == 0) W.status[env] = status | flags;
+  if (lane == 0) {
+    if (CHAINK) { if (status | flags) atomicOr(&W.status[env], status | flags); }
+    else W.status[env] = status | flags;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// chain kernel: ONE LANE PER FINGER CHAIN (64 chains per wavefront).  The chain stage is a few thousand strictly serial
+// instructions; inside the phase kernel it ran on 2 of 64 lanes of every env's wavefront, here 64 chains share one
+// instruction stream.  FINISH: qacc of the chain, its sensors, warmstart, integration.  BEGIN: kinematics, mass matrix,
+// bias, tendon/actuator, limit rows, box poses -> hand-off record (enum SGH_*) for the phase and PGS kernels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sg_chain_kernel(SgPhaseArgs a) {
+  const int lane = threadIdx.x;
+  const size_t st = (size_t)blockIdx.x * 64 + lane;
+  const SgPlanHeader& H = *a.H;
+  const int nv = H.nv, nu = H.nu;
+  const size_t S = 2 * (size_t)a.nenv;
+  if (st >= S) return;
+  const int env = (int)(st >> 1), c = (int)(st & 1);
+  if (a.mask && !a.mask[env]) return;
+  SgWork& W = a.w;
+  if (a.first && c == 0) { W.status[env] = 0; if (!a.do_finish) W.pending[env] = 0; }
+  if (c >= H.nchain) return;
+  const int status = a.first ? 0 : W.status[env];
+  if (status & (SG_FLAG_BADQPOS | SG_FLAG_BADQVEL | SG_FLAG_BADQACC)) return;
+  const SgChain& C = H.chain[c];
+  const double h = H.timestep;
+  double* gq = a.qpos + (size_t)env * nv;
+  double* gv = a.qvel + (size_t)env * nv;
+  double* gw = a.warm + (size_t)env * nv;
+  const double kenv = a.kenv[env];
+  double q[SG_CD], v[SG_CD], w[SG_CD], kk[SG_CD], act = 0, ctrl = 0;
+#pragma unroll
+  for (int d = 0; d < SG_CD; d++) {
+    int j = C.dof0 + d;
+    if (a.do_reset) { q[d] = C.qpos0[d]; v[d] = 0; w[d] = 0; }
+    else { q[d] = gq[j]; v[d] = gv[j]; w[d] = gw[j]; }
+    kk[d] = a.kmask_jnt[j] ? kenv : C.stiffness[d];
+  }
+  if (C.has_act) {
+    if (a.do_reset) a.ctrl[(size_t)env * nu + C.act_id] = 0;
+    else { act = a.act[(size_t)env * nu + C.act_id]; ctrl = a.ctrl[(size_t)env * nu + C.act_id]; }
+  }
+  const double kten = C.has_ten ? (a.kmask_ten[C.ten_id] ? kenv : C.ten_k0) : 0.0;
+  double* ch = W.chh + st * SG_CHW;
+  bool bad_acc = false;
+
+  if (a.do_finish && W.pending[env]) {
+    double aF[SG_CD], qacc_c[SG_CD];
+#pragma unroll
+    for (int d = 0; d < SG_CD; d++) {
+      aF[d] = W.saF[(size_t)d * S + st];
+      qacc_c[d] = ch[SGH_QSM + d] + aF[d];
+      if (isbad(qacc_c[d])) bad_acc = true;
+    }
+    ChainKin K;
+    {
+      double* kd = (double*)&K;
+#pragma unroll
+      for (int i = 0; i < 48; i++) kd[i] = ch[SGH_K + i];
+    }
+    if (a.sens) {
+      ChainMotion Mo;
+      chain_motion(C, K, v, qacc_c, H.gravity, Mo);
+      double* so = a.sens + (size_t)env * a.sens_stride;
+      for (int s = 0; s < C.nsite; s++) {
+        int bi = C.s_body[s];
+        double r3[3], sm[9], t[3], t2[3], acc[3], out[3], sbp[3], sbm[9], bw[3], bal[3];
+        chain_body_pose(K, bi, sbp, sbm);
+        mulmat3(r3, sbm, C.s_pos[s]);
+        mulmat33(sm, sbm, C.s_mat[s]);
+        for (int k = 0; k < 3; k++) { bw[k] = bi == 0 ? Mo.w[0][k] : Mo.w[SG_CB - 1][k]; bal[k] = bi == 0 ? Mo.al[0][k] : Mo.al[SG_CB - 1][k]; }
+        if (C.s_gyro_adr[s] >= 0) {
+          mulmatT3(out, sm, bw);
+          for (int k = 0; k < 3; k++) so[C.s_gyro_adr[s] + k] = out[k];
+        }
+        if (C.s_acc_adr[s] >= 0) {
+          for (int k = 0; k < 3; k++) acc[k] = bi == 0 ? Mo.a[0][k] : Mo.a[SG_CB - 1][k];
+          cross3(t, bal, r3); addscl3(acc, t, 1);
+          cross3(t, bw, r3); cross3(t2, bw, t); addscl3(acc, t2, 1);
+          mulmatT3(out, sm, acc);
+          for (int k = 0; k < 3; k++) so[C.s_acc_adr[s] + k] = out[k];
+        }
+      }
+    }
+    if (bad_acc) {
+      atomicOr(&W.status[env], SG_FLAG_BADQACC);
+    } else {
+#pragma unroll
+      for (int d = 0; d < SG_CD; d++) w[d] = qacc_c[d];
+      if (a.finish_integrate) {
+        bool damp = false;
+#pragma unroll
+        for (int d = 0; d < SG_CD; d++) damp |= C.damping[d] > 0;
+        double qa[SG_CD];
+        if (damp) {
+          double MhB[16], MhBinv[16], rhs[SG_CD], Mm[16];
+#pragma unroll
+          for (int i = 0; i < 16; i++) { Mm[i] = ch[SGH_M + i]; MhB[i] = Mm[i]; }
+#pragma unroll
+          for (int d = 0; d < SG_CD; d++) MhB[5 * d] += h * C.damping[d];
+          spd_inverse4(MhB, MhBinv);
+#pragma unroll
+          for (int a2 = 0; a2 < SG_CD; a2++) {
+            double s2 = ch[SGH_QFRC + a2];
+#pragma unroll
+            for (int b2 = 0; b2 < SG_CD; b2++) s2 += Mm[4 * a2 + b2] * aF[b2];
+            rhs[a2] = s2;
+          }
+#pragma unroll
+          for (int a2 = 0; a2 < SG_CD; a2++) {
+            double s2 = 0;
+#pragma unroll
+            for (int b2 = 0; b2 < SG_CD; b2++) s2 += MhBinv[4 * a2 + b2] * rhs[b2];
+            qa[a2] = s2;
+          }
+        } else {
+#pragma unroll
+          for (int d = 0; d < SG_CD; d++) qa[d] = qacc_c[d];
+        }
+        act += h * ch[SGH_ACTDOT];
+#pragma unroll
+        for (int d = 0; d < SG_CD; d++) { v[d] += h * qa[d]; q[d] += h * v[d]; }
+      }
+    }
+  }
+
+  if (a.do_begin && !bad_acc) {
+    int bad = 0;
+#pragma unroll
+    for (int d = 0; d < SG_CD; d++) bad |= (isbad(q[d]) ? SG_FLAG_BADQPOS : 0) | (isbad(v[d]) ? SG_FLAG_BADQVEL : 0);
+    if (bad) {
+      atomicOr(&W.status[env], bad);
+    } else {
+      ChainKin K;
+      ChainDyn D;
+      chain_kinematics(C, q, K);
+      chain_dynamics(C, K, q, v, act, ctrl, kk, kten, H.gravity, D);
+#pragma unroll
+      for (int d = 0; d < SG_CD; d++) { ch[SGH_QSM + d] = D.qacc_smooth[d]; ch[SGH_QFRC + d] = D.qfrc_smooth[d]; ch[SGH_V + d] = v[d]; ch[SGH_W + d] = w[d]; }
+      ch[SGH_ACTDOT] = D.act_dot;
+#pragma unroll
+      for (int i = 0; i < 16; i++) { ch[SGH_M + i] = D.M[i]; ch[SGH_MINV + i] = D.Minv[i]; W.sMinv[(size_t)i * S + st] = D.Minv[i]; }
+      {
+        const double* kd = (const double*)&K;
+#pragma unroll
+        for (int i = 0; i < 48; i++) ch[SGH_K + i] = kd[i];
+      }
+#pragma unroll
+      for (int g = 0; g < SG_CG; g++) {
+        double t[3] = {0, 0, 0}, bp_[3] = {0, 0, 0}, bm_[9], bm2[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) bm2[k] = 0;
+        if (g < C.ngeom) {
+          chain_body_pose(K, C.g_body[g], bp_, bm_);
+          mulmat3(t, bm_, C.g_pos[g]);
+          mulmat33(bm2, bm_, C.g_mat[g]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) ch[SGH_BOX + 12 * g + k] = bp_[k] + t[k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) ch[SGH_BOX + 12 * g + 3 + k] = bm2[k];
+      }
+      LimitRows L;
+      limits_build(C, q, v, D.qacc_smooth, w, L);
+      ch[SGH_LIMACT] = (double)L.active;
+#pragma unroll
+      for (int k = 0; k < SG_MAXLIM; k++) { ch[SGH_LIMSIGN + k] = L.sign[k]; ch[SGH_LIMR + k] = L.R[k]; ch[SGH_LIMB + k] = L.b[k]; ch[SGH_LIMF + k] = L.f[k]; }
+    }
+  }
+  // store the chain's state
+#pragma unroll
+  for (int d = 0; d < SG_CD; d++) { int j = C.dof0 + d; gq[j] = q[d]; gv[j] = v[d]; gw[j] = w[d]; }
+  if (C.has_act) a.act[(size_t)env * nu + C.act_id] = act;
 }
 
 // ------------------------------------------------------------------------------------------------
