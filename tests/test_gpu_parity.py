@@ -177,3 +177,52 @@ def test_manenv_and_dataset_on_gpu(tmp_path):
             s.step()
         ref.append(s.sensordata.copy())
     assert np.abs(np.array(d["data"][1]) - np.array(ref)).max() < TOL_SENSOR
+
+
+def test_bad_env_is_reset_like_mujoco_exception():
+    """reference manenv.py:47-51: a simulation warning makes ManEnv.step() reset the env (re-drawing its stiffness) and go on"""
+    import torch
+    from softgrip_amd import ManEnv
+    np.random.seed(0)
+    env = ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=4)
+    k0 = env.reset().copy()
+    env.close_hand()
+    for _ in range(20):
+        env.step()
+    st = env.env.get_state()
+    st["qvel"][2, 10] = float("nan")                          # corrupt env 2
+    env.env.set_state(qvel=st["qvel"].contiguous())
+    readings, contact = env.step()
+    assert torch.isfinite(readings).all()
+    assert env.stiffness[2] != k0[2] and np.array_equal(env.stiffness[[0, 1, 3]], k0[[0, 1, 3]])
+    q = env.env.get_state()["qpos"]
+    assert float(q[2].abs().max()) < 1e-3 and float(q[0].abs().max()) > 1e-2     # env 2 restarted, the others carried on
+    # raw flags: the kernels report the failure as data
+    st = env.env.get_state()
+    st["qpos"][1, 0] = 1e11
+    env.env.set_state(qpos=st["qpos"].contiguous())
+    flags = torch.zeros(4, dtype=torch.int32, device=env.env.device)
+    env.env.step(7, flags=flags)
+    assert flags.cpu().tolist() == [0, 1, 0, 0]
+
+
+def test_config5_online_regressor():
+    """configs[4]: the simulator's on-device [n,200,12] block feeds the ConvNet (PyTorch-ROCm) without leaving the GPU"""
+    import torch
+    from softgrip_amd import ManEnv, convnet
+    from softgrip_amd.create_dataset import episode_schedule
+    np.random.seed(1)
+    env = ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=64)
+    env.set_new_stiffness()
+    out, flags = env.rollout(episode_schedule())
+    assert out.shape == (64, 200, 12) and out.is_cuda and int((flags != 0).sum()) == 0
+    torch.manual_seed(0)
+    net = convnet.ConvNet().to(out.device)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    y = torch.tensor(env.stiffness, device=out.device)
+    mean, std = convnet.channel_stats(out)
+    l0, pred = convnet.train_step(net, opt, out, y, mean, std, add_noise=True)
+    assert pred.shape == (64,) and torch.isfinite(l0) and float(pred.min()) >= 300 and float(pred.max()) <= 1400
+    for _ in range(5):
+        l1, _ = convnet.train_step(net, opt, out, y, mean, std)
+    assert float(l1) < float(l0) * 1.5

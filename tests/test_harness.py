@@ -164,3 +164,17 @@ def test_contact_flag_modes(fake_native):
     assert env2._contact_flags().tolist() == [True]                # ncon > 0 is enough from now on
     env2.env.solver_stats = lambda: dict(ncon=torch.tensor([0], dtype=torch.int32))
     assert env2._contact_flags().tolist() == [False]
+
+
+def test_sharded_dataset_by_stiffness_bin(fake_native, tmp_path, monkeypatch):
+    """configs[3]: every rank draws its envs' stiffness from its own bin and writes its own shard (no collective)"""
+    paths = []
+    for rank in range(2):
+        monkeypatch.setenv("RANK", str(rank)); monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("LOCAL_RANK", "0")
+        np.random.seed(100 + rank)
+        paths.append(cd.log_into_file(_args(tmp_path, n_envs=8)))
+    assert [os.path.basename(p) for p in paths] == ["fx.rank0.pickle", "fx.rank1.pickle"]
+    k0 = pickle.load(open(paths[0], "rb"))["stiffness"]
+    k1 = pickle.load(open(paths[1], "rb"))["stiffness"]
+    assert len(k0) == 8 and len(k1) == 8
+    assert all(300 <= k < 850 for k in k0) and all(850 <= k < 1400 for k in k1)
