@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--scene", default="softbox")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL over xGMI) or gloo (for testing the multi-process path)")
+    ap.add_argument("--force-device", type=int, default=-1, help="testing only: put every rank on this GPU")
     args = ap.parse_args()
 
     import torch
@@ -90,11 +92,16 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if args.force_device >= 0:
+        local = args.force_device
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.dist_backend)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
 
@@ -154,8 +161,8 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms, launches = batch.profile_read(reset=True)
     batch.profile_enable(False)
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:  # the only collectives of the run: a barrier per side and this MAX (timing, not data path)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     nbad = int((flags_or != 0).sum().item())

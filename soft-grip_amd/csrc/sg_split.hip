@@ -24,12 +24,14 @@ using namespace sgm;
 #define SG_CAP 64        // contact capacity per stream in the split pipeline
 #define SG_NF 26         // constant fields of a contact record
 #define SG_RF 30         // record fields: 26 constants, 3 force components, slider index (as an int in a double slot)
-// Contact records are blocked for the PGS kernel: one block per (slot, PGS wavefront) holds SG_RF fields x 16 streams,
+// Contact records are blocked for the PGS kernel: one block per (slot, PGS wavefront) holds SG_RF fields x SG_SPW streams,
 // so a wavefront reads a whole record with ONE vector address plus immediate offsets (field stride 128 B), and its 16
 // stream lanes use every byte of the 128-B lines they touch.  Block index nwb (one past the last wave) is a dummy
 // target for the unconditional stores of idle lanes.
-#define SG_REC_INDEX(slot, wave, field, pos, nwb) (((((size_t)(slot)) * ((nwb) + 1) + (wave)) * SG_RF + (field)) * 16 + (pos))
-#define SG_G 8           // lanes per env in the PGS kernel
+#define SG_REC_INDEX(slot, wave, field, pos, nwb) (((((size_t)(slot)) * ((nwb) + 1) + (wave)) * SG_RF + (field)) * SG_SPW + (pos))
+#define SG_G 8           // lanes per env in the PGS kernel (8 measured best: 16 -> 1.35x slower PGS, 4 -> 1.07x slower)
+#define SG_EPW (64 / SG_G)   // envs per PGS wavefront
+#define SG_SPW (2 * SG_EPW)  // finger streams per PGS wavefront
 #define SG_CHW 160       // doubles of chain hand-off per stream (layout: see sg_chain_kernel)
 
 struct SgWork {          // device workspace of one batch (all pointers device memory)
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
       //      in registers for the warmstart test (g = Jf' f, Js.f, invm, f.(R f/2 + b), slider index)
       const int myn = high ? ns1 : ns0;
       const size_t st = 2 * (size_t)env + half;
-      const int nwb = (a.nenv + 7) / 8;
+      const int nwb = (a.nenv + SG_EPW - 1) / SG_EPW;
       double cg[CPL][SG_CD], cjsf[CPL], cinvm[CPL], ccost0[CPL];
       int csl_[CPL];
 #pragma unroll
@@ -532,22 +534,22 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           ccost0[k] = c.f[0] * (0.5 * c.R * c.f[0] + c.b[0]) + c.f[1] * (0.5 * c.R * c.f[1] + c.b[1]) + c.f[2] * (0.5 * c.R * c.f[2] + c.b[2]);
 #pragma unroll
           for (int d = 0; d < SG_CD; d++) cg[k][d] = c.Jf[0][d] * c.f[0] + c.Jf[1][d] * c.f[1] + c.Jf[2][d] * c.f[2];
-          double* ro = W.crec + SG_REC_INDEX(i, env >> 3, 0, 2 * (env & 7) + half, nwb);
+          double* ro = W.crec + SG_REC_INDEX(i, env / SG_EPW, 0, 2 * (env % SG_EPW) + half, nwb);
 #pragma unroll
           for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int d = 0; d < SG_CD; d++) ro[(4 * r + d) * 16] = c.Jf[r][d];
+            for (int d = 0; d < SG_CD; d++) ro[(4 * r + d) * SG_SPW] = c.Jf[r][d];
 #pragma unroll
-          for (int r = 0; r < 3; r++) ro[(12 + r) * 16] = c.Js[r];
+          for (int r = 0; r < 3; r++) ro[(12 + r) * SG_SPW] = c.Js[r];
 #pragma unroll
-          for (int q = 0; q < 6; q++) ro[(15 + q) * 16] = c.A[q];
+          for (int q = 0; q < 6; q++) ro[(15 + q) * SG_SPW] = c.A[q];
 #pragma unroll
-          for (int r = 0; r < 3; r++) ro[(21 + r) * 16] = c.b[r];
-          ro[24 * 16] = c.R;
-          ro[25 * 16] = c.invm;
+          for (int r = 0; r < 3; r++) ro[(21 + r) * SG_SPW] = c.b[r];
+          ro[24 * SG_SPW] = c.R;
+          ro[25 * SG_SPW] = c.invm;
 #pragma unroll
-          for (int r = 0; r < 3; r++) ro[(26 + r) * 16] = c.f[r];
-          ((int*)(ro + 29 * 16))[0] = sl;
+          for (int r = 0; r < 3; r++) ro[(26 + r) * SG_SPW] = c.f[r];
+          ((int*)(ro + 29 * SG_SPW))[0] = sl;
         }
       }
       // ---- equality rows ----
@@ -657,9 +659,9 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 #pragma unroll
             for (int d = 0; d < SG_CD; d++) cg[k][d] = 0;
             if (i < myn) {
-              double* ro = W.crec + SG_REC_INDEX(i, env >> 3, 0, 2 * (env & 7) + half, nwb);
+              double* ro = W.crec + SG_REC_INDEX(i, env / SG_EPW, 0, 2 * (env % SG_EPW) + half, nwb);
 #pragma unroll
-              for (int r = 0; r < 3; r++) ro[(26 + r) * 16] = 0.0;
+              for (int r = 0; r < 3; r++) ro[(26 + r) * SG_SPW] = 0.0;
             }
           }
           __syncthreads();
@@ -899,12 +901,12 @@ struct SgPgsArgs {
 
 __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
   extern __shared__ double lds[];  // [8 envs][4 arrays][N] + invm[N] + coef[N] + limits
-  const int lane = threadIdx.x, le = lane >> 3, g = lane & 7;
-  const int env = blockIdx.x * 8 + le;
+  const int lane = threadIdx.x, le = lane / SG_G, g = lane % SG_G;
+  const int env = blockIdx.x * SG_EPW + le;
   const SgPlanHeader& H = *a.H;
   const int N = H.nelem;
   const size_t S = 2 * (size_t)a.nenv;
-  const int nwb = (a.nenv + 7) / 8;
+  const int nwb = (a.nenv + SG_EPW - 1) / SG_EPW;
   const SgWork& W = a.w;
   const double mu[2] = {H.con_mu[0], H.con_mu[1]}, pgs_scale = H.pgs_scale, tolerance = H.tolerance;
   const int max_iter = H.iterations;
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
   if (!__ballot(valid)) return;
   double* Las = lds + (size_t)le * 4 * N;
   double *Lf = Las + N, *Lb = Lf + N, *LR = Lb + N;
-  double* Linvm = lds + (size_t)8 * 4 * N;
+  double* Linvm = lds + (size_t)SG_EPW * 4 * N;
   double* Lcoef = Linvm + N;
   double* Llim = Lcoef + N + (size_t)(le * 2) * 4 * SG_MAXLIM;  // per stream: sign, R, b, f x 8
   for (int j = lane; j < N; j += 64) { Linvm[j] = 1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]); Lcoef[j] = a.elem[(size_t)SGE_COEF * N + j]; }
@@ -957,8 +959,8 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
   // my record column inside the wave's block; idle lanes read their env's stream (same address as its stream lane)
   // and store to the dummy block
   double* const rec0 = W.crec + SG_REC_INDEX(0, blockIdx.x, 0, 2 * le + (g & 1), nwb);
-  double* const rec0_store = (valid && g < 2) ? rec0 : W.crec + SG_REC_INDEX(0, nwb, 0, lane & 15, nwb);
-  const size_t slot_stride = (size_t)(nwb + 1) * SG_RF * 16;
+  double* const rec0_store = (valid && g < 2) ? rec0 : W.crec + SG_REC_INDEX(0, nwb, 0, lane % SG_SPW, nwb);
+  const size_t slot_stride = (size_t)(nwb + 1) * SG_RF * SG_SPW;
 
   for (int it = 0; it < max_iter; it++) {
     if (!__ballot(running)) break;
@@ -975,7 +977,8 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
     }
     {  // tendon row: sum over the env's 8 lanes
       double Ja = tJap;
-      Ja += __shfl_xor(Ja, 1); Ja += __shfl_xor(Ja, 2); Ja += __shfl_xor(Ja, 4);
+#pragma unroll
+      for (int o = 1; o < SG_G; o <<= 1) Ja += __shfl_xor(Ja, o);
       if (running) {
         double old = tf, tfn = tf;
         double ch = scalar_update(tfn, tb, Ja, tR, tA, false);
@@ -1014,18 +1017,18 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
-          for (int d = 0; d < SG_CD; d++) c.Jf[r][d] = rec[(4 * r + d) * 16];
+          for (int d = 0; d < SG_CD; d++) c.Jf[r][d] = rec[(4 * r + d) * SG_SPW];
 #pragma unroll
-        for (int r = 0; r < 3; r++) c.Js[r] = rec[(12 + r) * 16];
+        for (int r = 0; r < 3; r++) c.Js[r] = rec[(12 + r) * SG_SPW];
 #pragma unroll
-        for (int q = 0; q < 6; q++) c.A[q] = rec[(15 + q) * 16];
+        for (int q = 0; q < 6; q++) c.A[q] = rec[(15 + q) * SG_SPW];
 #pragma unroll
-        for (int r = 0; r < 3; r++) c.b[r] = rec[(21 + r) * 16];
-        c.R = rec[24 * 16];
-        c.invm = rec[25 * 16];
+        for (int r = 0; r < 3; r++) c.b[r] = rec[(21 + r) * SG_SPW];
+        c.R = rec[24 * SG_SPW];
+        c.invm = rec[25 * SG_SPW];
 #pragma unroll
-        for (int r = 0; r < 3; r++) c.f[r] = rec[(26 + r) * 16];
-        c.sl = ((const int*)(rec + 29 * 16))[0];
+        for (int r = 0; r < 3; r++) c.f[r] = rec[(26 + r) * SG_SPW];
+        c.sl = ((const int*)(rec + 29 * SG_SPW))[0];
       };
       auto update_rec = [&](Contact& c, int i) {
         if (i < nsl) {
@@ -1040,9 +1043,10 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
         }
         double* recs = rec0_store + (size_t)i * slot_stride;
 #pragma unroll
-        for (int r = 0; r < 3; r++) recs[(26 + r) * 16] = c.f[r];
+        for (int r = 0; r < 3; r++) recs[(26 + r) * SG_SPW] = c.f[r];
       };
-      // two contacts per trip with the buffers swapping roles (no register copies)
+      // two contacts per trip with the buffers swapping roles (no register copies); requesting records two updates
+      // ahead (three buffers) measured no faster
       Contact ca, cb;
       load_rec(ca, 0);
       for (int i = 0; i < nsmax; i += 2) {
@@ -1054,7 +1058,8 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
       __syncthreads();
     }
     double imp = imp_acc;
-    imp += __shfl_xor(imp, 1); imp += __shfl_xor(imp, 2); imp += __shfl_xor(imp, 4);
+#pragma unroll
+    for (int o = 1; o < SG_G; o <<= 1) imp += __shfl_xor(imp, o);
     if (running) {
       iters = it + 1;
       if (imp * pgs_scale < tolerance) running = false;
@@ -1073,11 +1078,11 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
         if (lim_active >> k & 1) gF[k / 2] += mylim[k] * mylim[3 * SG_MAXLIM + k];
       for (int i = 0; i < ns; i++) {
         const double* rec = rec0 + (size_t)i * slot_stride;
-        double f0 = rec[26 * 16], f1 = rec[27 * 16], f2 = rec[28 * 16];
-        int sl = ((const int*)(rec + 29 * 16))[0];
-        if (sl >= 0) Las[sl] += rec[25 * 16] * (rec[12 * 16] * f0 + rec[13 * 16] * f1 + rec[14 * 16] * f2);
+        double f0 = rec[26 * SG_SPW], f1 = rec[27 * SG_SPW], f2 = rec[28 * SG_SPW];
+        int sl = ((const int*)(rec + 29 * SG_SPW))[0];
+        if (sl >= 0) Las[sl] += rec[25 * SG_SPW] * (rec[12 * SG_SPW] * f0 + rec[13 * SG_SPW] * f1 + rec[14 * SG_SPW] * f2);
 #pragma unroll
-        for (int d = 0; d < SG_CD; d++) gF[d] += rec[d * 16] * f0 + rec[(4 + d) * 16] * f1 + rec[(8 + d) * 16] * f2;
+        for (int d = 0; d < SG_CD; d++) gF[d] += rec[d * SG_SPW] * f0 + rec[(4 + d) * SG_SPW] * f1 + rec[(8 + d) * SG_SPW] * f2;
       }
     }
     __syncthreads();
