@@ -220,7 +220,6 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   pa.kenv = b->kenv; pa.kmask_jnt = b->kmask_jnt; pa.kmask_ten = b->kmask_ten;
   pa.mask = mask; pa.sens = nullptr; pa.sens_stride = stride > 0 ? stride : H.nsensordata;
   pa.w = b->w; pa.nenv = b->n;
-  { const char* ds = getenv("SG_DBG_SKIP"); pa.dbg_skip = ds ? atoi(ds) : 0; }
   SgPgsArgs ga;
   ga.H = b->dH; ga.elem = b->delem; ga.w = b->w; ga.nenv = b->n;
   const size_t lds = sizeof(double) * ((size_t)(4 * SG_EPW + 2) * H.nelem + SG_SPW * 4 * SG_MAXLIM);

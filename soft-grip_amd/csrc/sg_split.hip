@@ -59,7 +59,6 @@ struct SgPhaseArgs {
   SgWork w;
   int nenv;
   int do_reset, do_finish, finish_integrate, do_begin, first;
-  int dbg_skip;  // timing experiments only (SG_DBG_SKIP): bit0 chain stage, bit1 collision, bit2 warmstart test, bit3 finish
 };
 
 // chain hand-off record (doubles): written by the chain stage (phase kernel or sg_chain_kernel), read by FINISH and by BEGIN
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   __syncthreads();
 
   // =============================== FINISH the previous substep ===============================
-  if (a.do_finish && W.pending[env] && !(a.dbg_skip & 8)) {
+  if (a.do_finish && W.pending[env]) {
     int badacc = 0;
     double qacc_e[R], ase[R];
 #pragma unroll
@@ -315,7 +314,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             CS.lim_sign[k] = ch[SGH_LIMSIGN + k]; CS.lim_R[k] = ch[SGH_LIMR + k]; CS.lim_b[k] = ch[SGH_LIMB + k]; CS.lim_f[k] = ch[SGH_LIMF + k];
           }
         }
-      } else if (is_chain_lane && !(a.dbg_skip & 1)) {
+      } else if (is_chain_lane) {
         double qc[SG_CD], vc[SG_CD], wc[SG_CD], kc[SG_CD];
 #pragma unroll
         for (int d = 0; d < SG_CD; d++) { qc[d] = CS.q[d]; vc[d] = CS.v[d]; wc[d] = CS.w[d]; kc[d] = CS.k[d]; }
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         int overflow = 0;
 #pragma unroll
         for (int c = 0; c < SG_MAXCH; c++) {
-          if (c >= nchain || (a.dbg_skip & 2)) break;
+          if (c >= nchain) break;
           const SgChain& Cc = Sm.chain[c];
           int nsc = 0;
 #pragma unroll
@@ -619,7 +618,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         __syncthreads();
       };
       recompute_a();
-      if (!(a.dbg_skip & 4)) {
+      {
         double cp = 0, tJap = 0;
 #pragma unroll
         for (int r = 0; r < R; r++) {
