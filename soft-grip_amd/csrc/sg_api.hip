@@ -43,7 +43,7 @@ struct sg_batch {
   SgPlanHeader* dH;
   double *delem, *qpos, *qvel, *warm, *act, *ctrl, *kenv, *ctrl_row;
   int *kmask_jnt, *kmask_ten, *flags, *touch, *ncon, *nefc, *iters;
-  int pipeline;  // 0 fused (one kernel per call), 1 split (phase / pgs kernel chain)
+  int pipeline;  // 0 fused (one kernel per call), 1 split (chain / phase / pgs kernel chain), 2 split with the row-parallel PGS kernel
   SgWork w;
   std::vector<void*> wbufs;
   // profiling
@@ -132,6 +132,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
       return hipMemset(*p, 0, bytes) == hipSuccess;
     };
     bool ok = walloc((void**)&b->w.crec, sizeof(double) * SG_CAP * ((n + SG_EPW - 1) / SG_EPW + 1) * SG_RF * SG_SPW) && walloc((void**)&b->w.ns, sizeof(int) * S) &&
+              walloc((void**)&b->w.crow, sizeof(double) * SG_CAP * ((n + 7) / 8 + 1) * SG_RK * 64) &&
               walloc((void**)&b->w.envh, sizeof(double) * 4 * n) && walloc((void**)&b->w.shared, sizeof(int) * n) &&
               walloc((void**)&b->w.pending, sizeof(int) * n) && walloc((void**)&b->w.status, sizeof(int) * n) &&
               walloc((void**)&b->w.iters, sizeof(int) * n) && walloc((void**)&b->w.ncon, sizeof(int) * n) &&
@@ -144,7 +145,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
               walloc((void**)&b->w.chh, sizeof(double) * n * 2 * SG_CHW);
     if (!ok) { sg_batch_destroy(b); return fail(SG_ERR_NOMEM, "hipMalloc (split-pipeline workspace)"); }
     const char* pm = getenv("SG_PIPELINE");
-    b->pipeline = (pm && strcmp(pm, "fused") == 0) ? 0 : 1;
+    b->pipeline = (pm && strcmp(pm, "fused") == 0) ? 0 : (pm && strcmp(pm, "split") == 0) ? 1 : 2;
   }
 #undef ALLOC
   HIPCHK(hipMemcpy(b->dH, &H, sizeof H, hipMemcpyHostToDevice));
@@ -219,13 +220,14 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   pa.qpos = b->qpos; pa.qvel = b->qvel; pa.warm = b->warm; pa.act = b->act; pa.ctrl = b->ctrl;
   pa.kenv = b->kenv; pa.kmask_jnt = b->kmask_jnt; pa.kmask_ten = b->kmask_ten;
   pa.mask = mask; pa.sens = nullptr; pa.sens_stride = stride > 0 ? stride : H.nsensordata;
-  pa.w = b->w; pa.nenv = b->n;
+  pa.w = b->w; pa.nenv = b->n; pa.rowlayout = b->pipeline == 2;
   SgPgsArgs ga;
   ga.H = b->dH; ga.elem = b->delem; ga.w = b->w; ga.nenv = b->n;
   const size_t lds = sizeof(double) * ((size_t)(4 * SG_EPW + 2) * H.nelem + SG_SPW * 4 * SG_MAXLIM);
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   // forward passes to run: (mode 1: one non-integrating forward first) + nsub integrating ones
@@ -258,7 +260,8 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     phase(p);
     HIPCHK(hipGetLastError());
     if (k < nfwd) {
-      hipLaunchKernelGGL(sg_pgs_kernel, dim3((b->n + SG_EPW - 1) / SG_EPW), dim3(64), lds, s, ga);
+      if (b->pipeline == 2) hipLaunchKernelGGL(sg_pgs_rows_kernel, dim3((b->n + 7) / 8), dim3(64), lds, s, ga);
+      else hipLaunchKernelGGL(sg_pgs_kernel, dim3((b->n + SG_EPW - 1) / SG_EPW), dim3(64), lds, s, ga);
       HIPCHK(hipGetLastError());
     }
   }
@@ -284,7 +287,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
 
 static int launch(sg_batch* b, int mode, const uint8_t* mask, int nsub, double* sens, long long stride, int32_t* flags, int32_t* touch,
                   hipStream_t s) {
-  if (b->pipeline == 1) return launch_split(b, mode, mask, nsub, sens, stride, flags, touch, s);
+  if (b->pipeline >= 1) return launch_split(b, mode, mask, nsub, sens, stride, flags, touch, s);
   const SgPlanHeader& H = b->m->plan.h;
   SgKArgs a;
   a.H = b->dH; a.elem = b->delem;
@@ -365,7 +368,7 @@ int sg_get_solver_stats(sg_batch* b, int32_t* ncon, int32_t* nefc, int32_t* iter
 }
 
 int sg_set_pipeline(sg_batch* b, int pipeline) {
-  if (!b || pipeline < 0 || pipeline > 1) return fail(SG_ERR_INVALID, "sg_set_pipeline: bad argument");
+  if (!b || pipeline < 0 || pipeline > 2) return fail(SG_ERR_INVALID, "sg_set_pipeline: bad argument");
   b->pipeline = pipeline;
   return SG_OK;
 }

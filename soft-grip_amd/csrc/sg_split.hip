@@ -36,6 +36,7 @@ using namespace sgm;
 
 struct SgWork {          // device workspace of one batch (all pointers device memory)
   double* crec;          // [SG_CAP][nwb + 1][SG_RF][16]   nwb = ceil(nenv / 8) PGS wavefronts (+1 dummy block)
+  double* crow;          // [SG_CAP][nwb + 1][SG_RK][64]   row layout (sg_pgs_rows_kernel), +1 dummy block
   int* ns;               // [S]
   double* envh;          // [4][nenv]: tb, tR, tA, tf
   int *shared, *pending, *status, *iters, *ncon, *nefc, *touch;  // [nenv]
@@ -59,9 +60,17 @@ struct SgPhaseArgs {
   SgWork w;
   int nenv;
   int do_reset, do_finish, finish_integrate, do_begin, first;
+  int rowlayout;  // 1: export contact records in the row layout of sg_pgs_rows_kernel
 };
 
 // chain hand-off record (doubles): written by the chain stage (phase kernel or sg_chain_kernel), read by FINISH and by BEGIN
+// Row layout of the contact records for sg_pgs_rows_kernel: a finger stream is a QUAD of lanes, lane r < 3 holds row r
+// (normal, tangent 1, tangent 2) of every contact.  Block per (slot, wavefront): SG_RK fields x 64 lanes; field k of lane
+// (8 * env_in_wave + 4 * chain + r): 0..3 Jf[r][0..3], 4 Js[r], 5 b[r], 6 f[r], 7..9 A[r][0..2], 10 shared (r=0: R,
+// r=1: invm, r=2: slider index), 11..12 row r of the inverse friction block (r = 1: P11 P12, r = 2: P12 P22).
+#define SG_RK 13
+#define SG_ROW_INDEX(slot, wave, k, lane, nwb) (((((size_t)(slot)) * ((nwb) + 1) + (wave)) * SG_RK + (k)) * 64 + (lane))  // block nwb = dummy
+
 enum { SGH_QSM = 0, SGH_QFRC = 4, SGH_ACTDOT = 8, SGH_M = 9, SGH_K = 25, SGH_MINV = 73, SGH_V = 89, SGH_W = 93, SGH_BOX = 97,
        SGH_LIMACT = 121, SGH_LIMSIGN = 122, SGH_LIMR = 130, SGH_LIMB = 138, SGH_LIMF = 146 };
 
@@ -533,6 +542,28 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           ccost0[k] = c.f[0] * (0.5 * c.R * c.f[0] + c.b[0]) + c.f[1] * (0.5 * c.R * c.f[1] + c.b[1]) + c.f[2] * (0.5 * c.R * c.f[2] + c.b[2]);
 #pragma unroll
           for (int d = 0; d < SG_CD; d++) cg[k][d] = c.Jf[0][d] * c.f[0] + c.Jf[1][d] * c.f[1] + c.Jf[2][d] * c.f[2];
+          if (a.rowlayout) {
+            const int nwb8 = (a.nenv + 7) / 8;
+            double* rw = W.crow + SG_ROW_INDEX(i, env >> 3, 0, 8 * (env & 7) + 4 * half, nwb8);
+            const double S11 = c.A[3] * H.con_mu[0] * H.con_mu[0], S22 = c.A[5] * H.con_mu[1] * H.con_mu[1], S12 = c.A[4] * H.con_mu[0] * H.con_mu[1];
+            const double det = S11 * S22 - S12 * S12, di = det < 1e-10 ? 0.0 : sg_div(1.0, det);
+            const double P11 = S22 * di, P22 = S11 * di, P12 = -S12 * di;
+            const double Afull[3][3] = {{c.A[0], c.A[1], c.A[2]}, {c.A[1], c.A[3], c.A[4]}, {c.A[2], c.A[4], c.A[5]}};
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+#pragma unroll
+              for (int d = 0; d < SG_CD; d++) rw[(size_t)d * 64 + r] = c.Jf[r][d];
+              rw[(size_t)4 * 64 + r] = c.Js[r]; rw[(size_t)5 * 64 + r] = c.b[r]; rw[(size_t)6 * 64 + r] = c.f[r];
+#pragma unroll
+              for (int k2 = 0; k2 < 3; k2++) rw[(size_t)(7 + k2) * 64 + r] = Afull[r][k2];
+            }
+            rw[(size_t)10 * 64 + 0] = c.R; rw[(size_t)10 * 64 + 1] = c.invm;
+            ((int*)(rw + (size_t)10 * 64 + 2))[0] = sl; ((int*)(rw + (size_t)10 * 64 + 2))[1] = 0;
+            rw[(size_t)11 * 64 + 0] = 0; rw[(size_t)12 * 64 + 0] = 0;
+            rw[(size_t)11 * 64 + 1] = P11; rw[(size_t)12 * 64 + 1] = P12;
+            rw[(size_t)11 * 64 + 2] = P12; rw[(size_t)12 * 64 + 2] = P22;
+          }
+          if (!a.rowlayout) {
           double* ro = W.crec + SG_REC_INDEX(i, env / SG_EPW, 0, 2 * (env % SG_EPW) + half, nwb);
 #pragma unroll
           for (int r = 0; r < 3; r++)
@@ -549,6 +580,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 #pragma unroll
           for (int r = 0; r < 3; r++) ro[(26 + r) * SG_SPW] = c.f[r];
           ((int*)(ro + 29 * SG_SPW))[0] = sl;
+          }
         }
       }
       // ---- equality rows ----
@@ -658,9 +690,16 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 #pragma unroll
             for (int d = 0; d < SG_CD; d++) cg[k][d] = 0;
             if (i < myn) {
+              if (!a.rowlayout) {
               double* ro = W.crec + SG_REC_INDEX(i, env / SG_EPW, 0, 2 * (env % SG_EPW) + half, nwb);
 #pragma unroll
               for (int r = 0; r < 3; r++) ro[(26 + r) * SG_SPW] = 0.0;
+              }
+              if (a.rowlayout) {
+                double* rw = W.crow + SG_ROW_INDEX(i, env >> 3, 6, 8 * (env & 7) + 4 * half, (a.nenv + 7) / 8);
+#pragma unroll
+                for (int r = 0; r < 3; r++) rw[r] = 0.0;
+              }
             }
           }
           __syncthreads();
@@ -1097,6 +1136,256 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
   }
   if (valid) {
     for (int j = g; j < N; j += SG_G) W.as[(size_t)env * N + j] = Las[j];
+    if (g == 0) W.iters[env] = iters;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PGS kernel, row-parallel contact update: as sg_pgs_kernel (8 lanes per env, 8 envs per wavefront, joint-fix rows over
+// the env's 8 lanes) but each finger stream is a QUAD of lanes: lane r < 3 owns row r of every contact (normal, tangent
+// 1, tangent 2), so the 3 x 5 residual products, A f, A d, J' df ... take one instruction for the three rows instead of
+// three, and the few cross-row sums / broadcasts are DPP quad permutes (no LDS).  A lone wavefront issues one instruction
+// every ~6.3 cycles whatever it computes (scripts/ubench), so instructions per contact update are what this cuts.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double sg_dpp(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int R_>
+__device__ __forceinline__ double sg_qb(double x) { return sg_dpp<R_ * 0x55>(x); }  // value of quad lane R_ in all four lanes
+__device__ __forceinline__ double sg_qsum(double x) {                                   // (x0 + x1) + (x2 + x3) in all four lanes
+  x += sg_dpp<0xB1>(x);
+  x += sg_dpp<0x4E>(x);
+  return x;
+}
+
+__global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x, le = lane >> 3, g = lane & 7, c = g >> 2, r = g & 3;
+  const int env = blockIdx.x * 8 + le;
+  const SgPlanHeader& H = *a.H;
+  const int N = H.nelem;
+  const size_t S = 2 * (size_t)a.nenv;
+  const int nwb = (a.nenv + 7) / 8;
+  const SgWork& W = a.w;
+  const double mu0 = H.con_mu[0], mu1 = H.con_mu[1], pgs_scale = H.pgs_scale, tolerance = H.tolerance;
+  const double mur = r == 1 ? mu0 : mu1;
+  const int max_iter = H.iterations;
+  const bool valid = env < a.nenv && W.pending[env] != 0;
+  if (!__ballot(valid)) return;
+  double* Las = lds + (size_t)le * 4 * N;
+  double *Lf = Las + N, *Lb = Lf + N, *LR = Lb + N;
+  double* Linvm = lds + (size_t)8 * 4 * N;
+  double* Lcoef = Linvm + N;
+  double* mylim = Lcoef + N + (size_t)(le * 2 + c) * 4 * SG_MAXLIM;
+  for (int j = lane; j < N; j += 64) { Linvm[j] = 1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]); Lcoef[j] = a.elem[(size_t)SGE_COEF * N + j]; }
+  if (valid)
+    for (int j = g; j < N; j += 8) {
+      size_t o = (size_t)env * N + j;
+      Las[j] = W.as[o]; Lf[j] = W.eqf[o]; Lb[j] = W.eqb[o]; LR[j] = W.eqR[o];
+    }
+  const size_t st = 2 * (size_t)(env < a.nenv ? env : 0) + c;
+  int ns = 0, lim_active = 0, shared = 0;
+  double Minv[16], aF[SG_CD] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 16; i++) Minv[i] = 0;
+  double tb = 0, tR = 1, tA = 1, tf = 0;
+  if (valid) {
+    tb = W.envh[(size_t)0 * a.nenv + env]; tR = W.envh[(size_t)1 * a.nenv + env];
+    tA = W.envh[(size_t)2 * a.nenv + env]; tf = W.envh[(size_t)3 * a.nenv + env];
+    shared = W.shared[env];
+    ns = W.ns[st];
+    lim_active = W.lim_active[st];
+#pragma unroll
+    for (int i = 0; i < 16; i++) Minv[i] = W.sMinv[(size_t)i * S + st];
+#pragma unroll
+    for (int d = 0; d < SG_CD; d++) aF[d] = W.saF[(size_t)d * S + st];
+    if (r == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int k = 0; k < SG_MAXLIM; k++) mylim[q * SG_MAXLIM + k] = W.lim[((size_t)q * SG_MAXLIM + k) * S + st];
+    }
+  }
+  __syncthreads();
+  int nsmax = ns;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(nsmax, o); nsmax = t > nsmax ? t : nsmax; }
+  const unsigned long long any_lim = __ballot(lim_active != 0);
+
+  bool running = valid;
+  int iters = 0;
+  // my row's column in the wave's block, biased by 6 fields (immediate offsets).  Lane r == 3 carries no row: it reads and
+  // writes the dummy block, which only ever holds zeros (its force stays 0), so its row values are 0 without any select
+  const double* const row0 = (valid && r < 3) ? W.crow + SG_ROW_INDEX(0, blockIdx.x, 6, lane, nwb) : W.crow + SG_ROW_INDEX(0, nwb, 6, lane, nwb);
+  double* const row0_store = (double*)row0;
+  const size_t slot_stride = (size_t)(nwb + 1) * SG_RK * 64;
+
+  for (int it = 0; it < max_iter; it++) {
+    if (!__ballot(running)) break;
+    double imp_acc = 0, tJap = 0;
+    if (running) {
+      for (int j = g; j < N; j += 8) {
+        double ae = Las[j], f = Lf[j], old = f, im = Linvm[j];
+        double Rr = LR[j];
+        imp_acc -= scalar_update(f, Lb[j], ae, Rr, im + Rr, false);
+        ae += im * (f - old);
+        Lf[j] = f; Las[j] = ae;
+        tJap += Lcoef[j] * ae;
+      }
+    }
+    {
+      double Ja = tJap;
+      Ja += __shfl_xor(Ja, 1); Ja += __shfl_xor(Ja, 2); Ja += __shfl_xor(Ja, 4);
+      if (running) {
+        double old = tf, tfn = tf;
+        double ch = scalar_update(tfn, tb, Ja, tR, tA, false);
+        if (g == 0) imp_acc -= ch;
+        tf = tfn;
+        double dft = tf - old;
+        for (int j = g; j < N; j += 8) Las[j] += Linvm[j] * Lcoef[j] * dft;
+      }
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; pass++) {
+      const bool mine = running && ((c == 0 || !shared) ? pass == 0 : pass == 1);
+      if (!__ballot(mine)) continue;
+      if (any_lim) {  // limit rows: every lane of the quad computes the same scalars, lane 0 records the force
+#pragma unroll
+        for (int k = 0; k < SG_MAXLIM; k++) {
+          if (mine && (lim_active >> k & 1)) {
+            const int d = k / 2;
+            double f = mylim[3 * SG_MAXLIM + k], old = f, sg = mylim[k], Rr = mylim[SG_MAXLIM + k];
+            double ch = scalar_update(f, mylim[2 * SG_MAXLIM + k], sg * aF[d], Rr, Minv[5 * d] + Rr, true);
+            if (r == 0) { imp_acc -= ch; mylim[3 * SG_MAXLIM + k] = f; }
+            double df = sg * (f - old);
+#pragma unroll
+            for (int q = 0; q < SG_CD; q++) aF[q] += Minv[4 * q + d] * df;
+          }
+        }
+      }
+      const int nsl = mine ? ns : 0;
+      struct Row { double J0, J1, J2, J3, Js, b, f, A0, A1, A2, sh, Pa, Pb; };
+      auto load_row = [&](Row& w, int i) {
+        const double* p = row0 + (size_t)i * slot_stride;
+        w.J0 = p[-6 * 64]; w.J1 = p[-5 * 64]; w.J2 = p[-4 * 64]; w.J3 = p[-3 * 64]; w.Js = p[-2 * 64]; w.b = p[-1 * 64]; w.f = p[0];
+        w.A0 = p[1 * 64]; w.A1 = p[2 * 64]; w.A2 = p[3 * 64]; w.sh = p[4 * 64]; w.Pa = p[5 * 64]; w.Pb = p[6 * 64];
+      };
+      auto update_row = [&](Row& w, int i) {
+        if (i < nsl) {
+          const double J0 = w.J0, J1 = w.J1, J2 = w.J2, J3 = w.J3, Js = w.Js, bb = w.b, fo = w.f, A0 = w.A0, A1 = w.A1, A2 = w.A2;
+          const double Rr = sg_qb<0>(w.sh), invm = sg_qb<1>(w.sh);
+          const int sl = __double2loint(sg_qb<2>(w.sh));
+          const double as_ = sl >= 0 ? Las[sl] : 0.0;
+          const double res = ((bb + Js * as_) + (J0 * aF[0] + J1 * aF[1])) + ((Rr * fo + J2 * aF[2]) + J3 * aF[3]);  // 0 on lane 3
+          const double o0 = sg_qb<0>(fo), o1 = sg_qb<1>(fo), o2 = sg_qb<2>(fo);
+          // ---- normal or ray update
+          const double wv = A0 * o0 + A1 * o1 + A2 * o2;
+          const double denom = sg_qsum(fo * wv), num = sg_qsum(fo * res);
+          double x = denom >= SG_MINVAL ? sg_div(-num, denom) : 0.0;
+          x = (o0 + x * o0 < 0) ? -1.0 : x;
+          double gr = fo + x * fo;
+          if (o0 < SG_MINVAL) {  // uncommon: no normal force yet (lane 0 holds res_0 and A_00)
+            double gn = o0 - sg_div(res, A0);
+            gr = r == 0 ? (gn < 0 ? 0.0 : gn) : 0.0;
+          }
+          const double g0 = sg_qb<0>(gr);
+          // ---- friction rows with the normal force fixed
+          const double bc = res - (A1 * o1 + A2 * o2) + A0 * (g0 - o0);
+          const double bmu = bc * mur;
+          const double b1 = sg_qb<1>(bmu), b2 = sg_qb<2>(bmu);
+          const double u = -(w.Pa * b1 + w.Pb * b2);     // rows 1, 2; 0 on lanes 0, 3 and when the friction block is singular
+          const double val = sg_qsum(u * u) - g0 * g0;
+          double vr = u * mur;
+          if (!(val < 1e-10) && !(g0 < SG_MINVAL)) {  // uncommon: outside the cone -- the generic Newton iteration, on all four lanes
+            const double a11 = sg_qb<1>(A1), a12 = sg_qb<1>(A2), a22 = sg_qb<2>(A2);
+            const double Ac[4] = {a11, a12, a12, a22}, bcv[2] = {sg_qb<1>(bc), sg_qb<2>(bc)}, mu[2] = {mu0, mu1};
+            double v[2];
+            int active = qcqp2(v, Ac, bcv, mu, g0);
+            if (active) {
+              double s2 = v[0] * v[0] / (mu0 * mu0) + v[1] * v[1] / (mu1 * mu1);
+              s2 = sqrt(g0 * g0 / fmax(SG_MINVAL, s2));
+              v[0] *= s2; v[1] *= s2;
+            }
+            vr = r == 1 ? v[0] : (r == 2 ? v[1] : 0.0);
+          }
+          const bool nofric = g0 < SG_MINVAL;
+          double fn = r == 0 ? g0 : (nofric ? 0.0 : vr);  // lane 3: vr = 0
+          double dr = fn - fo;
+          const double d0 = sg_qb<0>(dr), d1 = sg_qb<1>(dr), d2 = sg_qb<2>(dr);
+          const double Ad = A0 * d0 + A1 * d1 + A2 * d2;
+          const double change = sg_qsum(dr * (0.5 * Ad + res));
+          const bool reject = change > 1e-10;
+          fn = reject ? fo : fn;
+          dr = reject ? 0.0 : dr;
+          if (r == 0) imp_acc -= reject ? 0.0 : change;
+          const double jsdf = sg_qsum(Js * dr);
+          if (sl >= 0 && r == 0) Las[sl] = as_ + invm * jsdf;
+          const double g0_ = sg_qsum(J0 * dr), g1_ = sg_qsum(J1 * dr), g2_ = sg_qsum(J2 * dr), g3_ = sg_qsum(J3 * dr);
+#pragma unroll
+          for (int q = 0; q < SG_CD; q++) aF[q] += (Minv[4 * q] * g0_ + Minv[4 * q + 1] * g1_) + (Minv[4 * q + 2] * g2_ + Minv[4 * q + 3] * g3_);
+          w.f = fn;
+        }
+        double* ps = row0_store + (size_t)i * slot_stride;
+        ps[0] = w.f;
+      };
+      Row ra, rb;
+      load_row(ra, 0);
+      for (int i = 0; i < nsmax; i += 2) {
+        load_row(rb, i + 1 < SG_CAP ? i + 1 : i);
+        update_row(ra, i);
+        load_row(ra, i + 2 < SG_CAP ? i + 2 : i);
+        update_row(rb, i + 1);
+      }
+      __syncthreads();
+    }
+    double imp = imp_acc;
+    imp += __shfl_xor(imp, 1); imp += __shfl_xor(imp, 2); imp += __shfl_xor(imp, 4);
+    if (running) {
+      iters = it + 1;
+      if (imp * pgs_scale < tolerance) running = false;
+    }
+  }
+  __syncthreads();
+  // ---- fresh M^-1 J' f from the final forces
+  if (valid)
+    for (int j = g; j < N; j += 8) Las[j] = Linvm[j] * (Lf[j] + Lcoef[j] * tf);
+  __syncthreads();
+  double gF[SG_CD] = {0, 0, 0, 0};
+  for (int pass = 0; pass < 2; pass++) {  // stream 0 then stream 1: deterministic when they share a slider
+    if (valid && c == pass) {
+      if (r == 0) {
+#pragma unroll
+        for (int k = 0; k < SG_MAXLIM; k++)
+          if (lim_active >> k & 1) gF[k / 2] += mylim[k] * mylim[3 * SG_MAXLIM + k];
+      }
+      for (int i = 0; i < ns; i++) {
+        const double* p = row0 + (size_t)i * slot_stride;
+        const double fr = p[0], Js = p[-2 * 64], sh = p[4 * 64];
+        const double invm = sg_qb<1>(sh);
+        const int sl = __double2loint(sg_qb<2>(sh));
+        const double jsf = sg_qsum(Js * fr);
+        if (sl >= 0 && r == 0) Las[sl] += invm * jsf;
+        const double t0 = sg_qsum(p[-6 * 64] * fr), t1 = sg_qsum(p[-5 * 64] * fr), t2 = sg_qsum(p[-4 * 64] * fr), t3 = sg_qsum(p[-3 * 64] * fr);
+        if (r == 0) { gF[0] += t0; gF[1] += t1; gF[2] += t2; gF[3] += t3; }
+      }
+    }
+    __syncthreads();
+  }
+  if (valid && r == 0) {
+#pragma unroll
+    for (int q = 0; q < SG_CD; q++) {
+      double s2 = 0;
+#pragma unroll
+      for (int d = 0; d < SG_CD; d++) s2 += Minv[4 * q + d] * gF[d];
+      W.saF[(size_t)q * S + st] = s2;
+    }
+  }
+  if (valid) {
+    for (int j = g; j < N; j += 8) W.as[(size_t)env * N + j] = Las[j];
     if (g == 0) W.iters[env] = iters;
   }
 }

@@ -155,7 +155,7 @@ class NativeBatch:
         return dict(ncon=out[0], nefc=out[1], iters=out[2])
 
     def set_pipeline(self, name):
-        check(lib().sg_set_pipeline(self.ptr, {"fused": 0, "split": 1}[name]))
+        check(lib().sg_set_pipeline(self.ptr, {"fused": 0, "split": 1, "rows": 2}[name]))
 
     def profile_enable(self, on=True):
         check(lib().sg_profile_enable(self.ptr, int(on)))
