@@ -132,7 +132,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
       return hipMemset(*p, 0, bytes) == hipSuccess;
     };
     bool ok = walloc((void**)&b->w.crec, sizeof(double) * SG_CAP * ((n + SG_EPW - 1) / SG_EPW + 1) * SG_RF * SG_SPW) && walloc((void**)&b->w.ns, sizeof(int) * S) &&
-              walloc((void**)&b->w.crow, sizeof(double) * SG_CAP * ((n + 7) / 8 + 1) * SG_RK * 64) &&
+              walloc((void**)&b->w.crow, sizeof(double) * (SG_CAP + 2) * ((n + 7) / 8 + 1) * SG_RK * 64) &&
               walloc((void**)&b->w.envh, sizeof(double) * 4 * n) && walloc((void**)&b->w.shared, sizeof(int) * n) &&
               walloc((void**)&b->w.pending, sizeof(int) * n) && walloc((void**)&b->w.status, sizeof(int) * n) &&
               walloc((void**)&b->w.iters, sizeof(int) * n) && walloc((void**)&b->w.ncon, sizeof(int) * n) &&
@@ -223,7 +223,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   pa.w = b->w; pa.nenv = b->n; pa.rowlayout = b->pipeline == 2;
   SgPgsArgs ga;
   ga.H = b->dH; ga.elem = b->delem; ga.w = b->w; ga.nenv = b->n;
-  const size_t lds = sizeof(double) * ((size_t)(4 * SG_EPW + 2) * H.nelem + SG_SPW * 4 * SG_MAXLIM);
+  const size_t lds = sizeof(double) * ((size_t)(4 * SG_EPW + 2) * H.nelem + 16 * 4 * SG_MAXLIM + 72);
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -1181,6 +1181,8 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   double* Linvm = lds + (size_t)8 * 4 * N;
   double* Lcoef = Linvm + N;
   double* mylim = Lcoef + N + (size_t)(le * 2 + c) * 4 * SG_MAXLIM;
+  double* Lzero = Lcoef + N + (size_t)16 * 4 * SG_MAXLIM;  // [0]: a word that stays 0 (reads of "no slider"), [1 + lane]: write sink
+  if (lane == 0) Lzero[0] = 0.0;
   for (int j = lane; j < N; j += 64) { Linvm[j] = 1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]); Lcoef[j] = a.elem[(size_t)SGE_COEF * N + j]; }
   if (valid)
     for (int j = g; j < N; j += 8) {
@@ -1269,17 +1271,16 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
       }
       const int nsl = mine ? ns : 0;
       struct Row { double J0, J1, J2, J3, Js, b, f, A0, A1, A2, sh, Pa, Pb; };
-      auto load_row = [&](Row& w, int i) {
-        const double* p = row0 + (size_t)i * slot_stride;
+      auto load_row = [&](Row& w, const double* p) {
         w.J0 = p[-6 * 64]; w.J1 = p[-5 * 64]; w.J2 = p[-4 * 64]; w.J3 = p[-3 * 64]; w.Js = p[-2 * 64]; w.b = p[-1 * 64]; w.f = p[0];
         w.A0 = p[1 * 64]; w.A1 = p[2 * 64]; w.A2 = p[3 * 64]; w.sh = p[4 * 64]; w.Pa = p[5 * 64]; w.Pb = p[6 * 64];
       };
-      auto update_row = [&](Row& w, int i) {
+      auto update_row = [&](Row& w, int i, double* ps) {
         if (i < nsl) {
           const double J0 = w.J0, J1 = w.J1, J2 = w.J2, J3 = w.J3, Js = w.Js, bb = w.b, fo = w.f, A0 = w.A0, A1 = w.A1, A2 = w.A2;
           const double Rr = sg_qb<0>(w.sh), invm = sg_qb<1>(w.sh);
           const int sl = __double2loint(sg_qb<2>(w.sh));
-          const double as_ = sl >= 0 ? Las[sl] : 0.0;
+          const double as_ = *(sl >= 0 ? &Las[sl] : &Lzero[0]);  // branch-free: "no slider" reads a zero word
           const double res = ((bb + Js * as_) + (J0 * aF[0] + J1 * aF[1])) + ((Rr * fo + J2 * aF[2]) + J3 * aF[3]);  // 0 on lane 3
           const double o0 = sg_qb<0>(fo), o1 = sg_qb<1>(fo), o2 = sg_qb<2>(fo);
           // ---- normal or ray update
@@ -1321,24 +1322,27 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           const bool reject = change > 1e-10;
           fn = reject ? fo : fn;
           dr = reject ? 0.0 : dr;
-          if (r == 0) imp_acc -= reject ? 0.0 : change;
+          imp_acc -= (reject || r != 0) ? 0.0 : change;
           const double jsdf = sg_qsum(Js * dr);
-          if (sl >= 0 && r == 0) Las[sl] = as_ + invm * jsdf;
+          *((sl >= 0 && r == 0) ? &Las[sl] : &Lzero[1 + lane]) = as_ + invm * jsdf;  // other lanes write to their sink word
           const double g0_ = sg_qsum(J0 * dr), g1_ = sg_qsum(J1 * dr), g2_ = sg_qsum(J2 * dr), g3_ = sg_qsum(J3 * dr);
 #pragma unroll
           for (int q = 0; q < SG_CD; q++) aF[q] += (Minv[4 * q] * g0_ + Minv[4 * q + 1] * g1_) + (Minv[4 * q + 2] * g2_ + Minv[4 * q + 3] * g3_);
           w.f = fn;
         }
-        double* ps = row0_store + (size_t)i * slot_stride;
         ps[0] = w.f;
       };
+      // slots 0 .. SG_CAP+1 exist in memory (two spare slots), so the look-ahead never needs a bound check
       Row ra, rb;
-      load_row(ra, 0);
+      double* pa = row0_store;
+      load_row(ra, pa);
       for (int i = 0; i < nsmax; i += 2) {
-        load_row(rb, i + 1 < SG_CAP ? i + 1 : i);
-        update_row(ra, i);
-        load_row(ra, i + 2 < SG_CAP ? i + 2 : i);
-        update_row(rb, i + 1);
+        double* pb = pa + slot_stride;
+        load_row(rb, pb);
+        update_row(ra, i, pa);
+        pa = pb + slot_stride;
+        load_row(ra, pa);
+        update_row(rb, i + 1, pb);
       }
       __syncthreads();
     }
