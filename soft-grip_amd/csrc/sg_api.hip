@@ -223,11 +223,13 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   pa.w = b->w; pa.nenv = b->n; pa.rowlayout = b->pipeline == 2;
   SgPgsArgs ga;
   ga.H = b->dH; ga.elem = b->delem; ga.w = b->w; ga.nenv = b->n;
-  const size_t lds = sizeof(double) * ((size_t)(4 * SG_EPW + 2) * H.nelem + 16 * 4 * SG_MAXLIM + 72);
+  const size_t lds = sizeof(double) * ((size_t)(5 * 8 + 2) * H.nelem + 16 * 4 * SG_MAXLIM + 72);
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   // forward passes to run: (mode 1: one non-integrating forward first) + nsub integrating ones
@@ -260,7 +262,12 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     phase(p);
     HIPCHK(hipGetLastError());
     if (k < nfwd) {
-      if (b->pipeline == 2) hipLaunchKernelGGL(sg_pgs_rows_kernel, dim3((b->n + 7) / 8), dim3(64), lds, s, ga);
+      if (b->pipeline == 2) {
+        const int nsl = (H.nelem + 7) / 8;
+        if (nsl <= 16) hipLaunchKernelGGL(sg_pgs_rows_kernel<16>, dim3((b->n + 7) / 8), dim3(64), lds, s, ga);
+        else if (nsl <= 24) hipLaunchKernelGGL(sg_pgs_rows_kernel<24>, dim3((b->n + 7) / 8), dim3(64), lds, s, ga);
+        else hipLaunchKernelGGL(sg_pgs_rows_kernel<32>, dim3((b->n + 7) / 8), dim3(64), lds, s, ga);
+      }
       else hipLaunchKernelGGL(sg_pgs_kernel, dim3((b->n + SG_EPW - 1) / SG_EPW), dim3(64), lds, s, ga);
       HIPCHK(hipGetLastError());
     }

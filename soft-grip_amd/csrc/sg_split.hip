@@ -1162,6 +1162,7 @@ __device__ __forceinline__ double sg_qsum(double x) {                           
   return x;
 }
 
+template <int NSL>  // NSL >= ceil(nelem / 8): joint-fix rows per lane, unrolled (their LDS reads issue back to back)
 __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x, le = lane >> 3, g = lane & 7, c = g >> 2, r = g & 3;
@@ -1178,7 +1179,8 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   if (!__ballot(valid)) return;
   double* Las = lds + (size_t)le * 4 * N;
   double *Lf = Las + N, *Lb = Lf + N, *LR = Lb + N;
-  double* Linvm = lds + (size_t)8 * 4 * N;
+  double* Lri = lds + (size_t)8 * 4 * N + (size_t)le * N;
+  double* Linvm = lds + (size_t)8 * 5 * N;
   double* Lcoef = Linvm + N;
   double* mylim = Lcoef + N + (size_t)(le * 2 + c) * 4 * SG_MAXLIM;
   double* Lzero = Lcoef + N + (size_t)16 * 4 * SG_MAXLIM;  // [0]: a word that stays 0 (reads of "no slider"), [1 + lane]: write sink
@@ -1187,7 +1189,9 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   if (valid)
     for (int j = g; j < N; j += 8) {
       size_t o = (size_t)env * N + j;
-      Las[j] = W.as[o]; Lf[j] = W.eqf[o]; Lb[j] = W.eqb[o]; LR[j] = W.eqR[o];
+      double Rr = W.eqR[o], im = 1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]);
+      Las[j] = W.as[o]; Lf[j] = W.eqf[o]; Lb[j] = W.eqb[o]; LR[j] = Rr;
+      Lri[j] = sg_div(1.0, im + Rr);  // 1 / (A_jj + R_j): sg_div(res, A_jj + R_j) == res * this
     }
   const size_t st = 2 * (size_t)(env < a.nenv ? env : 0) + c;
   int ns = 0, lim_active = 0, shared = 0;
@@ -1229,26 +1233,38 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   for (int it = 0; it < max_iter; it++) {
     if (!__ballot(running)) break;
     double imp_acc = 0, tJap = 0;
-    if (running) {
-      for (int j = g; j < N; j += 8) {
-        double ae = Las[j], f = Lf[j], old = f, im = Linvm[j];
-        double Rr = LR[j];
-        imp_acc -= scalar_update(f, Lb[j], ae, Rr, im + Rr, false);
-        ae += im * (f - old);
-        Lf[j] = f; Las[j] = ae;
-        tJap += Lcoef[j] * ae;
+    double ael[NSL];
+#pragma unroll
+    for (int t = 0; t < NSL; t++) {
+      const int j = g + 8 * t;
+      ael[t] = 0;
+      if (running && j < N) {
+        const double ae = Las[j], Rr = LR[j], im = Linvm[j], old = Lf[j];
+        const double res = Lb[j] + ae + Rr * old;
+        double fn = old - res * Lri[j];
+        const double d = fn - old, change = 0.5 * d * d * (im + Rr) + d * res;
+        const bool reject = change > 1e-10;
+        fn = reject ? old : fn;
+        imp_acc -= reject ? 0.0 : change;
+        Lf[j] = fn;
+        ael[t] = ae + im * (fn - old);
+        tJap += Lcoef[j] * ael[t];
       }
     }
     {
       double Ja = tJap;
       Ja += __shfl_xor(Ja, 1); Ja += __shfl_xor(Ja, 2); Ja += __shfl_xor(Ja, 4);
+      double old = tf, tfn = tf;
+      double ch = scalar_update(tfn, tb, Ja, tR, tA, false);
       if (running) {
-        double old = tf, tfn = tf;
-        double ch = scalar_update(tfn, tb, Ja, tR, tA, false);
         if (g == 0) imp_acc -= ch;
         tf = tfn;
-        double dft = tf - old;
-        for (int j = g; j < N; j += 8) Las[j] += Linvm[j] * Lcoef[j] * dft;
+      }
+      const double dft = tf - old;
+#pragma unroll
+      for (int t = 0; t < NSL; t++) {
+        const int j = g + 8 * t;
+        if (running && j < N) Las[j] = ael[t] + Linvm[j] * Lcoef[j] * dft;
       }
     }
     __syncthreads();
