@@ -1162,6 +1162,13 @@ __device__ __forceinline__ double sg_qsum(double x) {                           
   return x;
 }
 
+// sum over the 8 lanes of an env's group, result in all 8: two quad steps and a mirror inside the 8-lane half row (all DPP)
+__device__ __forceinline__ double sg_gsum8(double x) {
+  x = sg_qsum(x);
+  x += sg_dpp<0x141>(x);  // row_half_mirror: lane i <-> 7 - i, i.e. the other quad of the group (whose lanes all hold its sum)
+  return x;
+}
+
 template <int NSL>  // NSL >= ceil(nelem / 8): joint-fix rows per lane, unrolled (their LDS reads issue back to back)
 __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   extern __shared__ double lds[];
@@ -1253,7 +1260,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     }
     {
       double Ja = tJap;
-      Ja += __shfl_xor(Ja, 1); Ja += __shfl_xor(Ja, 2); Ja += __shfl_xor(Ja, 4);
+      Ja = sg_gsum8(Ja);
       double old = tf, tfn = tf;
       double ch = scalar_update(tfn, tb, Ja, tR, tA, false);
       if (running) {
@@ -1363,7 +1370,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
       __syncthreads();
     }
     double imp = imp_acc;
-    imp += __shfl_xor(imp, 1); imp += __shfl_xor(imp, 2); imp += __shfl_xor(imp, 4);
+    imp = sg_gsum8(imp);
     if (running) {
       iters = it + 1;
       if (imp * pgs_scale < tolerance) running = false;

@@ -30,7 +30,7 @@ def _bufs(b, n):
             torch.zeros(n, dtype=torch.int32, device=b.device))
 
 
-@pytest.mark.parametrize("pipeline", ["split", "fused"])
+@pytest.mark.parametrize("pipeline", ["rows", "split", "fused"])
 def test_softbox_episode_matches_oracle(pipeline):
     """both kernel pipelines (the default split chain and the single fused kernel) against the oracle, 9 envs so that the
     PGS kernel runs a full and a partial wavefront"""
@@ -70,7 +70,7 @@ def test_softbox_episode_matches_oracle(pipeline):
         np.testing.assert_allclose(st["act"][e].cpu().numpy(), s.act, atol=1e-13)
 
 
-@pytest.mark.parametrize("pipeline", ["split", "fused"])
+@pytest.mark.parametrize("pipeline", ["rows", "split", "fused"])
 @pytest.mark.parametrize("scene", ["softcylinder", "softball"])
 def test_other_scenes_first_substeps(scene, pipeline):
     """R = 3 / 4 kernel instantiations; these scenes start in deep penetration (chaotic), so only the first substeps
