@@ -172,11 +172,12 @@ def main():
         abytes = algorithmic_bytes_per_env_step(nm.nq, nm.nq, nm.nu, nm.nu, nsd)
         ach = abytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r01_v4_hbm_traffic.json")
-        if os.path.exists(tp) and args.scene == "softbox" and n == 4096 and os.environ.get("SG_PIPELINE", "split") != "fused":
+        pipe = os.environ.get("SG_PIPELINE", "rows")
+        tp = os.path.join(ROOT, "profiles", {"rows": "r01_v5_rows_hbm_traffic.json", "split": "r01_v4_hbm_traffic.json"}.get(pipe, "none"))
+        if os.path.exists(tp) and args.scene == "softbox" and n == 4096:
             # HBM-side bytes per sg_step call from the committed rocprofv3 PMC passes of this very workload (not re-measured here)
             traffic = json.load(open(tp))["per_sg_step_call_bytes"]
-            traffic_src = "profiles/r01_v4_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, raw)"
+            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, raw)" % os.path.basename(tp)
         res = {
             "metric": "env steps/sec (whole node) at batch=4096",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -187,10 +188,10 @@ def main():
                        "envs_per_gpu": n, "substeps_per_step": sim_step, "physics_substeps_per_s": value * sim_step,
                        "envs_flagged_bad": nbad, "launches_timed": launches},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "sg_phase_kernel + sg_pgs_kernel chain of one sg_step call (split pipeline)" if os.environ.get("SG_PIPELINE", "split") != "fused" else "sg_step_kernel",
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": {"rows": "sg_chain_kernel + sg_phase_kernel + sg_pgs_rows_kernel chain of one sg_step call (rows pipeline; dominant: sg_pgs_rows_kernel)", "split": "sg_chain_kernel + sg_phase_kernel + sg_pgs_kernel chain of one sg_step call (split pipeline)"}.get(pipe, "sg_step_kernel"),
                          "avg_kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": abytes,
-                         "note": "state stays on chip across the 7 substeps; the path is issue/latency-bound, not HBM-bound (DESIGN.md)"},
+                         "note": "one 'launch' = the kernel chain of one sg_step call (7 substeps); the path is instruction-issue-bound (serial Gauss-Seidel per finger), not HBM-bound; traffic is mostly contact blocks re-read from L2/Infinity Cache by each sweep (DESIGN.md 4.3)"},
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             cores = usable_cores()

@@ -104,9 +104,10 @@ int sg_set_state(sg_batch* b, const double* qpos, const double* qvel, const doub
  * number of contacts, constraint rows and PGS sweeps of the final substep */
 int sg_get_solver_stats(sg_batch* b, int32_t* ncon, int32_t* nefc, int32_t* iters, void* stream);
 
-/* kernel pipeline: 1 = split (default; phase / PGS kernel chain, one lane per finger stream in the solver),
- * 0 = fused (one kernel per call, everything on chip).  Same results; the env var SG_PIPELINE=fused|split sets
- * the default of new batches. */
+/* kernel pipeline (same results to round-off, all parity-tested): 2 = rows (default: chain / phase / row-parallel PGS
+ * kernels, a lane quad per finger stream in the solver), 1 = split (same chain with one lane per finger stream),
+ * 0 = fused (one kernel per call, everything on chip).  The env var SG_PIPELINE=fused|split|rows sets the default of
+ * new batches. */
 int sg_set_pipeline(sg_batch* b, int pipeline);
 
 /* kernel timing hook for bench.py: average device time (ms) of one sg_step/sg_reset call's kernels over the

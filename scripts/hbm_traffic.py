@@ -1,0 +1,52 @@
+"""Aggregate two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same bench.py command) into the
+per-sg_step-call HBM traffic figure bench.py reports as roofline.traffic.
+
+usage: hbm_traffic.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass> <n sg_step calls + 1 reset> <out.json> [pipeline]
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d, counter):
+    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    tot, n = collections.OrderedDict(), collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter or "sg_" not in r["Kernel_Name"]:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"]) * 1024.0  # counter unit: KiB
+        n[k] += 1
+    return tot, n
+
+
+def main():
+    rd, nrd = per_kernel(sys.argv[1], "FETCH_SIZE")
+    wr, nwr = per_kernel(sys.argv[2], "WRITE_SIZE")
+    calls = int(sys.argv[3])
+    pipeline = sys.argv[5] if len(sys.argv) > 5 else "rows"
+    kernels = {}
+    for k in rd:
+        kernels[k] = {"FETCH_SIZE_total_bytes": rd[k], "FETCH_SIZE_dispatches": nrd[k],
+                      "WRITE_SIZE_total_bytes": wr.get(k, 0.0), "WRITE_SIZE_dispatches": nwr.get(k, 0)}
+    total = sum(rd.values()) + sum(wr.values())
+    out = {
+        "unit": "bytes",
+        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps %d --warmup 0 "
+                "--no-cpu-baseline` (1 sg_reset + %d sg_step calls, 4096 envs, %s pipeline); counter unit = KiB (x1024). gfx950 "
+                "caveat (MI355X_MICROARCH.md, HBM): FETCH_SIZE is calibrated only for 16-B/lane streaming reads (where it reports "
+                "1/2 of the bytes); these kernels read 8 B/lane, so the read figure is a raw, uncorrected lower bound; "
+                "Infinity-Cache hits are included in these fabric-side counters." % (calls - 1, calls - 1, pipeline),
+        "kernels": kernels,
+        "episode_total_bytes": total,
+        "per_sg_step_call_bytes": total / calls,
+        "algorithmic_bytes_per_call": 5816 * 4096,
+    }
+    json.dump(out, open(sys.argv[4], "w"), indent=1)
+    print(json.dumps({k: out[k] for k in ("episode_total_bytes", "per_sg_step_call_bytes", "algorithmic_bytes_per_call")}))
+
+
+if __name__ == "__main__":
+    main()

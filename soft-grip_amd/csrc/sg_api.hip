@@ -25,6 +25,12 @@ __global__ void sg_fill_rows_kernel(double* dst, const double* row, int n, int w
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n * w) dst[i] = row[i % w];
 }
+#define SG_CTRL_BYVAL 8
+struct SgCtrlRow { double v[SG_CTRL_BYVAL]; };
+__global__ void sg_fill_rows_val_kernel(double* dst, SgCtrlRow row, int n, int w) {  // the row travels in the kernel arguments: no host sync
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * w) dst[i] = row.v[i % w];
+}
 __global__ void sg_masked_copy_kernel(const unsigned char* mask, int n, const int* s0, int* d0, const int* s1, int* d1, const int* s2, int* d2,
                                       const int* s3, int* d3, const int* s4, int* d4) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -199,7 +205,13 @@ int sg_set_ctrl(sg_batch* b, const double* ctrl, int broadcast, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int nu = b->m->plan.h.nu;
   if (nu == 0) return SG_OK;
-  if (broadcast) {
+  if (broadcast && nu <= SG_CTRL_BYVAL) {
+    SgCtrlRow row;
+    for (int i = 0; i < SG_CTRL_BYVAL; i++) row.v[i] = i < nu ? ctrl[i] : 0.0;
+    int total = b->n * nu;
+    hipLaunchKernelGGL(sg_fill_rows_val_kernel, dim3((total + 255) / 256), dim3(256), 0, s, b->ctrl, row, b->n, nu);
+    HIPCHK(hipGetLastError());
+  } else if (broadcast) {
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipMemcpy(b->ctrl_row, ctrl, sizeof(double) * nu, hipMemcpyHostToDevice));
     int total = b->n * nu;
