@@ -1,0 +1,53 @@
+"""Per-section cycle profile of the phase kernel (profiling build: `python soft-grip_amd/build_native.py --prof`, which
+compiles the SG_T stamps of csrc/sg_split.hip in).  Prints, for windows of the 200-step squeeze episode, the average cycles
+one wavefront spends in each section of sg_phase_kernel.
+
+usage (GPU box): SOFTGRIP_LIB=soft-grip_amd/libsoftgrip_prof.so python scripts/section_profile.py
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("SOFTGRIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "soft-grip_amd", "libsoftgrip_prof.so"))
+import softgrip_amd as sg  # noqa: E402
+from softgrip_amd import native  # noqa: E402
+from softgrip_amd.create_dataset import episode_schedule  # noqa: E402
+
+NAMES = ["0 prologue/load", "1 FINISH", "2 BEGIN elements", "3 narrowphase", "4 envelope checks", "5 contact rows+export",
+         "6 eq rows+recompute_a", "7 warmstart test", "8 export rest", "9 store state"]
+
+
+def main():
+    m = sg.load_model("models/softbox.sgmodel")
+    nm = native.NativeModel(m)
+    n = 4096
+    b = native.NativeBatch(nm, n, 0)
+    L = native.lib()
+    L.sg_debug_sections.argtypes = [C.c_void_p, C.c_void_p]
+    buf = (C.c_ulonglong * 32)()
+    b.set_stiffness(np.random.RandomState(0).uniform(300, 1400, n), list(range(11, 64)), [0])
+    b.reset(1)
+    L.sg_debug_sections(b.ptr, buf)
+    ctrl = np.zeros(2)
+    windows = {20: "idle (no contacts)", 60: "closing", 100: "squeeze peak", 199: "released"}
+    nl = 0
+    for t, c in enumerate(episode_schedule()):
+        if c is not None:
+            ctrl[:] = c
+            b.set_ctrl_broadcast(ctrl)
+        if t in windows:
+            L.sg_debug_sections(b.ptr, buf)  # clear
+        b.step(7)
+        if t in windows:
+            L.sg_debug_sections(b.ptr, buf)
+            v = np.array(buf[:10], dtype=np.float64) / (n * 8)  # 8 phase launches per sg_step call
+            print("step %d, %s: %.0f cycles per wavefront and launch" % (t, windows[t], v.sum()))
+            for k, name in enumerate(NAMES):
+                print("   %-26s %8.0f  %5.1f %%" % (name, v[k], 100 * v[k] / v.sum()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,22 @@
+import numpy as np, torch, sys
+sys.path.insert(0, ".")
+import softgrip_amd as sg
+from softgrip_amd import native
+from softgrip_amd.create_dataset import episode_schedule
+m = sg.load_model("models/softbox.sgmodel")
+nm = native.NativeModel(m)
+n = 4096
+b = native.NativeBatch(nm, n, 0)
+ks = np.random.RandomState(0).uniform(300, 1400, n)
+b.set_stiffness(ks, list(range(11, 64)), [0])
+b.reset(1)
+ctrl = np.zeros(2)
+for t, c in enumerate(episode_schedule()):
+    if c is not None:
+        ctrl[:] = c; b.set_ctrl_broadcast(ctrl)
+    b.step(7)
+    if t in (20, 45, 60, 80, 100, 119, 130, 150, 199):
+        st = b.solver_stats()
+        nc = st["ncon"].cpu().numpy(); it = st["iters"].cpu().numpy(); ne = st["nefc"].cpu().numpy()
+        w = nc.reshape(-1, 8)
+        print(t, "ncon mean %.1f max %d  wave-max mean %.1f | iters mean %.1f min %d max %d | nefc mean %.0f" % (nc.mean(), nc.max(), w.max(1).mean(), it.mean(), it.min(), it.max(), ne.mean()))

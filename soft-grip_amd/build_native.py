@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libsoftgrip.so")
 SOURCES = ["sg_api.hip", "sg_plan.cpp"]
-DEPS = SOURCES + ["sg_kernels.hip", "sg_math.h", "sg_plan.h", "../../include/softgrip.h", "../../include/softgrip_model.h"]
+DEPS = SOURCES + ["sg_kernels.hip", "sg_split.hip", "sg_math.h", "sg_plan.h", "../../include/softgrip.h", "../../include/softgrip_model.h"]
 
 
 def needs_build():
@@ -17,11 +17,18 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, prof=False):
+    """prof=True builds libsoftgrip_prof.so with the kernel section stamps (-DSG_SECTION_PROF) for scripts/section_profile.py"""
+    if prof:
+        return _compile(os.path.join(_HERE, "libsoftgrip_prof.so"), ["-DSG_SECTION_PROF"], verbose)
     if not force and not needs_build():
         return LIB
+    return _compile(LIB, [], verbose)
+
+
+def _compile(out, extra, verbose):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + \
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out] + extra + \
           [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
@@ -30,9 +37,9 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc failed:\n" + res.stderr[-4000:])
     if verbose:
         print(res.stderr)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
     import sys
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, prof="--prof" in sys.argv))

@@ -137,8 +137,8 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
       b->wbufs.push_back(*p);
       return hipMemset(*p, 0, bytes) == hipSuccess;
     };
-    bool ok = walloc((void**)&b->w.crec, sizeof(double) * SG_CAP * ((n + SG_EPW - 1) / SG_EPW + 1) * SG_RF * SG_SPW) && walloc((void**)&b->w.ns, sizeof(int) * S) &&
-              walloc((void**)&b->w.crow, sizeof(double) * (SG_CAP + 2) * ((n + 7) / 8 + 1) * SG_RK * 64) &&
+    bool ok = walloc((void**)&b->w.secprof, sizeof(unsigned long long) * 32) && walloc((void**)&b->w.crec, sizeof(double) * SG_CAP * ((n + SG_EPW - 1) / SG_EPW + 1) * SG_RF * SG_SPW) && walloc((void**)&b->w.ns, sizeof(int) * S) &&
+              walloc((void**)&b->w.crow, sizeof(double) * (SG_CAP + 2) * ((n + 7) / 8 + 2) * SG_RK * 64) &&
               walloc((void**)&b->w.envh, sizeof(double) * 4 * n) && walloc((void**)&b->w.shared, sizeof(int) * n) &&
               walloc((void**)&b->w.pending, sizeof(int) * n) && walloc((void**)&b->w.status, sizeof(int) * n) &&
               walloc((void**)&b->w.iters, sizeof(int) * n) && walloc((void**)&b->w.ncon, sizeof(int) * n) &&
@@ -391,6 +391,18 @@ int sg_set_pipeline(sg_batch* b, int pipeline) {
   b->pipeline = pipeline;
   return SG_OK;
 }
+
+#ifdef SG_SECTION_PROF
+// profiling build only (build_native.py --prof, scripts/section_profile.py): read and clear the per-section cycle sums
+int sg_debug_sections(sg_batch* b, unsigned long long* out32) {
+  if (!b || !out32) return fail(SG_ERR_INVALID, "sg_debug_sections: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out32, b->w.secprof, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(b->w.secprof, 0, sizeof(unsigned long long) * 32));
+  return SG_OK;
+}
+#endif
 
 int sg_profile_enable(sg_batch* b, int enable) {
   if (!b) return fail(SG_ERR_INVALID, "sg_profile_enable: bad argument");

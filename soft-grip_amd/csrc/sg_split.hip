@@ -36,7 +36,8 @@ using namespace sgm;
 
 struct SgWork {          // device workspace of one batch (all pointers device memory)
   double* crec;          // [SG_CAP][nwb + 1][SG_RF][16]   nwb = ceil(nenv / 8) PGS wavefronts (+1 dummy block)
-  double* crow;          // [SG_CAP][nwb + 1][SG_RK][64]   row layout (sg_pgs_rows_kernel), +1 dummy block
+  unsigned long long* secprof;  // [32] cycle sums per kernel section (only written when built with -DSG_SECTION_PROF)
+  double* crow;          // [SG_CAP + 2][nwb + 2][SG_RK / 2][64][2]   row layout (sg_pgs_rows_kernel), +2 dummy blocks
   int* ns;               // [S]
   double* envh;          // [4][nenv]: tb, tR, tA, tf
   int *shared, *pending, *status, *iters, *ncon, *nefc, *touch;  // [nenv]
@@ -65,11 +66,15 @@ struct SgPhaseArgs {
 
 // chain hand-off record (doubles): written by the chain stage (phase kernel or sg_chain_kernel), read by FINISH and by BEGIN
 // Row layout of the contact records for sg_pgs_rows_kernel: a finger stream is a QUAD of lanes, lane r < 3 holds row r
-// (normal, tangent 1, tangent 2) of every contact.  Block per (slot, wavefront): SG_RK fields x 64 lanes; field k of lane
-// (8 * env_in_wave + 4 * chain + r): 0..3 Jf[r][0..3], 4 Js[r], 5 b[r], 6 f[r], 7..9 A[r][0..2], 10 shared (r=0: R,
-// r=1: invm, r=2: slider index), 11..12 row r of the inverse friction block (r = 1: P11 P12, r = 2: P12 P22).
-#define SG_RK 13
-#define SG_ROW_INDEX(slot, wave, k, lane, nwb) (((((size_t)(slot)) * ((nwb) + 1) + (wave)) * SG_RK + (k)) * 64 + (lane))  // block nwb = dummy
+// (normal, tangent 1, tangent 2) of every contact.  Block per (slot, wavefront): 8 field PAIRS x 64 lanes x 2 doubles, so a
+// lane fetches two fields with one 16-byte load.  Field k of lane (8 * env_in_wave + 4 * chain + r):
+//   0..3 Jf[r][0..3] | 4 Js[r] | 5 b[r] | 6 f[r] | 7 (A f)[r] | 8..10 A[r][0..2] | 11 shared (r = 0: R, r = 2: slider index)
+//   12..14 inverse friction block P11 P12 P22 (same on the three rows) | 15 invm * Js[r]
+// f and A f (fields 6, 7: one pair) are the only fields the solver writes.  Blocks nwb and nwb + 1 of every slot are dummies:
+// lanes without a row read block nwb (all zero, never written) and write to block nwb + 1.
+#define SG_RK 16
+#define SG_ROW_INDEX(slot, wave, k, lane, nwb) \
+  ((((((size_t)(slot)) * ((nwb) + 2) + (wave)) * (SG_RK / 2) + (k) / 2) * 64 + (lane)) * 2 + ((k) & 1))
 
 enum { SGH_QSM = 0, SGH_QFRC = 4, SGH_ACTDOT = 8, SGH_M = 9, SGH_K = 25, SGH_MINV = 73, SGH_V = 89, SGH_W = 93, SGH_BOX = 97,
        SGH_LIMACT = 121, SGH_LIMSIGN = 122, SGH_LIMR = 130, SGH_LIMB = 138, SGH_LIMF = 146 };
@@ -106,6 +111,21 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
 
+// section timing for scripts/section_profile.py (build_native.py --prof): wave 0..n lane 0 adds the cycles since the previous
+// stamp to W.secprof[k].  Compiled out of the product library.
+#ifdef SG_SECTION_PROF
+#define SG_T0() unsigned long long t_prev_ = __builtin_readcyclecounter()
+#define SG_T(k)                                                                   \
+  do {                                                                            \
+    unsigned long long t_now_ = __builtin_readcyclecounter();                     \
+    if (threadIdx.x == 0) atomicAdd(&a.w.secprof[k], t_now_ - t_prev_);           \
+    t_prev_ = __builtin_readcyclecounter();                                       \
+  } while (0)
+#else
+#define SG_T0()
+#define SG_T(k)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // phase kernel: [finish previous substep] [begin next substep]
 // ------------------------------------------------------------------------------------------------
@@ -114,6 +134,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= a.nenv) return;
   if (a.mask && !a.mask[env]) return;
+  SG_T0();
   const SgPlanHeader& H = *a.H;
   const int N = H.nelem, nv = H.nv, nu = H.nu, e0 = H.elem_dof0, nchain = H.nchain;
   const size_t S = 2 * (size_t)a.nenv;
@@ -175,6 +196,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   }
   __syncthreads();
 
+  SG_T(0);
   // =============================== FINISH the previous substep ===============================
   if (a.do_finish && W.pending[env]) {
     int badacc = 0;
@@ -293,6 +315,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   }
   __syncthreads();
 
+  SG_T(1);
   // =============================== BEGIN the next substep ===============================
   int flags = 0;
   if (a.do_begin && !(status & SG_FLAG_BADQACC)) {
@@ -394,14 +417,17 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             Sm.owner[e] = -1;
           }
         }
+        SG_T(2);
         __syncthreads();
         int overflow = 0;
-#pragma unroll
+        // real loops over the (chain, box) pairs: unrolled, the four inlined narrowphase copies push the kernel far beyond the
+        // instruction cache (64 KB per CU pair) and every wavefront streams its code from L2
+#pragma unroll 1
         for (int c = 0; c < SG_MAXCH; c++) {
           if (c >= nchain) break;
           const SgChain& Cc = Sm.chain[c];
           int nsc = 0;
-#pragma unroll
+#pragma unroll 1
           for (int g = 0; g < SG_CG; g++) {
             if (g >= Cc.ngeom) break;
             const int b = c * SG_CG + g;
@@ -474,6 +500,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         }
         if (overflow) flags |= SG_FLAG_CONTACTFULL;
       }
+      SG_T(3);
       {  // envelope checks (same as the fused kernel)
         int nb = nchain * SG_CG, npairs = nb * H.nstatic;
         if (lane < npairs) {
@@ -501,6 +528,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         }
         if (__ballot(unsupported)) flags |= SG_FLAG_UNSUPPORTED_PAIR;
       }
+      SG_T(4);
       __syncthreads();
       int shared_slider = 0;
 #pragma unroll
@@ -544,24 +572,25 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           for (int d = 0; d < SG_CD; d++) cg[k][d] = c.Jf[0][d] * c.f[0] + c.Jf[1][d] * c.f[1] + c.Jf[2][d] * c.f[2];
           if (a.rowlayout) {
             const int nwb8 = (a.nenv + 7) / 8;
-            double* rw = W.crow + SG_ROW_INDEX(i, env >> 3, 0, 8 * (env & 7) + 4 * half, nwb8);
+            const int ql = 8 * (env & 7) + 4 * half;
             const double S11 = c.A[3] * H.con_mu[0] * H.con_mu[0], S22 = c.A[5] * H.con_mu[1] * H.con_mu[1], S12 = c.A[4] * H.con_mu[0] * H.con_mu[1];
             const double det = S11 * S22 - S12 * S12, di = det < 1e-10 ? 0.0 : sg_div(1.0, det);
             const double P11 = S22 * di, P22 = S11 * di, P12 = -S12 * di;
             const double Afull[3][3] = {{c.A[0], c.A[1], c.A[2]}, {c.A[1], c.A[3], c.A[4]}, {c.A[2], c.A[4], c.A[5]}};
 #pragma unroll
             for (int r = 0; r < 3; r++) {
+              double fld[SG_RK];
 #pragma unroll
-              for (int d = 0; d < SG_CD; d++) rw[(size_t)d * 64 + r] = c.Jf[r][d];
-              rw[(size_t)4 * 64 + r] = c.Js[r]; rw[(size_t)5 * 64 + r] = c.b[r]; rw[(size_t)6 * 64 + r] = c.f[r];
+              for (int d = 0; d < SG_CD; d++) fld[d] = c.Jf[r][d];
+              fld[4] = c.Js[r]; fld[5] = c.b[r]; fld[6] = c.f[r];
+              fld[7] = Afull[r][0] * c.f[0] + Afull[r][1] * c.f[1] + Afull[r][2] * c.f[2];
+              fld[8] = Afull[r][0]; fld[9] = Afull[r][1]; fld[10] = Afull[r][2];
+              fld[11] = r == 0 ? c.R : (r == 2 ? __hiloint2double(0, sl) : 0.0);
+              fld[12] = P11; fld[13] = P12; fld[14] = P22; fld[15] = c.invm * c.Js[r];
+              double2* rw = (double2*)(W.crow + SG_ROW_INDEX(i, env >> 3, 0, ql + r, nwb8));
 #pragma unroll
-              for (int k2 = 0; k2 < 3; k2++) rw[(size_t)(7 + k2) * 64 + r] = Afull[r][k2];
+              for (int pr = 0; pr < SG_RK / 2; pr++) rw[(size_t)pr * 64] = make_double2(fld[2 * pr], fld[2 * pr + 1]);
             }
-            rw[(size_t)10 * 64 + 0] = c.R; rw[(size_t)10 * 64 + 1] = c.invm;
-            ((int*)(rw + (size_t)10 * 64 + 2))[0] = sl; ((int*)(rw + (size_t)10 * 64 + 2))[1] = 0;
-            rw[(size_t)11 * 64 + 0] = 0; rw[(size_t)12 * 64 + 0] = 0;
-            rw[(size_t)11 * 64 + 1] = P11; rw[(size_t)12 * 64 + 1] = P12;
-            rw[(size_t)11 * 64 + 2] = P12; rw[(size_t)12 * 64 + 2] = P22;
           }
           if (!a.rowlayout) {
           double* ro = W.crec + SG_REC_INDEX(i, env / SG_EPW, 0, 2 * (env % SG_EPW) + half, nwb);
@@ -583,6 +612,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           }
         }
       }
+      SG_T(5);
       // ---- equality rows ----
       double eqR[R], eqb[R], eqf[R];
       double tbp = 0, tjp = 0, tAp = 0;
@@ -614,9 +644,11 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         }
         __syncthreads();
         double g[SG_CD] = {0, 0, 0, 0};
+#pragma unroll 1
         for (int pass = 0; pass < (shared_slider ? 2 : 1); pass++)
 #pragma unroll
           for (int k = 0; k < CPL; k++)
+#pragma unroll 1
             for (int ii = 0; ii < 32; ii++) {
               int i = 32 * k + ii;
               if (i >= nmaxs) break;
@@ -650,6 +682,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         __syncthreads();
       };
       recompute_a();
+      SG_T(6);
       {
         double cp = 0, tJap = 0;
 #pragma unroll
@@ -696,9 +729,9 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
               for (int r = 0; r < 3; r++) ro[(26 + r) * SG_SPW] = 0.0;
               }
               if (a.rowlayout) {
-                double* rw = W.crow + SG_ROW_INDEX(i, env >> 3, 6, 8 * (env & 7) + 4 * half, (a.nenv + 7) / 8);
 #pragma unroll
-                for (int r = 0; r < 3; r++) rw[r] = 0.0;
+                for (int r = 0; r < 3; r++)  // f and A f (one pair)
+                  *(double2*)(W.crow + SG_ROW_INDEX(i, env >> 3, 6, 8 * (env & 7) + 4 * half + r, (a.nenv + 7) / 8)) = make_double2(0.0, 0.0);
               }
             }
           }
@@ -706,6 +739,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           recompute_a();
         }
       }
+      SG_T(7);
       // ---- export the rest of the constraint problem ----
 #pragma unroll
       for (int r = 0; r < R; r++) {
@@ -738,6 +772,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
     }
   }
 
+  SG_T(8);
   // ---------------- store state ----------------
   __syncthreads();
   if (is_chain_lane && !CHAINK) {
@@ -754,6 +789,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
     if (CHAINK) { if (status | flags) atomicOr(&W.status[env], status | flags); }
     else W.status[env] = status | flags;
   }
+  SG_T(9);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1231,11 +1267,12 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
 
   bool running = valid;
   int iters = 0;
-  // my row's column in the wave's block, biased by 6 fields (immediate offsets).  Lane r == 3 carries no row: it reads and
-  // writes the dummy block, which only ever holds zeros (its force stays 0), so its row values are 0 without any select
-  const double* const row0 = (valid && r < 3) ? W.crow + SG_ROW_INDEX(0, blockIdx.x, 6, lane, nwb) : W.crow + SG_ROW_INDEX(0, nwb, 6, lane, nwb);
-  double* const row0_store = (double*)row0;
-  const size_t slot_stride = (size_t)(nwb + 1) * SG_RK * 64;
+  // my row's column in the wave's block, biased by 4 field pairs (immediate offsets -4096 .. 3072).  Lane r == 3 carries no
+  // row: it reads the all-zero dummy block, so its row values are 0 without any select, and writes to the sink block
+  const bool has_row = valid && r < 3;
+  const double2* const row0 = (const double2*)(W.crow + SG_ROW_INDEX(0, has_row ? (int)blockIdx.x : nwb, 8, lane, nwb));
+  const ptrdiff_t sink_off = has_row ? 0 : (ptrdiff_t)(SG_RK / 2) * 64;  // in double2 units: block nwb -> block nwb + 1
+  const size_t slot_stride = (size_t)(nwb + 2) * (SG_RK / 2) * 64;        // in double2 units
 
   for (int it = 0; it < max_iter; it++) {
     if (!__ballot(running)) break;
@@ -1293,22 +1330,24 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         }
       }
       const int nsl = mine ? ns : 0;
-      struct Row { double J0, J1, J2, J3, Js, b, f, A0, A1, A2, sh, Pa, Pb; };
-      auto load_row = [&](Row& w, const double* p) {
-        w.J0 = p[-6 * 64]; w.J1 = p[-5 * 64]; w.J2 = p[-4 * 64]; w.J3 = p[-3 * 64]; w.Js = p[-2 * 64]; w.b = p[-1 * 64]; w.f = p[0];
-        w.A0 = p[1 * 64]; w.A1 = p[2 * 64]; w.A2 = p[3 * 64]; w.sh = p[4 * 64]; w.Pa = p[5 * 64]; w.Pb = p[6 * 64];
+      struct Row { double2 j01, j23, jsb, fw, a01, a2s, p12, p3i; };
+      auto load_row = [&](Row& w, const double2* p) {
+        w.j01 = p[-4 * 64]; w.j23 = p[-3 * 64]; w.jsb = p[-2 * 64]; w.fw = p[-1 * 64];
+        w.a01 = p[0]; w.a2s = p[1 * 64]; w.p12 = p[2 * 64]; w.p3i = p[3 * 64];
       };
-      auto update_row = [&](Row& w, int i, double* ps) {
+      auto update_row = [&](Row& w, int i, const double2* pl) {
         if (i < nsl) {
-          const double J0 = w.J0, J1 = w.J1, J2 = w.J2, J3 = w.J3, Js = w.Js, bb = w.b, fo = w.f, A0 = w.A0, A1 = w.A1, A2 = w.A2;
-          const double Rr = sg_qb<0>(w.sh), invm = sg_qb<1>(w.sh);
-          const int sl = __double2loint(sg_qb<2>(w.sh));
+          const double J0 = w.j01.x, J1 = w.j01.y, J2 = w.j23.x, J3 = w.j23.y, Js = w.jsb.x, bb = w.jsb.y, fo = w.fw.x, wv = w.fw.y;
+          const double A0 = w.a01.x, A1 = w.a01.y, A2 = w.a2s.x, P11 = w.p12.x, P12 = w.p12.y, P22 = w.p3i.x, JsI = w.p3i.y;
+          const double Rr = sg_qb<0>(w.a2s.y);
+          const int sl = __double2loint(sg_qb<2>(w.a2s.y));
           const double as_ = *(sl >= 0 ? &Las[sl] : &Lzero[0]);  // branch-free: "no slider" reads a zero word
           const double res = ((bb + Js * as_) + (J0 * aF[0] + J1 * aF[1])) + ((Rr * fo + J2 * aF[2]) + J3 * aF[3]);  // 0 on lane 3
-          const double o0 = sg_qb<0>(fo), o1 = sg_qb<1>(fo), o2 = sg_qb<2>(fo);
-          // ---- normal or ray update
-          const double wv = A0 * o0 + A1 * o1 + A2 * o2;
-          const double denom = sg_qsum(fo * wv), num = sg_qsum(fo * res);
+          const double o0 = sg_qb<0>(fo);
+          // ---- normal or ray update (wv = row r of A f, kept with f)
+          double denom = fo * wv, num = fo * res;  // two quad sums, interleaved so the DPP read-after-write hazards hide each other
+          { const double t0 = sg_dpp<0xB1>(denom), t1 = sg_dpp<0xB1>(num); denom += t0; num += t1; }
+          { const double t0 = sg_dpp<0x4E>(denom), t1 = sg_dpp<0x4E>(num); denom += t0; num += t1; }
           double x = denom >= SG_MINVAL ? sg_div(-num, denom) : 0.0;
           x = (o0 + x * o0 < 0) ? -1.0 : x;
           double gr = fo + x * fo;
@@ -1317,13 +1356,14 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
             gr = r == 0 ? (gn < 0 ? 0.0 : gn) : 0.0;
           }
           const double g0 = sg_qb<0>(gr);
-          // ---- friction rows with the normal force fixed
-          const double bc = res - (A1 * o1 + A2 * o2) + A0 * (g0 - o0);
+          // ---- friction rows with the normal force fixed: every lane solves the 2 x 2 block, so the new force triple is
+          //      known on all lanes without broadcasts
+          const double bc = (res - wv) + A0 * g0;   // res - (A f)_r + A_r0 f_0 + A_r0 (g0 - f_0)
           const double bmu = bc * mur;
           const double b1 = sg_qb<1>(bmu), b2 = sg_qb<2>(bmu);
-          const double u = -(w.Pa * b1 + w.Pb * b2);     // rows 1, 2; 0 on lanes 0, 3 and when the friction block is singular
-          const double val = sg_qsum(u * u) - g0 * g0;
-          double vr = u * mur;
+          const double u1 = -(P11 * b1 + P12 * b2), u2 = -(P12 * b1 + P22 * b2);  // 0 when the friction block is singular
+          const double val = (u1 * u1 + u2 * u2) - g0 * g0;
+          double v1 = u1 * mu0, v2 = u2 * mu1;
           if (!(val < 1e-10) && !(g0 < SG_MINVAL)) {  // uncommon: outside the cone -- the generic Newton iteration, on all four lanes
             const double a11 = sg_qb<1>(A1), a12 = sg_qb<1>(A2), a22 = sg_qb<2>(A2);
             const double Ac[4] = {a11, a12, a12, a22}, bcv[2] = {sg_qb<1>(bc), sg_qb<2>(bc)}, mu[2] = {mu0, mu1};
@@ -1334,33 +1374,42 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
               s2 = sqrt(g0 * g0 / fmax(SG_MINVAL, s2));
               v[0] *= s2; v[1] *= s2;
             }
-            vr = r == 1 ? v[0] : (r == 2 ? v[1] : 0.0);
+            v1 = v[0]; v2 = v[1];
           }
           const bool nofric = g0 < SG_MINVAL;
-          double fn = r == 0 ? g0 : (nofric ? 0.0 : vr);  // lane 3: vr = 0
+          v1 = nofric ? 0.0 : v1; v2 = nofric ? 0.0 : v2;
+          double fn = r == 0 ? g0 : (r == 1 ? v1 : (r == 2 ? v2 : 0.0));
+          double wn = (A0 * g0 + A1 * v1) + A2 * v2;   // row r of A f_new
           double dr = fn - fo;
-          const double d0 = sg_qb<0>(dr), d1 = sg_qb<1>(dr), d2 = sg_qb<2>(dr);
-          const double Ad = A0 * d0 + A1 * d1 + A2 * d2;
-          const double change = sg_qsum(dr * (0.5 * Ad + res));
+          const double change = sg_qsum(dr * (0.5 * (wn - wv) + res));
           const bool reject = change > 1e-10;
           fn = reject ? fo : fn;
+          wn = reject ? wv : wn;
           dr = reject ? 0.0 : dr;
           imp_acc -= (reject || r != 0) ? 0.0 : change;
-          const double jsdf = sg_qsum(Js * dr);
-          *((sl >= 0 && r == 0) ? &Las[sl] : &Lzero[1 + lane]) = as_ + invm * jsdf;  // other lanes write to their sink word
-          const double g0_ = sg_qsum(J0 * dr), g1_ = sg_qsum(J1 * dr), g2_ = sg_qsum(J2 * dr), g3_ = sg_qsum(J3 * dr);
+          // five quad sums (invm J_s' df and J_F' df), stage by stage
+          double jsdf = JsI * dr, g0_ = J0 * dr, g1_ = J1 * dr, g2_ = J2 * dr, g3_ = J3 * dr;
+          {
+            const double t0 = sg_dpp<0xB1>(jsdf), t1 = sg_dpp<0xB1>(g0_), t2 = sg_dpp<0xB1>(g1_), t3 = sg_dpp<0xB1>(g2_), t4 = sg_dpp<0xB1>(g3_);
+            jsdf += t0; g0_ += t1; g1_ += t2; g2_ += t3; g3_ += t4;
+          }
+          {
+            const double t0 = sg_dpp<0x4E>(jsdf), t1 = sg_dpp<0x4E>(g0_), t2 = sg_dpp<0x4E>(g1_), t3 = sg_dpp<0x4E>(g2_), t4 = sg_dpp<0x4E>(g3_);
+            jsdf += t0; g0_ += t1; g1_ += t2; g2_ += t3; g3_ += t4;
+          }
+          *((sl >= 0 && r == 0) ? &Las[sl] : &Lzero[1 + lane]) = as_ + jsdf;  // other lanes write to their sink word
 #pragma unroll
           for (int q = 0; q < SG_CD; q++) aF[q] += (Minv[4 * q] * g0_ + Minv[4 * q + 1] * g1_) + (Minv[4 * q + 2] * g2_ + Minv[4 * q + 3] * g3_);
-          w.f = fn;
+          w.fw = make_double2(fn, wn);
         }
-        ps[0] = w.f;
+        ((double2*)pl)[sink_off - 1 * 64] = w.fw;
       };
       // slots 0 .. SG_CAP+1 exist in memory (two spare slots), so the look-ahead never needs a bound check
       Row ra, rb;
-      double* pa = row0_store;
+      const double2* pa = row0;
       load_row(ra, pa);
       for (int i = 0; i < nsmax; i += 2) {
-        double* pb = pa + slot_stride;
+        const double2* pb = pa + slot_stride;
         load_row(rb, pb);
         update_row(ra, i, pa);
         pa = pb + slot_stride;
@@ -1390,13 +1439,13 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           if (lim_active >> k & 1) gF[k / 2] += mylim[k] * mylim[3 * SG_MAXLIM + k];
       }
       for (int i = 0; i < ns; i++) {
-        const double* p = row0 + (size_t)i * slot_stride;
-        const double fr = p[0], Js = p[-2 * 64], sh = p[4 * 64];
-        const double invm = sg_qb<1>(sh);
-        const int sl = __double2loint(sg_qb<2>(sh));
-        const double jsf = sg_qsum(Js * fr);
-        if (sl >= 0 && r == 0) Las[sl] += invm * jsf;
-        const double t0 = sg_qsum(p[-6 * 64] * fr), t1 = sg_qsum(p[-5 * 64] * fr), t2 = sg_qsum(p[-4 * 64] * fr), t3 = sg_qsum(p[-3 * 64] * fr);
+        const double2* p = row0 + (size_t)i * slot_stride;
+        const double2 j01 = p[-4 * 64], j23 = p[-3 * 64];
+        const double fr = p[-1 * 64].x, JsI = p[3 * 64].y;
+        const int sl = __double2loint(sg_qb<2>(p[1 * 64].y));
+        const double jsf = sg_qsum(JsI * fr);
+        if (sl >= 0 && r == 0) Las[sl] += jsf;
+        const double t0 = sg_qsum(j01.x * fr), t1 = sg_qsum(j01.y * fr), t2 = sg_qsum(j23.x * fr), t3 = sg_qsum(j23.y * fr);
         if (r == 0) { gF[0] += t0; gF[1] += t1; gF[2] += t2; gF[3] += t3; }
       }
     }

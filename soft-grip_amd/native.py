@@ -35,7 +35,9 @@ def lib():
         raise ImportError(
             "libsoftgrip.so is missing (%s).  Build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
             "there is no CPU fallback for the simulator." % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    import torch  # noqa: F401  -- first: PyTorch-ROCm ships its own HIP runtime, and the process must end up with ONE (loading
+    # libsoftgrip.so first would pull in /opt/rocm's copy and torch would then find no devices)
+    L = C.CDLL(os.environ.get("SOFTGRIP_LIB", LIB_PATH))  # SOFTGRIP_LIB: the profiling build of scripts/section_profile.py
     vp, dp, ip, i64 = C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong
     L.sg_last_error.restype = C.c_char_p
     L.sg_version.restype = C.c_char_p
