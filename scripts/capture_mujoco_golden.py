@@ -1,0 +1,116 @@
+"""Golden capture for the day a compatible MuJoCo is at hand (SURVEY.md 8(c) gate iv).
+
+Neither MuJoCo nor mujoco_py exists in the build container or on the GPU boxes, so parity of the oracle with MuJoCo itself is
+UNPINNED.  This script is the other half of that gate: run it on any machine that has the reference checkout and
+either `mujoco_py` (2.0.2.x, what the reference used) or the `mujoco` bindings of a release that still compiles
+`<composite type="box|ellipsoid">` (2.x), commit the .npz it writes under tests/golden/, and tests/test_mujoco_golden.py
+turns from "skipped: MuJoCo parity not yet measured" into the real parity test (oracle vs MuJoCo, 1e-4 abs on every sensor
+sample, plus the compiled-model counts the MJCF compiler must reproduce).
+
+usage: capture_mujoco_golden.py --xml <reference>/data/gripper/soft_experiments_softbox_adjusted_for_2_fingers.xml \
+           --stiffness 700 903.6948543200572 300 1400 --out tests/golden/mujoco_softbox.npz
+
+It drives MuJoCo exactly as reference environment/manenv.py:44-109 and create_dataset.py:33-72 do: stiffness on joints 11..63 and
+tendon 0, reset + forward + sim_start(1) steps, then 200 env steps of sim_step(7) substeps under the 40 idle / close at 40 /
+toggle at 120 schedule.
+"""
+import argparse
+import json
+
+import numpy as np
+
+JOINT_IDS, TENDON_IDS = list(range(11, 64)), [0]
+SIM_START, SIM_STEP, N_STEPS, START_STEP, OPEN_CLOSE_DIV = 1, 7, 200, 40, 80
+
+
+class PyBackend:  # mujoco_py 2.0.x
+    def __init__(self, xml):
+        import mujoco_py
+        self.mj = mujoco_py
+        self.model = mujoco_py.load_model_from_path(xml)
+        self.sim = mujoco_py.MjSim(self.model)
+        self.data = self.sim.data
+        self.version = "mujoco_py " + getattr(mujoco_py, "__version__", "?")
+
+    def reset(self): self.sim.reset()
+    def forward(self): self.sim.forward()
+    def step(self): self.sim.step()
+    def iters(self): return int(self.data.solver_iter)
+
+
+class NewBackend:  # `mujoco` bindings
+    def __init__(self, xml):
+        import mujoco
+        self.mj = mujoco
+        self.model = mujoco.MjModel.from_xml_path(xml)
+        self.data = mujoco.MjData(self.model)
+        self.version = "mujoco " + mujoco.__version__
+
+    def reset(self): self.mj.mj_resetData(self.model, self.data)
+    def forward(self): self.mj.mj_forward(self.model, self.data)
+    def step(self): self.mj.mj_step(self.model, self.data)
+    def iters(self): return int(np.sum(np.atleast_1d(self.data.solver_niter)))
+
+
+def backend(xml):
+    try:
+        return PyBackend(xml)
+    except ImportError:
+        return NewBackend(xml)
+
+
+def schedule():
+    """ctrl value to set before env step t (None = unchanged): reference create_dataset.py:46-60"""
+    out, closing = [], True
+    for t in range(N_STEPS):
+        c = None
+        if t == START_STEP:
+            c, closing = -0.2, False
+        elif t > START_STEP and (t - START_STEP) % OPEN_CLOSE_DIV == 0:
+            c = 0.2 if not closing else -0.2
+            closing = not closing
+        out.append(c)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--xml", required=True)
+    ap.add_argument("--stiffness", type=float, nargs="+", default=[700.0, 903.6948543200572, 300.0, 1400.0])
+    ap.add_argument("--out", required=True)
+    args = ap.parse_args()
+    B = backend(args.xml)
+    m = B.model
+    meta = {"mujoco": B.version, "xml": args.xml.split("/")[-1],
+            "counts": {k: int(getattr(m, k)) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "ntendon", "neq", "nsensordata")},
+            "total_mass": float(np.sum(m.body_mass)), "tendon_length0": [float(x) for x in m.tendon_length0],
+            "dof_invweight0": [float(x) for x in m.dof_invweight0], "tendon_invweight0": [float(x) for x in m.tendon_invweight0],
+            "body_invweight0": np.asarray(m.body_invweight0).tolist(), "opt": {"timestep": float(m.opt.timestep), "iterations": int(m.opt.iterations),
+                                                                            "tolerance": float(m.opt.tolerance), "impratio": float(m.opt.impratio)}}
+    sens = np.zeros((len(args.stiffness), N_STEPS + 1, m.nsensordata))
+    ncon = np.zeros((len(args.stiffness), N_STEPS + 1), dtype=np.int32)
+    nefc = np.zeros_like(ncon)
+    iters = np.zeros_like(ncon)
+    qpos = np.zeros((len(args.stiffness), N_STEPS + 1, m.nq))
+    for i, k in enumerate(args.stiffness):
+        for j in JOINT_IDS:
+            m.jnt_stiffness[j] = k
+        for t in TENDON_IDS:
+            m.tendon_stiffness[t] = k
+        B.reset(); B.forward()
+        for _ in range(SIM_START):
+            B.step()
+        sens[i, 0], ncon[i, 0], nefc[i, 0], iters[i, 0], qpos[i, 0] = B.data.sensordata, B.data.ncon, B.data.nefc, B.iters(), B.data.qpos
+        for t, c in enumerate(schedule()):
+            if c is not None:
+                B.data.ctrl[:] = c
+            for _ in range(SIM_STEP):
+                B.step()
+            sens[i, t + 1], ncon[i, t + 1], nefc[i, t + 1], iters[i, t + 1], qpos[i, t + 1] = B.data.sensordata, B.data.ncon, B.data.nefc, B.iters(), B.data.qpos
+    np.savez_compressed(args.out, stiffness=np.array(args.stiffness), sensordata=sens, ncon=ncon, nefc=nefc, iters=iters, qpos=qpos,
+                        meta=json.dumps(meta))
+    print("wrote", args.out, meta["mujoco"], meta["counts"])
+
+
+if __name__ == "__main__":
+    main()
