@@ -236,11 +236,21 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   SgPgsArgs ga;
   ga.H = b->dH; ga.elem = b->delem; ga.w = b->w; ga.nenv = b->n;
   const size_t lds = sizeof(double) * ((size_t)(5 * 8 + 2) * H.nelem + 16 * 4 * SG_MAXLIM + 72);
+  // rows kernel: joint-fix rows per lane (template parameter, the smallest instantiated value >= ceil(nelem / 8)); its LDS
+  // arrays are padded to 8 * NSL rows
+  static const int nsl_set[] = {8, 14, 20, 26, 29, 32};
+  int nsl = 32;
+  for (int v : nsl_set)
+    if (v * 8 >= H.nelem) { nsl = v; break; }
+  const size_t lds_rows = sizeof(double) * ((size_t)(5 * 8 + 2) * 8 * nsl + 16 * 4 * SG_MAXLIM + 72);
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<26>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<29>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -275,10 +285,15 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     HIPCHK(hipGetLastError());
     if (k < nfwd) {
       if (b->pipeline == 2) {
-        const int nsl = (H.nelem + 7) / 8;
-        if (nsl <= 16) hipLaunchKernelGGL(sg_pgs_rows_kernel<16>, dim3((b->n + 7) / 8), dim3(64), lds, s, ga);
-        else if (nsl <= 24) hipLaunchKernelGGL(sg_pgs_rows_kernel<24>, dim3((b->n + 7) / 8), dim3(64), lds, s, ga);
-        else hipLaunchKernelGGL(sg_pgs_rows_kernel<32>, dim3((b->n + 7) / 8), dim3(64), lds, s, ga);
+        const dim3 grid((b->n + 7) / 8);
+        switch (nsl) {
+          case 8: hipLaunchKernelGGL(sg_pgs_rows_kernel<8>, grid, dim3(64), lds_rows, s, ga); break;
+          case 14: hipLaunchKernelGGL(sg_pgs_rows_kernel<14>, grid, dim3(64), lds_rows, s, ga); break;
+          case 20: hipLaunchKernelGGL(sg_pgs_rows_kernel<20>, grid, dim3(64), lds_rows, s, ga); break;
+          case 26: hipLaunchKernelGGL(sg_pgs_rows_kernel<26>, grid, dim3(64), lds_rows, s, ga); break;
+          case 29: hipLaunchKernelGGL(sg_pgs_rows_kernel<29>, grid, dim3(64), lds_rows, s, ga); break;
+          default: hipLaunchKernelGGL(sg_pgs_rows_kernel<32>, grid, dim3(64), lds_rows, s, ga); break;
+        }
       }
       else hipLaunchKernelGGL(sg_pgs_kernel, dim3((b->n + SG_EPW - 1) / SG_EPW), dim3(64), lds, s, ga);
       HIPCHK(hipGetLastError());

@@ -1205,7 +1205,7 @@ __device__ __forceinline__ double sg_gsum8(double x) {
   return x;
 }
 
-template <int NSL>  // NSL >= ceil(nelem / 8): joint-fix rows per lane, unrolled (their LDS reads issue back to back)
+template <int NSL>  // NSL >= ceil(nelem / 8): joint-fix rows per lane, unrolled and padded (straight-line code, LDS reads issue back to back)
 __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x, le = lane >> 3, g = lane & 7, c = g >> 2, r = g & 3;
@@ -1220,22 +1220,30 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   const int max_iter = H.iterations;
   const bool valid = env < a.nenv && W.pending[env] != 0;
   if (!__ballot(valid)) return;
-  double* Las = lds + (size_t)le * 4 * N;
-  double *Lf = Las + N, *Lb = Lf + N, *LR = Lb + N;
-  double* Lri = lds + (size_t)8 * 4 * N + (size_t)le * N;
-  double* Linvm = lds + (size_t)8 * 5 * N;
-  double* Lcoef = Linvm + N;
-  double* mylim = Lcoef + N + (size_t)(le * 2 + c) * 4 * SG_MAXLIM;
-  double* Lzero = Lcoef + N + (size_t)16 * 4 * SG_MAXLIM;  // [0]: a word that stays 0 (reads of "no slider"), [1 + lane]: write sink
+  // LDS: joint-fix rows padded to NR = 8 * NSL per env (padding rows are neutral: b = 0, R = 1, 1/(A+R) = 0, so their update
+  // is a no-op and the row loop needs no bound test).  Per env: AF[j] = (a_s, f) [the only pair written], BR[j] = (b, R),
+  // RI[j] = 1 / (A_jj + R_j); shared by the 8 envs: IC[j] = (1/m, tendon coefficient).  A row is three 16-byte reads + one 8-byte.
+  constexpr int NR = 8 * NSL;
+  double2* const AF = (double2*)lds + (size_t)le * NR;
+  double2* const BR = (double2*)lds + (size_t)8 * NR + (size_t)le * NR;
+  double* const RI = lds + (size_t)32 * NR + (size_t)le * NR;
+  double2* const IC = (double2*)(lds + (size_t)40 * NR);
+  double* mylim = lds + (size_t)42 * NR + (size_t)(le * 2 + c) * 4 * SG_MAXLIM;
+  double* Lzero = lds + (size_t)42 * NR + (size_t)16 * 4 * SG_MAXLIM;  // [0]: a word that stays 0 (reads of "no slider"), [1 + lane]: write sink
   if (lane == 0) Lzero[0] = 0.0;
-  for (int j = lane; j < N; j += 64) { Linvm[j] = 1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]); Lcoef[j] = a.elem[(size_t)SGE_COEF * N + j]; }
-  if (valid)
-    for (int j = g; j < N; j += 8) {
-      size_t o = (size_t)env * N + j;
-      double Rr = W.eqR[o], im = 1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]);
-      Las[j] = W.as[o]; Lf[j] = W.eqf[o]; Lb[j] = W.eqb[o]; LR[j] = Rr;
-      Lri[j] = sg_div(1.0, im + Rr);  // 1 / (A_jj + R_j): sg_div(res, A_jj + R_j) == res * this
+  for (int j = lane; j < NR; j += 64)
+    IC[j] = j < N ? make_double2(1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]), a.elem[(size_t)SGE_COEF * N + j]) : make_double2(0.0, 0.0);
+  for (int j = g; j < NR; j += 8) {
+    double2 af = make_double2(0.0, 0.0), br = make_double2(0.0, 1.0);
+    double ri = 0.0;
+    if (valid && j < N) {
+      const size_t o = (size_t)env * N + j;
+      const double Rr = W.eqR[o], im = 1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]);
+      af = make_double2(W.as[o], W.eqf[o]); br = make_double2(W.eqb[o], Rr);
+      ri = sg_div(1.0, im + Rr);  // 1 / (A_jj + R_j): sg_div(res, A_jj + R_j) == res * this
     }
+    AF[j] = af; BR[j] = br; RI[j] = ri;
+  }
   const size_t st = 2 * (size_t)(env < a.nenv ? env : 0) + c;
   int ns = 0, lim_active = 0, shared = 0;
   double Minv[16], aF[SG_CD] = {0, 0, 0, 0};
@@ -1277,22 +1285,24 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   for (int it = 0; it < max_iter; it++) {
     if (!__ballot(running)) break;
     double imp_acc = 0, tJap = 0;
-    double ael[NSL];
+    double ael[NSL], fnw[NSL], imc[NSL];
+    if (running) {
+      // joint-fix rows: unconstrained scalar rows, so the step d = -res / (A + R) always lowers the cost (change =
+      // -res^2 / (2 (A + R)) <= 0) and the generic "revert if the cost went up" test of the other row types can never fire
 #pragma unroll
-    for (int t = 0; t < NSL; t++) {
-      const int j = g + 8 * t;
-      ael[t] = 0;
-      if (running && j < N) {
-        const double ae = Las[j], Rr = LR[j], im = Linvm[j], old = Lf[j];
-        const double res = Lb[j] + ae + Rr * old;
-        double fn = old - res * Lri[j];
+      for (int t = 0; t < NSL; t++) {
+        const int j = g + 8 * t;
+        const double2 af = AF[j], br = BR[j], ic = IC[j];
+        const double ri = RI[j];
+        const double ae = af.x, old = af.y, Rr = br.y, im = ic.x;
+        const double res = br.x + ae + Rr * old;
+        const double fn = old - res * ri;
         const double d = fn - old, change = 0.5 * d * d * (im + Rr) + d * res;
-        const bool reject = change > 1e-10;
-        fn = reject ? old : fn;
-        imp_acc -= reject ? 0.0 : change;
-        Lf[j] = fn;
-        ael[t] = ae + im * (fn - old);
-        tJap += Lcoef[j] * ael[t];
+        imp_acc -= change;
+        fnw[t] = fn;
+        ael[t] = ae + im * d;
+        tJap += ic.y * ael[t];
+        imc[t] = im * ic.y;
       }
     }
     {
@@ -1305,10 +1315,9 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         tf = tfn;
       }
       const double dft = tf - old;
+      if (running) {
 #pragma unroll
-      for (int t = 0; t < NSL; t++) {
-        const int j = g + 8 * t;
-        if (running && j < N) Las[j] = ael[t] + Linvm[j] * Lcoef[j] * dft;
+        for (int t = 0; t < NSL; t++) AF[g + 8 * t] = make_double2(ael[t] + imc[t] * dft, fnw[t]);
       }
     }
     __syncthreads();
@@ -1341,7 +1350,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           const double A0 = w.a01.x, A1 = w.a01.y, A2 = w.a2s.x, P11 = w.p12.x, P12 = w.p12.y, P22 = w.p3i.x, JsI = w.p3i.y;
           const double Rr = sg_qb<0>(w.a2s.y);
           const int sl = __double2loint(sg_qb<2>(w.a2s.y));
-          const double as_ = *(sl >= 0 ? &Las[sl] : &Lzero[0]);  // branch-free: "no slider" reads a zero word
+          const double as_ = *(sl >= 0 ? (const double*)(AF + sl) : &Lzero[0]);  // branch-free: "no slider" reads a zero word
           const double res = ((bb + Js * as_) + (J0 * aF[0] + J1 * aF[1])) + ((Rr * fo + J2 * aF[2]) + J3 * aF[3]);  // 0 on lane 3
           const double o0 = sg_qb<0>(fo);
           // ---- normal or ray update (wv = row r of A f, kept with f)
@@ -1397,7 +1406,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
             const double t0 = sg_dpp<0x4E>(jsdf), t1 = sg_dpp<0x4E>(g0_), t2 = sg_dpp<0x4E>(g1_), t3 = sg_dpp<0x4E>(g2_), t4 = sg_dpp<0x4E>(g3_);
             jsdf += t0; g0_ += t1; g1_ += t2; g2_ += t3; g3_ += t4;
           }
-          *((sl >= 0 && r == 0) ? &Las[sl] : &Lzero[1 + lane]) = as_ + jsdf;  // other lanes write to their sink word
+          *((sl >= 0 && r == 0) ? (double*)(AF + sl) : &Lzero[1 + lane]) = as_ + jsdf;  // other lanes write to their sink word
 #pragma unroll
           for (int q = 0; q < SG_CD; q++) aF[q] += (Minv[4 * q] * g0_ + Minv[4 * q + 1] * g1_) + (Minv[4 * q + 2] * g2_ + Minv[4 * q + 3] * g3_);
           w.fw = make_double2(fn, wn);
@@ -1428,7 +1437,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   __syncthreads();
   // ---- fresh M^-1 J' f from the final forces
   if (valid)
-    for (int j = g; j < N; j += 8) Las[j] = Linvm[j] * (Lf[j] + Lcoef[j] * tf);
+    for (int j = g; j < N; j += 8) AF[j].x = IC[j].x * (AF[j].y + IC[j].y * tf);
   __syncthreads();
   double gF[SG_CD] = {0, 0, 0, 0};
   for (int pass = 0; pass < 2; pass++) {  // stream 0 then stream 1: deterministic when they share a slider
@@ -1444,7 +1453,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         const double fr = p[-1 * 64].x, JsI = p[3 * 64].y;
         const int sl = __double2loint(sg_qb<2>(p[1 * 64].y));
         const double jsf = sg_qsum(JsI * fr);
-        if (sl >= 0 && r == 0) Las[sl] += jsf;
+        if (sl >= 0 && r == 0) AF[sl].x += jsf;
         const double t0 = sg_qsum(j01.x * fr), t1 = sg_qsum(j01.y * fr), t2 = sg_qsum(j23.x * fr), t3 = sg_qsum(j23.y * fr);
         if (r == 0) { gF[0] += t0; gF[1] += t1; gF[2] += t2; gF[3] += t3; }
       }
@@ -1461,7 +1470,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     }
   }
   if (valid) {
-    for (int j = g; j < N; j += 8) W.as[(size_t)env * N + j] = Las[j];
+    for (int j = g; j < N; j += 8) W.as[(size_t)env * N + j] = AF[j].x;
     if (g == 0) W.iters[env] = iters;
   }
 }
