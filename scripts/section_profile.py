@@ -18,6 +18,8 @@ from softgrip_amd.create_dataset import episode_schedule  # noqa: E402
 
 NAMES = ["0 prologue/load", "1 FINISH", "2 BEGIN elements", "3 narrowphase", "4 envelope checks", "5 contact rows+export",
          "6 eq rows+recompute_a", "7 warmstart test", "8 export rest", "9 store state"]
+PGS_NAMES = {10: "loop head / imp reduction", 11: "joint-fix rows", 12: "tendon row + write-back", 13: "limit rows", 14: "contact rows",
+             15: "exit", 16: "final M^-1 J' f + export"}
 
 
 def main():
@@ -47,6 +49,11 @@ def main():
             print("step %d, %s: %.0f cycles per wavefront and launch" % (t, windows[t], v.sum()))
             for k, name in enumerate(NAMES):
                 print("   %-26s %8.0f  %5.1f %%" % (name, v[k], 100 * v[k] / v.sum()))
+            w = np.array(buf[:32], dtype=np.float64) / ((n // 8) * 7)  # 7 PGS launches per sg_step call, 8 envs per wavefront
+            tot = sum(w[k] for k in PGS_NAMES)
+            print("   sg_pgs_rows_kernel: %.0f cycles per wavefront and launch (after the prologue)" % tot)
+            for k, name in PGS_NAMES.items():
+                print("   %-26s %8.0f  %5.1f %%" % (name, w[k], 100 * w[k] / max(tot, 1)))
 
 
 if __name__ == "__main__":

@@ -1282,8 +1282,10 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   const ptrdiff_t sink_off = has_row ? 0 : (ptrdiff_t)(SG_RK / 2) * 64;  // in double2 units: block nwb -> block nwb + 1
   const size_t slot_stride = (size_t)(nwb + 2) * (SG_RK / 2) * 64;        // in double2 units
 
+  SG_T0();
   for (int it = 0; it < max_iter; it++) {
     if (!__ballot(running)) break;
+    SG_T(10);
     double imp_acc = 0, tJap = 0;
     double ael[NSL], fnw[NSL], imc[NSL];
     if (running) {
@@ -1305,6 +1307,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         imc[t] = im * ic.y;
       }
     }
+    SG_T(11);
     {
       double Ja = tJap;
       Ja = sg_gsum8(Ja);
@@ -1321,6 +1324,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
       }
     }
     __syncthreads();
+    SG_T(12);
     for (int pass = 0; pass < 2; pass++) {
       const bool mine = running && ((c == 0 || !shared) ? pass == 0 : pass == 1);
       if (!__ballot(mine)) continue;
@@ -1338,6 +1342,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           }
         }
       }
+      SG_T(13);
       const int nsl = mine ? ns : 0;
       struct Row { double2 j01, j23, jsb, fw, a01, a2s, p12, p3i; };
       auto load_row = [&](Row& w, const double2* p) {
@@ -1426,6 +1431,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         update_row(rb, i + 1, pb);
       }
       __syncthreads();
+      SG_T(14);
     }
     double imp = imp_acc;
     imp = sg_gsum8(imp);
@@ -1434,6 +1440,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
       if (imp * pgs_scale < tolerance) running = false;
     }
   }
+  SG_T(15);
   __syncthreads();
   // ---- fresh M^-1 J' f from the final forces
   if (valid)
@@ -1473,4 +1480,5 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     for (int j = g; j < N; j += 8) W.as[(size_t)env * N + j] = AF[j].x;
     if (g == 0) W.iters[env] = iters;
   }
+  SG_T(16);
 }
