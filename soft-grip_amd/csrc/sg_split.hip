@@ -99,8 +99,10 @@ struct Smem2 {
   double boxp[SG_MAXCH * SG_CG][3], boxm[SG_MAXCH * SG_CG][9];
   double ve[R * 64], asme[R * 64], we[R * 64], as[R * 64];
   StageRec2 stage[SG_MAXCH][32 * CPL];
-  int owner[R * 64];
+  int owner[R * 64];                                  // bit c set: chain c has a contact on this element's slider
+  unsigned short pairs[SG_MAXCH * SG_CG * (R * 64 + 2)];  // broadphase survivors, (box << 12) | element, in contact order
 };
+#define SG_PAIR_CENTER 0xFFF  // element code of the object's centre sphere
 
 __device__ __forceinline__ double wave_sum2(double x) {
 #pragma unroll
@@ -414,90 +416,104 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             cpos[r][0] = EL(SGE_GX, e) + ax[0] * dq; cpos[r][1] = EL(SGE_GY, e) + ax[1] * dq; cpos[r][2] = EL(SGE_GZ, e) + ax[2] * dq;
             if (!(qe[r] > EL(SGE_QLO, e) && qe[r] < EL(SGE_QHI, e))) unsupported = 1;
             Sm.ve[e] = ve[r]; Sm.asme[e] = asme[r]; Sm.we[e] = we[r];
-            Sm.owner[e] = -1;
+            Sm.owner[e] = 0;
+            Sm.as[e] = qe[r];  // scratch until recompute_a: the dense narrowphase below reads other lanes' slider positions
           }
         }
         SG_T(2);
         __syncthreads();
         int overflow = 0;
-        // real loops over the (chain, box) pairs: unrolled, the four inlined narrowphase copies push the kernel far beyond the
-        // instruction cache (64 KB per CU pair) and every wavefront streams its code from L2
+        // ---- broadphase: (box, element) pairs that pass MuJoCo's bounding-sphere filter and the grown-box test, listed in
+        //      contact order (chain, box, element; the object's centre sphere precedes the box's capsules).  Real loops: unrolled,
+        //      the inlined narrowphase copies push the kernel far beyond the instruction cache
+        int np = 0;
 #pragma unroll 1
-        for (int c = 0; c < SG_MAXCH; c++) {
-          if (c >= nchain) break;
+        for (int b = 0; b < nchain * SG_CG; b++) {
+          const int c = b / SG_CG, g = b % SG_CG;
           const SgChain& Cc = Sm.chain[c];
-          int nsc = 0;
-#pragma unroll 1
-          for (int g = 0; g < SG_CG; g++) {
-            if (g >= Cc.ngeom) break;
-            const int b = c * SG_CG + g;
-            double bp[3], bm[9], sz[3];
+          if (g >= Cc.ngeom) continue;
+          double bp[3], bm[9], sz[3];
 #pragma unroll
-            for (int k = 0; k < 3; k++) { bp[k] = Sm.boxp[b][k]; sz[k] = Cc.g_size[g][k]; }
+          for (int k = 0; k < 3; k++) { bp[k] = Sm.boxp[b][k]; sz[k] = Cc.g_size[g][k]; }
 #pragma unroll
-            for (int k = 0; k < 9; k++) bm[k] = Sm.boxm[b][k];
-            const double rb = Cc.g_rbound[g];
-            if (H.has_center) {
-              double dif[3] = {bp[0] - H.center_pos[0], bp[1] - H.center_pos[1], bp[2] - H.center_pos[2]}, bound = H.center_radius + rb + H.con_margin;
-              ConRec rc;
-              if (dot3(dif, dif) <= bound * bound && sphere_box(H.center_pos, H.center_radius, bp, bm, sz, H.con_margin, rc) && rc.dist < H.con_margin) {
-                int slot = nsc;
-                if (slot < 32 * CPL) {
-                  if (lane == 0) {
-                    StageRec2& s = Sm.stage[c][slot];
-                    s.dist = rc.dist; s.sl = -1; s.box = g;
-                    for (int k = 0; k < 3; k++) { s.pos[k] = rc.pos[k]; s.n[k] = rc.n[k]; }
-                  }
-                  nsc = slot + 1;
-                  touch |= 1 << b;
-                } else overflow = 1;
-              }
-            }
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-              int e = r * 64 + lane, n = 0;
-              ConRec r0, r1;
-              bool v0 = false, v1 = false;
-              // broadphase: bounding spheres (MuJoCo's filter), then the capsule centre against the box grown by the capsule's
-              // bounding radius in the box frame -- still conservative, so the contact set is unchanged
-              double dif[3] = {cpos[r][0] - bp[0], cpos[r][1] - bp[1], cpos[r][2] - bp[2]}, bound = H.cap_rbound + rb + H.con_margin;
-              bool near = e < N && dot3(dif, dif) <= bound * bound;
-              if (near) {
-                double lc[3], grow = H.cap_rbound + H.con_margin;
-                mulmatT3(lc, bm, dif);
-                near = fabs(lc[0]) <= sz[0] + grow && fabs(lc[1]) <= sz[1] + grow && fabs(lc[2]) <= sz[2] + grow;
-              }
-              if (near) {
-                double cax[3] = {EL(SGE_CX, e), EL(SGE_CY, e), EL(SGE_CZ, e)};
-                int mk = capsule_box(cpos[r], cax, H.cap_radius, H.cap_hl, bp, bm, sz, H.con_margin, r0, r1);
-                v0 = (mk & 1) && r0.dist < H.con_margin;
-                v1 = (mk & 2) && r1.dist < H.con_margin;
-                n = (int)v0 + (int)v1;
-              }
-              unsigned long long m1 = __ballot(n >= 1), m2 = __ballot(n >= 2);
-              int base = nsc + lanes_below2(m1) + lanes_below2(m2);
-              int total = __popcll(m1) + __popcll(m2);
-              if (v0 && base < 32 * CPL) {
-                StageRec2& s = Sm.stage[c][base];
-                s.dist = r0.dist; s.sl = e; s.box = g;
-                for (int q = 0; q < 3; q++) { s.pos[q] = r0.pos[q]; s.n[q] = r0.n[q]; }
-              }
-              if (v1 && base + (int)v0 < 32 * CPL) {
-                StageRec2& s = Sm.stage[c][base + (int)v0];
-                s.dist = r1.dist; s.sl = e; s.box = g;
-                for (int q = 0; q < 3; q++) { s.pos[q] = r1.pos[q]; s.n[q] = r1.n[q]; }
-              }
-              if (n > 0) {
-                int o = Sm.owner[e];
-                Sm.owner[e] = (o < 0 || o == c) ? c : 2;
-              }
-              if (total) touch |= 1 << b;
-              nsc += total;
-              if (nsc > 32 * CPL) { nsc = 32 * CPL; overflow = 1; }
+          for (int k = 0; k < 9; k++) bm[k] = Sm.boxm[b][k];
+          const double rb = Cc.g_rbound[g];
+          if (H.has_center) {
+            double dif[3] = {bp[0] - H.center_pos[0], bp[1] - H.center_pos[1], bp[2] - H.center_pos[2]}, bound = H.center_radius + rb + H.con_margin;
+            if (dot3(dif, dif) <= bound * bound) {
+              if (lane == 0) Sm.pairs[np] = (unsigned short)((b << 12) | SG_PAIR_CENTER);
+              np++;
             }
           }
-          if (c == 0) ns0 = nsc; else ns1 = nsc;
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            const int e = r * 64 + lane;
+            // bounding spheres, then the capsule centre against the box grown by the capsule's bounding radius in the box frame --
+            // still conservative, so the contact set is unchanged
+            double dif[3] = {cpos[r][0] - bp[0], cpos[r][1] - bp[1], cpos[r][2] - bp[2]}, bound = H.cap_rbound + rb + H.con_margin;
+            bool near = e < N && dot3(dif, dif) <= bound * bound;
+            if (near) {
+              double lc[3], grow = H.cap_rbound + H.con_margin;
+              mulmatT3(lc, bm, dif);
+              near = fabs(lc[0]) <= sz[0] + grow && fabs(lc[1]) <= sz[1] + grow && fabs(lc[2]) <= sz[2] + grow;
+            }
+            const unsigned long long m = __ballot(near);
+            if (near) Sm.pairs[np + lanes_below2(m)] = (unsigned short)((b << 12) | e);
+            np += __popcll(m);
+          }
         }
+        __syncthreads();
+        // ---- narrowphase over the dense pair list, 64 pairs per pass (every lane works; the per-box loop ran 8 passes at 10-30 %
+        //      lane occupancy), then ordered compaction into the two finger streams
+        int nsc[SG_MAXCH] = {0, 0};
+#pragma unroll 1
+        for (int p0 = 0; p0 < np; p0 += 64) {
+          const bool have = p0 + lane < np;
+          const int code = have ? (int)Sm.pairs[p0 + lane] : 0, b = code >> 12, e = code & 0xFFF, c = b / SG_CG, g = b % SG_CG;
+          const bool is_center = have && e == SG_PAIR_CENTER;
+          ConRec r0, r1;
+          bool v0 = false, v1 = false;
+          double bp[3], bm[9], sz[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) { bp[k] = Sm.boxp[b][k]; sz[k] = Sm.chain[c].g_size[g][k]; }
+#pragma unroll
+          for (int k = 0; k < 9; k++) bm[k] = Sm.boxm[b][k];
+          if (__ballot(is_center)) {
+            if (is_center) v0 = sphere_box(H.center_pos, H.center_radius, bp, bm, sz, H.con_margin, r0) && r0.dist < H.con_margin;
+          }
+          if (have && !is_center) {
+            const double dq = Sm.as[e] - EL(SGE_QPOS0, e);
+            double cp[3] = {EL(SGE_GX, e) + EL(SGE_AX, e) * dq, EL(SGE_GY, e) + EL(SGE_AY, e) * dq, EL(SGE_GZ, e) + EL(SGE_AZ, e) * dq};
+            double cax[3] = {EL(SGE_CX, e), EL(SGE_CY, e), EL(SGE_CZ, e)};
+            int mk = capsule_box(cp, cax, H.cap_radius, H.cap_hl, bp, bm, sz, H.con_margin, r0, r1);
+            v0 = (mk & 1) && r0.dist < H.con_margin;
+            v1 = (mk & 2) && r1.dist < H.con_margin;
+          }
+          const int n = (int)v0 + (int)v1;
+#pragma unroll
+          for (int cc = 0; cc < SG_MAXCH; cc++) {
+            const bool mine = have && c == cc;
+            const unsigned long long m1 = __ballot(mine && n >= 1), m2 = __ballot(mine && n >= 2);
+            const int base = nsc[cc] + lanes_below2(m1) + lanes_below2(m2);
+            if (mine && v0 && base < 32 * CPL) {
+              StageRec2& s = Sm.stage[cc][base];
+              s.dist = r0.dist; s.sl = is_center ? -1 : e; s.box = g;
+              for (int q = 0; q < 3; q++) { s.pos[q] = r0.pos[q]; s.n[q] = r0.n[q]; }
+            }
+            if (mine && v1 && base + (int)v0 < 32 * CPL) {
+              StageRec2& s = Sm.stage[cc][base + (int)v0];
+              s.dist = r1.dist; s.sl = e; s.box = g;
+              for (int q = 0; q < 3; q++) { s.pos[q] = r1.pos[q]; s.n[q] = r1.n[q]; }
+            }
+            nsc[cc] += __popcll(m1) + __popcll(m2);
+            if (nsc[cc] > 32 * CPL) { nsc[cc] = 32 * CPL; overflow = 1; }
+          }
+          if (n > 0 && !is_center) atomicOr(&Sm.owner[e], 1 << c);
+#pragma unroll
+          for (int bb = 0; bb < SG_MAXCH * SG_CG; bb++)
+            if (__ballot(n > 0 && b == bb)) touch |= 1 << bb;
+        }
+        ns0 = nsc[0]; ns1 = nsc[1];
         if (overflow) flags |= SG_FLAG_CONTACTFULL;
       }
       SG_T(3);
@@ -534,7 +550,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 #pragma unroll
       for (int r = 0; r < R; r++) {
         int e = r * 64 + lane;
-        if (e < N && Sm.owner[e] == 2) shared_slider = 1;
+        if (e < N && Sm.owner[e] == 3) shared_slider = 1;
       }
       shared_slider = __ballot(shared_slider) != 0;
 
