@@ -93,7 +93,6 @@ struct ChainLds2 {
 
 template <int R, int CPL>
 struct Smem2 {
-  SgChain chain[SG_MAXCH];  // the chains' model constants, staged once per kernel (the chain lanes read them hundreds of times)
   ChainKin K[SG_MAXCH];
   ChainLds2 cs[SG_MAXCH];
   double boxp[SG_MAXCH * SG_CG][3], boxm[SG_MAXCH * SG_CG][9];
@@ -113,19 +112,26 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
 
-// section timing for scripts/section_profile.py (build_native.py --prof): wave 0..n lane 0 adds the cycles since the previous
-// stamp to W.secprof[k].  Compiled out of the product library.
+// section timing for scripts/section_profile.py (build_native.py --prof): every wavefront sums the cycles between stamps per
+// section in registers and adds them to W.secprof[] once, at its end.  Compiled out of the product library.
 #ifdef SG_SECTION_PROF
-#define SG_T0() unsigned long long t_prev_ = __builtin_readcyclecounter()
-#define SG_T(k)                                                                   \
-  do {                                                                            \
-    unsigned long long t_now_ = __builtin_readcyclecounter();                     \
-    if (threadIdx.x == 0) atomicAdd(&a.w.secprof[k], t_now_ - t_prev_);           \
-    t_prev_ = __builtin_readcyclecounter();                                       \
+#define SG_T0() unsigned long long t_prev_ = __builtin_readcyclecounter(), t_acc_[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define SG_T(k)                                                   \
+  do {                                                            \
+    unsigned long long t_now_ = __builtin_readcyclecounter();     \
+    t_acc_[k] += t_now_ - t_prev_;                                \
+    t_prev_ = __builtin_readcyclecounter();                       \
+  } while (0)
+#define SG_TEND()                                                 \
+  do {                                                            \
+    if (threadIdx.x == 0)                                         \
+      for (int k_ = 0; k_ < 17; k_++)                             \
+        if (t_acc_[k_]) atomicAdd(&a.w.secprof[k_], t_acc_[k_]);  \
   } while (0)
 #else
 #define SG_T0()
 #define SG_T(k)
+#define SG_TEND()
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -146,14 +152,9 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   const int half = lane >> 5;
   const bool high = half != 0;
   const bool is_chain_lane = (lane & 31) == 0 && half < nchain;
-  {
-    static_assert(sizeof(SgChain) % 8 == 0, "SgChain must be a whole number of doubles");
-    const double* src = (const double*)&H.chain[0];
-    double* dst = (double*)&Sm.chain[0];
-    for (int i = lane; i < (int)(SG_MAXCH * sizeof(SgChain) / 8); i += 64) dst[i] = src[i];
-  }
-  __syncthreads();
-  const SgChain& C = Sm.chain[half < nchain ? half : 0];
+  // the chains' model constants are read straight from the plan header (a few cached loads per wavefront); the chain stage itself,
+  // which read them hundreds of times, runs in sg_chain_kernel
+  const SgChain& C = H.chain[half < nchain ? half : 0];
   ChainLds2& CS = Sm.cs[half];
   SgWork& W = a.w;
 
@@ -332,20 +333,28 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
       flags |= (__ballot(bad & 1) ? 1 : 0) | (__ballot(bad & 2) ? 2 : 0);
     } else {
       // ---- chains ----
-      if (CHAINK) {  // the chain stage ran in sg_chain_kernel: import its hand-off record
-        if (is_chain_lane) {
+      if (CHAINK) {  // the chain stage ran in sg_chain_kernel: import its hand-off record, the 32 lanes of a half sharing the loads
+        if (half < nchain) {
           const double* ch = W.chh + ((size_t)env * 2 + half) * SG_CHW;
-          double* kd = (double*)&Sm.K[half];
-          for (int i = 0; i < 48; i++) kd[i] = ch[SGH_K + i];
-          for (int i = 0; i < 16; i++) CS.Minv[i] = ch[SGH_MINV + i];
-          for (int d = 0; d < SG_CD; d++) { CS.qacc_smooth[d] = ch[SGH_QSM + d]; CS.v[d] = ch[SGH_V + d]; CS.w[d] = ch[SGH_W + d]; }
-          for (int g = 0; g < SG_CG; g++) {
-            for (int k = 0; k < 3; k++) Sm.boxp[half * SG_CG + g][k] = ch[SGH_BOX + 12 * g + k];
-            for (int k = 0; k < 9; k++) Sm.boxm[half * SG_CG + g][k] = ch[SGH_BOX + 12 * g + 3 + k];
-          }
-          CS.lim_active = (int)ch[SGH_LIMACT];
-          for (int k = 0; k < SG_MAXLIM; k++) {
-            CS.lim_sign[k] = ch[SGH_LIMSIGN + k]; CS.lim_R[k] = ch[SGH_LIMR + k]; CS.lim_b[k] = ch[SGH_LIMB + k]; CS.lim_f[k] = ch[SGH_LIMF + k];
+          double* const kd = (double*)&Sm.K[half];
+          double* const box = &Sm.boxp[half * SG_CG][0];
+          double* const boxm = &Sm.boxm[half * SG_CG][0];
+          double* const lim = CS.lim_sign;  // lim_sign, lim_R, lim_b, lim_f are contiguous, as SGH_LIMSIGN .. SGH_LIMF are
+#pragma unroll
+          for (int j0 = 0; j0 < SG_CHW; j0 += 32) {
+            const int j = j0 + (lane & 31);
+            const double v = j < SG_CHW ? ch[j] : 0.0;
+            if (j >= SGH_QSM && j < SGH_QSM + SG_CD) CS.qacc_smooth[j - SGH_QSM] = v;
+            else if (j >= SGH_K && j < SGH_K + 48) kd[j - SGH_K] = v;
+            else if (j >= SGH_MINV && j < SGH_MINV + 16) CS.Minv[j - SGH_MINV] = v;
+            else if (j >= SGH_V && j < SGH_V + SG_CD) CS.v[j - SGH_V] = v;
+            else if (j >= SGH_W && j < SGH_W + SG_CD) CS.w[j - SGH_W] = v;
+            else if (j >= SGH_BOX && j < SGH_BOX + 12 * SG_CG) {
+              const int g = (j - SGH_BOX) / 12, k = (j - SGH_BOX) % 12;
+              if (k < 3) box[3 * g + k] = v; else boxm[9 * g + k - 3] = v;
+            }
+            else if (j == SGH_LIMACT) CS.lim_active = (int)v;
+            else if (j >= SGH_LIMSIGN && j < SGH_LIMSIGN + 4 * SG_MAXLIM) lim[j - SGH_LIMSIGN] = v;
           }
         }
       } else if (is_chain_lane) {
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 #pragma unroll 1
         for (int b = 0; b < nchain * SG_CG; b++) {
           const int c = b / SG_CG, g = b % SG_CG;
-          const SgChain& Cc = Sm.chain[c];
+          const SgChain& Cc = H.chain[c];
           if (g >= Cc.ngeom) continue;
           double bp[3], bm[9], sz[3];
 #pragma unroll
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           bool v0 = false, v1 = false;
           double bp[3], bm[9], sz[3];
 #pragma unroll
-          for (int k = 0; k < 3; k++) { bp[k] = Sm.boxp[b][k]; sz[k] = Sm.chain[c].g_size[g][k]; }
+          for (int k = 0; k < 3; k++) { bp[k] = Sm.boxp[b][k]; sz[k] = H.chain[c].g_size[g][k]; }
 #pragma unroll
           for (int k = 0; k < 9; k++) bm[k] = Sm.boxm[b][k];
           if (__ballot(is_center)) {
@@ -768,13 +777,12 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
       if (is_chain_lane) {
         W.ns[st] = myn < SG_CAP ? myn : SG_CAP;
         W.lim_active[st] = CS.lim_active;
-#pragma unroll
-        for (int k = 0; k < SG_MAXLIM; k++) {
-          W.lim[((size_t)0 * SG_MAXLIM + k) * S + st] = CS.lim_sign[k]; W.lim[((size_t)1 * SG_MAXLIM + k) * S + st] = CS.lim_R[k];
-          W.lim[((size_t)2 * SG_MAXLIM + k) * S + st] = CS.lim_b[k]; W.lim[((size_t)3 * SG_MAXLIM + k) * S + st] = CS.lim_f[k];
-        }
-#pragma unroll
-        for (int d = 0; d < SG_CD; d++) W.saF[(size_t)d * S + st] = aF[d];
+      }
+      if (half < nchain) {  // the 32 lanes of a half write its chain's 4 x SG_MAXLIM limit values (contiguous in CS) and M^-1 J' f
+        static_assert(4 * SG_MAXLIM == 32, "one limit value per lane of a half");
+        const int i = lane & 31;
+        W.lim[(size_t)i * S + st] = (&CS.lim_sign[0])[i];
+        if (i < SG_CD) W.saF[(size_t)i * S + st] = i == 0 ? aF[0] : (i == 1 ? aF[1] : (i == 2 ? aF[2] : aF[3]));
       }
       if (lane == 0) {
         W.envh[(size_t)0 * a.nenv + env] = tb; W.envh[(size_t)1 * a.nenv + env] = tR;
@@ -806,6 +814,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
     else W.status[env] = status | flags;
   }
   SG_T(9);
+  SG_TEND();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1497,4 +1506,5 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     if (g == 0) W.iters[env] = iters;
   }
   SG_T(16);
+  SG_TEND();
 }
