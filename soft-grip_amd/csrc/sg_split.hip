@@ -100,6 +100,8 @@ struct Smem2 {
   StageRec2 stage[SG_MAXCH][32 * CPL];
   int owner[R * 64];                                  // bit c set: chain c has a contact on this element's slider
   unsigned short pairs[SG_MAXCH * SG_CG * (R * 64 + 2)];  // broadphase survivors, (box << 12) | element, in contact order
+  unsigned short eslot[R * 64][SG_MAXCH * SG_CG];         // per element and box: first contact slot | (contact count << 8)
+  double cval[SG_MAXCH][32 * CPL];                        // per contact slot: invm * Js' f (its push on the slider)
 };
 #define SG_PAIR_CENTER 0xFFF  // element code of the object's centre sphere
 
@@ -426,6 +428,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             if (!(qe[r] > EL(SGE_QLO, e) && qe[r] < EL(SGE_QHI, e))) unsupported = 1;
             Sm.ve[e] = ve[r]; Sm.asme[e] = asme[r]; Sm.we[e] = we[r];
             Sm.owner[e] = 0;
+            *(unsigned long long*)&Sm.eslot[e][0] = 0ull;
             Sm.as[e] = qe[r];  // scratch until recompute_a: the dense narrowphase below reads other lanes' slider positions
           }
         }
@@ -514,6 +517,10 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
               s.dist = r1.dist; s.sl = e; s.box = g;
               for (int q = 0; q < 3; q++) { s.pos[q] = r1.pos[q]; s.n[q] = r1.n[q]; }
             }
+            if (mine && n > 0 && !is_center) {
+              const int room = 32 * CPL - base, nst = n < room ? n : (room > 0 ? room : 0);
+              Sm.eslot[e][b] = (unsigned short)(base | (nst << 8));
+            }
             nsc[cc] += __popcll(m1) + __popcll(m2);
             if (nsc[cc] > 32 * CPL) { nsc[cc] = 32 * CPL; overflow = 1; }
           }
@@ -592,6 +599,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           contact_build(c, rec, Sm.K[half], nd, CS.Minv, CS.v, CS.qacc_smooth, CS.w, C.b_invw_tran[bi], sl, ax, ve_, as_, we_, im, bw, H);
           csl_[k] = sl; cinvm[k] = c.invm;
           cjsf[k] = c.Js[0] * c.f[0] + c.Js[1] * c.f[1] + c.Js[2] * c.f[2];
+          Sm.cval[half][i] = c.invm * cjsf[k];
           ccost0[k] = c.f[0] * (0.5 * c.R * c.f[0] + c.b[0]) + c.f[1] * (0.5 * c.R * c.f[1] + c.b[1]) + c.f[2] * (0.5 * c.R * c.f[2] + c.b[2]);
 #pragma unroll
           for (int d = 0; d < SG_CD; d++) cg[k][d] = c.Jf[0][d] * c.f[0] + c.Jf[1][d] * c.f[1] + c.Jf[2][d] * c.f[2];
@@ -662,24 +670,25 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 
       double aF[SG_CD];
       auto recompute_a = [&]() {
+        __syncthreads();
+        // slider accelerations M^-1 J' f: every element lane adds the pushes of its own contacts, finger 0's slots then finger 1's,
+        // ascending -- the order of the solver's stream sweep (a serial loop over all contact slots used to do this)
 #pragma unroll
         for (int r = 0; r < R; r++) {
           int e = r * 64 + lane;
-          if (e < N) Sm.as[e] = invm[r] * (eqf[r] + coef[r] * tf);
+          if (e < N) {
+            double as_ = invm[r] * (eqf[r] + coef[r] * tf);
+#pragma unroll
+            for (int cb = 0; cb < SG_MAXCH * SG_CG; cb++) {
+              const int u = Sm.eslot[e][cb], i0 = u & 0xFF, nst = u >> 8;
+              if (nst >= 1) as_ += Sm.cval[cb / SG_CG][i0];
+              if (nst >= 2) as_ += Sm.cval[cb / SG_CG][i0 + 1];
+            }
+            Sm.as[e] = as_;
+          }
         }
         __syncthreads();
         double g[SG_CD] = {0, 0, 0, 0};
-#pragma unroll 1
-        for (int pass = 0; pass < (shared_slider ? 2 : 1); pass++)
-#pragma unroll
-          for (int k = 0; k < CPL; k++)
-#pragma unroll 1
-            for (int ii = 0; ii < 32; ii++) {
-              int i = 32 * k + ii;
-              if (i >= nmaxs) break;
-              bool mine = (lane & 31) == ii && i < myn && (!shared_slider || half == pass);
-              if (mine && csl_[k] >= 0) Sm.as[csl_[k]] += cinvm[k] * cjsf[k];
-            }
 #pragma unroll
         for (int k = 0; k < CPL; k++)
 #pragma unroll
@@ -748,6 +757,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 #pragma unroll
             for (int d = 0; d < SG_CD; d++) cg[k][d] = 0;
             if (i < myn) {
+              Sm.cval[half][i] = 0.0;
               if (!a.rowlayout) {
               double* ro = W.crec + SG_REC_INDEX(i, env / SG_EPW, 0, 2 * (env % SG_EPW) + half, nwb);
 #pragma unroll
