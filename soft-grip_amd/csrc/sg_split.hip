@@ -1482,23 +1482,45 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     for (int j = g; j < N; j += 8) AF[j].x = IC[j].x * (AF[j].y + IC[j].y * tf);
   __syncthreads();
   double gF[SG_CD] = {0, 0, 0, 0};
-  for (int pass = 0; pass < 2; pass++) {  // stream 0 then stream 1: deterministic when they share a slider
-    if (valid && c == pass) {
-      if (r == 0) {
+  for (int pass = 0; pass < 2; pass++) {  // one pass, or finger 0 then finger 1 when they share a slider (deterministic sums)
+    const bool mine = valid && ((c == 0 || !shared) ? pass == 0 : pass == 1);
+    if (!__ballot(mine)) continue;
+    if (mine && r == 0) {
 #pragma unroll
-        for (int k = 0; k < SG_MAXLIM; k++)
-          if (lim_active >> k & 1) gF[k / 2] += mylim[k] * mylim[3 * SG_MAXLIM + k];
-      }
-      for (int i = 0; i < ns; i++) {
-        const double2* p = row0 + (size_t)i * slot_stride;
-        const double2 j01 = p[-4 * 64], j23 = p[-3 * 64];
-        const double fr = p[-1 * 64].x, JsI = p[3 * 64].y;
-        const int sl = __double2loint(sg_qb<2>(p[1 * 64].y));
-        const double jsf = sg_qsum(JsI * fr);
+      for (int k = 0; k < SG_MAXLIM; k++)
+        if (lim_active >> k & 1) gF[k / 2] += mylim[k] * mylim[3 * SG_MAXLIM + k];
+    }
+    const int nsl = mine ? ns : 0;
+    struct FRow { double2 j01, j23; double fr, sh, JsI; };
+    auto load_f = [&](FRow& w, const double2* p) {
+      w.j01 = p[-4 * 64]; w.j23 = p[-3 * 64]; w.fr = p[-1 * 64].x; w.sh = p[1 * 64].y; w.JsI = p[3 * 64].y;
+    };
+    auto add_f = [&](const FRow& w, int i) {
+      if (i < nsl) {
+        const int sl = __double2loint(sg_qb<2>(w.sh));
+        double jsf = w.JsI * w.fr, t0 = w.j01.x * w.fr, t1 = w.j01.y * w.fr, t2 = w.j23.x * w.fr, t3 = w.j23.y * w.fr;
+        {
+          const double u0 = sg_dpp<0xB1>(jsf), u1 = sg_dpp<0xB1>(t0), u2 = sg_dpp<0xB1>(t1), u3 = sg_dpp<0xB1>(t2), u4 = sg_dpp<0xB1>(t3);
+          jsf += u0; t0 += u1; t1 += u2; t2 += u3; t3 += u4;
+        }
+        {
+          const double u0 = sg_dpp<0x4E>(jsf), u1 = sg_dpp<0x4E>(t0), u2 = sg_dpp<0x4E>(t1), u3 = sg_dpp<0x4E>(t2), u4 = sg_dpp<0x4E>(t3);
+          jsf += u0; t0 += u1; t1 += u2; t2 += u3; t3 += u4;
+        }
         if (sl >= 0 && r == 0) AF[sl].x += jsf;
-        const double t0 = sg_qsum(j01.x * fr), t1 = sg_qsum(j01.y * fr), t2 = sg_qsum(j23.x * fr), t3 = sg_qsum(j23.y * fr);
         if (r == 0) { gF[0] += t0; gF[1] += t1; gF[2] += t2; gF[3] += t3; }
       }
+    };
+    FRow fa, fb;  // the next record is requested before the current one is summed (spare slots: no bound check)
+    const double2* pa = row0;
+    load_f(fa, pa);
+    for (int i = 0; i < nsmax; i += 2) {
+      const double2* pb = pa + slot_stride;
+      load_f(fb, pb);
+      add_f(fa, i);
+      pa = pb + slot_stride;
+      load_f(fa, pa);
+      add_f(fb, i + 1);
     }
     __syncthreads();
   }
