@@ -20,6 +20,8 @@ NAMES = ["0 prologue/load", "1 FINISH", "2 BEGIN elements", "3 narrowphase", "4 
          "6 eq rows+recompute_a", "7 warmstart test", "8 export rest", "9 store state"]
 PGS_NAMES = {10: "loop head / imp reduction", 11: "joint-fix rows", 12: "tendon row + write-back", 13: "limit rows", 14: "contact rows",
              15: "exit", 16: "final M^-1 J' f + export"}
+CHAIN_NAMES = {17: "load state", 18: "FINISH", 19: "kinematics", 20: "dynamics (M, M^-1, bias, tendon)", 21: "hand-off stores, boxes",
+               22: "limit rows", 23: "store state"}
 
 
 def main():
@@ -54,6 +56,11 @@ def main():
             print("   sg_pgs_rows_kernel: %.0f cycles per wavefront and launch (after the prologue)" % tot)
             for k, name in PGS_NAMES.items():
                 print("   %-26s %8.0f  %5.1f %%" % (name, w[k], 100 * w[k] / max(tot, 1)))
+            cw = np.array(buf[:32], dtype=np.float64) / ((n // 64) * 2 * 8)  # 8 chain launches per sg_step call, 64 chains per wavefront
+            tot = sum(cw[k] for k in CHAIN_NAMES)
+            print("   sg_chain_kernel: %.0f cycles per wavefront and launch" % tot)
+            for k, name in CHAIN_NAMES.items():
+                print("   %-34s %8.0f  %5.1f %%" % (name, cw[k], 100 * cw[k] / max(tot, 1)))
 
 
 if __name__ == "__main__":

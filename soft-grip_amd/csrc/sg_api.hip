@@ -278,7 +278,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     p.do_begin = k < nfwd;
     p.sens = (k == nfwd) ? sens : nullptr;
     if (nfwd == 0) { p.do_begin = 0; p.do_finish = 0; }
-    hipLaunchKernelGGL(sg_chain_kernel, dim3((2 * b->n + 63) / 64), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(sg_chain_kernel, dim3(2 * ((b->n + 63) / 64)), dim3(64), 0, s, p);
     HIPCHK(hipGetLastError());
     p.sens = nullptr;  // the chain kernel writes the sensors (they all sit on finger sites)
     phase(p);

@@ -75,6 +75,16 @@ SG_HD double sg_div(double a, double b) {
 #endif
 }
 
+// "some lane of the wavefront has x": a wavefront-uniform condition, so the guarded block is a real (scalar) branch that the
+// compiler cannot flatten into predicated code executed by everyone.  Host (lane-serial emulation): just x.
+SG_HD bool sg_any(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(x) != 0;
+#else
+  return x;
+#endif
+}
+
 // constraint impedance d(pos) (App. B.5)
 SG_HD double impedance(const double* si, double pos, double margin) {
   double s0 = fmin(SG_MAXIMP, fmax(SG_MINIMP, si[0])), s1 = fmin(SG_MAXIMP, fmax(SG_MINIMP, si[1])), s2 = fmax(0.0, si[2]),
@@ -698,7 +708,8 @@ SG_HD void limits_build(const SgChain& C, const double* q, const double* v, cons
       L.sign[k] = -side; L.R[k] = 1; L.b[k] = 0; L.f[k] = 0;
       if (!C.limited[d]) continue;
       double dist = side * (C.range[d][sd] - q[d]);
-      if (dist < C.jmargin[d]) {
+      const bool on = dist < C.jmargin[d];
+      if (sg_any(on) && on) {  // a joint sits at one of its limits only now and then: the ~150-instruction row is skipped as a whole
         double sg = -side, imp = impedance(C.lim_solimp[d], dist, C.jmargin[d]);
         double R = fmax(SG_MINVAL, (1 - imp) / imp * C.invw[d]);
         double aref = -C.lim_B[d] * sg * v[d] - C.lim_K[d] * imp * (dist - C.jmargin[d]);

@@ -117,7 +117,7 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
 // section timing for scripts/section_profile.py (build_native.py --prof): every wavefront sums the cycles between stamps per
 // section in registers and adds them to W.secprof[] once, at its end.  Compiled out of the product library.
 #ifdef SG_SECTION_PROF
-#define SG_T0() unsigned long long t_prev_ = __builtin_readcyclecounter(), t_acc_[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define SG_T0() unsigned long long t_prev_ = __builtin_readcyclecounter(), t_acc_[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define SG_T(k)                                                   \
   do {                                                            \
     unsigned long long t_now_ = __builtin_readcyclecounter();     \
@@ -127,7 +127,7 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
 #define SG_TEND()                                                 \
   do {                                                            \
     if (threadIdx.x == 0)                                         \
-      for (int k_ = 0; k_ < 17; k_++)                             \
+      for (int k_ = 0; k_ < 24; k_++)                             \
         if (t_acc_[k_]) atomicAdd(&a.w.secprof[k_], t_acc_[k_]);  \
   } while (0)
 #else
@@ -828,19 +828,21 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// chain kernel: ONE LANE PER FINGER CHAIN (64 chains per wavefront).  The chain stage is a few thousand strictly serial
+// chain kernel: ONE LANE PER FINGER CHAIN (64 chains per wavefront, all with the same chain index).  The chain stage is a few thousand strictly serial
 // instructions; inside the phase kernel it ran on 2 of 64 lanes of every env's wavefront, here 64 chains share one
 // instruction stream.  FINISH: qacc of the chain, its sensors, warmstart, integration.  BEGIN: kinematics, mass matrix,
 // bias, tendon/actuator, limit rows, box poses -> hand-off record (enum SGH_*) for the phase and PGS kernels.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void sg_chain_kernel(SgPhaseArgs a) {
-  const int lane = threadIdx.x;
-  const size_t st = (size_t)blockIdx.x * 64 + lane;
+  // wavefront 2 b + c holds chain c of envs 64 b .. 64 b + 63: the chain index is uniform over the wavefront, so the chain's model
+  // constants (SgChain, ~230 doubles read all over the stage) are scalar loads / SGPR operands instead of per-lane vector loads
+  const int lane = threadIdx.x, c = blockIdx.x & 1, env = (int)(blockIdx.x >> 1) * 64 + lane;
+  SG_T0();
   const SgPlanHeader& H = *a.H;
   const int nv = H.nv, nu = H.nu;
   const size_t S = 2 * (size_t)a.nenv;
-  if (st >= S) return;
-  const int env = (int)(st >> 1), c = (int)(st & 1);
+  if (env >= a.nenv) return;
+  const size_t st = 2 * (size_t)env + c;
   if (a.mask && !a.mask[env]) return;
   SgWork& W = a.w;
   if (a.first && c == 0) { W.status[env] = 0; if (!a.do_finish) W.pending[env] = 0; }
@@ -869,6 +871,7 @@ __global__ __launch_bounds__(64) void sg_chain_kernel(SgPhaseArgs a) {
   double* ch = W.chh + st * SG_CHW;
   bool bad_acc = false;
 
+  SG_T(17);
   if (a.do_finish && W.pending[env]) {
     double aF[SG_CD], qacc_c[SG_CD];
 #pragma unroll
@@ -949,6 +952,7 @@ __global__ __launch_bounds__(64) void sg_chain_kernel(SgPhaseArgs a) {
     }
   }
 
+  SG_T(18);
   if (a.do_begin && !bad_acc) {
     int bad = 0;
 #pragma unroll
@@ -959,16 +963,23 @@ __global__ __launch_bounds__(64) void sg_chain_kernel(SgPhaseArgs a) {
       ChainKin K;
       ChainDyn D;
       chain_kinematics(C, q, K);
+      SG_T(19);
       chain_dynamics(C, K, q, v, act, ctrl, kk, kten, H.gravity, D);
+      SG_T(20);
+      // hand-off record: assembled in registers and written as 16-byte stores (a lane's record is 1280 contiguous bytes; every store
+      // instruction touches 64 different lines, so their number is what counts)
+      double rec[SG_CHW];
 #pragma unroll
-      for (int d = 0; d < SG_CD; d++) { ch[SGH_QSM + d] = D.qacc_smooth[d]; ch[SGH_QFRC + d] = D.qfrc_smooth[d]; ch[SGH_V + d] = v[d]; ch[SGH_W + d] = w[d]; }
-      ch[SGH_ACTDOT] = D.act_dot;
+      for (int i = 0; i < SG_CHW; i++) rec[i] = 0.0;
 #pragma unroll
-      for (int i = 0; i < 16; i++) { ch[SGH_M + i] = D.M[i]; ch[SGH_MINV + i] = D.Minv[i]; W.sMinv[(size_t)i * S + st] = D.Minv[i]; }
+      for (int d = 0; d < SG_CD; d++) { rec[SGH_QSM + d] = D.qacc_smooth[d]; rec[SGH_QFRC + d] = D.qfrc_smooth[d]; rec[SGH_V + d] = v[d]; rec[SGH_W + d] = w[d]; }
+      rec[SGH_ACTDOT] = D.act_dot;
+#pragma unroll
+      for (int i = 0; i < 16; i++) { rec[SGH_M + i] = D.M[i]; rec[SGH_MINV + i] = D.Minv[i]; W.sMinv[(size_t)i * S + st] = D.Minv[i]; }
       {
         const double* kd = (const double*)&K;
 #pragma unroll
-        for (int i = 0; i < 48; i++) ch[SGH_K + i] = kd[i];
+        for (int i = 0; i < 48; i++) rec[SGH_K + i] = kd[i];
       }
 #pragma unroll
       for (int g = 0; g < SG_CG; g++) {
@@ -981,21 +992,28 @@ __global__ __launch_bounds__(64) void sg_chain_kernel(SgPhaseArgs a) {
           mulmat33(bm2, bm_, C.g_mat[g]);
         }
 #pragma unroll
-        for (int k = 0; k < 3; k++) ch[SGH_BOX + 12 * g + k] = bp_[k] + t[k];
+        for (int k = 0; k < 3; k++) rec[SGH_BOX + 12 * g + k] = bp_[k] + t[k];
 #pragma unroll
-        for (int k = 0; k < 9; k++) ch[SGH_BOX + 12 * g + 3 + k] = bm2[k];
+        for (int k = 0; k < 9; k++) rec[SGH_BOX + 12 * g + 3 + k] = bm2[k];
       }
+      SG_T(21);
       LimitRows L;
       limits_build(C, q, v, D.qacc_smooth, w, L);
-      ch[SGH_LIMACT] = (double)L.active;
+      rec[SGH_LIMACT] = (double)L.active;
 #pragma unroll
-      for (int k = 0; k < SG_MAXLIM; k++) { ch[SGH_LIMSIGN + k] = L.sign[k]; ch[SGH_LIMR + k] = L.R[k]; ch[SGH_LIMB + k] = L.b[k]; ch[SGH_LIMF + k] = L.f[k]; }
+      for (int k = 0; k < SG_MAXLIM; k++) { rec[SGH_LIMSIGN + k] = L.sign[k]; rec[SGH_LIMR + k] = L.R[k]; rec[SGH_LIMB + k] = L.b[k]; rec[SGH_LIMF + k] = L.f[k]; }
+      static_assert(SG_CHW % 2 == 0 && SGH_LIMF + SG_MAXLIM <= SG_CHW, "hand-off record layout");
+#pragma unroll
+      for (int i = 0; i < (SGH_LIMF + SG_MAXLIM + 1) / 2; i++) ((double2*)ch)[i] = make_double2(rec[2 * i], rec[2 * i + 1]);
     }
   }
+  SG_T(22);
   // store the chain's state
 #pragma unroll
   for (int d = 0; d < SG_CD; d++) { int j = C.dof0 + d; gq[j] = q[d]; gv[j] = v[d]; gw[j] = w[d]; }
   if (C.has_act) a.act[(size_t)env * nu + C.act_id] = act;
+  SG_T(23);
+  SG_TEND();
 }
 
 // ------------------------------------------------------------------------------------------------
