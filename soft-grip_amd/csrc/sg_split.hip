@@ -1270,6 +1270,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   const SgWork& W = a.w;
   const double mu0 = H.con_mu[0], mu1 = H.con_mu[1], pgs_scale = H.pgs_scale, tolerance = H.tolerance;
   const double mur = r == 1 ? mu0 : mu1;
+  const double rsel0 = r == 0 ? 1.0 : 0.0, rsel1 = r == 1 ? 1.0 : 0.0, rsel2 = r == 2 ? 1.0 : 0.0;
   const int max_iter = H.iterations;
   const bool valid = env < a.nenv && W.pending[env] != 0;
   if (!__ballot(valid)) return;
@@ -1426,12 +1427,13 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           // ---- friction rows with the normal force fixed: every lane solves the 2 x 2 block, so the new force triple is
           //      known on all lanes without broadcasts
           const double bc = (res - wv) + A0 * g0;   // res - (A f)_r + A_r0 f_0 + A_r0 (g0 - f_0)
-          const double bmu = bc * mur;
+          const bool nofric = g0 < SG_MINVAL;
+          const double bmu = bc * (nofric ? 0.0 : mur);  // no normal force, no friction: zero right-hand sides give u = v = 0
           const double b1 = sg_qb<1>(bmu), b2 = sg_qb<2>(bmu);
           const double u1 = -(P11 * b1 + P12 * b2), u2 = -(P12 * b1 + P22 * b2);  // 0 when the friction block is singular
           const double val = (u1 * u1 + u2 * u2) - g0 * g0;
           double v1 = u1 * mu0, v2 = u2 * mu1;
-          if (!(val < 1e-10) && !(g0 < SG_MINVAL)) {  // uncommon: outside the cone -- the generic Newton iteration, on all four lanes
+          if (!(val < 1e-10) && !nofric) {  // uncommon: outside the cone -- the generic Newton iteration
             const double a11 = sg_qb<1>(A1), a12 = sg_qb<1>(A2), a22 = sg_qb<2>(A2);
             const double Ac[4] = {a11, a12, a12, a22}, bcv[2] = {sg_qb<1>(bc), sg_qb<2>(bc)}, mu[2] = {mu0, mu1};
             double v[2];
@@ -1443,9 +1445,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
             }
             v1 = v[0]; v2 = v[1];
           }
-          const bool nofric = g0 < SG_MINVAL;
-          v1 = nofric ? 0.0 : v1; v2 = nofric ? 0.0 : v2;
-          double fn = r == 0 ? g0 : (r == 1 ? v1 : (r == 2 ? v2 : 0.0));
+          double fn = rsel0 * g0 + (rsel1 * v1 + rsel2 * v2);  // my row of (g0, v1, v2): exact, two of the three terms are 0
           double wn = (A0 * g0 + A1 * v1) + A2 * v2;   // row r of A f_new
           double dr = fn - fo;
           const double change = sg_qsum(dr * (0.5 * (wn - wv) + res));
