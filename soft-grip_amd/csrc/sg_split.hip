@@ -1282,7 +1282,6 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   double2* const BR = (double2*)lds + (size_t)8 * NR + (size_t)le * NR;
   double* const RI = lds + (size_t)32 * NR + (size_t)le * NR;
   double2* const IC = (double2*)(lds + (size_t)40 * NR);
-  double* mylim = lds + (size_t)42 * NR + (size_t)(le * 2 + c) * 4 * SG_MAXLIM;
   double* Lzero = lds + (size_t)42 * NR + (size_t)16 * 4 * SG_MAXLIM;  // [0]: a word that stays 0 (reads of "no slider"), [1 + lane]: write sink
   if (lane == 0) Lzero[0] = 0.0;
   for (int j = lane; j < NR; j += 64)
@@ -1304,6 +1303,9 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; i++) Minv[i] = 0;
   double tb = 0, tR = 1, tA = 1, tf = 0;
+  double lsign[SG_MAXLIM], lR[SG_MAXLIM], lb[SG_MAXLIM], lf[SG_MAXLIM];
+#pragma unroll
+  for (int k = 0; k < SG_MAXLIM; k++) { lsign[k] = 0; lR[k] = 1; lb[k] = 0; lf[k] = 0; }
   if (valid) {
     tb = W.envh[(size_t)0 * a.nenv + env]; tR = W.envh[(size_t)1 * a.nenv + env];
     tA = W.envh[(size_t)2 * a.nenv + env]; tf = W.envh[(size_t)3 * a.nenv + env];
@@ -1314,11 +1316,10 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     for (int i = 0; i < 16; i++) Minv[i] = W.sMinv[(size_t)i * S + st];
 #pragma unroll
     for (int d = 0; d < SG_CD; d++) aF[d] = W.saF[(size_t)d * S + st];
-    if (r == 0) {
 #pragma unroll
-      for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int k = 0; k < SG_MAXLIM; k++) mylim[q * SG_MAXLIM + k] = W.lim[((size_t)q * SG_MAXLIM + k) * S + st];
+    for (int k = 0; k < SG_MAXLIM; k++) {  // the stream's limit rows live in registers, the same values on the four lanes of its quad
+      lsign[k] = W.lim[((size_t)0 * SG_MAXLIM + k) * S + st]; lR[k] = W.lim[((size_t)1 * SG_MAXLIM + k) * S + st];
+      lb[k] = W.lim[((size_t)2 * SG_MAXLIM + k) * S + st]; lf[k] = W.lim[((size_t)3 * SG_MAXLIM + k) * S + st];
     }
   }
   __syncthreads();
@@ -1387,9 +1388,10 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         for (int k = 0; k < SG_MAXLIM; k++) {
           if (mine && (lim_active >> k & 1)) {
             const int d = k / 2;
-            double f = mylim[3 * SG_MAXLIM + k], old = f, sg = mylim[k], Rr = mylim[SG_MAXLIM + k];
-            double ch = scalar_update(f, mylim[2 * SG_MAXLIM + k], sg * aF[d], Rr, Minv[5 * d] + Rr, true);
-            if (r == 0) { imp_acc -= ch; mylim[3 * SG_MAXLIM + k] = f; }
+            double f = lf[k], old = f, sg = lsign[k], Rr = lR[k];
+            double ch = scalar_update(f, lb[k], sg * aF[d], Rr, Minv[5 * d] + Rr, true);
+            lf[k] = f;
+            if (r == 0) imp_acc -= ch;
             double df = sg * (f - old);
 #pragma unroll
             for (int q = 0; q < SG_CD; q++) aF[q] += Minv[4 * q + d] * df;
@@ -1506,7 +1508,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     if (mine && r == 0) {
 #pragma unroll
       for (int k = 0; k < SG_MAXLIM; k++)
-        if (lim_active >> k & 1) gF[k / 2] += mylim[k] * mylim[3 * SG_MAXLIM + k];
+        if (lim_active >> k & 1) gF[k / 2] += lsign[k] * lf[k];
     }
     const int nsl = mine ? ns : 0;
     struct FRow { double2 j01, j23; double fr, sh, JsI; };
