@@ -263,10 +263,10 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   }
   auto phase = [&](const SgPhaseArgs& p) {
     switch (b->m->rounds) {
-      case 1: hipLaunchKernelGGL((sg_phase_kernel<1, 2, true>), dim3(b->n), dim3(64), 0, s, p); break;
-      case 2: hipLaunchKernelGGL((sg_phase_kernel<2, 2, true>), dim3(b->n), dim3(64), 0, s, p); break;
-      case 3: hipLaunchKernelGGL((sg_phase_kernel<3, 2, true>), dim3(b->n), dim3(64), 0, s, p); break;
-      default: hipLaunchKernelGGL((sg_phase_kernel<4, 2, true>), dim3(b->n), dim3(64), 0, s, p); break;
+      case 1: hipLaunchKernelGGL((sg_phase_kernel<1, 2>), dim3(b->n), dim3(64), 0, s, p); break;
+      case 2: hipLaunchKernelGGL((sg_phase_kernel<2, 2>), dim3(b->n), dim3(64), 0, s, p); break;
+      case 3: hipLaunchKernelGGL((sg_phase_kernel<3, 2>), dim3(b->n), dim3(64), 0, s, p); break;
+      default: hipLaunchKernelGGL((sg_phase_kernel<4, 2>), dim3(b->n), dim3(64), 0, s, p); break;
     }
   };
   for (int k = 0; k <= nfwd; k++) {

@@ -84,11 +84,10 @@ struct StageRec2 {
   int sl, box;
 };
 
-struct ChainLds2 {
-  double q[SG_CD], v[SG_CD], w[SG_CD], k[SG_CD], act, ctrl, kten, act_dot;
-  double qfrc_smooth[SG_CD], qacc_smooth[SG_CD], M[16], Minv[16];
+struct ChainLds2 {  // what the phase kernel needs of a finger chain (imported from sg_chain_kernel's hand-off record)
+  double v[SG_CD], w[SG_CD], qacc_smooth[SG_CD], Minv[16];
   int lim_active, pad;
-  double lim_sign[SG_MAXLIM], lim_R[SG_MAXLIM], lim_b[SG_MAXLIM], lim_f[SG_MAXLIM];
+  double lim_sign[SG_MAXLIM], lim_R[SG_MAXLIM], lim_b[SG_MAXLIM], lim_f[SG_MAXLIM];  // contiguous, in the hand-off record's order
 };
 
 template <int R, int CPL>
@@ -139,7 +138,7 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
 // ------------------------------------------------------------------------------------------------
 // phase kernel: [finish previous substep] [begin next substep]
 // ------------------------------------------------------------------------------------------------
-template <int R, int CPL, bool CHAINK>
+template <int R, int CPL>
 __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= a.nenv) return;
@@ -160,8 +159,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   ChainLds2& CS = Sm.cs[half];
   SgWork& W = a.w;
 
-  int status = (a.first && !CHAINK) ? 0 : W.status[env];
-  if (!CHAINK && a.first && lane == 0) { W.status[env] = 0; if (!a.do_finish) W.pending[env] = 0; }
+  int status = W.status[env];  // sg_chain_kernel, which runs first, resets it at the start of a call
   const bool dead = (status & (SG_FLAG_BADQPOS | SG_FLAG_BADQVEL | SG_FLAG_BADQACC)) != 0;
   if (dead) return;  // the env stopped integrating earlier in this call
 
@@ -173,22 +171,6 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 
   // ---------------- load state ----------------
   double qe[R], ve[R], we[R], ke[R];
-  if (is_chain_lane && !CHAINK) {
-#pragma unroll
-    for (int d = 0; d < SG_CD; d++) {
-      int j = C.dof0 + d;
-      if (a.do_reset) { CS.q[d] = C.qpos0[d]; CS.v[d] = 0; CS.w[d] = 0; }
-      else { CS.q[d] = gq[j]; CS.v[d] = gv[j]; CS.w[d] = gw[j]; }
-      CS.k[d] = a.kmask_jnt[j] ? kenv : C.stiffness[d];
-    }
-    double act = 0, ctrl = 0;
-    if (C.has_act) {
-      if (a.do_reset) a.ctrl[(size_t)env * nu + C.act_id] = 0;
-      else { act = a.act[(size_t)env * nu + C.act_id]; ctrl = a.ctrl[(size_t)env * nu + C.act_id]; }
-    }
-    CS.act = act; CS.ctrl = ctrl; CS.act_dot = 0;
-    CS.kten = C.has_ten ? (a.kmask_ten[C.ten_id] ? kenv : C.ten_k0) : 0.0;
-  }
 #pragma unroll
   for (int r = 0; r < R; r++) {
     int e = r * 64 + lane;
@@ -216,91 +198,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         if (isbad(qacc_e[r])) badacc = 1;
       }
     }
-    double aF[SG_CD] = {0, 0, 0, 0}, qsm[SG_CD] = {0, 0, 0, 0};
-    const double* ch = W.chh + ((size_t)env * 2 + half) * SG_CHW;
-    if (is_chain_lane && !CHAINK) {
-#pragma unroll
-      for (int d = 0; d < SG_CD; d++) {
-        aF[d] = W.saF[(size_t)d * S + 2 * env + half];
-        qsm[d] = ch[d];
-        if (isbad(qsm[d] + aF[d])) badacc = 1;
-      }
-    }
     const bool anybadacc = __ballot(badacc) != 0;
-    if (is_chain_lane && !CHAINK) {
-      double qacc_c[SG_CD], vc[SG_CD];
-#pragma unroll
-      for (int d = 0; d < SG_CD; d++) { qacc_c[d] = qsm[d] + aF[d]; vc[d] = CS.v[d]; }
-      if (a.sens) {
-        ChainKin K;
-        {
-          const double* kk = ch + 25;
-          double* kd = (double*)&K;
-#pragma unroll
-          for (int i = 0; i < 48; i++) kd[i] = kk[i];
-        }
-        ChainMotion Mo;
-        chain_motion(C, K, vc, qacc_c, H.gravity, Mo);
-        double* so = a.sens + (size_t)env * a.sens_stride;
-        for (int s = 0; s < C.nsite; s++) {
-          int bi = C.s_body[s];
-          double r3[3], sm[9], t[3], t2[3], acc[3], out[3], sbp[3], sbm[9], bw[3], bal[3];
-          chain_body_pose(K, bi, sbp, sbm);
-          mulmat3(r3, sbm, C.s_pos[s]);
-          mulmat33(sm, sbm, C.s_mat[s]);
-          for (int k = 0; k < 3; k++) { bw[k] = bi == 0 ? Mo.w[0][k] : Mo.w[SG_CB - 1][k]; bal[k] = bi == 0 ? Mo.al[0][k] : Mo.al[SG_CB - 1][k]; }
-          if (C.s_gyro_adr[s] >= 0) {
-            mulmatT3(out, sm, bw);
-            for (int k = 0; k < 3; k++) so[C.s_gyro_adr[s] + k] = out[k];
-          }
-          if (C.s_acc_adr[s] >= 0) {
-            for (int k = 0; k < 3; k++) acc[k] = bi == 0 ? Mo.a[0][k] : Mo.a[SG_CB - 1][k];
-            cross3(t, bal, r3); addscl3(acc, t, 1);
-            cross3(t, bw, r3); cross3(t2, bw, t); addscl3(acc, t2, 1);
-            mulmatT3(out, sm, acc);
-            for (int k = 0; k < 3; k++) so[C.s_acc_adr[s] + k] = out[k];
-          }
-        }
-      }
-      if (!anybadacc) {
-#pragma unroll
-        for (int d = 0; d < SG_CD; d++) CS.w[d] = qacc_c[d];
-        if (a.finish_integrate) {
-          bool damp = false;
-#pragma unroll
-          for (int d = 0; d < SG_CD; d++) damp |= C.damping[d] > 0;
-          double qa[SG_CD];
-          if (damp) {
-            double MhB[16], MhBinv[16], rhs[SG_CD], Mm[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) { Mm[i] = ch[9 + i]; MhB[i] = Mm[i]; }
-#pragma unroll
-            for (int d = 0; d < SG_CD; d++) MhB[5 * d] += h * C.damping[d];
-            spd_inverse4(MhB, MhBinv);
-#pragma unroll
-            for (int a2 = 0; a2 < SG_CD; a2++) {
-              double s = ch[4 + a2];
-#pragma unroll
-              for (int b2 = 0; b2 < SG_CD; b2++) s += Mm[4 * a2 + b2] * aF[b2];
-              rhs[a2] = s;
-            }
-#pragma unroll
-            for (int a2 = 0; a2 < SG_CD; a2++) {
-              double s = 0;
-#pragma unroll
-              for (int b2 = 0; b2 < SG_CD; b2++) s += MhBinv[4 * a2 + b2] * rhs[b2];
-              qa[a2] = s;
-            }
-          } else {
-#pragma unroll
-            for (int d = 0; d < SG_CD; d++) qa[d] = qacc_c[d];
-          }
-          CS.act += h * ch[8];
-#pragma unroll
-          for (int d = 0; d < SG_CD; d++) { double vn = CS.v[d] + h * qa[d]; CS.v[d] = vn; CS.q[d] += h * vn; }
-        }
-      }
-    }
     if (anybadacc) {
       status |= SG_FLAG_BADQACC;
     } else {
@@ -327,15 +225,11 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
     int bad = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) bad |= (isbad(qe[r]) ? SG_FLAG_BADQPOS : 0) | (isbad(ve[r]) ? SG_FLAG_BADQVEL : 0);
-    if (is_chain_lane && !CHAINK) {
-#pragma unroll
-      for (int d = 0; d < SG_CD; d++) bad |= (isbad(CS.q[d]) ? SG_FLAG_BADQPOS : 0) | (isbad(CS.v[d]) ? SG_FLAG_BADQVEL : 0);
-    }
     if (__ballot(bad != 0)) {
       flags |= (__ballot(bad & 1) ? 1 : 0) | (__ballot(bad & 2) ? 2 : 0);
     } else {
       // ---- chains ----
-      if (CHAINK) {  // the chain stage ran in sg_chain_kernel: import its hand-off record, the 32 lanes of a half sharing the loads
+      {  // the chain stage ran in sg_chain_kernel: import its hand-off record, the 32 lanes of a half sharing the loads
         if (half < nchain) {
           const double* ch = W.chh + ((size_t)env * 2 + half) * SG_CHW;
           double* const kd = (double*)&Sm.K[half];
@@ -359,43 +253,6 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             else if (j >= SGH_LIMSIGN && j < SGH_LIMSIGN + 4 * SG_MAXLIM) lim[j - SGH_LIMSIGN] = v;
           }
         }
-      } else if (is_chain_lane) {
-        double qc[SG_CD], vc[SG_CD], wc[SG_CD], kc[SG_CD];
-#pragma unroll
-        for (int d = 0; d < SG_CD; d++) { qc[d] = CS.q[d]; vc[d] = CS.v[d]; wc[d] = CS.w[d]; kc[d] = CS.k[d]; }
-        ChainKin K;
-        ChainDyn D;
-        chain_kinematics(C, qc, K);
-        chain_dynamics(C, K, qc, vc, CS.act, CS.ctrl, kc, CS.kten, H.gravity, D);
-        Sm.K[half] = K;
-        double* ch = W.chh + ((size_t)env * 2 + half) * SG_CHW;
-#pragma unroll
-        for (int i = 0; i < 16; i++) { CS.Minv[i] = D.Minv[i]; ch[9 + i] = D.M[i]; W.sMinv[(size_t)i * S + 2 * env + half] = D.Minv[i]; }
-#pragma unroll
-        for (int d = 0; d < SG_CD; d++) { CS.qacc_smooth[d] = D.qacc_smooth[d]; ch[d] = D.qacc_smooth[d]; ch[4 + d] = D.qfrc_smooth[d]; }
-        ch[8] = D.act_dot;
-        {
-          const double* kd = (const double*)&K;
-#pragma unroll
-          for (int i = 0; i < 48; i++) ch[25 + i] = kd[i];
-        }
-#pragma unroll
-        for (int g = 0; g < SG_CG; g++)
-          if (g < C.ngeom) {
-            double t[3], bp_[3], bm_[9], bm2[9];
-            chain_body_pose(K, C.g_body[g], bp_, bm_);
-            mulmat3(t, bm_, C.g_pos[g]);
-            mulmat33(bm2, bm_, C.g_mat[g]);
-#pragma unroll
-            for (int k = 0; k < 3; k++) Sm.boxp[half * SG_CG + g][k] = bp_[k] + t[k];
-#pragma unroll
-            for (int k = 0; k < 9; k++) Sm.boxm[half * SG_CG + g][k] = bm2[k];
-          }
-        LimitRows L;
-        limits_build(C, qc, vc, D.qacc_smooth, wc, L);
-        CS.lim_active = L.active;
-#pragma unroll
-        for (int k = 0; k < SG_MAXLIM; k++) { CS.lim_sign[k] = L.sign[k]; CS.lim_R[k] = L.R[k]; CS.lim_b[k] = L.b[k]; CS.lim_f[k] = L.f[k]; }
       }
       // ---- elements ----
       double invm[R], asme[R], coef[R];
@@ -809,19 +666,13 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   SG_T(8);
   // ---------------- store state ----------------
   __syncthreads();
-  if (is_chain_lane && !CHAINK) {
-#pragma unroll
-    for (int d = 0; d < SG_CD; d++) { int j = C.dof0 + d; gq[j] = CS.q[d]; gv[j] = CS.v[d]; gw[j] = CS.w[d]; }
-    if (C.has_act) a.act[(size_t)env * nu + C.act_id] = CS.act;
-  }
 #pragma unroll
   for (int r = 0; r < R; r++) {
     int e = r * 64 + lane;
     if (e < N) { gq[e0 + e] = qe[r]; gv[e0 + e] = ve[r]; gw[e0 + e] = we[r]; }
   }
   if (lane == 0) {
-    if (CHAINK) { if (status | flags) atomicOr(&W.status[env], status | flags); }
-    else W.status[env] = status | flags;
+    if (status | flags) atomicOr(&W.status[env], status | flags);
   }
   SG_T(9);
   SG_TEND();
