@@ -186,7 +186,9 @@ def main():
             "config": {"workload": "configs[2]: %d envs/GPU, %s scene (nv=%d), stiffness ~ U(300,1400)%s, reference 200-step squeeze "
                                    "schedule from reset, 7 substeps per env step" % (n, args.scene, nm.nq, " split in per-rank bins" if world > 1 else ""),
                        "envs_per_gpu": n, "substeps_per_step": sim_step, "physics_substeps_per_s": value * sim_step,
-                       "envs_flagged_bad": nbad, "launches_timed": launches},
+                       "envs_flagged_bad": nbad, "launches_timed": launches,
+                       "timed_region": ("%d whole episode(s) from reset" % (args.steps // T)) if args.steps % T == 0 else
+                                       ("the first %d env steps of the episode loop -- NOT the episode average (use --steps as a multiple of %d)" % (args.steps, T))},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": {"rows": "sg_chain_kernel + sg_phase_kernel + sg_pgs_rows_kernel chain of one sg_step call (rows pipeline; dominant: sg_pgs_rows_kernel)", "split": "sg_chain_kernel + sg_phase_kernel + sg_pgs_kernel chain of one sg_step call (split pipeline)"}.get(pipe, "sg_step_kernel"),
                          "avg_kernel_ms": kernel_ms,
