@@ -52,6 +52,7 @@ struct sg_batch {
   int pipeline;  // 0 fused (one kernel per call), 1 split (chain / phase / pgs kernel chain), 2 split with the row-parallel PGS kernel
   SgWork w;
   std::vector<void*> wbufs;
+  bool lds_attr_set;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this batch's device
   // profiling
   bool prof;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -108,7 +109,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   HIPCHK(hipSetDevice(device));
   sg_batch* b = new sg_batch();
   memset((void*)b, 0, sizeof(void*) * 0);
-  b->m = m; b->n = n_envs; b->device = device; b->prof = false; b->prof_ms = 0; b->prof_n = 0;
+  b->m = m; b->n = n_envs; b->device = device; b->lds_attr_set = false; b->prof = false; b->prof_ms = 0; b->prof_n = 0;
   b->dH = nullptr; b->delem = b->qpos = b->qvel = b->warm = b->act = b->ctrl = b->kenv = b->ctrl_row = nullptr;
   b->kmask_jnt = b->kmask_ten = b->flags = b->touch = b->ncon = b->nefc = b->iters = nullptr;
   const SgPlanHeader& H = m->plan.h;
@@ -243,8 +244,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   for (int v : nsl_set)
     if (v * 8 >= H.nelem) { nsl = v; break; }
   const size_t lds_rows = sizeof(double) * ((size_t)(5 * 8 + 2) * 8 * nsl + 16 * 4 * SG_MAXLIM + 72);
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!b->lds_attr_set) {  // per device: a batch on another GPU of the same process needs its own call
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -252,7 +252,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<26>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<29>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    b->lds_attr_set = true;
   }
   // forward passes to run: (mode 1: one non-integrating forward first) + nsub integrating ones
   const int nfwd = nsub + (mode == 1 ? 1 : 0);

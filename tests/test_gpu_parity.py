@@ -130,6 +130,33 @@ def test_full_size_properties():
     assert np.isfinite(s1).all() and np.abs(s1[:, 2] - 9.81).max() < 5.0       # accelerometer z stays near gravity
 
 
+def test_cfg2_uniform_stiffness_batch_is_bit_identical_across_envs():
+    """SURVEY 8(d) cfg 2: B = 1024, every env k = 700 (the XML value).  Identical envs must give bit-identical trajectories
+    whatever lane, quad or wavefront they sit in; env 0 is checked against the oracle."""
+    n = 1024
+    m, nm, b = _gpu_batch("softbox", np.full(n, 700.0))
+    sens, flags, touch = _bufs(b, n)
+    s0 = oracle_sim(m, 700.0)
+    s0.reset(); s0.forward(); s0.step()
+    b.reset(1, sens=sens, flags=flags, touch=touch)
+    ctrl = np.zeros(2)
+    for t, c in enumerate(episode_schedule()):
+        if c is not None:
+            ctrl[:] = c
+            b.set_ctrl_broadcast(ctrl)
+            s0.ctrl[:] = c
+        b.step(7, sens=sens, flags=flags, touch=touch)
+        for _ in range(7):
+            s0.step()
+        if t in (39, 60, 100, 119, 150, 199):
+            got = sens.cpu().numpy()
+            assert np.array_equal(got, np.broadcast_to(got[0], got.shape)), "envs differ at step %d" % t
+            assert np.abs(got[0] - s0.sensordata).max() < TOL_SENSOR
+            assert int(flags.abs().sum()) == 0
+            tc = touch.cpu().numpy()
+            assert (tc == tc[0]).all()
+
+
 def test_state_roundtrip_and_masked_reset():
     import torch
     ks = [700.0, 800.0, 900.0]
