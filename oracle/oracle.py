@@ -46,6 +46,13 @@ def lib():
                   "sgo_site_xpos", "sgo_efc_force"):
             getattr(L, f).restype = dp
             getattr(L, f).argtypes = [vp]
+        for f in ("sgo_efc_AR", "sgo_efc_b"):
+            getattr(L, f).restype = dp
+            getattr(L, f).argtypes = [vp]
+        for f in ("sgo_efc_type", "sgo_efc_id"):
+            getattr(L, f).restype = ip
+            getattr(L, f).argtypes = [vp]
+        L.sgo_contact_friction.argtypes = [vp, C.c_int, dp]
         for f in ("sgo_ncon", "sgo_nefc", "sgo_solver_iter"):
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [vp]
@@ -120,6 +127,20 @@ class OracleSim:
 
     def efc_force(self):
         return np.ctypeslib.as_array(lib().sgo_efc_force(self.ptr), shape=(self.nefc,)).copy()
+
+    def constraint_problem(self):
+        """(A + R, b, row types, contact id per row, friction per contact) of the last forward pass"""
+        n = self.nefc
+        AR = np.ctypeslib.as_array(lib().sgo_efc_AR(self.ptr), shape=(n, n)).copy()
+        b = np.ctypeslib.as_array(lib().sgo_efc_b(self.ptr), shape=(n,)).copy()
+        ty = np.ctypeslib.as_array(lib().sgo_efc_type(self.ptr), shape=(n,)).copy()
+        ids = np.ctypeslib.as_array(lib().sgo_efc_id(self.ptr), shape=(n,)).copy()
+        mu = np.zeros((self.ncon, 5))
+        for i in range(self.ncon):
+            buf = (C.c_double * 5)()
+            lib().sgo_contact_friction(self.ptr, i, buf)
+            mu[i] = np.array(buf)
+        return AR, b, ty, ids, mu
 
     def contacts(self):
         out = []

@@ -342,6 +342,14 @@ double* sgo_qfrc_bias(sgo_data* d) { return d->qfrc_bias; }
 double* sgo_qM(sgo_data* d) { return d->qM; }
 double* sgo_site_xpos(sgo_data* d) { return d->site_xpos; }
 double* sgo_efc_force(sgo_data* d) { return d->efc_force; }
+/* the constraint problem of the last forward pass (tests/test_oracle_kat.py checks the PGS fixed point against its KKT
+ * conditions): dense A + R (nefc x nefc, row-major), b with res = (A + R) f + b, row types (0 equality, 3 limit, 7 elliptic
+ * contact: three consecutive rows), contact id of a row, and a contact's friction coefficients */
+double* sgo_efc_AR(sgo_data* d) { return d->AR; }
+double* sgo_efc_b(sgo_data* d) { return d->efc_b; }
+int* sgo_efc_type(sgo_data* d) { return d->efc_type; }
+int* sgo_efc_id(sgo_data* d) { return d->efc_id; }
+void sgo_contact_friction(const sgo_data* d, int i, double* mu5) { for (int k = 0; k < 5; k++) mu5[k] = d->contact[i].friction[k]; }
 int sgo_ncon(const sgo_data* d) { return d->ncon; }
 int sgo_nefc(const sgo_data* d) { return d->nefc; }
 int sgo_solver_iter(const sgo_data* d) { return d->solver_iter; }

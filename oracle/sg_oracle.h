@@ -56,6 +56,11 @@ double* sgo_qfrc_bias(sgo_data*);
 double* sgo_qM(sgo_data*);               /* dense nv x nv */
 double* sgo_site_xpos(sgo_data*);
 double* sgo_efc_force(sgo_data*);
+double* sgo_efc_AR(sgo_data*);   /* dense (A + R), nefc x nefc, of the last forward pass */
+double* sgo_efc_b(sgo_data*);    /* res = (A + R) f + b */
+int* sgo_efc_type(sgo_data*);    /* 0 equality, 3 limit, 7 elliptic contact (three consecutive rows) */
+int* sgo_efc_id(sgo_data*);
+void sgo_contact_friction(const sgo_data*, int i, double* mu5);
 int sgo_ncon(const sgo_data*);
 int sgo_nefc(const sgo_data*);
 int sgo_solver_iter(const sgo_data*);

@@ -103,3 +103,59 @@ def test_contact_appears_when_finger_closes():
         assert abs(np.linalg.norm(c["frame"][:3]) - 1) < 1e-12 and c["dist"] < 0.0
         F = c["frame"].reshape(3, 3)
         np.testing.assert_allclose(F @ F.T, np.eye(3), atol=1e-12)
+
+
+def test_pgs_fixed_point_satisfies_the_cone_qp_kkt_conditions():
+    """Independent check of the solver math (row projections, elliptic cone handling, QCQP): run to the fixed point (3000
+    sweeps instead of 30), the PGS force must solve  min 1/2 f'(A+R)f + f'b  over  equality rows free, limit rows f >= 0,
+    contact triples in the elliptic cone K = {f0 >= |(f1/mu1, f2/mu2)|}: residual r = (A+R)f + b must vanish on equality
+    rows, be complementary to f >= 0 on limit rows, lie in the dual cone K* = {r0 >= |(mu1 r1, mu2 r2)|} with f'r = 0 on
+    contacts."""
+    import copy
+    m = sg.load_model(model_path("softbox"))
+    s = oracle_sim(m, 903.6948543200572)
+    s.reset(); s.forward(); s.step()
+    ctrl = -0.2
+    for t in range(40 * 7):
+        s.step()
+    s.ctrl[:] = ctrl
+    for t in range(30 * 7):           # 30 env steps into the closing phase: two dozen contacts, limits active
+        assert s.step() == 0
+    assert s.ncon >= 10
+    m2 = copy.copy(m)
+    m2.opt_iterations, m2.opt_tolerance = 3000, 0.0
+    s2 = oracle_sim(m2, 903.6948543200572)
+    s2.reset()
+    s2.qpos[:] = s.qpos; s2.qvel[:] = s.qvel; s2.act[:] = s.act; s2.ctrl[:] = s.ctrl; s2.qacc_warmstart[:] = s.qacc_warmstart
+    s2.forward()
+    AR, b, ty, ids, mu = s2.constraint_problem()
+    f = s2.efc_force()
+    r = AR @ f + b
+    scale = np.abs(b).max() + np.abs(AR @ f).max()
+    tol = 1e-7 * scale
+    n_eq = n_lim = n_con = 0
+    i = 0
+    while i < len(f):
+        if ty[i] == 0:
+            assert abs(r[i]) < tol, ("equality row", i, r[i])
+            n_eq += 1; i += 1
+        elif ty[i] == 3:
+            assert f[i] >= 0 and r[i] > -tol and abs(f[i] * r[i]) < tol * max(1.0, abs(f[i])), ("limit row", i, f[i], r[i])
+            n_lim += 1; i += 1
+        else:
+            assert ty[i] == 7
+            mu1, mu2 = mu[ids[i], 0], mu[ids[i], 1]
+            f0, f1, f2 = f[i:i + 3]
+            r0, r1, r2 = r[i:i + 3]
+            assert f0 >= 0 and np.hypot(f1 / mu1, f2 / mu2) <= f0 * (1 + 1e-9) + 1e-12, ("primal cone", i, f[i:i + 3])
+            assert r0 >= np.hypot(mu1 * r1, mu2 * r2) - tol, ("dual cone", i, r[i:i + 3])
+            assert abs(f0 * r0 + f1 * r1 + f2 * r2) < tol * max(1.0, f0), ("complementarity", i)
+            n_con += 1; i += 3
+    assert n_eq == 111 and n_lim >= 1 and n_con == s2.ncon
+    # and the 30-sweep answer of the production settings is a cost-decreasing step towards it
+    cost = lambda x: 0.5 * x @ AR @ x + x @ b
+    s3 = oracle_sim(m, 903.6948543200572)
+    s3.reset()
+    s3.qpos[:] = s.qpos; s3.qvel[:] = s.qvel; s3.act[:] = s.act; s3.ctrl[:] = s.ctrl; s3.qacc_warmstart[:] = s.qacc_warmstart
+    s3.forward()
+    assert cost(f) <= cost(s3.efc_force()) + 1e-9 * abs(cost(f))
