@@ -159,3 +159,28 @@ def test_pgs_fixed_point_satisfies_the_cone_qp_kkt_conditions():
     s3.qpos[:] = s.qpos; s3.qvel[:] = s.qvel; s3.act[:] = s.act; s3.ctrl[:] = s.ctrl; s3.qacc_warmstart[:] = s.qacc_warmstart
     s3.forward()
     assert cost(f) <= cost(s3.efc_force()) + 1e-9 * abs(cost(f))
+
+
+def test_gyro_reads_the_hinge_rate_of_its_own_finger_only():
+    """a gyro on a finger site measures the body's angular velocity in the site frame: with a single hinge turning at rate w
+    the reading has norm w if that hinge is an ancestor of the sensor's body and 0 otherwise (rotation frames do not change
+    norms); sliders of the object never reach a finger gyro"""
+    m = sg.load_model(model_path("softbox"))
+    s = oracle_sim(m, 700.0)
+    hinges = [j for j in range(m.nv) if not m.jnt_names[j].startswith("OBJ")]
+    assert len(hinges) == 8
+    hit = np.zeros((len(hinges), 2), dtype=bool)
+    for a, j in enumerate(hinges):
+        s.reset()
+        s.qvel[j] = 0.7
+        s.forward()
+        for g in range(2):
+            w = np.linalg.norm(s.sensordata[6 + 3 * g:9 + 3 * g])
+            assert abs(w - 0.7) < 1e-12 or w < 1e-12, (m.jnt_names[j], g, w)
+            hit[a, g] = w > 0.5
+    assert hit.any(axis=0).all()            # every gyro is driven by some hinge
+    assert (hit.sum(axis=1) <= 1).all()     # and no hinge drives both fingers
+    s.reset()
+    s.qvel[m.nv - 1] = 0.7                  # an object slider
+    s.forward()
+    assert np.abs(s.sensordata[6:12]).max() < 1e-12
