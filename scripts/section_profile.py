@@ -51,6 +51,7 @@ def main():
             print("step %d, %s: %.0f cycles per wavefront and launch" % (t, windows[t], v.sum()))
             for k, name in enumerate(NAMES):
                 print("   %-26s %8.0f  %5.1f %%" % (name, v[k], 100 * v[k] / v.sum()))
+            print("   broadphase survivors per env and launch: %.1f pairs, %.2f dense narrowphase passes" % (buf[30] / (n * 8.0), buf[31] / (n * 8.0)))
             w = np.array(buf[:32], dtype=np.float64) / ((n // 8) * 7)  # 7 PGS launches per sg_step call, 8 envs per wavefront
             tot = sum(w[k] for k in PGS_NAMES)
             print("   sg_pgs_rows_kernel: %.0f cycles per wavefront and launch (after the prologue)" % tot)

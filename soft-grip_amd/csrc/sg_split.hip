@@ -325,6 +325,13 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
               double lc[3], grow = H.cap_rbound + H.con_margin;
               mulmatT3(lc, bm, dif);
               near = fabs(lc[0]) <= sz[0] + grow && fabs(lc[1]) <= sz[1] + grow && fabs(lc[2]) <= sz[2] + grow;
+              if (near) {  // third filter: the capsule's own extent along the box axes (|half segment| + radius) instead of its bounding radius
+                const double cax[3] = {EL(SGE_CX, e), EL(SGE_CY, e), EL(SGE_CZ, e)}, rm = H.cap_radius + H.con_margin;
+                double hb[3];
+                mulmatT3(hb, bm, cax);
+                near = fabs(lc[0]) <= sz[0] + rm + H.cap_hl * fabs(hb[0]) && fabs(lc[1]) <= sz[1] + rm + H.cap_hl * fabs(hb[1]) &&
+                       fabs(lc[2]) <= sz[2] + rm + H.cap_hl * fabs(hb[2]);
+              }
             }
             const unsigned long long m = __ballot(near);
             if (near) Sm.pairs[np + lanes_below2(m)] = (unsigned short)((b << 12) | e);
@@ -387,6 +394,9 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             if (__ballot(n > 0 && b == bb)) touch |= 1 << bb;
         }
         ns0 = nsc[0]; ns1 = nsc[1];
+#ifdef SG_SECTION_PROF
+        if (lane == 0) { atomicAdd(&a.w.secprof[30], (unsigned long long)np); atomicAdd(&a.w.secprof[31], (unsigned long long)((np + 63) / 64)); }
+#endif
         if (overflow) flags |= SG_FLAG_CONTACTFULL;
       }
       SG_T(3);
