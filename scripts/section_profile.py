@@ -16,7 +16,7 @@ import softgrip_amd as sg  # noqa: E402
 from softgrip_amd import native  # noqa: E402
 from softgrip_amd.create_dataset import episode_schedule  # noqa: E402
 
-NAMES = ["0 prologue/load", "1 FINISH", "2 BEGIN elements", "3 narrowphase", "4 envelope checks", "5 contact rows+export",
+NAMES = ["0 prologue/load", "1 FINISH", "2 BEGIN elements", "3 narrowphase", "4 envelope checks", "5 contact export (stores)",
          "6 eq rows+recompute_a", "7 warmstart test", "8 export rest", "9 store state"]
 PGS_NAMES = {10: "loop head / imp reduction", 11: "joint-fix rows", 12: "tendon row + write-back", 13: "limit rows", 14: "contact rows",
              15: "exit", 16: "final M^-1 J' f + export"}
@@ -49,8 +49,10 @@ def main():
             L.sg_debug_sections(b.ptr, buf)
             v = np.array(buf[:10], dtype=np.float64) / (n * 8)  # 8 phase launches per sg_step call
             print("step %d, %s: %.0f cycles per wavefront and launch" % (t, windows[t], v.sum()))
+            v24 = buf[24] / (n * 8.0)
             for k, name in enumerate(NAMES):
-                print("   %-26s %8.0f  %5.1f %%" % (name, v[k], 100 * v[k] / v.sum()))
+                print("   %-26s %8.0f  %5.1f %%" % (name, v[k], 100 * v[k] / (v.sum() + v24)))
+            print("   %-26s %8.0f  %5.1f %%" % ("24 contact rows (build)", v24, 100 * v24 / (v.sum() + v24)))
             print("   broadphase survivors per env and launch: %.1f pairs, %.2f dense narrowphase passes" % (buf[30] / (n * 8.0), buf[31] / (n * 8.0)))
             w = np.array(buf[:32], dtype=np.float64) / ((n // 8) * 7)  # 7 PGS launches per sg_step call, 8 envs per wavefront
             tot = sum(w[k] for k in PGS_NAMES)

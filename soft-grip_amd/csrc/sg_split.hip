@@ -116,7 +116,7 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
 // section timing for scripts/section_profile.py (build_native.py --prof): every wavefront sums the cycles between stamps per
 // section in registers and adds them to W.secprof[] once, at its end.  Compiled out of the product library.
 #ifdef SG_SECTION_PROF
-#define SG_T0() unsigned long long t_prev_ = __builtin_readcyclecounter(), t_acc_[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define SG_T0() unsigned long long t_prev_ = __builtin_readcyclecounter(), t_acc_[25] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define SG_T(k)                                                   \
   do {                                                            \
     unsigned long long t_now_ = __builtin_readcyclecounter();     \
@@ -126,7 +126,7 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
 #define SG_TEND()                                                 \
   do {                                                            \
     if (threadIdx.x == 0)                                         \
-      for (int k_ = 0; k_ < 24; k_++)                             \
+      for (int k_ = 0; k_ < 25; k_++)                             \
         if (t_acc_[k_]) atomicAdd(&a.w.secprof[k_], t_acc_[k_]);  \
   } while (0)
 #else
@@ -450,6 +450,11 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         csl_[k] = -1; cjsf[k] = cinvm[k] = ccost0[k] = 0;
 #pragma unroll
         for (int d = 0; d < SG_CD; d++) cg[k][d] = 0;
+        double2 fp[3][SG_RK / 2];  // my contact's three rows in the solver's field pairs (row layout only)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int pr = 0; pr < SG_RK / 2; pr++) fp[r][pr] = make_double2(0.0, 0.0);
         if (i < myn) {
           Contact c;
           const StageRec2& sr = Sm.stage[half][i];
@@ -470,9 +475,8 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           ccost0[k] = c.f[0] * (0.5 * c.R * c.f[0] + c.b[0]) + c.f[1] * (0.5 * c.R * c.f[1] + c.b[1]) + c.f[2] * (0.5 * c.R * c.f[2] + c.b[2]);
 #pragma unroll
           for (int d = 0; d < SG_CD; d++) cg[k][d] = c.Jf[0][d] * c.f[0] + c.Jf[1][d] * c.f[1] + c.Jf[2][d] * c.f[2];
+          SG_T(24);
           if (a.rowlayout) {
-            const int nwb8 = (a.nenv + 7) / 8;
-            const int ql = 8 * (env & 7) + 4 * half;
             const double S11 = c.A[3] * H.con_mu[0] * H.con_mu[0], S22 = c.A[5] * H.con_mu[1] * H.con_mu[1], S12 = c.A[4] * H.con_mu[0] * H.con_mu[1];
             const double det = S11 * S22 - S12 * S12, di = det < 1e-10 ? 0.0 : sg_div(1.0, det);
             const double P11 = S22 * di, P22 = S11 * di, P12 = -S12 * di;
@@ -487,9 +491,8 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
               fld[8] = Afull[r][0]; fld[9] = Afull[r][1]; fld[10] = Afull[r][2];
               fld[11] = r == 0 ? c.R : (r == 2 ? __hiloint2double(0, sl) : 0.0);
               fld[12] = P11; fld[13] = P12; fld[14] = P22; fld[15] = c.invm * c.Js[r];
-              double2* rw = (double2*)(W.crow + SG_ROW_INDEX(i, env >> 3, 0, ql + r, nwb8));
 #pragma unroll
-              for (int pr = 0; pr < SG_RK / 2; pr++) rw[(size_t)pr * 64] = make_double2(fld[2 * pr], fld[2 * pr + 1]);
+              for (int pr = 0; pr < SG_RK / 2; pr++) fp[r][pr] = make_double2(fld[2 * pr], fld[2 * pr + 1]);
             }
           }
           if (!a.rowlayout) {
@@ -509,6 +512,32 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 #pragma unroll
           for (int r = 0; r < 3; r++) ro[(26 + r) * SG_SPW] = c.f[r];
           ((int*)(ro + 29 * SG_SPW))[0] = sl;
+          }
+        }
+        // ---- export in row layout, transposed through LDS so that every store instruction writes whole 128-byte lines: the line
+        //      (slot, pair) of this env is the 8 lanes (finger, row) x 16 B, held by two contact lanes (fingers 0 and 1 of slot i).
+        //      The staging area is the part of Sm.stage this pass has consumed (slots 32 k .. 32 k + 31 of both fingers: 2 x 2 KB).
+        const int nk = (ns0 > ns1 ? ns0 : ns1) - 32 * k;  // slots of this pass that any finger uses
+        if (a.rowlayout && nk > 0) {
+          const int nwb8 = (a.nenv + 7) / 8;
+          const int li = lane & 31;
+          auto X = [&](int sl_, int L) -> double2* {                                   // entry (slot, lane-of-8) for the reads
+            return (double2*)&Sm.stage[sl_ >> 4][32 * k] + ((sl_ & 15) * 8 + L);
+          };
+          __syncthreads();  // every lane has copied its stage record
+          // my entries: (slot li, lane-of-8 4 half + r); slot li lives in piece li >> 4
+          double2* const e0 = (double2*)&Sm.stage[li >> 4][32 * k] + ((li & 15) * 8 + 4 * half);
+#pragma unroll
+          for (int pr = 0; pr < SG_RK / 2; pr++) {
+            e0[0] = fp[0][pr]; e0[1] = fp[1][pr]; e0[2] = fp[2][pr]; e0[3] = make_double2(0.0, 0.0);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (8 * j >= nk) break;  // 8 slots per store instruction
+              const int e = j * 64 + lane, s_ = e >> 3, L = e & 7;
+              if (s_ < nk) *(double2*)(W.crow + SG_ROW_INDEX(32 * k + s_, env >> 3, 2 * pr, 8 * (env & 7) + L, nwb8)) = *X(s_, L);
+            }
+            __syncthreads();
           }
         }
       }
