@@ -1236,11 +1236,16 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     if (running) {
       // joint-fix rows: unconstrained scalar rows, so the step d = -res / (A + R) always lowers the cost (change =
       // -res^2 / (2 (A + R)) <= 0) and the generic "revert if the cost went up" test of the other row types can never fire
+      // the LDS reads of row t + 2 are issued before row t is computed (three register sets in flight)
+      double2 afq[NSL], brq[NSL], icq[NSL];
+      double riq[NSL];
+#pragma unroll
+      for (int t = 0; t < 2 && t < NSL; t++) { afq[t] = AF[g + 8 * t]; brq[t] = BR[g + 8 * t]; icq[t] = IC[g + 8 * t]; riq[t] = RI[g + 8 * t]; }
 #pragma unroll
       for (int t = 0; t < NSL; t++) {
-        const int j = g + 8 * t;
-        const double2 af = AF[j], br = BR[j], ic = IC[j];
-        const double ri = RI[j];
+        if (t + 2 < NSL) { const int jn = g + 8 * (t + 2); afq[t + 2] = AF[jn]; brq[t + 2] = BR[jn]; icq[t + 2] = IC[jn]; riq[t + 2] = RI[jn]; }
+        const double2 af = afq[t], br = brq[t], ic = icq[t];
+        const double ri = riq[t];
         const double ae = af.x, old = af.y, Rr = br.y, im = ic.x;
         const double res = br.x + ae + Rr * old;
         const double fn = old - res * ri;
