@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define SG_BLOB_MAGIC 0x4D474753u /* 'SGGM' */
-#define SG_BLOB_VERSION 1u
+#define SG_BLOB_VERSION 2u  /* 2: eq_obj2id (two-joint equalities) */
 
 enum { SG_DT_F64 = 1, SG_DT_I32 = 2, SG_DT_U8 = 3 };
 

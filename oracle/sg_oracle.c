@@ -61,7 +61,7 @@ struct sgo_model {
   const int *jnt_type, *jnt_bodyid, *jnt_limited, *dof_parentid;
   const int *geom_type, *geom_bodyid, *geom_contype, *geom_conaffinity, *geom_condim, *geom_priority;
   const int *site_bodyid, *tendon_adr, *tendon_num, *wrap_type, *wrap_objid;
-  const int *eq_type, *eq_obj1id, *actuator_trnid, *sensor_type, *sensor_objid, *sensor_adr;
+  const int *eq_type, *eq_obj1id, *eq_obj2id, *actuator_trnid, *sensor_type, *sensor_objid, *sensor_adr;
   /* derived at load */
   double* geom_lmat; /* ngeom x 9 local rotation */
   double* site_lmat;
@@ -209,7 +209,7 @@ sgo_model* sgo_model_load(const void* blob, size_t nbytes, char* err, size_t err
   GETI(jnt_type); GETI(jnt_bodyid); GETI(jnt_limited); GETI(dof_parentid);
   GETI(geom_type); GETI(geom_bodyid); GETI(geom_contype); GETI(geom_conaffinity); GETI(geom_condim); GETI(geom_priority);
   GETI(site_bodyid); GETI(tendon_adr); GETI(tendon_num); GETI(wrap_type); GETI(wrap_objid);
-  GETI(eq_type); GETI(eq_obj1id); GETI(actuator_trnid);
+  GETI(eq_type); GETI(eq_obj1id); GETI(eq_obj2id); GETI(actuator_trnid);
   GETI(sensor_type); m->nsensor = (int)cnt;
   GETI(sensor_objid); GETI(sensor_adr);
 
@@ -784,9 +784,19 @@ static void make_constraint(const sgo_model* m, sgo_data* d) {
   /* equality rows, by id */
   for (int e = 0; e < m->neq; e++) {
     if (m->eq_type[e] == SG_EQ_JOINT) {
-      int j = m->eq_obj1id[e];
-      double one = 1.0;
-      add_row(d, EFC_EQUALITY, e, d->qpos[j] - m->qpos0[j] - m->eq_data[5 * e], 0, 1, &j, &one);
+      int j = m->eq_obj1id[e], j2 = m->eq_obj2id[e];
+      const double* pc = m->eq_data + 5 * e; /* polycoef */
+      if (j2 < 0) {
+        double one = 1.0;
+        add_row(d, EFC_EQUALITY, e, d->qpos[j] - m->qpos0[j] - pc[0], 0, 1, &j, &one);
+      } else { /* two joints: (q1 - q1_0) = poly(q2 - q2_0), J = (+1 on joint 1, -poly' on joint 2) */
+        double dif = d->qpos[j2] - m->qpos0[j2];
+        double poly = pc[0] + dif * (pc[1] + dif * (pc[2] + dif * (pc[3] + dif * pc[4])));
+        double der = pc[1] + dif * (2 * pc[2] + dif * (3 * pc[3] + dif * 4 * pc[4]));
+        int cc[2] = {j, j2};
+        double vv[2] = {1.0, -der};
+        add_row(d, EFC_EQUALITY, e, d->qpos[j] - m->qpos0[j] - poly, 0, 2, cc, vv);
+      }
     } else {
       int t = m->eq_obj1id[e], n = 0;
       for (int i = 0; i < nv; i++)
@@ -827,7 +837,10 @@ static void make_constraint(const sgo_model* m, sgo_data* d) {
     int id = d->efc_id[i];
     if (d->efc_type[i] == EFC_EQUALITY) {
       solref = m->eq_solref + 2 * id; solimp = m->eq_solimp + 5 * id;
-      dA = m->eq_type[id] == SG_EQ_JOINT ? m->dof_invweight0[m->eq_obj1id[id]] : m->tendon_invweight0[m->eq_obj1id[id]];
+      if (m->eq_type[id] == SG_EQ_JOINT) /* joint equality: the invweights of its one or two dofs */
+        dA = m->dof_invweight0[m->eq_obj1id[id]] + (m->eq_obj2id[id] >= 0 ? m->dof_invweight0[m->eq_obj2id[id]] : 0.0);
+      else
+        dA = m->tendon_invweight0[m->eq_obj1id[id]];
     } else if (d->efc_type[i] == EFC_LIMIT) {
       solref = m->jnt_solref + 2 * id; solimp = m->jnt_solimp + 5 * id; dA = m->dof_invweight0[id];
     } else {

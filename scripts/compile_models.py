@@ -25,4 +25,12 @@ if __name__ == "__main__":
         out = os.path.join(ROOT, "models", name + ".sgmodel")
         with open(out, "wb") as f:
             f.write(m.to_blob())
-        print(name, "nv", m.nv, "->", out, os.path.getsize(out), "bytes")
+        print(name, "nv", m.nv, "neq", m.neq, "->", out, os.path.getsize(out), "bytes")
+    # the scenes without the composite's neighbour equalities: the model class the fused and split
+    # pipelines and the lane-serial harness (tests/emu) support, kept for their parity tests
+    for name, xml in SCENES.items():
+        m = sg.compile_mjcf(os.path.join(REF, xml), composite_neighbors=False)
+        out = os.path.join(ROOT, "models", name + "_fixonly.sgmodel")
+        with open(out, "wb") as f:
+            f.write(m.to_blob())
+        print(name + "_fixonly", "nv", m.nv, "neq", m.neq, "->", out, os.path.getsize(out), "bytes")

@@ -48,6 +48,8 @@ struct sg_batch {
   int n, device;
   SgPlanHeader* dH;
   double *delem, *qpos, *qvel, *warm, *act, *ctrl, *kenv, *ctrl_row;
+  int* dnbtab;       // SgPlan::nbtab on the device (neighbour-row models)
+  SgEqSlot* dsched;  // SgPlan::sched + one spare round of idle slots
   int *kmask_jnt, *kmask_ten, *flags, *touch, *ncon, *nefc, *iters;
   int pipeline;  // 0 fused (one kernel per call), 1 split (chain / phase / pgs kernel chain), 2 split with the row-parallel PGS kernel
   SgWork w;
@@ -78,6 +80,13 @@ int sg_model_create(const void* blob, size_t nbytes, sg_model** out) {
     delete m;
     return fail(SG_ERR_MODEL, "sg_model_create: more than 256 composite elements");
   }
+  if (m->plan.h.nnb > 0) {  // the rows PGS kernel keeps every equality row of 8 envs in LDS (launch_split)
+    const size_t na = 8 * (size_t)((m->plan.h.nelem + 7) / 8) + 8 + 48, neqp = (size_t)m->plan.h.nelem + m->plan.h.nnb + 1;
+    if (sizeof(double) * (10 * na + 24 * neqp + 72) > 160 * 1024) {
+      delete m;
+      return fail(SG_ERR_MODEL, "sg_model_create: too many neighbour equality rows for the PGS kernel's LDS");
+    }
+  }
   *out = m;
   return SG_OK;
 }
@@ -91,7 +100,7 @@ int sg_model_nelem(const sg_model* m) { return m->plan.h.nelem; }
 void sg_batch_destroy(sg_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  void* ptrs[] = {b->dH, b->delem, b->qpos, b->qvel, b->warm, b->act, b->ctrl, b->kenv, b->ctrl_row, b->kmask_jnt, b->kmask_ten,
+  void* ptrs[] = {b->dnbtab, b->dsched, b->dH, b->delem, b->qpos, b->qvel, b->warm, b->act, b->ctrl, b->kenv, b->ctrl_row, b->kmask_jnt, b->kmask_ten,
                   b->flags, b->touch, b->ncon, b->nefc, b->iters};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -110,6 +119,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   sg_batch* b = new sg_batch();
   memset((void*)b, 0, sizeof(void*) * 0);
   b->m = m; b->n = n_envs; b->device = device; b->lds_attr_set = false; b->prof = false; b->prof_ms = 0; b->prof_n = 0;
+  b->dnbtab = nullptr; b->dsched = nullptr;
   b->dH = nullptr; b->delem = b->qpos = b->qvel = b->warm = b->act = b->ctrl = b->kenv = b->ctrl_row = nullptr;
   b->kmask_jnt = b->kmask_ten = b->flags = b->touch = b->ncon = b->nefc = b->iters = nullptr;
   const SgPlanHeader& H = m->plan.h;
@@ -149,10 +159,23 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
               walloc((void**)&b->w.as, sizeof(double) * n * N) && walloc((void**)&b->w.eqf, sizeof(double) * n * N) &&
               walloc((void**)&b->w.eqb, sizeof(double) * n * N) && walloc((void**)&b->w.eqR, sizeof(double) * n * N) &&
               walloc((void**)&b->w.asme, sizeof(double) * n * N) && walloc((void**)&b->w.fsm, sizeof(double) * n * N) &&
-              walloc((void**)&b->w.chh, sizeof(double) * n * 2 * SG_CHW);
+              walloc((void**)&b->w.chh, sizeof(double) * n * 2 * SG_CHW) &&
+              walloc((void**)&b->w.nbf, sizeof(double) * n * (H.nnb + 1)) && walloc((void**)&b->w.nbb, sizeof(double) * n * (H.nnb + 1)) &&
+              walloc((void**)&b->w.nbR, sizeof(double) * n * (H.nnb + 1));
     if (!ok) { sg_batch_destroy(b); return fail(SG_ERR_NOMEM, "hipMalloc (split-pipeline workspace)"); }
     const char* pm = getenv("SG_PIPELINE");
     b->pipeline = (pm && strcmp(pm, "fused") == 0) ? 0 : (pm && strcmp(pm, "split") == 0) ? 1 : 2;
+    if (H.nnb > 0) b->pipeline = 2;  // neighbour equality rows exist in the rows pipeline only
+  }
+  if (H.nnb > 0) {
+    std::vector<SgEqSlot> sch = m->plan.sched;
+    SgEqSlot idle;
+    idle.e1 = idle.e2 = H.nelem; idle.row = H.nelem + H.nnb; idle.pad = 0; idle.im1 = idle.im2 = 0;
+    for (int g = 0; g < 8; g++) sch.push_back(idle);  // the kernel requests round k + 1 before it computes round k
+    ALLOC(b->dnbtab, sizeof(int) * m->plan.nbtab.size());
+    ALLOC(b->dsched, sizeof(SgEqSlot) * sch.size());
+    HIPCHK(hipMemcpy(b->dnbtab, m->plan.nbtab.data(), sizeof(int) * m->plan.nbtab.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->dsched, sch.data(), sizeof(SgEqSlot) * sch.size(), hipMemcpyHostToDevice));
   }
 #undef ALLOC
   HIPCHK(hipMemcpy(b->dH, &H, sizeof H, hipMemcpyHostToDevice));
@@ -234,7 +257,9 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   pa.kenv = b->kenv; pa.kmask_jnt = b->kmask_jnt; pa.kmask_ten = b->kmask_ten;
   pa.mask = mask; pa.sens = nullptr; pa.sens_stride = stride > 0 ? stride : H.nsensordata;
   pa.w = b->w; pa.nenv = b->n; pa.rowlayout = b->pipeline == 2;
+  pa.nbtab = b->dnbtab;
   SgPgsArgs ga;
+  ga.sched = b->dsched; ga.nbtab = b->dnbtab;
   ga.H = b->dH; ga.elem = b->delem; ga.w = b->w; ga.nenv = b->n;
   const size_t lds = sizeof(double) * ((size_t)(5 * 8 + 2) * H.nelem + 16 * 4 * SG_MAXLIM + 72);
   // rows kernel: joint-fix rows per lane (template parameter, the smallest instantiated value >= ceil(nelem / 8)); its LDS
@@ -243,15 +268,17 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   int nsl = 32;
   for (int v : nsl_set)
     if (v * 8 >= H.nelem) { nsl = v; break; }
-  const size_t lds_rows = sizeof(double) * ((size_t)(5 * 8 + 2) * 8 * nsl + 16 * 4 * SG_MAXLIM + 72);
+  const bool nbm = H.nnb > 0;
+  const size_t na = 8 * (size_t)nsl + 8, neqp = (size_t)H.nelem + H.nnb + 1;
+  const size_t lds_rows = nbm ? sizeof(double) * (10 * na + 24 * neqp + 72)
+                              : sizeof(double) * ((size_t)(5 * 8 + 2) * 8 * nsl + 16 * 4 * SG_MAXLIM + 72);
   if (!b->lds_attr_set) {  // per device: a batch on another GPU of the same process needs its own call
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<26>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<29>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define SG_ATTR(v)                                                                                                                    \
+  HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<v, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+  HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<v, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    SG_ATTR(8); SG_ATTR(14); SG_ATTR(20); SG_ATTR(26); SG_ATTR(29); SG_ATTR(32);
+#undef SG_ATTR
     b->lds_attr_set = true;
   }
   // forward passes to run: (mode 1: one non-integrating forward first) + nsub integrating ones
@@ -286,14 +313,19 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     if (k < nfwd) {
       if (b->pipeline == 2) {
         const dim3 grid((b->n + 7) / 8);
+#define SG_ROWS(v)                                                                                       \
+  case v:                                                                                                \
+    if (nbm) hipLaunchKernelGGL((sg_pgs_rows_kernel<v, true>), grid, dim3(64), lds_rows, s, ga);         \
+    else hipLaunchKernelGGL((sg_pgs_rows_kernel<v, false>), grid, dim3(64), lds_rows, s, ga);            \
+    break
         switch (nsl) {
-          case 8: hipLaunchKernelGGL(sg_pgs_rows_kernel<8>, grid, dim3(64), lds_rows, s, ga); break;
-          case 14: hipLaunchKernelGGL(sg_pgs_rows_kernel<14>, grid, dim3(64), lds_rows, s, ga); break;
-          case 20: hipLaunchKernelGGL(sg_pgs_rows_kernel<20>, grid, dim3(64), lds_rows, s, ga); break;
-          case 26: hipLaunchKernelGGL(sg_pgs_rows_kernel<26>, grid, dim3(64), lds_rows, s, ga); break;
-          case 29: hipLaunchKernelGGL(sg_pgs_rows_kernel<29>, grid, dim3(64), lds_rows, s, ga); break;
-          default: hipLaunchKernelGGL(sg_pgs_rows_kernel<32>, grid, dim3(64), lds_rows, s, ga); break;
+          SG_ROWS(8); SG_ROWS(14); SG_ROWS(20); SG_ROWS(26); SG_ROWS(29);
+          default:
+            if (nbm) hipLaunchKernelGGL((sg_pgs_rows_kernel<32, true>), grid, dim3(64), lds_rows, s, ga);
+            else hipLaunchKernelGGL((sg_pgs_rows_kernel<32, false>), grid, dim3(64), lds_rows, s, ga);
+            break;
         }
+#undef SG_ROWS
       }
       else hipLaunchKernelGGL(sg_pgs_kernel, dim3((b->n + SG_EPW - 1) / SG_EPW), dim3(64), lds, s, ga);
       HIPCHK(hipGetLastError());
@@ -403,6 +435,8 @@ int sg_get_solver_stats(sg_batch* b, int32_t* ncon, int32_t* nefc, int32_t* iter
 
 int sg_set_pipeline(sg_batch* b, int pipeline) {
   if (!b || pipeline < 0 || pipeline > 2) return fail(SG_ERR_INVALID, "sg_set_pipeline: bad argument");
+  if (b->m->plan.h.nnb > 0 && pipeline != 2)
+    return fail(SG_ERR_MODEL, "sg_set_pipeline: the model has neighbour equality rows, which only the rows pipeline supports");
   b->pipeline = pipeline;
   return SG_OK;
 }

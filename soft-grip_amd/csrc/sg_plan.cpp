@@ -3,7 +3,10 @@
 // environment/manenv.py:27) that turns a parsed model into solver-ready constants.
 #include "sg_plan.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -103,7 +106,7 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
   NEEDI(geom_type, "geom_type"); NEEDI(geom_bodyid, "geom_bodyid"); NEEDI(geom_contype, "geom_contype"); NEEDI(geom_conaffinity, "geom_conaffinity");
   NEEDI(geom_condim, "geom_condim"); NEEDI(geom_priority, "geom_priority"); NEEDI(site_bodyid, "site_bodyid");
   NEEDI(tendon_adr, "tendon_adr"); NEEDI(tendon_num, "tendon_num"); NEEDI(wrap_type, "wrap_type"); NEEDI(wrap_objid, "wrap_objid");
-  NEEDI(eq_type, "eq_type"); NEEDI(eq_obj1id, "eq_obj1id"); NEEDI(actuator_trnid, "actuator_trnid");
+  NEEDI(eq_type, "eq_type"); NEEDI(eq_obj1id, "eq_obj1id"); NEEDI(eq_obj2id, "eq_obj2id"); NEEDI(actuator_trnid, "actuator_trnid");
   NEEDI(sensor_type, "sensor_type");
   const int nsensor = (int)cnt;
   NEEDI(sensor_objid, "sensor_objid"); NEEDI(sensor_adr, "sensor_adr");
@@ -295,8 +298,7 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
   }
   if (H.t0_id < 0) FAIL("model has no fixed tendon over the elements");
 
-  // ---- equality rows: [joint-fix per element in order][tendon-fix] ----
-  if (neq != nelem + 1) FAIL("expected one joint equality per element plus one tendon equality");
+  // ---- equality rows: [joint-fix of element e, then its neighbour rows (e -> e')] for e in order, [tendon-fix] ----
   auto kb = [&](const double* sr, const double* si, double* K, double* Bd) {
     double dmax = fmin(0.9999, fmax(1e-4, si[1]));
     if (sr[0] > 0 && sr[1] > 0) {
@@ -308,16 +310,99 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
       *Bd = -sr[1] / fmax(1e-15, dmax);
     }
   };
-  for (int e = 0; e < nelem; e++) {
-    if (eq_type[e] != SG_EQ_JOINT || eq_obj1id[e] != H.elem_dof0 + e) FAIL("equality e must fix element slider e");
-    if (eq_data[5 * e] != 0) FAIL("joint equality offsets are not supported");
-    if (memcmp(eq_solref + 2 * e, eq_solref, 16) || memcmp(eq_solimp + 5 * e, eq_solimp, 40)) FAIL("joint equalities must share solref/solimp");
+  if (neq < nelem + 1) FAIL("expected one joint equality per element plus one tendon equality");
+  std::vector<int> row_e1, row_e2;  // every joint equality in id order; e2 = -1 for a fix row
+  {
+    int nfix = 0;
+    for (int q = 0; q < neq - 1; q++) {
+      if (eq_type[q] != SG_EQ_JOINT) FAIL("only the last equality may be a tendon equality");
+      if (memcmp(eq_solref + 2 * q, eq_solref, 16) || memcmp(eq_solimp + 5 * q, eq_solimp, 40)) FAIL("joint equalities must share solref/solimp");
+      const int e1 = eq_obj1id[q] - H.elem_dof0, e2 = eq_obj2id[q] < 0 ? -1 : eq_obj2id[q] - H.elem_dof0;
+      if (e1 < 0 || e1 >= nelem) FAIL("joint equalities must act on element sliders");
+      if (eq_obj2id[q] < 0) {
+        if (e1 != nfix) FAIL("the joint-fix equalities must come in element order");
+        if (eq_data[5 * q] != 0) FAIL("joint equality offsets are not supported");
+        nfix++;
+      } else {
+        if (e2 < 0 || e2 >= nelem || e2 == e1) FAIL("neighbour equalities must couple two different element sliders");
+        if (e1 != nfix - 1) FAIL("an element's neighbour equalities must follow its joint-fix equality");
+        const double* pc = eq_data + 5 * q;
+        if (pc[0] != 0 || pc[1] != 1 || pc[2] != 0 || pc[3] != 0 || pc[4] != 0) FAIL("neighbour equalities must be q1 = q2 (polycoef 0 1 0 0 0)");
+      }
+      row_e1.push_back(e1); row_e2.push_back(e2);
+    }
+    if (nfix != nelem) FAIL("expected one joint-fix equality per element");
+  }
+  H.nnb = neq - 1 - nelem;
+  H.eq_rounds = 0;
+  if (H.nnb > 0) {
+    const int N = nelem, nnb = H.nnb;
+    P.nbtab.assign((size_t)9 * N + 2 * nnb, -1);
+    int* out_e2 = P.nbtab.data(); int* out_id = out_e2 + 3 * N; int* in_id = out_id + 3 * N; int* r_e1 = in_id + 3 * N; int* r_e2 = r_e1 + nnb;
+    std::vector<int> nout(N, 0), nin(N, 0), unified(row_e1.size());
+    int k = 0;
+    for (size_t q = 0; q < row_e1.size(); q++) {
+      const int e1 = row_e1[q], e2 = row_e2[q];
+      if (e2 < 0) { unified[q] = e1; continue; }
+      if (nout[e1] >= 3 || nin[e2] >= 3) FAIL("more than three neighbour equalities on one side of an element");
+      out_e2[nout[e1] * N + e1] = e2; out_id[nout[e1] * N + e1] = k; nout[e1]++;
+      in_id[nin[e2] * N + e2] = k; nin[e2]++;
+      r_e1[k] = e1; r_e2[k] = e2;
+      unified[q] = N + k;
+      k++;
+    }
+    // list scheduling, longest remaining dependency chain first
+    const int nr = (int)row_e1.size();
+    std::vector<std::vector<int>> pred(nr), succ(nr);
+    {
+      std::vector<int> last(N, -1);
+      for (int q = 0; q < nr; q++) {
+        const int sl[2] = {row_e1[q], row_e2[q]};
+        for (int t = 0; t < 2; t++) {
+          if (sl[t] < 0) continue;
+          const int p = last[sl[t]];
+          if (p >= 0 && (pred[q].empty() || pred[q].back() != p)) { pred[q].push_back(p); succ[p].push_back(q); }
+          last[sl[t]] = q;
+        }
+      }
+    }
+    std::vector<int> height(nr, 1), round_of(nr, -1);
+    for (int q = nr - 1; q >= 0; q--)
+      for (int t : succ[q]) height[q] = height[q] > 1 + height[t] ? height[q] : 1 + height[t];
+    int left = nr, rnd = 0;
+    auto invm = [&](int e) { return 1.0 / (P.elem[(size_t)SGE_MASS * N + e] + P.elem[(size_t)SGE_ARMATURE * N + e]); };
+    while (left > 0) {
+      std::vector<int> ready;
+      for (int q = 0; q < nr; q++) {
+        if (round_of[q] >= 0) continue;
+        bool ok = true;
+        for (int p : pred[q]) ok = ok && round_of[p] >= 0 && round_of[p] < rnd;
+        if (ok) ready.push_back(q);
+      }
+      std::stable_sort(ready.begin(), ready.end(), [&](int a, int b) { return height[a] > height[b]; });
+      for (int g = 0; g < 8; g++) {
+        SgEqSlot s;
+        s.e1 = N; s.e2 = N; s.row = N + nnb; s.pad = 0; s.im1 = 0; s.im2 = 0;
+        if (g < (int)ready.size()) {
+          const int q = ready[g];
+          round_of[q] = rnd; left--;
+          s.e1 = row_e1[q]; s.row = unified[q]; s.im1 = invm(row_e1[q]);
+          if (row_e2[q] >= 0) { s.e2 = row_e2[q]; s.im2 = invm(row_e2[q]); }
+        }
+        P.sched.push_back(s);
+      }
+      rnd++;
+    }
+    H.eq_rounds = rnd;
   }
   kb(eq_solref, eq_solimp, &H.eqj_K, &H.eqj_B);
   memcpy(H.eqj_solimp, eq_solimp, 40);
-  if (eq_type[nelem] != SG_EQ_TENDON || eq_obj1id[nelem] != H.t0_id || eq_data[5 * nelem] != 0) FAIL("the last equality must fix the element tendon");
-  kb(eq_solref + 2 * nelem, eq_solimp + 5 * nelem, &H.eqt_K, &H.eqt_B);
-  memcpy(H.eqt_solimp, eq_solimp + 5 * nelem, 40);
+  {
+    const int qt = neq - 1;
+    if (eq_type[qt] != SG_EQ_TENDON || eq_obj1id[qt] != H.t0_id || eq_data[5 * qt] != 0) FAIL("the last equality must fix the element tendon");
+    kb(eq_solref + 2 * qt, eq_solimp + 5 * qt, &H.eqt_K, &H.eqt_B);
+    memcpy(H.eqt_solimp, eq_solimp + 5 * qt, 40);
+  }
 
   // ---- actuators and sensors ----
   for (int u = 0; u < nu; u++) {
@@ -416,15 +501,20 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
       FAIL("unsupported static geom type");
     }
   }
-  // Safe slider range per element: while q stays inside (QLO, QHI) the capsule's bounding sphere cannot touch a static box or the
-  // plane, so those pairs (legal in the model, never active in the reference scenes) need no narrowphase; outside it the kernels
+  // Safe slider range per element: while q stays inside (QLO, QHI) the capsule cannot touch the plane (exact: the lower of its two
+  // end spheres) and its bounding sphere cannot touch a static box, so those pairs (legal in the model, never active in the reference scenes) need no narrowphase; outside it the kernels
   // raise the "unsupported pair" flag.  The distance to a convex static geom is convex in q, so the unsafe set is one interval.
   for (int e = 0; e < nelem; e++) {
     double ax[3] = {E(SGE_AX, e), E(SGE_AY, e), E(SGE_AZ, e)}, g0[3] = {E(SGE_GX, e), E(SGE_GY, e), E(SGE_GZ, e)}, q0 = E(SGE_QPOS0, e);
     double qlo = -1e30, qhi = 1e30;
     auto clearance = [&](int kind, int k, double q) {  // >0: bounding sphere clear of static geom k
       double c[3] = {g0[0] + ax[0] * (q - q0), g0[1] + ax[1] * (q - q0), g0[2] + ax[2] * (q - q0)};
-      if (kind == 0) return (c[0] - H.plane_pos[0]) * H.plane_normal[0] + (c[1] - H.plane_pos[1]) * H.plane_normal[1] + (c[2] - H.plane_pos[2]) * H.plane_normal[2] - H.cap_rbound;
+      if (kind == 0) {  // capsule against the plane: exact (a bounding sphere leaves the bottom corner elements of a box shell ~1 cm of travel)
+        const double cax[3] = {E(SGE_CX, e), E(SGE_CY, e), E(SGE_CZ, e)};
+        const double dc = (c[0] - H.plane_pos[0]) * H.plane_normal[0] + (c[1] - H.plane_pos[1]) * H.plane_normal[1] + (c[2] - H.plane_pos[2]) * H.plane_normal[2];
+        const double da = cax[0] * H.plane_normal[0] + cax[1] * H.plane_normal[1] + cax[2] * H.plane_normal[2];
+        return dc - H.cap_hl * fabs(da) - H.cap_radius;
+      }
       double t[3] = {c[0] - H.st_pos[k][0], c[1] - H.st_pos[k][1], c[2] - H.st_pos[k][2]}, o2 = 0, in = -1e300;
       for (int a = 0; a < 3; a++) {
         double l = t[0] * H.st_mat[k][a] + t[1] * H.st_mat[k][3 + a] + t[2] * H.st_mat[k][6 + a], ex = fabs(l) - H.st_size[k][a];
@@ -453,6 +543,7 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
         }
       }
     E(SGE_QLO, e) = qlo; E(SGE_QHI, e) = qhi;
+    if (getenv("SG_PLAN_DEBUG")) fprintf(stderr, "elem %d safe slider range (%g, %g)\n", e, qlo - q0, qhi - q0);
   }
   // mixed contact parameters of the reference pair
   {

@@ -7,8 +7,10 @@
 //     the accelerometer/gyro sites;
 //   * N ELEMENTS: leaf bodies of a <composite> shell -- one slide joint each, static
 //     parent, one capsule -- so their mass-matrix blocks are 1x1 and constant;
-//   * constraints: one joint-fix equality per element, one tendon-fix equality over
-//     all elements, hinge limits, box-capsule / box-sphere contacts.
+//   * constraints: one joint-fix equality per element, optionally followed by the
+//     composite's neighbour equalities (slider e = slider e', towards the next shell
+//     elements along +x, +y, +z), one tendon-fix equality over all elements, hinge
+//     limits, box-capsule / box-sphere contacts.
 // sg_plan_build() verifies a model has exactly this structure and refuses it otherwise.
 #pragma once
 #include <cstdint>
@@ -59,7 +61,10 @@ enum {
 };
 
 struct SgPlanHeader {
-  int nv, nu, nsensordata, ntendon, nchain, nelem, elem_dof0, iterations, nstatic, has_center, has_plane, center_geom, plane_geom, pad[3];
+  int nv, nu, nsensordata, ntendon, nchain, nelem, elem_dof0, iterations, nstatic, has_center, has_plane, center_geom, plane_geom;
+  int nnb;        // neighbour equality rows (0: the model has none)
+  int eq_rounds;  // rounds of the equality-row schedule (SgPlan::sched), 0 when nnb == 0
+  int pad;
   double timestep, gravity[3], tolerance, impratio, meaninertia, pgs_scale;
   // element-uniform parameters
   double cap_radius, cap_hl, cap_rbound;
@@ -76,8 +81,25 @@ struct SgPlanHeader {
   SgChain chain[SG_MAXCH];
 };
 
+// One slot of the equality-row schedule (neighbour-row models).  MuJoCo sweeps the equality rows in id order
+// [fix_0, nb_0.., fix_1, nb_1.., ...]; two rows that share a slider must keep that order, rows that share none commute
+// exactly.  The plan list-schedules the rows into rounds of 8 (one per lane of an env's group in the PGS kernel): every
+// row sits in a later round than the rows it depends on, so executing the rounds in order, all slots of a round at once,
+// IS the sequential sweep.
+struct SgEqSlot {
+  int e1, e2;   // sliders of the row (element indices); e2 = nelem (a per-env dummy word that stays 0) for a fix row
+  int row;      // record index: fix row of element e -> e, neighbour row k -> nelem + k, idle slot -> nelem + nnb (dummy)
+  int pad;
+  double im1, im2;  // 1 / (mass + armature) of the two sliders (im2 = 0 for a fix row, both 0 for an idle slot)
+};
+
 struct SgPlan {
   SgPlanHeader h;
+  // neighbour rows: ints [9 * nelem + 2 * nnb] = out_e2[3][nelem] | out_id[3][nelem] | in_id[3][nelem] | row_e1[nnb] | row_e2[nnb]
+  //   out_*: the (up to 3) neighbour rows registered for element e, in MuJoCo's order: partner element / row id, -1 = none
+  //   in_id: the (up to 3) neighbour rows that have element e as their second joint
+  std::vector<int> nbtab;
+  std::vector<SgEqSlot> sched;     // eq_rounds x 8
   std::vector<double> elem;        // SGE_NFIELD x nelem
   std::vector<int> elem_geom;      // geom id of each element's capsule
   std::vector<int> elem_dofmap;    // (informational) global dof of element e = elem_dof0 + e

@@ -47,6 +47,7 @@ struct SgWork {          // device workspace of one batch (all pointers device m
   double *as, *eqf, *eqb, *eqR;  // [nenv][N]
   double *asme, *fsm;    // [nenv][N]  begin -> finish hand-off
   double* chh;           // [nenv][2][SG_CHW]  chain hand-off (enum SGH_*)
+  double *nbf, *nbb, *nbR;  // [nenv][nnb]  neighbour equality rows (models with H.nnb > 0): force, right-hand side, regulariser
 };
 
 struct SgPhaseArgs {
@@ -62,6 +63,7 @@ struct SgPhaseArgs {
   int nenv;
   int do_reset, do_finish, finish_integrate, do_begin, first;
   int rowlayout;  // 1: export contact records in the row layout of sg_pgs_rows_kernel
+  const int* nbtab;  // SgPlan::nbtab (neighbour rows per element), nullptr when H.nnb == 0
 };
 
 // chain hand-off record (doubles): written by the chain stage (phase kernel or sg_chain_kernel), read by FINISH and by BEGIN
@@ -101,6 +103,7 @@ struct Smem2 {
   unsigned short pairs[SG_MAXCH * SG_CG * (R * 64 + 2)];  // broadphase survivors, (box << 12) | element, in contact order
   unsigned short eslot[R * 64][SG_MAXCH * SG_CG];         // per element and box: first contact slot | (contact count << 8)
   double cval[SG_MAXCH][32 * CPL];                        // per contact slot: invm * Js' f (its push on the slider)
+  double nbf[3 * R * 64];                                 // neighbour equality rows: warmstart force, by row id
 };
 #define SG_PAIR_CENTER 0xFFF  // element code of the object's centre sphere
 
@@ -558,6 +561,37 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           tbp += coef[r] * asme[r]; tjp += coef[r] * we[r]; tAp += coef[r] * coef[r] * invm[r];
         }
       }
+      // ---- neighbour rows (slider e = slider e2, J = +1 / -1): built by the lane of their first element, up to three each.
+      //      b and R go straight to the workspace; the warmstart force lives in LDS (Sm.nbf, by row id) for the gathers below
+      const int nnb = H.nnb;
+      int nbe2[R][3], nbid[R][3];
+      double nbc0[R][3];  // f (R f / 2 + b)
+#pragma unroll
+      for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) { nbe2[r][d] = -1; nbid[r][d] = -1; nbc0[r][d] = 0; }
+      if (nnb > 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const int e = r * 64 + lane;
+          if (e < N) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+              const int e2 = a.nbtab[d * N + e];
+              if (e2 >= 0) {
+                const int id = a.nbtab[(3 + d) * N + e];
+                const double pos = (qe[r] - EL(SGE_QPOS0, e)) - (Sm.as[e2] - EL(SGE_QPOS0, e2)), imp = impedance(H.eqj_solimp, pos, 0);
+                const double Rr = fmax(SG_MINVAL, (1 - imp) / imp * (EL(SGE_INVW, e) + EL(SGE_INVW, e2)));
+                const double aref = -H.eqj_B * (ve[r] - Sm.ve[e2]) - H.eqj_K * imp * pos;
+                const double bb = (asme[r] - Sm.asme[e2]) - aref, ff = -((we[r] - Sm.we[e2]) - aref) / Rr;
+                nbe2[r][d] = e2; nbid[r][d] = id; nbc0[r][d] = ff * (0.5 * Rr * ff + bb);
+                Sm.nbf[id] = ff;
+                W.nbb[(size_t)env * nnb + id] = bb; W.nbR[(size_t)env * nnb + id] = Rr;
+              }
+            }
+          }
+        }
+      }
       const double tpos = L0 - H.t0_L0, timp = impedance(H.eqt_solimp, tpos, 0), tR = fmax(SG_MINVAL, (1 - timp) / timp * H.eqt_invw);
       const double taref = -H.eqt_B * Ld - H.eqt_K * timp * tpos;
       const double tb = wave_sum2(tbp) - taref, tjar = wave_sum2(tjp) - taref, tA = wave_sum2(tAp) + tR;
@@ -573,7 +607,14 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         for (int r = 0; r < R; r++) {
           int e = r * 64 + lane;
           if (e < N) {
-            double as_ = invm[r] * (eqf[r] + coef[r] * tf);
+            double fe = eqf[r] + coef[r] * tf;
+            if (nnb > 0) {  // + its own neighbour rows (J = +1), - the rows that have it as second joint (J = -1), in row order per side
+#pragma unroll
+              for (int d = 0; d < 3; d++) if (nbid[r][d] >= 0) fe += Sm.nbf[nbid[r][d]];
+#pragma unroll
+              for (int d = 0; d < 3; d++) { const int ii = a.nbtab[(6 + d) * N + e]; if (ii >= 0) fe -= Sm.nbf[ii]; }
+            }
+            double as_ = invm[r] * fe;
 #pragma unroll
             for (int cb = 0; cb < SG_MAXCH * SG_CG; cb++) {
               const int u = Sm.eslot[e][cb], i0 = u & 0xFF, nst = u >> 8;
@@ -618,7 +659,12 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
           int e = r * 64 + lane;
-          if (e < N) { double ae = Sm.as[e]; cp += eqf[r] * (0.5 * (ae + eqR[r] * eqf[r]) + eqb[r]); tJap += coef[r] * ae; }
+          if (e < N) {
+            double ae = Sm.as[e]; cp += eqf[r] * (0.5 * (ae + eqR[r] * eqf[r]) + eqb[r]); tJap += coef[r] * ae;
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+              if (nbid[r][d] >= 0) cp += 0.5 * Sm.nbf[nbid[r][d]] * (ae - Sm.as[nbe2[r][d]]) + nbc0[r][d];
+          }
         }
         double tJa = wave_sum2(tJap);
         if (lane == 0) cp += tf * (0.5 * (tJa + tR * tf) + tb);
@@ -640,7 +686,11 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         double cost = wave_sum2(cp);
         if (cost > 0) {
 #pragma unroll
-          for (int r = 0; r < R; r++) eqf[r] = 0;
+          for (int r = 0; r < R; r++) {
+            eqf[r] = 0;
+#pragma unroll
+            for (int d = 0; d < 3; d++) if (nbid[r][d] >= 0) Sm.nbf[nbid[r][d]] = 0.0;
+          }
           tf = 0;
           if (is_chain_lane) {
 #pragma unroll
@@ -678,6 +728,9 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         if (e < N) {
           size_t o = (size_t)env * N + e;
           W.as[o] = Sm.as[e]; W.eqf[o] = eqf[r]; W.eqb[o] = eqb[r]; W.eqR[o] = eqR[r];
+#pragma unroll
+          for (int d = 0; d < 3; d++)
+            if (nbid[r][d] >= 0) W.nbf[(size_t)env * nnb + nbid[r][d]] = Sm.nbf[nbid[r][d]];
         }
       }
       if (is_chain_lane) {
@@ -696,7 +749,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         W.shared[env] = shared_slider;
         W.pending[env] = 1;
         W.ncon[env] = ns0 + ns1;
-        W.nefc[env] = N + 1 + 3 * (ns0 + ns1) + __popc(Sm.cs[0].lim_active) + (nchain > 1 ? __popc(Sm.cs[1].lim_active) : 0);
+        W.nefc[env] = N + nnb + 1 + 3 * (ns0 + ns1) + __popc(Sm.cs[0].lim_active) + (nchain > 1 ? __popc(Sm.cs[1].lim_active) : 0);
         W.touch[env] = touch;
       }
     }
@@ -910,6 +963,8 @@ __global__ __launch_bounds__(64) void sg_chain_kernel(SgPhaseArgs a) {
 // PGS kernel: 8 lanes per env, 8 envs per wavefront
 // ------------------------------------------------------------------------------------------------
 struct SgPgsArgs {
+  const SgEqSlot* sched;  // SgPlan::sched (equality-row schedule of neighbour-row models), nullptr when H.nnb == 0
+  const int* nbtab;       // SgPlan::nbtab
   const SgPlanHeader* H;
   const double* elem;
   SgWork w;
@@ -1148,7 +1203,14 @@ __device__ __forceinline__ double sg_gsum8(double x) {
   return x;
 }
 
-template <int NSL>  // NSL >= ceil(nelem / 8): joint-fix rows per lane, unrolled and padded (straight-line code, LDS reads issue back to back)
+// NB = true: the model has neighbour equality rows (slider e = slider e2).  The joint-fix rows are then no longer mutually
+// independent, and the equality block of a sweep -- MuJoCo's order [fix_0, nb_0.., fix_1, nb_1.., ...] -- runs as the plan's
+// list schedule (SgEqSlot): H.eq_rounds rounds, one row per lane of the env's group and round, rows of a round share no
+// slider and every row comes after the rows it depends on, so the rounds in order ARE the sequential sweep.  Per row the LDS
+// holds g = b + R f (instead of f), R and 1 / (A + R); the update is res = g + a1 - a2, t = res / (A + R), a1 -= t / m1,
+// a2 += t / m2, g -= R t.  The slider accelerations are kept incrementally (every update is applied to them as it happens),
+// so the final "fresh M^-1 J' f" pass only concerns the finger chains.
+template <int NSL, bool NB>  // NSL >= ceil(nelem / 8): joint-fix rows per lane, unrolled and padded (straight-line code, LDS reads issue back to back)
 __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x, le = lane >> 3, g = lane & 7, c = g >> 2, r = g & 3;
@@ -1168,14 +1230,25 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   // is a no-op and the row loop needs no bound test).  Per env: AF[j] = (a_s, f) [the only pair written], BR[j] = (b, R),
   // RI[j] = 1 / (A_jj + R_j); shared by the 8 envs: IC[j] = (1/m, tendon coefficient).  A row is three 16-byte reads + one 8-byte.
   constexpr int NR = 8 * NSL;
+  // NB layout: Ae[NA] slider accelerations per env (word N is a dummy that stays 0: "no second slider"), IC[NA] shared,
+  // Ge[NEQP] / RRe[NEQP] per env: g and (R, 1 / (A + R)) of fix row e at e, of neighbour row k at N + k, dummy record at N + nnb
+  constexpr int NA = NR + 8;
+  const int nnb = NB ? H.nnb : 0, NEQP = N + nnb + 1;
   double2* const AF = (double2*)lds + (size_t)le * NR;
   double2* const BR = (double2*)lds + (size_t)8 * NR + (size_t)le * NR;
   double* const RI = lds + (size_t)32 * NR + (size_t)le * NR;
-  double2* const IC = (double2*)(lds + (size_t)40 * NR);
-  double* Lzero = lds + (size_t)42 * NR + (size_t)16 * 4 * SG_MAXLIM;  // [0]: a word that stays 0 (reads of "no slider"), [1 + lane]: write sink
+  double2* const IC = NB ? (double2*)(lds + (size_t)8 * NA) : (double2*)(lds + (size_t)40 * NR);
+  double* const Ae = lds + (size_t)le * NA;
+  double* const Ge = lds + (size_t)10 * NA + (size_t)le * NEQP;
+  double2* const RRe = (double2*)(lds + (size_t)10 * NA + (size_t)8 * NEQP) + (size_t)le * NEQP;
+  double* Lzero = NB ? lds + (size_t)10 * NA + (size_t)24 * NEQP
+                     : lds + (size_t)42 * NR + (size_t)16 * 4 * SG_MAXLIM;  // [0]: a word that stays 0 (reads of "no slider"), [1 + lane]: write sink
+  double* const ASb = NB ? Ae : (double*)AF;  // slider acceleration of element j: ASb[ASS * j]
+  constexpr int ASS = NB ? 1 : 2;
   if (lane == 0) Lzero[0] = 0.0;
-  for (int j = lane; j < NR; j += 64)
+  for (int j = lane; j < (NB ? NA : NR); j += 64)
     IC[j] = j < N ? make_double2(1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]), a.elem[(size_t)SGE_COEF * N + j]) : make_double2(0.0, 0.0);
+  if constexpr (!NB) {
   for (int j = g; j < NR; j += 8) {
     double2 af = make_double2(0.0, 0.0), br = make_double2(0.0, 1.0);
     double ri = 0.0;
@@ -1186,6 +1259,29 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
       ri = sg_div(1.0, im + Rr);  // 1 / (A_jj + R_j): sg_div(res, A_jj + R_j) == res * this
     }
     AF[j] = af; BR[j] = br; RI[j] = ri;
+  }
+  } else {
+    auto EIM = [&](int e) { return 1.0 / (a.elem[(size_t)SGE_MASS * N + e] + a.elem[(size_t)SGE_ARMATURE * N + e]); };
+    for (int j = g; j < NA; j += 8) Ae[j] = (valid && j < N) ? W.as[(size_t)env * N + j] : 0.0;
+    for (int u = g; u < NEQP; u += 8) {
+      double gg = 0.0;
+      double2 rr = make_double2(0.0, 0.0);
+      if (valid && u < N + nnb) {
+        double bb, Rr, ff, ims;
+        if (u < N) {
+          const size_t o = (size_t)env * N + u;
+          bb = W.eqb[o]; Rr = W.eqR[o]; ff = W.eqf[o]; ims = EIM(u);
+        } else {
+          const int k = u - N;
+          const size_t o = (size_t)env * nnb + k;
+          bb = W.nbb[o]; Rr = W.nbR[o]; ff = W.nbf[o];
+          ims = EIM(a.nbtab[9 * N + k]) + EIM(a.nbtab[9 * N + nnb + k]);
+        }
+        gg = bb + Rr * ff;
+        rr = make_double2(Rr, sg_div(1.0, ims + Rr));
+      }
+      Ge[u] = gg; RRe[u] = rr;
+    }
   }
   const size_t st = 2 * (size_t)(env < a.nenv ? env : 0) + c;
   int ns = 0, lim_active = 0, shared = 0;
@@ -1232,6 +1328,45 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     if (!__ballot(running)) break;
     SG_T(10);
     double imp_acc = 0, tJap = 0;
+    if constexpr (NB) {
+      // equality block as the plan's schedule; the slot of round k + 1 is requested before round k is computed
+      const SgEqSlot* sp = a.sched + g;
+      int4 sa = *(const int4*)sp;
+      double2 sb = *(const double2*)&sp->im1;
+      for (int k = 0; k < H.eq_rounds; k++) {
+        sp += 8;  // the table has one spare round at its end (idle slots), so the look-ahead needs no bound check
+        const int4 na = *(const int4*)sp;
+        const double2 nb = *(const double2*)&sp->im1;
+        if (running) {
+          const double a1 = Ae[sa.x], a2 = Ae[sa.y], gg = Ge[sa.z];
+          const double2 rr = RRe[sa.z];
+          const double res = (gg + a1) - a2, t = res * rr.y;
+          Ae[sa.x] = a1 - sb.x * t;
+          Ae[sa.y] = a2 + sb.y * t;
+          Ge[sa.z] = gg - rr.x * t;
+          imp_acc += 0.5 * res * t;
+        }
+        sa = na; sb = nb;
+      }
+      SG_T(11);
+      // tendon row over the current slider accelerations, then its push on every slider
+      if (running) {
+#pragma unroll
+        for (int t = 0; t < NSL + 1; t++) tJap += IC[g + 8 * t].y * Ae[g + 8 * t];
+      }
+      double Ja = sg_gsum8(tJap);
+      double old = tf, tfn = tf;
+      double ch = scalar_update(tfn, tb, Ja, tR, tA, false);
+      if (running) {
+        if (g == 0) imp_acc -= ch;
+        tf = tfn;
+      }
+      const double dft = tf - old;
+      if (running) {
+#pragma unroll
+        for (int t = 0; t < NSL + 1; t++) { const double2 ic = IC[g + 8 * t]; Ae[g + 8 * t] += ic.x * ic.y * dft; }
+      }
+    } else {
     double ael[NSL], fnw[NSL], imc[NSL];
     if (running) {
       // joint-fix rows: unconstrained scalar rows, so the step d = -res / (A + R) always lowers the cost (change =
@@ -1273,6 +1408,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         for (int t = 0; t < NSL; t++) AF[g + 8 * t] = make_double2(ael[t] + imc[t] * dft, fnw[t]);
       }
     }
+    }
     __syncthreads();
     SG_T(12);
     for (int pass = 0; pass < 2; pass++) {
@@ -1306,7 +1442,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           const double A0 = w.a01.x, A1 = w.a01.y, A2 = w.a2s.x, P11 = w.p12.x, P12 = w.p12.y, P22 = w.p3i.x, JsI = w.p3i.y;
           const double Rr = sg_qb<0>(w.a2s.y);
           const int sl = __double2loint(sg_qb<2>(w.a2s.y));
-          const double as_ = *(sl >= 0 ? (const double*)(AF + sl) : &Lzero[0]);  // branch-free: "no slider" reads a zero word
+          const double as_ = *(sl >= 0 ? (const double*)(ASb + ASS * sl) : &Lzero[0]);  // branch-free: "no slider" reads a zero word
           const double res = ((bb + Js * as_) + (J0 * aF[0] + J1 * aF[1])) + ((Rr * fo + J2 * aF[2]) + J3 * aF[3]);  // 0 on lane 3
           const double o0 = sg_qb<0>(fo);
           // ---- normal or ray update (wv = row r of A f, kept with f)
@@ -1361,7 +1497,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
             const double t0 = sg_dpp<0x4E>(jsdf), t1 = sg_dpp<0x4E>(g0_), t2 = sg_dpp<0x4E>(g1_), t3 = sg_dpp<0x4E>(g2_), t4 = sg_dpp<0x4E>(g3_);
             jsdf += t0; g0_ += t1; g1_ += t2; g2_ += t3; g3_ += t4;
           }
-          *((sl >= 0 && r == 0) ? (double*)(AF + sl) : &Lzero[1 + lane]) = as_ + jsdf;  // other lanes write to their sink word
+          *((sl >= 0 && r == 0) ? (double*)(ASb + ASS * sl) : &Lzero[1 + lane]) = as_ + jsdf;  // other lanes write to their sink word
 #pragma unroll
           for (int q = 0; q < SG_CD; q++) aF[q] += (Minv[4 * q] * g0_ + Minv[4 * q + 1] * g1_) + (Minv[4 * q + 2] * g2_ + Minv[4 * q + 3] * g3_);
           w.fw = make_double2(fn, wn);
@@ -1393,8 +1529,10 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   SG_T(15);
   __syncthreads();
   // ---- fresh M^-1 J' f from the final forces
-  if (valid)
-    for (int j = g; j < N; j += 8) AF[j].x = IC[j].x * (AF[j].y + IC[j].y * tf);
+  if constexpr (!NB) {
+    if (valid)
+      for (int j = g; j < N; j += 8) AF[j].x = IC[j].x * (AF[j].y + IC[j].y * tf);
+  }
   __syncthreads();
   double gF[SG_CD] = {0, 0, 0, 0};
   for (int pass = 0; pass < 2; pass++) {  // one pass, or finger 0 then finger 1 when they share a slider (deterministic sums)
@@ -1422,7 +1560,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           const double u0 = sg_dpp<0x4E>(jsf), u1 = sg_dpp<0x4E>(t0), u2 = sg_dpp<0x4E>(t1), u3 = sg_dpp<0x4E>(t2), u4 = sg_dpp<0x4E>(t3);
           jsf += u0; t0 += u1; t1 += u2; t2 += u3; t3 += u4;
         }
-        if (sl >= 0 && r == 0) AF[sl].x += jsf;
+        if (!NB && sl >= 0 && r == 0) AF[sl].x += jsf;
         if (r == 0) { gF[0] += t0; gF[1] += t1; gF[2] += t2; gF[3] += t3; }
       }
     };
@@ -1449,7 +1587,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     }
   }
   if (valid) {
-    for (int j = g; j < N; j += 8) W.as[(size_t)env * N + j] = AF[j].x;
+    for (int j = g; j < N; j += 8) W.as[(size_t)env * N + j] = ASb[ASS * j];
     if (g == 0) W.iters[env] = iters;
   }
   SG_T(16);

@@ -10,7 +10,8 @@ implements exactly the MJCF feature subset listed in SURVEY.md App. A.1:
 * spatial tendons through sites (no wrapping geoms / pulleys), fixed tendons
 * ``cylinder`` actuators on tendons, ``accelerometer`` / ``gyro`` sensors
 * ``<composite type="box"|"ellipsoid">`` shells (radial sliders, joint-fix
-  equalities, one fixed tendon with a tendon-fix equality)
+  equalities, neighbour equalities between adjacent shell sliders, one fixed
+  tendon with a tendon-fix equality)
 
 Section processing order follows MuJoCo's XML reader (all ``<default>`` first,
 then every ``<worldbody>`` in document order, then ``<tendon>``, ``<actuator>``,
@@ -44,7 +45,7 @@ SENS_ACCELEROMETER, SENS_GYRO = 1, 3
 MJ_MINVAL = 1e-15
 
 BLOB_MAGIC = 0x4D474753  # 'SGGM'
-BLOB_VERSION = 1
+BLOB_VERSION = 2
 
 
 # ----------------------------------------------------------------------------
@@ -234,6 +235,7 @@ class _Equality:
     solref: np.ndarray
     solimp: np.ndarray
     data: np.ndarray
+    name2: Optional[str] = None  # second joint of a two-joint equality (q1 - q1_0 = poly(q2 - q2_0), data = polycoef)
 
 
 _DEF_SOLREF = np.array([0.02, 1.0])
@@ -255,8 +257,9 @@ def _bool(s, default=False):
 
 
 class _Compiler:
-    def __init__(self, path: str):
+    def __init__(self, path: str, composite_neighbors: bool = True):
         self.root = _load_xml(path)
+        self.composite_neighbors = composite_neighbors
         self.defaults = _Defaults()
         self.bodies: List[_Body] = [_Body("world", np.zeros(3), np.array([1.0, 0, 0, 0]), -1)]
         self.tendons: List[_Tendon] = []
@@ -477,6 +480,18 @@ class _Compiler:
                     self.bodies.append(b)
                     self.equalities.append(_Equality(EQ_JOINT, j.name, eq_j["solref"], eq_j["solimp"], np.zeros(5)))
                     ten.wraps.append((j.name, 1.0))
+                    if self.composite_neighbors:
+                        # "each joint is equality-constrained to remain equal to its neighbor joints" (MuJoCo 2.x composite
+                        # documentation, box / cylinder / ellipsoid): one two-joint equality towards the next shell element
+                        # along +x, +y, +z, registered right after the element's own fix row, same solreffix / solimpfix
+                        for d in range(3):
+                            q = [ix, iy, iz]
+                            q[d] = min(q[d] + 1, count[d] - 1)
+                            if q == [ix, iy, iz] or not any(q[k] in (0, count[k] - 1) for k in range(3)):
+                                continue
+                            self.equalities.append(_Equality(EQ_JOINT, j.name, eq_j["solref"], eq_j["solimp"],
+                                                             np.array([0.0, 1.0, 0.0, 0.0, 0.0]),
+                                                             prefix + "J%d_%d_%d" % tuple(q)))
         self.equalities.append(_Equality(EQ_TENDON, ten.name, eq_t["solref"], eq_t["solimp"], np.zeros(5)))
 
     # -- tendons ------------------------------------------------------------
@@ -660,6 +675,8 @@ class _Compiler:
         m.eq_type = np.array([e.type for e in self.equalities], np.int32).reshape(ne)
         m.eq_obj1id = np.array([jidx[e.name1] if e.type == EQ_JOINT else tidx[e.name1]
                                 for e in self.equalities], np.int32).reshape(ne)
+        m.eq_obj2id = np.array([jidx[e.name2] if e.name2 is not None else -1 for e in self.equalities],
+                               np.int32).reshape(ne)
         m.eq_solref = np.array([e.solref for e in self.equalities]).reshape(ne, 2)
         m.eq_solimp = np.array([e.solimp for e in self.equalities]).reshape(ne, 5)
         m.eq_data = np.array([e.data for e in self.equalities]).reshape(ne, 5)
@@ -878,7 +895,7 @@ class Model:
         "jnt_type", "jnt_bodyid", "jnt_limited", "dof_parentid",
         "geom_type", "geom_bodyid", "geom_contype", "geom_conaffinity", "geom_condim", "geom_priority",
         "site_bodyid", "tendon_adr", "tendon_num", "wrap_type", "wrap_objid",
-        "eq_type", "eq_obj1id", "actuator_trnid", "sensor_type", "sensor_objid", "sensor_adr",
+        "eq_type", "eq_obj1id", "eq_obj2id", "actuator_trnid", "sensor_type", "sensor_objid", "sensor_adr",
     ]
 
     def to_blob(self) -> bytes:
@@ -956,9 +973,12 @@ class Model:
         return "\n".join(out)
 
 
-def compile_mjcf(path: str) -> Model:
-    """Counterpart of ``mujoco_py.load_model_from_path`` (reference environment/manenv.py:27)."""
-    return _Compiler(path).run()
+def compile_mjcf(path: str, composite_neighbors: bool = True) -> Model:
+    """Counterpart of ``mujoco_py.load_model_from_path`` (reference environment/manenv.py:27).
+
+    ``composite_neighbors=False`` leaves out the neighbour equalities of box / ellipsoid / cylinder composites (SURVEY.md
+    App. A.2, unknown U2) -- kept as a switch because no MuJoCo is available to confirm them."""
+    return _Compiler(path, composite_neighbors).run()
 
 
 def load_model(path: str) -> Model:

@@ -40,6 +40,11 @@ Emu* emu_new(const void* blob, size_t n, char* err, size_t errlen) {
     return nullptr;
   }
   const SgPlanHeader& H = E->P.h;
+  if (H.nnb > 0) {  // the harness emulates the fused kernel, which has no neighbour rows (models/softbox_fixonly.sgmodel)
+    snprintf(err, errlen, "the lane-serial harness does not support neighbour equality rows");
+    delete E;
+    return nullptr;
+  }
   E->N = H.nelem;
   E->qe.resize(E->N); E->ve.resize(E->N); E->we.resize(E->N); E->ke.resize(E->N);
   E->sens.assign(H.nsensordata, 0.0);

@@ -13,7 +13,7 @@ def test_rest_sensors_read_gravity():
     s.reset()
     assert s.forward() == 0
     np.testing.assert_allclose(s.sensordata, [0, 0, 9.81, 0, 0, 9.81, 0, 0, 0, 0, 0, 0], atol=1e-12)
-    assert s.ncon == 0 and s.nefc == 111
+    assert s.ncon == 0 and s.nefc == 111 + 216   # 110 joint-fix + 216 neighbour + 1 tendon-fix equality rows
 
 
 def test_cylinder_actuator_filter():
@@ -83,9 +83,9 @@ def test_joint_limit_pushes_back():
     s.reset()
     s.qpos[1] = 0.05   # twist joint, range +-0.01
     s.forward()
-    assert s.nefc == 112
+    assert s.nefc == 328
     f = s.efc_force()
-    assert f[111] > 0 and s.qacc[1] < 0
+    assert f[327] > 0 and s.qacc[1] < 0
 
 
 def test_contact_appears_when_finger_closes():
@@ -151,7 +151,7 @@ def test_pgs_fixed_point_satisfies_the_cone_qp_kkt_conditions():
             assert r0 >= np.hypot(mu1 * r1, mu2 * r2) - tol, ("dual cone", i, r[i:i + 3])
             assert abs(f0 * r0 + f1 * r1 + f2 * r2) < tol * max(1.0, f0), ("complementarity", i)
             n_con += 1; i += 3
-    assert n_eq == 111 and n_lim >= 1 and n_con == s2.ncon
+    assert n_eq == 327 and n_lim >= 1 and n_con == s2.ncon
     # and the 30-sweep answer of the production settings is a cost-decreasing step towards it
     cost = lambda x: 0.5 * x @ AR @ x + x @ b
     s3 = oracle_sim(m, 903.6948543200572)
