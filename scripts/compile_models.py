@@ -20,17 +20,12 @@ SCENES = {
 
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "models"), exist_ok=True)
-    for name, xml in SCENES.items():
-        m = sg.compile_mjcf(os.path.join(REF, xml))
-        out = os.path.join(ROOT, "models", name + ".sgmodel")
-        with open(out, "wb") as f:
-            f.write(m.to_blob())
-        print(name, "nv", m.nv, "neq", m.neq, "->", out, os.path.getsize(out), "bytes")
-    # the scenes without the composite's neighbour equalities: the model class the fused and split
-    # pipelines and the lane-serial harness (tests/emu) support, kept for their parity tests
-    for name, xml in SCENES.items():
-        m = sg.compile_mjcf(os.path.join(REF, xml), composite_neighbors=False)
-        out = os.path.join(ROOT, "models", name + "_fixonly.sgmodel")
-        with open(out, "wb") as f:
-            f.write(m.to_blob())
-        print(name + "_fixonly", "nv", m.nv, "neq", m.neq, "->", out, os.path.getsize(out), "bytes")
+    # <scene>.sgmodel: the composite as fix rows + tendon row (the default); <scene>_nb.sgmodel: the same scene with
+    # the composite's neighbour equalities switched on -- rows pipeline only
+    for suffix, nb in (("", False), ("_nb", True)):
+        for name, xml in SCENES.items():
+            m = sg.compile_mjcf(os.path.join(REF, xml), composite_neighbors=nb)
+            out = os.path.join(ROOT, "models", name + suffix + ".sgmodel")
+            with open(out, "wb") as f:
+                f.write(m.to_blob())
+            print(name + suffix, "nv", m.nv, "neq", m.neq, "->", out, os.path.getsize(out), "bytes")

@@ -25,7 +25,7 @@ CHAIN_NAMES = {17: "load state", 18: "FINISH", 19: "kinematics", 20: "dynamics (
 
 
 def main():
-    m = sg.load_model("models/softbox.sgmodel")
+    m = sg.load_model("models/%s.sgmodel" % (sys.argv[1] if len(sys.argv) > 1 else "softbox"))
     nm = native.NativeModel(m)
     n = 4096
     b = native.NativeBatch(nm, n, 0)
@@ -57,6 +57,9 @@ def main():
             w = np.array(buf[:32], dtype=np.float64) / ((n // 8) * 7)  # 7 PGS launches per sg_step call, 8 envs per wavefront
             tot = sum(w[k] for k in PGS_NAMES)
             print("   sg_pgs_rows_kernel: %.0f cycles per wavefront and launch (after the prologue)" % tot)
+            print("   contact passes per wavefront and launch: %.1f, contact slots swept: %.0f" % (w[29], w[28]))
+            print("   contact updates per stream and launch: %.0f, of which outside the friction cone (Newton / QCQP path): %.0f" % (
+                buf[26] / (2.0 * n * 7), buf[27] / (2.0 * n * 7)))
             for k, name in PGS_NAMES.items():
                 print("   %-26s %8.0f  %5.1f %%" % (name, w[k], 100 * w[k] / max(tot, 1)))
             cw = np.array(buf[:32], dtype=np.float64) / ((n // 64) * 2 * 8)  # 8 chain launches per sg_step call, 64 chains per wavefront

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 
 d = sys.argv[1]
-f = glob.glob(d + "/*/*_kernel_trace.csv")[0]
+f = (glob.glob(d + "/*/*_kernel_trace.csv") + glob.glob(d + "/*_kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3

@@ -171,7 +171,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
     std::vector<SgEqSlot> sch = m->plan.sched;
     SgEqSlot idle;
     idle.e1 = idle.e2 = H.nelem; idle.row = H.nelem + H.nnb; idle.pad = 0; idle.im1 = idle.im2 = 0;
-    for (int g = 0; g < 8; g++) sch.push_back(idle);  // the kernel requests round k + 1 before it computes round k
+    for (int g = 0; g < 8 * 8; g++) sch.push_back(idle);  // the kernel works in groups of four rounds and requests slots four rounds ahead
     ALLOC(b->dnbtab, sizeof(int) * m->plan.nbtab.size());
     ALLOC(b->dsched, sizeof(SgEqSlot) * sch.size());
     HIPCHK(hipMemcpy(b->dnbtab, m->plan.nbtab.data(), sizeof(int) * m->plan.nbtab.size(), hipMemcpyHostToDevice));
@@ -289,12 +289,16 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     HIPCHK(hipEventRecord(e0, s));
   }
   auto phase = [&](const SgPhaseArgs& p) {
+#define SG_PHASE(r)                                                                                   \
+  if (nbm) hipLaunchKernelGGL((sg_phase_kernel<r, 2, true>), dim3(b->n), dim3(64), 0, s, p);          \
+  else hipLaunchKernelGGL((sg_phase_kernel<r, 2, false>), dim3(b->n), dim3(64), 0, s, p)
     switch (b->m->rounds) {
-      case 1: hipLaunchKernelGGL((sg_phase_kernel<1, 2>), dim3(b->n), dim3(64), 0, s, p); break;
-      case 2: hipLaunchKernelGGL((sg_phase_kernel<2, 2>), dim3(b->n), dim3(64), 0, s, p); break;
-      case 3: hipLaunchKernelGGL((sg_phase_kernel<3, 2>), dim3(b->n), dim3(64), 0, s, p); break;
-      default: hipLaunchKernelGGL((sg_phase_kernel<4, 2>), dim3(b->n), dim3(64), 0, s, p); break;
+      case 1: SG_PHASE(1); break;
+      case 2: SG_PHASE(2); break;
+      case 3: SG_PHASE(3); break;
+      default: SG_PHASE(4); break;
     }
+#undef SG_PHASE
   };
   for (int k = 0; k <= nfwd; k++) {
     SgPhaseArgs p = pa;

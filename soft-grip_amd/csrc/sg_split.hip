@@ -92,7 +92,7 @@ struct ChainLds2 {  // what the phase kernel needs of a finger chain (imported f
   double lim_sign[SG_MAXLIM], lim_R[SG_MAXLIM], lim_b[SG_MAXLIM], lim_f[SG_MAXLIM];  // contiguous, in the hand-off record's order
 };
 
-template <int R, int CPL>
+template <int R, int CPL, bool NB>
 struct Smem2 {
   ChainKin K[SG_MAXCH];
   ChainLds2 cs[SG_MAXCH];
@@ -103,7 +103,7 @@ struct Smem2 {
   unsigned short pairs[SG_MAXCH * SG_CG * (R * 64 + 2)];  // broadphase survivors, (box << 12) | element, in contact order
   unsigned short eslot[R * 64][SG_MAXCH * SG_CG];         // per element and box: first contact slot | (contact count << 8)
   double cval[SG_MAXCH][32 * CPL];                        // per contact slot: invm * Js' f (its push on the slider)
-  double nbf[3 * R * 64];                                 // neighbour equality rows: warmstart force, by row id
+  double nbf[NB ? 3 * R * 64 : 1];                        // neighbour equality rows: warmstart force, by row id
 };
 #define SG_PAIR_CENTER 0xFFF  // element code of the object's centre sphere
 
@@ -141,7 +141,7 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
 // ------------------------------------------------------------------------------------------------
 // phase kernel: [finish previous substep] [begin next substep]
 // ------------------------------------------------------------------------------------------------
-template <int R, int CPL>
+template <int R, int CPL, bool NB>  // NB: the model has neighbour equality rows (H.nnb > 0)
 __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= a.nenv) return;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   const int N = H.nelem, nv = H.nv, nu = H.nu, e0 = H.elem_dof0, nchain = H.nchain;
   const size_t S = 2 * (size_t)a.nenv;
   const double h = H.timestep;
-  __shared__ Smem2<R, CPL> Sm;
+  __shared__ Smem2<R, CPL, NB> Sm;
   auto EL = [&](int f, int e) { return a.elem[(size_t)f * N + e]; };
   const int half = lane >> 5;
   const bool high = half != 0;
@@ -563,14 +563,15 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
       }
       // ---- neighbour rows (slider e = slider e2, J = +1 / -1): built by the lane of their first element, up to three each.
       //      b and R go straight to the workspace; the warmstart force lives in LDS (Sm.nbf, by row id) for the gathers below
-      const int nnb = H.nnb;
+      const int nnb = NB ? H.nnb : 0;
+      constexpr int ND = NB ? 3 : 0;  // neighbour rows per element (loops over d vanish without them)
       int nbe2[R][3], nbid[R][3];
       double nbc0[R][3];  // f (R f / 2 + b)
 #pragma unroll
       for (int r = 0; r < R; r++)
 #pragma unroll
         for (int d = 0; d < 3; d++) { nbe2[r][d] = -1; nbid[r][d] = -1; nbc0[r][d] = 0; }
-      if (nnb > 0) {
+      if constexpr (NB) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
           const int e = r * 64 + lane;
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           int e = r * 64 + lane;
           if (e < N) {
             double fe = eqf[r] + coef[r] * tf;
-            if (nnb > 0) {  // + its own neighbour rows (J = +1), - the rows that have it as second joint (J = -1), in row order per side
+            if constexpr (NB) {  // + its own neighbour rows (J = +1), - the rows that have it as second joint (J = -1), in row order per side
 #pragma unroll
               for (int d = 0; d < 3; d++) if (nbid[r][d] >= 0) fe += Sm.nbf[nbid[r][d]];
 #pragma unroll
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           if (e < N) {
             double ae = Sm.as[e]; cp += eqf[r] * (0.5 * (ae + eqR[r] * eqf[r]) + eqb[r]); tJap += coef[r] * ae;
 #pragma unroll
-            for (int d = 0; d < 3; d++)
+            for (int d = 0; d < ND; d++)
               if (nbid[r][d] >= 0) cp += 0.5 * Sm.nbf[nbid[r][d]] * (ae - Sm.as[nbe2[r][d]]) + nbc0[r][d];
           }
         }
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           for (int r = 0; r < R; r++) {
             eqf[r] = 0;
 #pragma unroll
-            for (int d = 0; d < 3; d++) if (nbid[r][d] >= 0) Sm.nbf[nbid[r][d]] = 0.0;
+            for (int d = 0; d < ND; d++) if (nbid[r][d] >= 0) Sm.nbf[nbid[r][d]] = 0.0;
           }
           tf = 0;
           if (is_chain_lane) {
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           size_t o = (size_t)env * N + e;
           W.as[o] = Sm.as[e]; W.eqf[o] = eqf[r]; W.eqb[o] = eqb[r]; W.eqR[o] = eqR[r];
 #pragma unroll
-          for (int d = 0; d < 3; d++)
+          for (int d = 0; d < ND; d++)
             if (nbid[r][d] >= 0) W.nbf[(size_t)env * nnb + nbid[r][d]] = Sm.nbf[nbid[r][d]];
         }
       }
@@ -1329,24 +1330,35 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     SG_T(10);
     double imp_acc = 0, tJap = 0;
     if constexpr (NB) {
-      // equality block as the plan's schedule; the slot of round k + 1 is requested before round k is computed
+      // equality block as the plan's schedule.  The slot of round k + 4 is requested when round k is computed (four register
+      // sets in flight: with one round of look-ahead every round waited ~300 cycles for its slot, profiles/r01_v11); the table
+      // ends with four spare rounds of idle slots, so the look-ahead needs no bound check
       const SgEqSlot* sp = a.sched + g;
-      int4 sa = *(const int4*)sp;
-      double2 sb = *(const double2*)&sp->im1;
-      for (int k = 0; k < H.eq_rounds; k++) {
-        sp += 8;  // the table has one spare round at its end (idle slots), so the look-ahead needs no bound check
-        const int4 na = *(const int4*)sp;
-        const double2 nb = *(const double2*)&sp->im1;
+      int4 sa[4];
+      double2 sb[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { sa[q] = *(const int4*)(sp + 8 * q); sb[q] = *(const double2*)&(sp + 8 * q)->im1; }
+      sp += 32;
+      auto eq_round = [&](const int4& ia, const double2& im) {
         if (running) {
-          const double a1 = Ae[sa.x], a2 = Ae[sa.y], gg = Ge[sa.z];
-          const double2 rr = RRe[sa.z];
+          const double a1 = Ae[ia.x], a2 = Ae[ia.y], gg = Ge[ia.z];
+          const double2 rr = RRe[ia.z];
           const double res = (gg + a1) - a2, t = res * rr.y;
-          Ae[sa.x] = a1 - sb.x * t;
-          Ae[sa.y] = a2 + sb.y * t;
-          Ge[sa.z] = gg - rr.x * t;
+          Ae[ia.x] = a1 - im.x * t;
+          Ae[ia.y] = a2 + im.y * t;
+          Ge[ia.z] = gg - rr.x * t;
           imp_acc += 0.5 * res * t;
         }
-        sa = na; sb = nb;
+      };
+      for (int k = 0; k < H.eq_rounds; k += 4) {  // rounds past eq_rounds are idle slots (no-ops)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int4 ia = sa[q];
+          const double2 im = sb[q];
+          sa[q] = *(const int4*)(sp + 8 * q); sb[q] = *(const double2*)&(sp + 8 * q)->im1;
+          eq_round(ia, im);
+        }
+        sp += 32;
       }
       SG_T(11);
       // tendon row over the current slider accelerations, then its push on every slider
@@ -1452,6 +1464,9 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           double x = denom >= SG_MINVAL ? sg_div(-num, denom) : 0.0;
           x = (o0 + x * o0 < 0) ? -1.0 : x;
           double gr = fo + x * fo;
+#ifdef SG_SECTION_PROF
+          if (r == 0) atomicAdd(&a.w.secprof[26], 1ull);  // contact updates (per stream)
+#endif
           if (o0 < SG_MINVAL) {  // uncommon: no normal force yet (lane 0 holds res_0 and A_00)
             double gn = o0 - sg_div(res, A0);
             gr = r == 0 ? (gn < 0 ? 0.0 : gn) : 0.0;
@@ -1467,6 +1482,9 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           const double val = (u1 * u1 + u2 * u2) - g0 * g0;
           double v1 = u1 * mu0, v2 = u2 * mu1;
           if (!(val < 1e-10) && !nofric) {  // uncommon: outside the cone -- the generic Newton iteration
+#ifdef SG_SECTION_PROF
+            if (r == 0) atomicAdd(&a.w.secprof[27], 1ull);  // sliding contact updates (per stream)
+#endif
             const double a11 = sg_qb<1>(A1), a12 = sg_qb<1>(A2), a22 = sg_qb<2>(A2);
             const double Ac[4] = {a11, a12, a12, a22}, bcv[2] = {sg_qb<1>(bc), sg_qb<2>(bc)}, mu[2] = {mu0, mu1};
             double v[2];
@@ -1504,6 +1522,9 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         }
         ((double2*)pl)[sink_off - 1 * 64] = w.fw;
       };
+#ifdef SG_SECTION_PROF
+      if (lane == 0) { atomicAdd(&a.w.secprof[28], (unsigned long long)nsmax); atomicAdd(&a.w.secprof[29], 1ull); }
+#endif
       // slots 0 .. SG_CAP+1 exist in memory (two spare slots), so the look-ahead never needs a bound check
       Row ra, rb;
       const double2* pa = row0;

@@ -40,7 +40,7 @@ Emu* emu_new(const void* blob, size_t n, char* err, size_t errlen) {
     return nullptr;
   }
   const SgPlanHeader& H = E->P.h;
-  if (H.nnb > 0) {  // the harness emulates the fused kernel, which has no neighbour rows (models/softbox_fixonly.sgmodel)
+  if (H.nnb > 0) {  // the harness emulates the fused kernel, which has no neighbour rows (models/*_nb.sgmodel)
     snprintf(err, errlen, "the lane-serial harness does not support neighbour equality rows");
     delete E;
     return nullptr;

@@ -21,7 +21,7 @@ def _pair(scene, k):
 
 @pytest.mark.parametrize("k", [903.6948543200572, 300.0])
 def test_softbox_full_episode(k):
-    m, e, s = _pair("softbox_fixonly", k)
+    m, e, s = _pair("softbox", k)
     worst = 0.0
     for t, c in enumerate(episode_schedule()):
         if c is not None:
@@ -40,7 +40,7 @@ def test_softbox_full_episode(k):
 @pytest.mark.parametrize("scene", ["softcylinder", "softball"])
 def test_penetrating_scenes_first_steps(scene):
     """these scenes start in deep penetration and are chaotic; the two implementations agree until the first tie-break"""
-    m, e, s = _pair(scene + "_fixonly", 700.0)
+    m, e, s = _pair(scene, 700.0)
     for _ in range(2):
         e.substep(True); s.step()
         q, v, w, a = e.state()

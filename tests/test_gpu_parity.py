@@ -33,21 +33,20 @@ def _bufs(b, n):
 FREE_RUN_STEPS = 50  # env steps over which the neighbour-row scene is also compared free-running (contact starts at ~45)
 
 
-@pytest.mark.parametrize("scene,pipeline", [("softbox", "rows"), ("softbox_fixonly", "rows"), ("softbox_fixonly", "split"),
-                                            ("softbox_fixonly", "fused")])
+@pytest.mark.parametrize("scene,pipeline", [("softbox", "rows"), ("softbox", "split"), ("softbox", "fused"), ("softbox_nb", "rows")])
 def test_softbox_episode_matches_oracle(scene, pipeline):
     """every kernel pipeline against the oracle over the whole reference episode, 9 envs so that the PGS kernel runs a full
-    and a partial wavefront.  softbox = the scene as compiled by default (with the composite's neighbour equalities: rows
-    pipeline only); softbox_fixonly = the same scene without them (all three pipelines).
+    and a partial wavefront.  softbox = the scene as compiled by default (all three pipelines); softbox_nb = the same scene with
+    the composite's neighbour equalities switched on (rows pipeline only).
 
-    softbox_fixonly is compared free-running over the 200 steps.  With the neighbour rows the squeeze is sensitive to
-    round-off (two runs that differ in the last bit part by a factor ~10 every 5 env steps once the fingers touch),
-    so softbox is compared (a) free-running up to FREE_RUN_STEPS and (b) over the whole episode step by step along the
+    softbox is compared free-running over the 200 steps.  With the neighbour rows the squeeze is sensitive to round-off (two
+    runs that differ in the last bit part by a factor ~10 every 5 env steps once the fingers touch), so softbox_nb
+    is compared (a) free-running up to FREE_RUN_STEPS and (b) over the whole episode step by step along the
     oracle's trajectory: after every env step the batch is re-seated on the oracle's state, and what is bounded is the error
     the kernels add in one env step (7 substeps) -- every step of the episode, contact sets and iteration counts exactly."""
     import torch
     ks = [700.0, 903.6948543200572, 300.0, 1400.0, 512.25, 350.0, 1000.0, 1250.0, 640.0]
-    reseat = scene == "softbox"
+    reseat = scene == "softbox_nb"
     m, nm, b = _gpu_batch(scene, ks, pipeline)
     sens, flags, touch = _bufs(b, len(ks))
     sims = [oracle_sim(m, k) for k in ks]
@@ -92,10 +91,9 @@ def test_softbox_episode_matches_oracle(scene, pipeline):
         np.testing.assert_allclose(st["act"][e].cpu().numpy(), s.act, atol=1e-13)
 
 
-@pytest.mark.parametrize("scene,pipeline", [("softcylinder", "rows"), ("softball", "rows"),
-                                            ("softcylinder_fixonly", "rows"), ("softball_fixonly", "rows"),
-                                            ("softcylinder_fixonly", "split"), ("softball_fixonly", "split"),
-                                            ("softcylinder_fixonly", "fused"), ("softball_fixonly", "fused")])
+@pytest.mark.parametrize("scene,pipeline", [("softcylinder", "rows"), ("softball", "rows"), ("softcylinder", "split"), ("softball", "split"),
+                                            ("softcylinder", "fused"), ("softball", "fused"),
+                                            ("softcylinder_nb", "rows"), ("softball_nb", "rows")])
 def test_other_scenes_first_substeps(scene, pipeline):
     """R = 3 / 4 kernel instantiations; these scenes start in deep penetration (chaotic), so only the first substeps
     are compared point-wise"""
@@ -143,7 +141,7 @@ def test_full_size_properties():
     s2, q2 = outs[1]
     assert np.array_equal(s1[0::2], s1[1::2]) and np.array_equal(q1[0::2], q1[1::2])
     assert np.array_equal(s1[perm], s2) and np.array_equal(q1[perm], q2)
-    assert np.isfinite(s1).all() and np.isfinite(q1).all()
+    assert np.isfinite(s1).all() and np.abs(s1[:, 2] - 9.81).max() < 5.0       # accelerometer z stays near gravity
 
 
 def test_pipelines_agree_at_full_size():
@@ -153,7 +151,7 @@ def test_pipelines_agree_at_full_size():
     ks = np.random.RandomState(0).uniform(300, 1400, n)
     outs = []
     for pipeline in ("rows", "fused"):
-        _, _, b = _gpu_batch("softbox_fixonly", ks, pipeline)
+        _, _, b = _gpu_batch("softbox", ks, pipeline)
         sens, flags, touch = _bufs(b, n)
         b.reset(1, sens=sens, flags=flags, touch=touch)
         b.set_ctrl_broadcast(np.array([-0.2, -0.2]))
@@ -165,7 +163,7 @@ def test_pipelines_agree_at_full_size():
 
 def test_neighbour_row_model_refuses_other_pipelines():
     from softgrip_amd import native
-    m, nm, b = _gpu_batch("softbox", [700.0])
+    m, nm, b = _gpu_batch("softbox_nb", [700.0])
     with pytest.raises(native.SoftgripError):
         b.set_pipeline("fused")
 
@@ -191,8 +189,7 @@ def test_cfg2_uniform_stiffness_batch_is_bit_identical_across_envs():
         if t in (39, 48, 60, 100, 119, 150, 199):
             got = sens.cpu().numpy()
             assert np.array_equal(got, np.broadcast_to(got[0], got.shape)), "envs differ at step %d" % t
-            if t < FREE_RUN_STEPS:  # free-running against the oracle: before round-off is amplified (see test_softbox_episode_matches_oracle)
-                assert np.abs(got[0] - s0.sensordata).max() < TOL_SENSOR
+            assert np.abs(got[0] - s0.sensordata).max() < TOL_SENSOR
             assert int(flags.abs().sum()) == 0
             tc = touch.cpu().numpy()
             assert (tc == tc[0]).all()
@@ -244,8 +241,7 @@ def test_manenv_and_dataset_on_gpu(tmp_path):
         for _ in range(7):
             s.step()
         ref.append(s.sensordata.copy())
-    diff = np.abs(np.array(d["data"][1]) - np.array(ref))
-    assert diff[:FREE_RUN_STEPS].max() < TOL_SENSOR and np.isfinite(np.array(d["data"])).all()
+    assert np.abs(np.array(d["data"][1]) - np.array(ref)).max() < TOL_SENSOR
 
 
 def test_bad_env_is_reset_like_mujoco_exception():

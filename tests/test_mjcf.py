@@ -15,11 +15,11 @@ def test_blob_sizes_and_mass(scene):
     m = sg.load_model(model_path(scene))
     nbody, nv, ngeom, nelem = SIZES[scene]
     assert (m.nbody, m.nv, m.ngeom) == (nbody, nv, ngeom)
-    nnb = {"softbox": 216, "softcylinder": 380, "softball": 432}[scene]   # neighbour equalities
-    assert m.neq == nelem + nnb + 1 and m.ntendon == 3
-    assert (m.eq_obj2id >= 0).sum() == nnb and m.eq_type[-1] == 3 and m.eq_obj2id[0] == -1
-    mf = sg.load_model(model_path(scene + "_fixonly"))
-    assert mf.neq == nelem + 1 and (mf.eq_obj2id < 0).all() and mf.nv == nv and m.nu == 2 and m.nsensordata == 12
+    assert m.neq == nelem + 1 and m.ntendon == 3 and (m.eq_obj2id < 0).all()
+    nnb = {"softbox": 216, "softcylinder": 380, "softball": 432}[scene]   # the neighbour-equality variant
+    mn = sg.load_model(model_path(scene + "_nb"))
+    assert mn.neq == nelem + nnb + 1 and (mn.eq_obj2id >= 0).sum() == nnb and mn.eq_type[-1] == 3 and mn.eq_obj2id[0] == -1
+    assert mn.nv == nv and np.array_equal(mn.body_mass, m.body_mass) and m.nu == 2 and m.nsensordata == 12
     assert abs(m.body_mass.sum() - 0.45) < 1e-14              # settotalmass
     assert m.opt_timestep == 0.005 and m.opt_iterations == 30 and m.opt_tolerance == 1e-7
     assert m.tendon_names[0] == "OBJT"                        # the tendon the reference randomises (manenv.py:13)

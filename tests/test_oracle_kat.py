@@ -3,6 +3,7 @@ these (plus the harness fixture) are all the pinning the oracle has: PARITY WITH
 import os
 
 import numpy as np
+import pytest
 
 import softgrip_amd as sg
 from helpers import ROOT, model_path, oracle_sim
@@ -13,7 +14,7 @@ def test_rest_sensors_read_gravity():
     s.reset()
     assert s.forward() == 0
     np.testing.assert_allclose(s.sensordata, [0, 0, 9.81, 0, 0, 9.81, 0, 0, 0, 0, 0, 0], atol=1e-12)
-    assert s.ncon == 0 and s.nefc == 111 + 216   # 110 joint-fix + 216 neighbour + 1 tendon-fix equality rows
+    assert s.ncon == 0 and s.nefc == 111
 
 
 def test_cylinder_actuator_filter():
@@ -83,9 +84,9 @@ def test_joint_limit_pushes_back():
     s.reset()
     s.qpos[1] = 0.05   # twist joint, range +-0.01
     s.forward()
-    assert s.nefc == 328
+    assert s.nefc == 112
     f = s.efc_force()
-    assert f[327] > 0 and s.qacc[1] < 0
+    assert f[111] > 0 and s.qacc[1] < 0
 
 
 def test_contact_appears_when_finger_closes():
@@ -105,14 +106,57 @@ def test_contact_appears_when_finger_closes():
         np.testing.assert_allclose(F @ F.T, np.eye(3), atol=1e-12)
 
 
-def test_pgs_fixed_point_satisfies_the_cone_qp_kkt_conditions():
+def test_neighbour_equality_rows_known_answers():
+    """the composite's neighbour equalities (models/*_nb): row q couples sliders (j1, j2) with J = (+1, -1), so against the other
+    rows A = J M^-1 J' has 1/m1 + 1/m2 on its diagonal, +1/m1 / -1/m2 towards the fix rows of its two sliders, and R =
+    (1 - d)/d (invweight(j1) + invweight(j2)) with d = solimp[0] at zero violation; the rows follow their element's fix row"""
+    m = sg.load_model(model_path("softbox_nb"))
+    s = oracle_sim(m, 700.0)
+    s.reset()
+    assert s.forward() == 0 and s.ncon == 0 and s.nefc == m.neq == 327
+    AR, b, ty, ids, mu = s.constraint_problem()
+    assert (ty == 0).all() and ids.tolist() == list(range(327))
+    fix_row = {int(m.eq_obj1id[q]): q for q in range(m.neq - 1) if m.eq_obj2id[q] < 0}
+    im = 1.0 / np.diag(s.qM)
+    d0 = m.eq_solimp[0, 0]
+    nnb = 0
+    for q in range(m.neq - 1):
+        j1, j2 = int(m.eq_obj1id[q]), int(m.eq_obj2id[q])
+        if j2 < 0:
+            continue
+        nnb += 1
+        assert fix_row[j1] < q < fix_row.get(j1 + 1, m.neq)              # registered right after its element's fix row
+        R = (1 - d0) / d0 * (m.dof_invweight0[j1] + m.dof_invweight0[j2])
+        np.testing.assert_allclose(AR[q, q], im[j1] + im[j2] + R, rtol=1e-13)
+        np.testing.assert_allclose(AR[q, fix_row[j1]], im[j1], rtol=1e-13)
+        np.testing.assert_allclose(AR[q, fix_row[j2]], -im[j2], rtol=1e-13)
+        np.testing.assert_allclose(AR[q, -1], im[j1] - im[j2], atol=1e-9)  # against the tendon row (all coefficients 1)
+    assert nnb == 216
+    # a uniform offset of all sliders violates no neighbour row; a single displaced slider violates exactly its own rows
+    s.reset(); s.qpos[8:] = 0.01; s.forward()
+    _, b1, _, _, _ = s.constraint_problem()
+    s.reset(); s.forward()
+    _, b0, _, _, _ = s.constraint_problem()
+    nb_rows = [q for q in range(m.neq - 1) if m.eq_obj2id[q] >= 0]
+    np.testing.assert_allclose(b1[nb_rows], b0[nb_rows], atol=1e-9)
+    s.reset(); s.qpos[8 + 40] = 0.01; s.forward()
+    _, b2, _, _, _ = s.constraint_problem()
+    touched = [q for q in nb_rows if 8 + 40 in (m.eq_obj1id[q], m.eq_obj2id[q])]
+    others = [q for q in nb_rows if q not in touched]
+    assert 2 <= len(touched) <= 6 and np.abs(b2[touched] - b0[touched]).min() > 0.5
+    # (the displaced slider's spring pulls on the shared tendon, which shifts every slider's smooth acceleration by the same amount)
+    np.testing.assert_allclose(b2[others], b0[others], atol=1e-9)
+
+
+@pytest.mark.parametrize("scene,n_eq_rows,sweeps", [("softbox", 111, 3000), ("softbox_nb", 327, 30000)])
+def test_pgs_fixed_point_satisfies_the_cone_qp_kkt_conditions(scene, n_eq_rows, sweeps):
     """Independent check of the solver math (row projections, elliptic cone handling, QCQP): run to the fixed point (3000
     sweeps instead of 30), the PGS force must solve  min 1/2 f'(A+R)f + f'b  over  equality rows free, limit rows f >= 0,
     contact triples in the elliptic cone K = {f0 >= |(f1/mu1, f2/mu2)|}: residual r = (A+R)f + b must vanish on equality
     rows, be complementary to f >= 0 on limit rows, lie in the dual cone K* = {r0 >= |(mu1 r1, mu2 r2)|} with f'r = 0 on
     contacts."""
     import copy
-    m = sg.load_model(model_path("softbox"))
+    m = sg.load_model(model_path(scene))
     s = oracle_sim(m, 903.6948543200572)
     s.reset(); s.forward(); s.step()
     ctrl = -0.2
@@ -123,7 +167,7 @@ def test_pgs_fixed_point_satisfies_the_cone_qp_kkt_conditions():
         assert s.step() == 0
     assert s.ncon >= 10
     m2 = copy.copy(m)
-    m2.opt_iterations, m2.opt_tolerance = 3000, 0.0
+    m2.opt_iterations, m2.opt_tolerance = sweeps, 0.0
     s2 = oracle_sim(m2, 903.6948543200572)
     s2.reset()
     s2.qpos[:] = s.qpos; s2.qvel[:] = s.qvel; s2.act[:] = s.act; s2.ctrl[:] = s.ctrl; s2.qacc_warmstart[:] = s.qacc_warmstart
@@ -151,7 +195,7 @@ def test_pgs_fixed_point_satisfies_the_cone_qp_kkt_conditions():
             assert r0 >= np.hypot(mu1 * r1, mu2 * r2) - tol, ("dual cone", i, r[i:i + 3])
             assert abs(f0 * r0 + f1 * r1 + f2 * r2) < tol * max(1.0, f0), ("complementarity", i)
             n_con += 1; i += 3
-    assert n_eq == 327 and n_lim >= 1 and n_con == s2.ncon
+    assert n_eq == n_eq_rows and n_lim >= 1 and n_con == s2.ncon
     # and the 30-sweep answer of the production settings is a cost-decreasing step towards it
     cost = lambda x: 0.5 * x @ AR @ x + x @ b
     s3 = oracle_sim(m, 903.6948543200572)
