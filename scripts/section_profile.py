@@ -31,7 +31,7 @@ def main():
     b = native.NativeBatch(nm, n, 0)
     L = native.lib()
     L.sg_debug_sections.argtypes = [C.c_void_p, C.c_void_p]
-    buf = (C.c_ulonglong * 32)()
+    buf = (C.c_ulonglong * 48)()
     b.set_stiffness(np.random.RandomState(0).uniform(300, 1400, n), list(range(11, 64)), [0])
     b.reset(1)
     L.sg_debug_sections(b.ptr, buf)
@@ -58,8 +58,11 @@ def main():
             tot = sum(w[k] for k in PGS_NAMES)
             print("   sg_pgs_rows_kernel: %.0f cycles per wavefront and launch (after the prologue)" % tot)
             print("   contact passes per wavefront and launch: %.1f, contact slots swept: %.0f" % (w[29], w[28]))
-            print("   contact updates per stream and launch: %.0f, of which outside the friction cone (Newton / QCQP path): %.0f" % (
-                buf[26] / (2.0 * n * 7), buf[27] / (2.0 * n * 7)))
+            if buf[26]:  # counting build (build_native.py --count): the cycle figures of such a run are not timings
+                print("   contact updates per stream and launch: %.0f, of which outside the friction cone (Newton / QCQP path): %.0f" % (
+                    buf[26] / (2.0 * n * 7), buf[27] / (2.0 * n * 7)))
+                print("   QCQP fallback per wavefront and launch: entered on %.0f slots, %.0f further Newton evaluations" % (
+                    buf[32] / ((n // 8) * 7.0), buf[33] / ((n // 8) * 7.0)))
             for k, name in PGS_NAMES.items():
                 print("   %-26s %8.0f  %5.1f %%" % (name, w[k], 100 * w[k] / max(tot, 1)))
             cw = np.array(buf[:32], dtype=np.float64) / ((n // 64) * 2 * 8)  # 8 chain launches per sg_step call, 64 chains per wavefront

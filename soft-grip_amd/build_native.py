@@ -17,8 +17,12 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=False, prof=False):
-    """prof=True builds libsoftgrip_prof.so with the kernel section stamps (-DSG_SECTION_PROF) for scripts/section_profile.py"""
+def build(force=False, verbose=False, prof=False, count=False):
+    """prof=True builds libsoftgrip_prof.so with the kernel section stamps (-DSG_SECTION_PROF) for scripts/section_profile.py;
+    count=True builds libsoftgrip_count.so, which also counts events inside the contact update (-DSG_SECTION_COUNT: contact
+    updates, updates outside the friction cone, QCQP fallback entries and Newton evaluations) -- its cycle stamps are not timings"""
+    if count:
+        return _compile(os.path.join(_HERE, "libsoftgrip_count.so"), ["-DSG_SECTION_PROF", "-DSG_SECTION_COUNT"], verbose)
     if prof:
         return _compile(os.path.join(_HERE, "libsoftgrip_prof.so"), ["-DSG_SECTION_PROF"], verbose)
     if not force and not needs_build():
@@ -42,4 +46,4 @@ def _compile(out, extra, verbose):
 
 if __name__ == "__main__":
     import sys
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, prof="--prof" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, prof="--prof" in sys.argv, count="--count" in sys.argv))

@@ -148,7 +148,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
       b->wbufs.push_back(*p);
       return hipMemset(*p, 0, bytes) == hipSuccess;
     };
-    bool ok = walloc((void**)&b->w.secprof, sizeof(unsigned long long) * 32) && walloc((void**)&b->w.crec, sizeof(double) * SG_CAP * ((n + SG_EPW - 1) / SG_EPW + 1) * SG_RF * SG_SPW) && walloc((void**)&b->w.ns, sizeof(int) * S) &&
+    bool ok = walloc((void**)&b->w.secprof, sizeof(unsigned long long) * 48) && walloc((void**)&b->w.crec, sizeof(double) * SG_CAP * ((n + SG_EPW - 1) / SG_EPW + 1) * SG_RF * SG_SPW) && walloc((void**)&b->w.ns, sizeof(int) * S) &&
               walloc((void**)&b->w.crow, sizeof(double) * (SG_CAP + 2) * ((n + 7) / 8 + 2) * SG_RK * 64) &&
               walloc((void**)&b->w.envh, sizeof(double) * 4 * n) && walloc((void**)&b->w.shared, sizeof(int) * n) &&
               walloc((void**)&b->w.pending, sizeof(int) * n) && walloc((void**)&b->w.status, sizeof(int) * n) &&
@@ -451,8 +451,8 @@ int sg_debug_sections(sg_batch* b, unsigned long long* out32) {
   if (!b || !out32) return fail(SG_ERR_INVALID, "sg_debug_sections: bad argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(out32, b->w.secprof, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemset(b->w.secprof, 0, sizeof(unsigned long long) * 32));
+  HIPCHK(hipMemcpy(out32, b->w.secprof, sizeof(unsigned long long) * 48, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(b->w.secprof, 0, sizeof(unsigned long long) * 48));
   return SG_OK;
 }
 #endif

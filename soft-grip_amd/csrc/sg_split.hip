@@ -119,7 +119,7 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
 // section timing for scripts/section_profile.py (build_native.py --prof): every wavefront sums the cycles between stamps per
 // section in registers and adds them to W.secprof[] once, at its end.  Compiled out of the product library.
 #ifdef SG_SECTION_PROF
-#define SG_T0() unsigned long long t_prev_ = __builtin_readcyclecounter(), t_acc_[25] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define SG_T0() unsigned long long t_prev_ = __builtin_readcyclecounter(), t_acc_[26] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define SG_T(k)                                                   \
   do {                                                            \
     unsigned long long t_now_ = __builtin_readcyclecounter();     \
@@ -129,7 +129,7 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
 #define SG_TEND()                                                 \
   do {                                                            \
     if (threadIdx.x == 0)                                         \
-      for (int k_ = 0; k_ < 25; k_++)                             \
+      for (int k_ = 0; k_ < 26; k_++)                             \
         if (t_acc_[k_]) atomicAdd(&a.w.secprof[k_], t_acc_[k_]);  \
   } while (0)
 #else
@@ -1464,7 +1464,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           double x = denom >= SG_MINVAL ? sg_div(-num, denom) : 0.0;
           x = (o0 + x * o0 < 0) ? -1.0 : x;
           double gr = fo + x * fo;
-#ifdef SG_SECTION_PROF
+#ifdef SG_SECTION_COUNT  // event counters (build_native.py --count): atomics inside the update, so the cycle stamps of such a build are not timings
           if (r == 0) atomicAdd(&a.w.secprof[26], 1ull);  // contact updates (per stream)
 #endif
           if (o0 < SG_MINVAL) {  // uncommon: no normal force yet (lane 0 holds res_0 and A_00)
@@ -1482,19 +1482,52 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           const double val = (u1 * u1 + u2 * u2) - g0 * g0;
           double v1 = u1 * mu0, v2 = u2 * mu1;
           if (!(val < 1e-10) && !nofric) {  // uncommon: outside the cone -- the generic Newton iteration
-#ifdef SG_SECTION_PROF
+#ifdef SG_SECTION_COUNT
             if (r == 0) atomicAdd(&a.w.secprof[27], 1ull);  // sliding contact updates (per stream)
+            if (lane == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&a.w.secprof[32], 1ull);  // fallback entries per wavefront
 #endif
-            const double a11 = sg_qb<1>(A1), a12 = sg_qb<1>(A2), a22 = sg_qb<2>(A2);
-            const double Ac[4] = {a11, a12, a12, a22}, bcv[2] = {sg_qb<1>(bc), sg_qb<2>(bc)}, mu[2] = {mu0, mu1};
-            double v[2];
-            int active = qcqp2(v, Ac, bcv, mu, g0);
-            if (active) {
-              double s2 = v[0] * v[0] / (mu0 * mu0) + v[1] * v[1] / (mu1 * mu1);
-              s2 = sqrt(g0 * g0 / fmax(SG_MINVAL, s2));
-              v[0] *= s2; v[1] *= s2;
+            // mju_QCQP2's Newton iteration on the multiplier la of |v(la)|^2 = g0^2, v(la) = -(S + la)^-1 b in friction-scaled
+            // coordinates, continued from its first evaluation (la = 0: P, (u1, u2) and val are the fast path's).  Same iterates
+            // and stopping rules (val < 1e-10, step < 1e-10, singular block, 20 evaluations).  A wavefront runs as many
+            // evaluations as its slowest stream needs and an evaluation is one dependent chain, so it is written (a) without
+            // data-dependent branches and (b) with ONE division: with w = -adj(S + la) b and det = |S + la|, v = w / det,
+            // val = (|w|^2 - g0^2 det^2) / det^2 and the Newton step -val / (d val / d la) = (|w|^2 - g0^2 det^2) det / (2 w' adj w);
+            // v itself is only needed after the last evaluation.  (Two divisions and three nested exec-mask branches per
+            // evaluation before: 460 cycles each, profiles/r01_v11_nb_kernel_sections.txt.)
+            const double S11 = sg_qb<1>(A1) * mu0 * mu0, S22 = sg_qb<2>(A2) * mu1 * mu1, S12 = sg_qb<1>(A2) * mu0 * mu1, r2 = g0 * g0;
+            double w1 = u1, w2 = u2, wdet = 1.0, la = 0.0;  // last accepted evaluation: v = (w1, w2) / wdet
+            bool run = true, sing = false;
+            {
+              const double deriv = -2.0 * (P11 * u1 * u1 + 2.0 * P12 * u1 * u2 + P22 * u2 * u2), delta = sg_div(-val, deriv);
+              run = !(delta < 1e-10);
+              la = run ? delta : 0.0;
             }
-            v1 = v[0]; v2 = v[1];
+            for (int it = 1; it < 20; it++) {
+              if (!__ballot(run)) break;
+#ifdef SG_SECTION_COUNT
+              if (lane == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&a.w.secprof[33], 1ull);  // Newton iterations per wavefront
+#endif
+              const double ca = S11 + la, cc = S22 + la, det = ca * cc - S12 * S12;
+              const double t1 = S12 * b2 - cc * b1, t2 = S12 * b1 - ca * b2;       // -adj(S + la) b
+              const double d2 = det * det, num = (t1 * t1 + t2 * t2) - r2 * d2;    // val det^2
+              const double qf = (cc * t1 * t1 + ca * t2 * t2) - 2.0 * S12 * t1 * t2;  // w' adj w
+              const double delta = sg_div(num * det, 2.0 * qf);
+              const bool bad = det < 1e-10, stop = bad || num < 1e-10 * d2 || delta < 1e-10;
+              sing = run ? bad : sing;
+              const bool take = run && !bad;
+              w1 = take ? t1 : w1; w2 = take ? t2 : w2; wdet = take ? det : wdet;
+              la = (run && !stop) ? la + delta : la;
+              run = run && !stop;
+            }
+            const bool active = la != 0.0 && !sing;
+            // v = w / wdet, then rescaled onto the cone when the constraint is active: |(v1 / mu0, v2 / mu1)| = g0, i.e.
+            // (w1, w2) -> g0 / |w| (w1, w2) in scaled coordinates (the division by wdet cancels)
+            const double q = fmax(SG_MINVAL, active ? w1 * w1 + w2 * w2 : wdet * wdet);
+            double y = __builtin_amdgcn_rsq(q);
+            y = y * (1.5 - 0.5 * q * y * y);
+            y = y * (1.5 - 0.5 * q * y * y);  // active: 1 / |w|; otherwise 1 / |wdet| (wdet > 0)
+            const double sc = sing ? 0.0 : (active ? g0 * y : y);
+            v1 = w1 * mu0 * sc; v2 = w2 * mu1 * sc;
           }
           double fn = rsel0 * g0 + (rsel1 * v1 + rsel2 * v2);  // my row of (g0, v1, v2): exact, two of the three terms are 0
           double wn = (A0 * g0 + A1 * v1) + A2 * v2;   // row r of A f_new
