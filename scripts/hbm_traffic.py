@@ -11,7 +11,7 @@ import sys
 
 
 def per_kernel(d, counter):
-    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*_counter_collection.csv") + glob.glob(d + "/*_counter_collection.csv"))[0]
     tot, n = collections.OrderedDict(), collections.Counter()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter or "sg_" not in r["Kernel_Name"]:
@@ -28,17 +28,23 @@ def main():
     calls = int(sys.argv[3])
     pipeline = sys.argv[5] if len(sys.argv) > 5 else "rows"
     kernels = {}
+    total = 0.0
     for k in rd:
-        kernels[k] = {"FETCH_SIZE_total_bytes": rd[k], "FETCH_SIZE_dispatches": nrd[k],
-                      "WRITE_SIZE_total_bytes": wr.get(k, 0.0), "WRITE_SIZE_dispatches": nwr.get(k, 0)}
-    total = sum(rd.values()) + sum(wr.values())
+        # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of the bytes of 16-B-per-lane streaming reads.  The rows
+        # PGS kernel reads its contact rows as 16-byte pairs (its whole traffic but a few per cent), so its figure is doubled; the
+        # phase and chain kernels read 8 B per lane (uncalibrated width): raw.  WRITE_SIZE needs no correction.
+        corr = 2.0 if "sg_pgs_rows_kernel" in k else 1.0
+        kernels[k] = {"FETCH_SIZE_raw_bytes": rd[k], "FETCH_SIZE_correction": corr, "FETCH_SIZE_total_bytes": corr * rd[k],
+                      "FETCH_SIZE_dispatches": nrd[k], "WRITE_SIZE_total_bytes": wr.get(k, 0.0), "WRITE_SIZE_dispatches": nwr.get(k, 0)}
+        total += corr * rd[k] + wr.get(k, 0.0)
     out = {
         "unit": "bytes",
         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps %d --warmup 0 "
                 "--no-cpu-baseline` (1 sg_reset + %d sg_step calls, 4096 envs, %s pipeline); counter unit = KiB (x1024). gfx950 "
-                "caveat (MI355X_MICROARCH.md, HBM): FETCH_SIZE is calibrated only for 16-B/lane streaming reads (where it reports "
-                "1/2 of the bytes); these kernels read 8 B/lane, so the read figure is a raw, uncorrected lower bound; "
-                "Infinity-Cache hits are included in these fabric-side counters." % (calls - 1, calls - 1, pipeline),
+                "correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of the bytes of 16-B/lane streaming reads -- applied (x2) to "
+                "sg_pgs_rows_kernel, whose contact rows are read as 16-byte pairs; the phase and chain kernels read 8 B/lane "
+                "(uncalibrated width): raw.  These are fabric-side counters: Infinity-Cache hits are included, so this is L2<->fabric "
+                "traffic, an upper bound of the HBM traffic." % (calls - 1, calls - 1, pipeline),
         "kernels": kernels,
         "episode_total_bytes": total,
         "per_sg_step_call_bytes": total / calls,
