@@ -107,7 +107,9 @@ int sg_get_solver_stats(sg_batch* b, int32_t* ncon, int32_t* nefc, int32_t* iter
 /* kernel pipeline (same results to round-off, all parity-tested): 2 = rows (default: chain / phase / row-parallel PGS
  * kernels, a lane quad per finger stream in the solver), 1 = split (same chain with one lane per finger stream),
  * 0 = fused (one kernel per call, everything on chip).  The env var SG_PIPELINE=fused|split|rows sets the default of
- * new batches. */
+ * new batches.  A model compiled with the composite's neighbour equalities (two-joint equality rows, eq_obj2id >= 0;
+ * softgrip_model.h, mjcf.py composite_neighbors=True) runs in the rows pipeline only: its batches start there and
+ * sg_set_pipeline(b, 0 or 1) returns SG_ERR_MODEL. */
 int sg_set_pipeline(sg_batch* b, int pipeline);
 
 /* kernel timing hook for bench.py: average device time (ms) of one sg_step/sg_reset call's kernels over the

@@ -469,7 +469,9 @@ SG_HD int capsule_box(const double* cp, const double* cax, double r, double hl, 
   return mask;
 }
 
-// separating-axis overlap test of two boxes (detection only: such pairs are outside the supported envelope)
+// separating-axis overlap test of two boxes (detection only: such pairs are outside the supported envelope).  The axes are
+// not normalised: |T.L| > ra + rb scales with |L| on both sides (the 9 edge-edge axes cost a square root and three divisions
+// each otherwise); near-parallel edge pairs (|L|^2 < 1e-18) are skipped as before.
 SG_HD bool box_box_overlap(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2,
                            double margin) {
   double T[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, ax[6][3];
@@ -477,20 +479,21 @@ SG_HD bool box_box_overlap(const double* p1, const double* R1, const double* s1,
     ax[k][0] = R1[k]; ax[k][1] = R1[3 + k]; ax[k][2] = R1[6 + k];
     ax[3 + k][0] = R2[k]; ax[3 + k][1] = R2[3 + k]; ax[3 + k][2] = R2[6 + k];
   }
+  bool separated = false;
   for (int a = 0; a < 15; a++) {
-    double L[3];
+    double L[3], n2 = 1.0;
     if (a < 6) { L[0] = ax[a][0]; L[1] = ax[a][1]; L[2] = ax[a][2]; }
     else {
       cross3(L, ax[(a - 6) / 3], ax[3 + (a - 6) % 3]);
-      double n = sqrt(dot3(L, L));
-      if (n < 1e-9) continue;
-      L[0] /= n; L[1] /= n; L[2] /= n;
+      n2 = dot3(L, L);
     }
     double ra = 0, rb = 0;
     for (int k = 0; k < 3; k++) { ra += s1[k] * fabs(dot3(L, ax[k])); rb += s2[k] * fabs(dot3(L, ax[3 + k])); }
-    if (fabs(dot3(T, L)) > ra + rb + margin) return false;
+    const double nrm = a < 6 ? 1.0 : sqrt(n2);  // margin is a length: scale it like the projections (0 in every call of the kernels)
+    if (n2 >= 1e-18 && fabs(dot3(T, L)) > ra + rb + margin * nrm) separated = true;
+    if (!sg_any(!separated)) break;  // device: every lane of the wavefront that runs the test has found a separating axis
   }
-  return true;
+  return !separated;
 }
 
 SG_HD void make_frame(const double* n, double* fr) {  // mju_makeFrame with an undefined tangent hint

@@ -403,23 +403,36 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         if (overflow) flags |= SG_FLAG_CONTACTFULL;
       }
       SG_T(3);
-      {  // envelope checks (same as the fused kernel)
+      {  // envelope checks (same pairs as the fused kernel).  Finger box against static box (lanes 0 .. npairs-1) and finger box
+         // against finger box (lanes 32 .. 35) go through ONE separating-axis test: each lane sets up its pair, then all of
+         // them run the 15 axes together (two copies of the test, one per kind of pair, ran one after the other before)
         int nb = nchain * SG_CG, npairs = nb * H.nstatic;
+        const double *p1 = nullptr, *R1 = nullptr, *s1 = nullptr, *p2 = nullptr, *R2 = nullptr, *s2 = nullptr;
+        double bd = 0;
+        bool pair = false;
         if (lane < npairs) {
           int b = lane / H.nstatic, s = lane % H.nstatic, c = b / SG_CG, g = b % SG_CG;
           if (g < H.chain[c].ngeom) {
-            const SgChain& Cc = H.chain[c];
-            double dif[3] = {Sm.boxp[b][0] - H.st_pos[s][0], Sm.boxp[b][1] - H.st_pos[s][1], Sm.boxp[b][2] - H.st_pos[s][2]}, bd = Cc.g_rbound[g] + H.st_rbound[s];
-            if (dot3(dif, dif) <= bd * bd && box_box_overlap(Sm.boxp[b], Sm.boxm[b], Cc.g_size[g], H.st_pos[s], H.st_mat[s], H.st_size[s], 0)) unsupported = 1;
+            pair = true;
+            p1 = Sm.boxp[b]; R1 = Sm.boxm[b]; s1 = H.chain[c].g_size[g];
+            p2 = H.st_pos[s]; R2 = H.st_mat[s]; s2 = H.st_size[s];
+            bd = H.chain[c].g_rbound[g] + H.st_rbound[s];
           }
         } else if (lane >= 32 && lane < 32 + SG_CG * SG_CG && nchain == 2) {
           int g = (lane - 32) / SG_CG, g2 = (lane - 32) % SG_CG;
           if (g < H.chain[0].ngeom && g2 < H.chain[1].ngeom) {
             int b = g, b2 = SG_CG + g2;
-            double dif[3] = {Sm.boxp[b][0] - Sm.boxp[b2][0], Sm.boxp[b][1] - Sm.boxp[b2][1], Sm.boxp[b][2] - Sm.boxp[b2][2]}, bd = H.chain[0].g_rbound[g] + H.chain[1].g_rbound[g2];
-            if (dot3(dif, dif) <= bd * bd && box_box_overlap(Sm.boxp[b], Sm.boxm[b], H.chain[0].g_size[g], Sm.boxp[b2], Sm.boxm[b2], H.chain[1].g_size[g2], 0)) unsupported = 1;
+            pair = true;
+            p1 = Sm.boxp[b]; R1 = Sm.boxm[b]; s1 = H.chain[0].g_size[g];
+            p2 = Sm.boxp[b2]; R2 = Sm.boxm[b2]; s2 = H.chain[1].g_size[g2];
+            bd = H.chain[0].g_rbound[g] + H.chain[1].g_rbound[g2];
           }
-        } else if (lane >= 48 && lane < 48 + SG_MAXCH * SG_CG && H.has_plane) {
+        }
+        if (pair) {
+          double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+          if (dot3(dif, dif) <= bd * bd && box_box_overlap(p1, R1, s1, p2, R2, s2, 0)) unsupported = 1;
+        }
+        if (lane >= 48 && lane < 48 + SG_MAXCH * SG_CG && H.has_plane) {
           int b = lane - 48, c = b / SG_CG, g = b % SG_CG;
           if (c < nchain && g < H.chain[c].ngeom) {
             double dif[3] = {Sm.boxp[b][0] - H.plane_pos[0], Sm.boxp[b][1] - H.plane_pos[1], Sm.boxp[b][2] - H.plane_pos[2]}, ext = 0;
