@@ -199,9 +199,19 @@ def main():
             cores = usable_cores()
             envs = 16 * cores  # 16 full episodes per core: about 10-20 s of wall time
             v, cdt = cpu_baseline(model, ks, sim_step, sched, envs, cores)
+            v1, cdt1 = cpu_baseline(model, ks, sim_step, sched, 8, 1)   # a 1-thread figure beside the all-cores one
+            probe = []
+            for mod in ("mujoco", "mujoco_py"):                          # time MuJoCo itself iff it exists on the box -- probe, never assume
+                try:
+                    __import__(mod)
+                    probe.append(mod + ": importable (not timed: no MJCF on this box)")
+                except Exception as e:  # noqa: BLE001
+                    probe.append("%s: absent (%s)" % (mod, type(e).__name__))
             res["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
                                    "sample": "%d envs x one 200-step episode (same scene/schedule/stiffness draws) on the fp64 C oracle, "
-                                             "OpenMP over envs, %.1f s" % (envs, cdt)}
+                                             "OpenMP over envs, %.1f s" % (envs, cdt),
+                                   "one_thread": {"value": v1, "sample": "8 envs x one episode on 1 thread, %.1f s" % cdt1},
+                                   "mujoco_probe": "; ".join(probe)}
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
