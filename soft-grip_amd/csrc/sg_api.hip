@@ -34,7 +34,7 @@ __global__ void sg_fill_rows_val_kernel(double* dst, SgCtrlRow row, int n, int w
 __global__ void sg_masked_copy_kernel(const unsigned char* mask, int n, const int* s0, int* d0, const int* s1, int* d1, const int* s2, int* d2,
                                       const int* s3, int* d3, const int* s4, int* d4) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && mask[i]) { d0[i] = s0[i]; d1[i] = s1[i]; d2[i] = s2[i]; d3[i] = s3[i]; d4[i] = s4[i]; }
+  if (i < n && (!mask || mask[i])) { d0[i] = s0[i]; d1[i] = s1[i]; d2[i] = s2[i]; d3[i] = s3[i]; d4[i] = s4[i]; }
 }
 }  // namespace
 
@@ -117,7 +117,6 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   if (device < 0 || device >= ndev) return fail(SG_ERR_NO_DEVICE, "sg_batch_create: device index out of range");
   HIPCHK(hipSetDevice(device));
   sg_batch* b = new sg_batch();
-  memset((void*)b, 0, sizeof(void*) * 0);
   b->m = m; b->n = n_envs; b->device = device; b->lds_attr_set = false; b->prof = false; b->prof_ms = 0; b->prof_n = 0;
   b->dnbtab = nullptr; b->dsched = nullptr;
   b->dH = nullptr; b->delem = b->qpos = b->qvel = b->warm = b->act = b->ctrl = b->kenv = b->ctrl_row = nullptr;
@@ -339,19 +338,11 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     HIPCHK(hipEventRecord(e1, s));
     b->ev.emplace_back(e0, e1);
   }
-  // outputs of the call
-  const size_t nb = sizeof(int) * (size_t)b->n;
-  if (mask == nullptr) {
-    HIPCHK(hipMemcpyAsync(flags ? flags : b->flags, b->w.status, nb, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(touch ? touch : b->touch, b->w.touch, nb, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->ncon, b->w.ncon, nb, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->nefc, b->w.nefc, nb, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->iters, b->w.iters, nb, hipMemcpyDeviceToDevice, s));
-  } else {  // masked reset: only the selected envs' entries may change
-    hipLaunchKernelGGL(sg_masked_copy_kernel, dim3((b->n + 255) / 256), dim3(256), 0, s, mask, b->n, b->w.status, flags ? flags : b->flags,
-                       b->w.touch, touch ? touch : b->touch, b->w.ncon, b->ncon, b->w.nefc, b->nefc, b->w.iters, b->iters);
-    HIPCHK(hipGetLastError());
-  }
+  // outputs of the call: one small kernel for the five per-env int arrays (five device-to-device copies cost 1 % of a step);
+  // with a mask (masked reset) only the selected envs' entries may change
+  hipLaunchKernelGGL(sg_masked_copy_kernel, dim3((b->n + 255) / 256), dim3(256), 0, s, mask, b->n, b->w.status, flags ? flags : b->flags,
+                     b->w.touch, touch ? touch : b->touch, b->w.ncon, b->ncon, b->w.nefc, b->nefc, b->w.iters, b->iters);
+  HIPCHK(hipGetLastError());
   return SG_OK;
 }
 
