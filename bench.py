@@ -173,7 +173,7 @@ def main():
         ach = abytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic, traffic_src = None, None
         pipe = os.environ.get("SG_PIPELINE", "rows")
-        tp = os.path.join(ROOT, "profiles", {"rows": "r01_v11_rows_hbm_traffic.json", "split": "r01_v4_hbm_traffic.json"}.get(pipe, "none"))
+        tp = os.path.join(ROOT, "profiles", {"rows": "r01_v12_rows_hbm_traffic.json", "split": "r01_v4_hbm_traffic.json"}.get(pipe, "none"))
         if os.path.exists(tp) and args.scene == "softbox" and n == 4096:
             # HBM-side bytes per sg_step call from the committed rocprofv3 PMC passes of this very workload (not re-measured here)
             traffic = json.load(open(tp))["per_sg_step_call_bytes"]
