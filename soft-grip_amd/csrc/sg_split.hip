@@ -1528,30 +1528,35 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
             // v itself is only needed after the last evaluation.  (Two divisions and three nested exec-mask branches per
             // evaluation before: 460 cycles each, profiles/r01_v11_nb_kernel_sections.txt.)
             const double S11 = sg_qb<1>(A1) * mu0 * mu0, S22 = sg_qb<2>(A2) * mu1 * mu1, S12 = sg_qb<1>(A2) * mu0 * mu1, r2 = g0 * g0;
-            double w1 = u1, w2 = u2, wdet = 1.0, la = 0.0;  // last accepted evaluation: v = (w1, w2) / wdet
-            bool run = true, sing = false;
+            double la = 0.0;
+            bool run = true;
             {
               const double deriv = -2.0 * (P11 * u1 * u1 + 2.0 * P12 * u1 * u2 + P22 * u2 * u2), delta = sg_div(-val, deriv);
               run = !(delta < 1e-10);
               la = run ? delta : 0.0;
             }
+            // A stream that has stopped keeps evaluating with its la frozen while the wavefront's slowest stream finishes: the
+            // same inputs give the same t, det every time, so nothing but la needs a guarded update inside the loop, and a
+            // stream's result does not depend on its wavefront mates (streams that never started take the fast path's values)
+            const bool ever = run;
+            double t1 = u1, t2 = u2, det = 1.0;
             for (int it = 1; it < 20; it++) {
               if (!__ballot(run)) break;
 #ifdef SG_SECTION_COUNT
               if (lane == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&a.w.secprof[33], 1ull);  // Newton iterations per wavefront
 #endif
-              const double ca = S11 + la, cc = S22 + la, det = ca * cc - S12 * S12;
-              const double t1 = S12 * b2 - cc * b1, t2 = S12 * b1 - ca * b2;       // -adj(S + la) b
+              const double ca = S11 + la, cc = S22 + la;
+              det = ca * cc - S12 * S12;
+              t1 = S12 * b2 - cc * b1; t2 = S12 * b1 - ca * b2;                    // -adj(S + la) b
               const double d2 = det * det, num = (t1 * t1 + t2 * t2) - r2 * d2;    // val det^2
               const double qf = (cc * t1 * t1 + ca * t2 * t2) - 2.0 * S12 * t1 * t2;  // w' adj w
               const double delta = sg_div(num * det, 2.0 * qf);
-              const bool bad = det < 1e-10, stop = bad || num < 1e-10 * d2 || delta < 1e-10;
-              sing = run ? bad : sing;
-              const bool take = run && !bad;
-              w1 = take ? t1 : w1; w2 = take ? t2 : w2; wdet = take ? det : wdet;
-              la = (run && !stop) ? la + delta : la;
-              run = run && !stop;
+              const bool go = run && !(det < 1e-10 || num < 1e-10 * d2 || delta < 1e-10);
+              la = go ? la + delta : la;
+              run = go;
             }
+            const bool sing = ever && det < 1e-10;
+            const double w1 = ever ? t1 : u1, w2 = ever ? t2 : u2, wdet = ever ? det : 1.0;  // last evaluation: v = (w1, w2) / wdet
             const bool active = la != 0.0 && !sing;
             // v = w / wdet, then rescaled onto the cone when the constraint is active: |(v1 / mu0, v2 / mu1)| = g0, i.e.
             // (w1, w2) -> g0 / |w| (w1, w2) in scaled coordinates (the division by wdet cancels)
