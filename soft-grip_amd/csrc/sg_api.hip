@@ -159,8 +159,8 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
               walloc((void**)&b->w.eqb, sizeof(double) * n * N) && walloc((void**)&b->w.eqR, sizeof(double) * n * N) &&
               walloc((void**)&b->w.asme, sizeof(double) * n * N) && walloc((void**)&b->w.fsm, sizeof(double) * n * N) &&
               walloc((void**)&b->w.chh, sizeof(double) * n * 2 * SG_CHW) &&
-              walloc((void**)&b->w.nbf, sizeof(double) * n * (H.nnb + 1)) && walloc((void**)&b->w.nbb, sizeof(double) * n * (H.nnb + 1)) &&
-              walloc((void**)&b->w.nbR, sizeof(double) * n * (H.nnb + 1));
+              walloc((void**)&b->w.nbf, sizeof(double) * n * (3 * N + 1)) && walloc((void**)&b->w.nbb, sizeof(double) * n * (3 * N + 1)) &&
+              walloc((void**)&b->w.nbR, sizeof(double) * n * (3 * N + 1));
     if (!ok) { sg_batch_destroy(b); return fail(SG_ERR_NOMEM, "hipMalloc (split-pipeline workspace)"); }
     const char* pm = getenv("SG_PIPELINE");
     b->pipeline = (pm && strcmp(pm, "fused") == 0) ? 0 : (pm && strcmp(pm, "split") == 0) ? 1 : 2;

@@ -337,17 +337,19 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
   H.eq_rounds = 0;
   if (H.nnb > 0) {
     const int N = nelem, nnb = H.nnb;
-    P.nbtab.assign((size_t)9 * N + 2 * nnb, -1);
+    P.nbtab.assign((size_t)9 * N + 3 * nnb, -1);
     int* out_e2 = P.nbtab.data(); int* out_id = out_e2 + 3 * N; int* in_id = out_id + 3 * N; int* r_e1 = in_id + 3 * N; int* r_e2 = r_e1 + nnb;
+    int* r_slot = r_e2 + nnb;
     std::vector<int> nout(N, 0), nin(N, 0), unified(row_e1.size());
     int k = 0;
     for (size_t q = 0; q < row_e1.size(); q++) {
       const int e1 = row_e1[q], e2 = row_e2[q];
       if (e2 < 0) { unified[q] = e1; continue; }
       if (nout[e1] >= 3 || nin[e2] >= 3) FAIL("more than three neighbour equalities on one side of an element");
-      out_e2[nout[e1] * N + e1] = e2; out_id[nout[e1] * N + e1] = k; nout[e1]++;
-      in_id[nin[e2] * N + e2] = k; nin[e2]++;
-      r_e1[k] = e1; r_e2[k] = e2;
+      const int slot = nout[e1] * N + e1;  // workspace slot of the row: (its rank among e1's rows, e1) -- lanes = elements store coalesced
+      out_e2[slot] = e2; out_id[slot] = slot; nout[e1]++;
+      in_id[nin[e2] * N + e2] = slot; nin[e2]++;
+      r_e1[k] = e1; r_e2[k] = e2; r_slot[k] = slot;
       unified[q] = N + k;
       k++;
     }

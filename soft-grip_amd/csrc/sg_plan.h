@@ -95,9 +95,10 @@ struct SgEqSlot {
 
 struct SgPlan {
   SgPlanHeader h;
-  // neighbour rows: ints [9 * nelem + 2 * nnb] = out_e2[3][nelem] | out_id[3][nelem] | in_id[3][nelem] | row_e1[nnb] | row_e2[nnb]
-  //   out_*: the (up to 3) neighbour rows registered for element e, in MuJoCo's order: partner element / row id, -1 = none
-  //   in_id: the (up to 3) neighbour rows that have element e as their second joint
+  // neighbour rows: ints [9 * nelem + 3 * nnb] = out_e2[3][nelem] | out_slot[3][nelem] | in_slot[3][nelem] | row_e1[nnb] | row_e2[nnb] | row_slot[nnb]
+  //   a row's workspace SLOT is d * nelem + e1 (d = its rank among the rows registered for element e1, MuJoCo's order): per env the
+  //   workspace arrays nbf / nbb / nbR have 3 * nelem slots, so the phase kernel's lanes (= elements) store them coalesced
+  //   out_*: the (up to 3) neighbour rows of element e: partner element / slot, -1 = none; in_slot: the (up to 3) rows that have e as second joint
   std::vector<int> nbtab;
   std::vector<SgEqSlot> sched;     // eq_rounds x 8
   std::vector<double> elem;        // SGE_NFIELD x nelem

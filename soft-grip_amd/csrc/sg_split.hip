@@ -47,7 +47,7 @@ struct SgWork {          // device workspace of one batch (all pointers device m
   double *as, *eqf, *eqb, *eqR;  // [nenv][N]
   double *asme, *fsm;    // [nenv][N]  begin -> finish hand-off
   double* chh;           // [nenv][2][SG_CHW]  chain hand-off (enum SGH_*)
-  double *nbf, *nbb, *nbR;  // [nenv][nnb]  neighbour equality rows (models with H.nnb > 0): force, right-hand side, regulariser
+  double *nbf, *nbb, *nbR;  // [nenv][3 N]  neighbour equality rows (models with H.nnb > 0) by slot (SgPlan::nbtab): force, right-hand side, regulariser
 };
 
 struct SgPhaseArgs {
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
                 const double bb = (asme[r] - Sm.asme[e2]) - aref, ff = -((we[r] - Sm.we[e2]) - aref) / Rr;
                 nbe2[r][d] = e2; nbid[r][d] = id; nbc0[r][d] = ff * (0.5 * Rr * ff + bb);
                 Sm.nbf[id] = ff;
-                W.nbb[(size_t)env * nnb + id] = bb; W.nbR[(size_t)env * nnb + id] = Rr;
+                W.nbb[(size_t)env * 3 * N + id] = bb; W.nbR[(size_t)env * 3 * N + id] = Rr;
               }
             }
           }
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           W.as[o] = Sm.as[e]; W.eqf[o] = eqf[r]; W.eqb[o] = eqb[r]; W.eqR[o] = eqR[r];
 #pragma unroll
           for (int d = 0; d < ND; d++)
-            if (nbid[r][d] >= 0) W.nbf[(size_t)env * nnb + nbid[r][d]] = Sm.nbf[nbid[r][d]];
+            if (nbid[r][d] >= 0) W.nbf[(size_t)env * 3 * N + nbid[r][d]] = Sm.nbf[nbid[r][d]];
         }
       }
       if (is_chain_lane) {
@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           bb = W.eqb[o]; Rr = W.eqR[o]; ff = W.eqf[o]; ims = EIM(u);
         } else {
           const int k = u - N;
-          const size_t o = (size_t)env * nnb + k;
+          const size_t o = (size_t)env * 3 * N + a.nbtab[9 * N + 2 * nnb + k];
           bb = W.nbb[o]; Rr = W.nbR[o]; ff = W.nbf[o];
           ims = EIM(a.nbtab[9 * N + k]) + EIM(a.nbtab[9 * N + nnb + k]);
         }
