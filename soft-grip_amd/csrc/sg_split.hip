@@ -71,9 +71,9 @@ struct SgPhaseArgs {
 // (normal, tangent 1, tangent 2) of every contact, lane 3 what the rows share; lane q also OWNS finger acceleration aF[q].
 // Block per (slot, wavefront): 8 field PAIRS x 64 lanes x 2 doubles, so a lane fetches two fields with one 16-byte load.
 // Field k of lane (8 * env_in_wave + 4 * chain + r), r < 3:
-//   0..3 Jf[r][0..3] | 4 Js[r] | 5 b[r] | 6 f[r] | 7 (A f)[r] | 8..10 A[r][0..2] | 11 invm * Js[r] | 12..14 W_0[r] W_1[r] W_2[r] | 15 -
+//   0..3 Jf[r][0..3] | 4 Js[r] | 5 b[r] | 6 f[r] | 7 (A f)[r] | 8..10 A[r][0..2] | 11 invm * Js[r] | 12..14 W_0[r] W_1[r] W_2[r] | 15 R
 // of lane r = 3:
-//   0..2 inverse friction block P11 P12 P22 | 3 R | 4 slider index | 5..11 zero | 12..14 W_0[3] W_1[3] W_2[3] | 15 -
+//   0..2 inverse friction block P11 P12 P22 | 3 zero | 4 slider index | 5..11 zero | 12..14 W_0[3] W_1[3] W_2[3] | 15 zero
 // W_k = M^-1 J_F[k]' (4 values per row k; lane q keeps the q-th of each): the finger update aF[q] += sum_k W_k[q] df_k is three
 // multiply-adds on lane q after broadcasting the three force changes, instead of four more quad sums and a 4 x 4 product on
 // every lane.  f and A f (fields 6, 7: one pair) are the only fields the solver writes.  Blocks nwb and nwb + 1 of every slot
@@ -523,8 +523,9 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
                 fld[7] = Afull[r][0] * c.f[0] + Afull[r][1] * c.f[1] + Afull[r][2] * c.f[2];
                 fld[8] = Afull[r][0]; fld[9] = Afull[r][1]; fld[10] = Afull[r][2];
                 fld[11] = c.invm * c.Js[r];
-              } else {  // the fourth lane carries what the three rows share
-                fld[0] = P11; fld[1] = P12; fld[2] = P22; fld[3] = c.R; fld[4] = __hiloint2double(0, sl);
+                fld[15] = c.R;
+              } else {  // the fourth lane carries what the three rows share (R is replicated on the row lanes: no broadcast)
+                fld[0] = P11; fld[1] = P12; fld[2] = P22; fld[4] = __hiloint2double(0, sl);
               }
               fld[12] = Wm[0][r]; fld[13] = Wm[1][r]; fld[14] = Wm[2][r];
 #pragma unroll
@@ -1484,7 +1485,8 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           const double J0 = w.j01.x, J1 = w.j01.y, J2 = w.j23.x, J3 = w.j23.y, Js = w.jsb.x, bb = w.jsb.y, fo = w.fw.x, wv = w.fw.y;
           const double A0 = w.a01.x, A1 = w.a01.y, A2 = w.a2s.x, JsI = w.a2s.y, W0 = w.p12.x, W1 = w.p12.y, W2 = w.p3i.x;
           // what the rows share sits on lane 3 (fields 0 .. 4); its own "row" is inert: f = A f = A = invm Js = 0 and no rsel
-          const double P11 = sg_qb<3>(J0), P12 = sg_qb<3>(J1), P22 = sg_qb<3>(J2), Rr = sg_qb<3>(J3);
+          const double Rr = w.p3i.y;  // R: replicated on the row lanes (field 15), 0 on lane 3
+          const double P11 = sg_qb<3>(J0), P12 = sg_qb<3>(J1), P22 = sg_qb<3>(J2);  // early: off the update's dependency chain
           const int sl = __double2loint(sg_qb<3>(Js));
           const double as_ = *(sl >= 0 ? (const double*)(ASb + ASS * sl) : &Lzero[0]);  // branch-free: "no slider" reads a zero word
           const double f0_ = sg_qb<0>(aFo), f1_ = sg_qb<1>(aFo), f2_ = sg_qb<2>(aFo), f3_ = sg_qb<3>(aFo);  // the finger's four accelerations
