@@ -31,6 +31,24 @@ struct Emu {
 
 extern "C" {
 
+// The plan's equality-row schedule of a neighbour-row model (SgPlan::sched), flattened for tests/test_plan_schedule.py:
+// out[4 * i .. 4 * i + 3] = (round, e1, e2, row) of slot i; returns the number of slots (rounds * 8) or -1.
+int emu_plan_schedule(const void* blob, size_t n, int* out, int cap, int* nelem, int* nnb, char* err, size_t errlen) {
+  SgPlan P;
+  std::string e;
+  if (!sg_plan_build(blob, n, &P, &e)) {
+    snprintf(err, errlen, "%s", e.c_str());
+    return -1;
+  }
+  *nelem = P.h.nelem; *nnb = P.h.nnb;
+  const int ns = (int)P.sched.size();
+  if (ns != 8 * P.h.eq_rounds || ns > cap) return -1;
+  for (int i = 0; i < ns; i++) {
+    out[4 * i] = i / 8; out[4 * i + 1] = P.sched[i].e1; out[4 * i + 2] = P.sched[i].e2; out[4 * i + 3] = P.sched[i].row;
+  }
+  return ns;
+}
+
 Emu* emu_new(const void* blob, size_t n, char* err, size_t errlen) {
   Emu* E = new Emu();
   std::string e;

@@ -34,6 +34,23 @@ def test_model_create_and_errors():
     assert ei.value.code == native.SG_ERR_MODEL
 
 
+@pytest.mark.parametrize("scene,nelem", [("softbox_nb", 110), ("softcylinder_nb", 192), ("softball_nb", 218)])
+def test_neighbour_row_models_are_accepted(scene, nelem):
+    """the plan builder takes the composite's neighbour equalities (two-joint rows, right after their element's fix row) and
+    refuses what it cannot schedule: a neighbour row with a polynomial other than q1 = q2"""
+    m = sg.load_model(model_path(scene))
+    nm = native.NativeModel(m)
+    assert nm.nelem == nelem
+    import copy
+    bad = copy.copy(m)
+    bad.eq_data = m.eq_data.copy()
+    k = int((m.eq_obj2id >= 0).nonzero()[0][0])
+    bad.eq_data[k, 1] = 2.0
+    with pytest.raises(native.SoftgripError) as ei:
+        native.NativeModel(bad)
+    assert ei.value.code == native.SG_ERR_MODEL and "polycoef" in str(ei.value)
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
