@@ -195,6 +195,20 @@ def main():
                          "algorithmic_bytes_per_env_step": abytes,
                          "note": "one 'launch' = the kernel chain of one sg_step call (7 substeps); the path is instruction-issue-bound (serial Gauss-Seidel per finger), not HBM-bound; traffic is mostly contact blocks re-read from L2/Infinity Cache by each sweep (DESIGN.md 4.3)"},
         }
+        # secondary roofline (the binding limit is instruction issue, not HBM): VALU wavefront-instructions per env
+        # step from the committed SQ-counter pass of this very command, times the measured rate, against what the chip's 1024
+        # SIMDs can issue (one fp64 wavefront instruction per 4 cycles each)
+        sp = os.path.join(ROOT, "profiles", "r01_v12_sq_totals.json")
+        if os.path.exists(sp) and args.scene == "softbox" and n == 4096 and pipe == "rows":
+            sq = json.load(open(sp))["per_env_step"]
+            peak = 1024 * 2.4e9 / 4.0
+            ach = sq["SQ_INSTS_VALU"] * value / world   # per GPU
+            res["roofline"]["secondary"] = {
+                "bound": "fp64 VALU issue", "unit": "wavefront-instructions/s", "achieved": ach, "peak": peak, "frac": ach / peak,
+                "valu_insts_per_env_step": sq["SQ_INSTS_VALU"], "salu_insts_per_env_step": sq["SQ_INSTS_SALU"],
+                "lds_insts_per_env_step": sq["SQ_INSTS_LDS"],
+                "source": "profiles/r01_v12_sq_totals.json (rocprofv3 --pmc SQ_INSTS_*, own pass); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per "
+                          "fp64 wavefront instruction; the PGS kernel, 70 % of the time, can only put wavefronts on 512 SIMDs at 4096 envs"}
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             cores = usable_cores()
             envs = 16 * cores  # 16 full episodes per core: about 10-20 s of wall time
