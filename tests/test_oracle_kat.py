@@ -228,3 +228,23 @@ def test_gyro_reads_the_hinge_rate_of_its_own_finger_only():
     s.qvel[m.nv - 1] = 0.7                  # an object slider
     s.forward()
     assert np.abs(s.sensordata[6:12]).max() < 1e-12
+
+
+def test_oracle_regression_fixture():
+    """the oracle against its own committed outputs (scripts/gen_oracle_regression.py): pins the checker against silent changes.  The
+    default scene over the whole episode; the neighbour-row variant over its first 47 steps (beyond, round-off is amplified: DESIGN 2)"""
+    from softgrip_amd.create_dataset import episode_schedule
+    g = np.load(os.path.join(ROOT, "tests", "golden", "oracle_regression.npz"))
+    k = float(g["stiffness"])
+    for scene, nsteps in (("softbox", 200), ("softbox_nb", 47)):
+        s = oracle_sim(sg.load_model(model_path(scene)), k)
+        s.reset(); s.forward(); s.step()
+        for t, c in enumerate(episode_schedule()[:nsteps]):
+            if c is not None:
+                s.ctrl[:] = c
+            for _ in range(7):
+                assert s.step() == 0
+            np.testing.assert_allclose(s.sensordata, g[scene + "_sens"][t], atol=1e-7, err_msg="%s step %d" % (scene, t))
+            assert s.ncon == g[scene + "_ncon"][t]
+        if scene == "softbox":
+            np.testing.assert_allclose(s.qpos, g["softbox_qpos_end"], atol=1e-9)
