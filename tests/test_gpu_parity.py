@@ -291,3 +291,30 @@ def test_config5_online_regressor():
     for _ in range(5):
         l1, _ = convnet.train_step(net, opt, out, y, mean, std)
     assert float(l1) < float(l0) * 1.5
+
+
+@pytest.mark.parametrize("scene,n", [("softbox", 1), ("softbox", 65), ("softbox_nb", 1), ("softbox_nb", 13)])
+def test_ragged_batches(scene, n):
+    """batch sizes that fill neither a PGS wavefront (8 envs) nor a chain wavefront (64 chains): every env against the oracle
+    through reset, the idle phase and the first contacts (45 env steps)"""
+    ks = np.linspace(320.0, 1380.0, n)
+    m, nm, b = _gpu_batch(scene, ks)
+    sens, flags, touch = _bufs(b, n)
+    sims = [oracle_sim(m, k) for k in ks]
+    for s in sims:
+        s.reset(); s.forward(); s.step()
+    b.reset(1, sens=sens, flags=flags, touch=touch)
+    ctrl = np.zeros(2)
+    for t, c in enumerate(episode_schedule()[:45]):
+        if c is not None:
+            ctrl[:] = c
+            b.set_ctrl_broadcast(ctrl)
+            for s in sims:
+                s.ctrl[:] = c
+        b.step(7, sens=sens, flags=flags, touch=touch)
+        for s in sims:
+            for _ in range(7):
+                assert s.step() == 0
+    assert np.abs(sens.cpu().numpy() - np.stack([s.sensordata for s in sims])).max() < TOL_SENSOR
+    assert int(flags.abs().sum()) == 0
+    assert b.solver_stats()["ncon"].cpu().tolist() == [s.ncon for s in sims]
