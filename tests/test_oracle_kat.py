@@ -248,3 +248,31 @@ def test_oracle_regression_fixture():
             assert s.ncon == g[scene + "_ncon"][t]
         if scene == "softbox":
             np.testing.assert_allclose(s.qpos, g["softbox_qpos_end"], atol=1e-9)
+
+
+def test_capsule_box_narrowphase_known_answers():
+    """tests/data/capbox.xml: a box on an x-slider (face at x = 0.8 + q) against two static capsules (radius 0.1, half-length 0.3):
+    one parallel to the face (MuJoCo: two contacts, one per end cap, same depth) and one tilted by 0.5 rad about y (one contact, at
+    the end cap nearer to the box).  Distances, positions (midway between the two surfaces) and normals (capsule -> box) are analytic."""
+    m = sg.compile_mjcf(os.path.join(ROOT, "tests", "data", "capbox.xml"))
+    s = oracle_sim(m)
+    s.reset()
+    s.qpos[0] = -0.75                                   # face at x = 0.05
+    assert s.forward() == 0 and s.ncon == 3
+    c = s.contacts()
+    for k, z in ((0, -0.3), (1, 0.3)):
+        assert (c[k]["geom1"], c[k]["geom2"]) == (0, 2)
+        np.testing.assert_allclose(c[k]["dist"], 0.05 - 0.1, atol=1e-15)
+        np.testing.assert_allclose(c[k]["pos"], [0.075, 0.0, z], atol=1e-15)
+        np.testing.assert_allclose(c[k]["frame"][:3], [1, 0, 0], atol=1e-15)
+    ax = np.array([np.sin(0.5), 0.0, np.cos(0.5)])
+    end = np.array([0.0, 2.0, 0.0]) + 0.3 * ax
+    assert (c[2]["geom1"], c[2]["geom2"]) == (1, 2)
+    np.testing.assert_allclose(c[2]["dist"], 0.05 - (end[0] + 0.1), atol=1e-14)
+    np.testing.assert_allclose(c[2]["pos"], [0.5 * (0.05 + end[0] + 0.1), 2.0, end[2]], atol=1e-14)
+    np.testing.assert_allclose(c[2]["frame"][:3], [1, 0, 0], atol=1e-14)
+    # just out of reach: no contact; the contact force pushes the box away (+x)
+    s.reset(); s.qpos[0] = -0.45; s.forward()
+    assert s.ncon == 0
+    s.reset(); s.qpos[0] = -0.75; s.forward()
+    assert s.qacc[0] > 0
