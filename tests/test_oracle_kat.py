@@ -276,3 +276,61 @@ def test_capsule_box_narrowphase_known_answers():
     assert s.ncon == 0
     s.reset(); s.qpos[0] = -0.75; s.forward()
     assert s.qacc[0] > 0
+
+
+def test_single_contact_soft_constraint_closed_form():
+    """one contact, one dof, everything at rest (tests/data/capbox.xml with only the tilted capsule touching): MuJoCo's soft
+    constraint gives  a = aref A / (A + R)  with  aref = k d |r|  (standard solref (0.02, 1): k = 1 / (dmax^2 tau^2), tau >= 2h;
+    d = dmax = 0.95 once |r| exceeds the solimp width 0.001),  A = 1/m  and  R = (1 - d)/d * diagApprox,  diagApprox = the
+    box body's translational invweight (1/m over three directions, one of them mobile) + 0 for the static capsule"""
+    m = sg.compile_mjcf(os.path.join(ROOT, "tests", "data", "capbox.xml"))
+    s = oracle_sim(m)
+    s.reset()
+    s.qpos[0] = -0.65                                   # face at x = 0.15: the parallel capsule (reach 0.1) is clear
+    assert s.forward() == 0 and s.ncon == 1
+    r = 0.15 - (0.3 * np.sin(0.5) + 0.1)
+    np.testing.assert_allclose(s.contacts()[0]["dist"], r, atol=1e-14)
+    mass, dmax, tau = float(m.body_mass[-1]), 0.95, 0.02
+    np.testing.assert_allclose(m.body_invweight0[-1, 0], 1 / (3 * mass), rtol=1e-12)
+    k = 1 / (dmax ** 2 * tau ** 2)
+    aref = k * dmax * abs(r)
+    A, R = 1 / mass, (1 - dmax) / dmax * m.body_invweight0[-1, 0]
+    np.testing.assert_allclose(s.qacc[0], aref * A / (A + R), rtol=1e-9)
+    f = s.efc_force()
+    np.testing.assert_allclose(f, [aref / (A + R), 0, 0], atol=1e-9 * aref)   # no tangential motion: no friction force
+    # moving apart at v: aref loses b v with b = 2 / (dmax tau); the contact stops pushing once aref <= 0
+    b = 2 / (dmax * tau)
+    s.qvel[0] = 0.5 * aref / b
+    s.forward()
+    np.testing.assert_allclose(s.qacc[0], 0.5 * aref * A / (A + R), rtol=1e-9)
+    s.qvel[0] = 2 * aref / b
+    s.forward()
+    assert s.ncon == 1 and abs(s.qacc[0]) < 1e-12
+
+
+def test_elliptic_friction_stick_and_slip_closed_form():
+    """tests/data/capbox_slide.xml: a box that can only slide along z, pressed (by 0.094 of penetration) against the end cap of a
+    static capsule, mu = 0.1.  The normal row has J = 0 (f_n = aref_n / R_n), the z tangent has A = 1/m and aref_t = -b v:
+    slow -> inside the cone, f_t = -b v / (A + R); fast -> on the cone, and the cone QP's optimum along f_t = -mu f_n is
+    f_n = (aref_n + mu b v) / (R_n + mu^2 (A + R_t)),  R_t = R_n (impratio 1)."""
+    m = sg.compile_mjcf(os.path.join(ROOT, "tests", "data", "capbox_slide.xml"))
+    s = oracle_sim(m)
+    s.reset()
+    assert s.forward() == 0 and s.ncon == 1
+    c = s.contacts()[0]
+    r = 0.35 - 0.2 - (0.3 * np.sin(0.5) + 0.1)
+    np.testing.assert_allclose(c["dist"], r, atol=1e-14)
+    np.testing.assert_allclose(c["frame"], [1, 0, 0, 0, 1, 0, 0, 0, 1], atol=1e-14)      # tangent 2 = z, the slider's axis
+    mass, mu, dmax, tau = float(m.body_mass[-1]), 0.1, 0.95, 0.02
+    Rn = (1 - dmax) / dmax / (3 * mass)
+    A, b = 1 / mass, 2 / (dmax * tau)
+    aref = abs(r) * dmax / (dmax ** 2 * tau ** 2)
+    np.testing.assert_allclose(s.efc_force(), [aref / Rn, 0, 0], rtol=1e-10, atol=1e-9)
+    for v in (0.001, -0.002):                                                              # stick
+        s.reset(); s.qvel[0] = v; s.forward()
+        np.testing.assert_allclose(s.efc_force(), [aref / Rn, 0, -b * v / (A + Rn)], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(s.qacc[0], -b * v / (A + Rn) * A, rtol=1e-9)
+    for v in (20.0, -30.0):                                                                # slip
+        s.reset(); s.qvel[0] = v; s.forward()
+        fn = (aref + mu * b * abs(v)) / (Rn + mu * mu * (A + Rn))
+        np.testing.assert_allclose(s.efc_force(), [fn, 0, -np.sign(v) * mu * fn], rtol=1e-7)
