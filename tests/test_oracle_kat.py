@@ -334,3 +334,29 @@ def test_elliptic_friction_stick_and_slip_closed_form():
         s.reset(); s.qvel[0] = v; s.forward()
         fn = (aref + mu * b * abs(v)) / (Rn + mu * mu * (A + Rn))
         np.testing.assert_allclose(s.efc_force(), [fn, 0, -np.sign(v) * mu * fn], rtol=1e-7)
+
+
+def test_joint_limit_closed_form_and_impedance_profile():
+    """tests/data/limit.xml: a free slider (m = 0.4) beyond its upper limit by delta.  One limit row, J = -1, A = 1/m,
+    R = (1 - d)/d * dof_invweight0 = (1 - d)/d / m, so  qacc = -aref d  with  aref = k d delta - b (-v)...: at rest
+    qacc = -k d^2 delta.  d follows the default solimp (0.9, 0.95, 0.001, 0.5, 2): 0.95 beyond the 1 mm width, and inside it the
+    power-2 sigmoid  y = 2 x^2 (x <= 1/2),  1 - 2 (1 - x)^2 (x > 1/2),  d = 0.9 + 0.05 y  (App. B.5)."""
+    m = sg.compile_mjcf(os.path.join(ROOT, "tests", "data", "limit.xml"))
+    s = oracle_sim(m)
+    tau, dmax = 0.02, 0.95
+    k, b = 1 / (dmax ** 2 * tau ** 2), 2 / (dmax * tau)
+    for delta, d in ((0.05, 0.95), (0.0005, 0.9 + 0.05 * 0.5), (0.00025, 0.9 + 0.05 * 2 * 0.25 ** 2), (0.00075, 0.9 + 0.05 * (1 - 2 * 0.25 ** 2))):
+        s.reset(); s.qpos[0] = 0.1 + delta
+        assert s.forward() == 0 and s.nefc == 1
+        np.testing.assert_allclose(s.qacc[0], -k * d * d * delta, rtol=1e-9)
+        np.testing.assert_allclose(s.efc_force(), [k * d * d * delta * 0.4], rtol=1e-9)
+    # moving out of the limit at v the reference acceleration gains b v; moving back in fast enough the row goes slack (f >= 0)
+    s.reset(); s.qpos[0] = 0.15; s.qvel[0] = 0.3; s.forward()
+    np.testing.assert_allclose(s.qacc[0], -0.95 * (k * 0.95 * 0.05 + b * 0.3), rtol=1e-9)
+    s.reset(); s.qpos[0] = 0.15; s.qvel[0] = -2 * k * 0.95 * 0.05 / b; s.forward()
+    assert s.nefc == 1 and abs(s.qacc[0]) < 1e-12 and s.efc_force()[0] == 0
+    # lower limit, and inside the range: no row
+    s.reset(); s.qpos[0] = -0.12; s.forward()
+    np.testing.assert_allclose(s.qacc[0], k * 0.95 * 0.95 * 0.02, rtol=1e-9)
+    s.reset(); s.qpos[0] = 0.05; s.forward()
+    assert s.nefc == 0 and s.qacc[0] == 0
