@@ -360,3 +360,16 @@ def test_joint_limit_closed_form_and_impedance_profile():
     np.testing.assert_allclose(s.qacc[0], k * 0.95 * 0.95 * 0.02, rtol=1e-9)
     s.reset(); s.qpos[0] = 0.05; s.forward()
     assert s.nefc == 0 and s.qacc[0] == 0
+
+
+def test_accelerometer_centripetal_and_gyro_closed_form():
+    """tests/data/hinge_sensor.xml: an arm turning about the vertical at rate w, sensor site at radius rho = 0.6 on the arm's x axis.
+    No torque acts (gravity is along the axis), so qacc = 0 and the accelerometer reads the centripetal acceleration -w^2 rho
+    along the arm plus the reaction to gravity (+9.81 along z), in the site's (= the body's) frame whatever the angle; gyro = (0, 0, w)."""
+    m = sg.compile_mjcf(os.path.join(ROOT, "tests", "data", "hinge_sensor.xml"))
+    s = oracle_sim(m)
+    for q, w in ((0.0, 3.0), (1.1, -2.0), (2.5, 0.0)):
+        s.reset(); s.qpos[0] = q; s.qvel[0] = w
+        assert s.forward() == 0
+        assert abs(s.qacc[0]) < 1e-12
+        np.testing.assert_allclose(s.sensordata, [-w * w * 0.6, 0, 9.81, 0, 0, w], atol=1e-12)
