@@ -373,3 +373,20 @@ def test_accelerometer_centripetal_and_gyro_closed_form():
         assert s.forward() == 0
         assert abs(s.qacc[0]) < 1e-12
         np.testing.assert_allclose(s.sensordata, [-w * w * 0.6, 0, 9.81, 0, 0, w], atol=1e-12)
+
+
+def test_spatial_tendon_spring_damper_and_cylinder_actuator_closed_form():
+    """tests/data/tendon.xml: a unit arm on a z hinge, a tendon from the world point (0, -1, 0) to the arm's tip: L = sqrt(2 + 2 sin q),
+    dL/dq = cos q / L.  The hinge torque is dL/dq * (-k (L - L0) - c dL/dq qdot + area * act), the inertia about the hinge that of
+    the box (m (a^2 + b^2) / 3 about its centre + m d^2)."""
+    m = sg.compile_mjcf(os.path.join(ROOT, "tests", "data", "tendon.xml"))
+    s = oracle_sim(m)
+    inertia = 0.6 * (0.5 ** 2 + 0.05 ** 2) / 3 + 0.6 * 0.5 ** 2
+    np.testing.assert_allclose(m.tendon_lengthspring, np.sqrt(2), rtol=1e-15)
+    for q, v, act in ((0.0, 0.0, 0.0), (0.4, 0.0, 0.0), (0.4, 1.5, 0.0), (0.4, 0.0, -0.1), (-0.7, -0.8, 0.05)):
+        s.reset(); s.qpos[0] = q; s.qvel[0] = v; s.act[0] = act
+        assert s.forward() == 0
+        L = np.sqrt(2 + 2 * np.sin(q)); dL = np.cos(q) / L
+        np.testing.assert_allclose(s.ten_length[0], L, rtol=1e-14)
+        np.testing.assert_allclose(s.qM[0, 0], inertia, rtol=1e-13)
+        np.testing.assert_allclose(s.qacc[0] * inertia, dL * (-40 * (L - np.sqrt(2)) - 2 * dL * v + 1000 * act), rtol=1e-12, atol=1e-12)
