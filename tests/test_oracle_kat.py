@@ -390,3 +390,27 @@ def test_spatial_tendon_spring_damper_and_cylinder_actuator_closed_form():
         np.testing.assert_allclose(s.ten_length[0], L, rtol=1e-14)
         np.testing.assert_allclose(s.qM[0, 0], inertia, rtol=1e-13)
         np.testing.assert_allclose(s.qacc[0] * inertia, dL * (-40 * (L - np.sqrt(2)) - 2 * dL * v + 1000 * act), rtol=1e-12, atol=1e-12)
+
+
+def test_two_link_arm_mass_matrix_coriolis_gravity_closed_form():
+    """tests/data/arm2.xml: the textbook planar 2R arm (links of length 1, centres of mass at 1/2, gravity along -y):
+    M11 = I1 + I2 + m1 lc^2 + m2 (l^2 + lc^2 + 2 l lc cos q2), M12 = I2 + m2 (lc^2 + l lc cos q2), M22 = I2 + m2 lc^2;
+    Coriolis h = m2 l lc sin q2: c = (-h (2 w1 w2 + w2^2), h w1^2); gravity G1 = (m1 lc + m2 l) g cos q1 + m2 lc g cos(q1 + q2),
+    G2 = m2 lc g cos(q1 + q2).  qacc = -M^-1 (c + G): composite-inertia and Newton-Euler passes of a serial chain."""
+    m = sg.compile_mjcf(os.path.join(ROOT, "tests", "data", "arm2.xml"))
+    s = oracle_sim(m)
+    m1, m2, l, lc, g = 0.6, 0.3, 1.0, 0.5, 9.81
+    I1 = m1 * (0.5 ** 2 + 0.05 ** 2) / 3
+    I2 = m2 * (0.5 ** 2 + 0.04 ** 2) / 3
+    for q1, q2, w1, w2 in ((0.0, 0.0, 0.0, 0.0), (0.3, -0.8, 1.2, -0.7), (-1.1, 2.0, -0.4, 2.5)):
+        s.reset(); s.qpos[:] = [q1, q2]; s.qvel[:] = [w1, w2]
+        assert s.forward() == 0
+        M = np.array([[I1 + I2 + m1 * lc ** 2 + m2 * (l ** 2 + lc ** 2 + 2 * l * lc * np.cos(q2)), I2 + m2 * (lc ** 2 + l * lc * np.cos(q2))],
+                      [0.0, I2 + m2 * lc ** 2]])
+        M[1, 0] = M[0, 1]
+        np.testing.assert_allclose(s.qM, M, rtol=1e-13)
+        h = m2 * l * lc * np.sin(q2)
+        c = np.array([-h * (2 * w1 * w2 + w2 * w2), h * w1 * w1])
+        G = np.array([(m1 * lc + m2 * l) * g * np.cos(q1) + m2 * lc * g * np.cos(q1 + q2), m2 * lc * g * np.cos(q1 + q2)])
+        np.testing.assert_allclose(s.qfrc_bias, c + G, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(s.qacc, -np.linalg.solve(M, c + G), rtol=1e-11, atol=1e-11)
