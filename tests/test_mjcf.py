@@ -68,3 +68,34 @@ def test_rejects_unsupported():
     with pytest.raises(ValueError):
         sg.compile_mjcf(f.name)
     os.unlink(f.name)
+
+
+@pytest.mark.parametrize("scene,count,spacing,centre", [("softbox", (4, 5, 7), 0.3, (1.7, 0.0, 1.0)), ("softball", (7, 7, 7), 0.31, (1.7, 0.0, 1.0)),
+                                                         ("softcylinder", (6, 8, 6), 0.3, (1.5, -0.04, 1.0))])
+def test_composite_shell_geometry(scene, count, spacing, centre):
+    """composite expansion: shell grid points in ix-outer / iz-inner order; box: grid * half-size, ellipsoid: unit
+    direction * half-size; every element's slider axis and capsule axis point from the centre to the element, and the capsule is shifted
+    inwards by radius + half-length so that its outer tip lies on the shell surface."""
+    m = sg.load_model(model_path(scene))
+    half = np.array([0.5 * spacing * (c - 1) for c in count])
+    pts = []
+    for ix in range(count[0]):
+        for iy in range(count[1]):
+            for iz in range(count[2]):
+                if ix in (0, count[0] - 1) or iy in (0, count[1] - 1) or iz in (0, count[2] - 1):
+                    p = np.array([2.0 * ix / (count[0] - 1) - 1, 2.0 * iy / (count[1] - 1) - 1, 2.0 * iz / (count[2] - 1) - 1])
+                    pts.append(p * half if scene == "softbox" else p / np.linalg.norm(p) * half)
+    pts = np.array(pts)
+    n = len(pts)
+    assert n == m.nv - 8
+    np.testing.assert_allclose(m.body_pos[-n:], pts, atol=1e-14)                 # relative to the static parent at `centre`
+    np.testing.assert_allclose(m.body_pos[10], centre, atol=1e-14)
+    radial = pts / np.linalg.norm(pts, axis=1)[:, None]
+    r, hl = m.geom_size[-1, 0], m.geom_size[-1, 1]
+    # capsule centres sit radius + half-length inside the surface point, along the radial direction (geom_pos = (0, 0, -(r + hl)) in a frame whose z is radial)
+    np.testing.assert_allclose(m.geom_pos[-n:], np.tile([0, 0, -(r + hl)], (n, 1)), atol=1e-15)
+    from softgrip_amd.mjcf import quat_to_mat
+    zaxis = np.array([np.asarray(quat_to_mat(q)).reshape(3, 3)[:, 2] for q in m.body_quat[-n:]])
+    np.testing.assert_allclose(zaxis, radial, atol=1e-12)
+    np.testing.assert_allclose(m.jnt_axis[-n:], np.tile([0, 0, 1.0], (n, 1)), atol=0)
+    assert (m.jnt_type[-n:] == 2).all() and m.geom_size[9, 0] == 2 * r            # slide joints; centre sphere = twice the element radius
