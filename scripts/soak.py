@@ -1,0 +1,48 @@
+"""Soak / determinism check on the GPU box: E episodes of the reference schedule at 4096 envs, twice from scratch; no env may raise
+a flag, every sample must be finite, and the two runs must agree bit for bit.  usage: soak.py [scene] [episodes]"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import softgrip_amd as sg  # noqa: E402
+from softgrip_amd import native  # noqa: E402
+from softgrip_amd.create_dataset import episode_schedule  # noqa: E402
+
+scene = sys.argv[1] if len(sys.argv) > 1 else "softbox"
+episodes = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+n = 4096
+m = sg.load_model(os.path.join(ROOT, "models", scene + ".sgmodel"))
+nm = native.NativeModel(m)
+sched = episode_schedule()
+digests = []
+for run in range(2):
+    b = native.NativeBatch(nm, n, 0)
+    rng = np.random.RandomState(7)
+    out = torch.zeros(n, len(sched), 12, dtype=torch.float64, device=b.device)
+    flags = torch.zeros(n, dtype=torch.int32, device=b.device)
+    h = hashlib.sha256()
+    nbad = 0
+    for ep in range(episodes):
+        b.set_stiffness(rng.uniform(300, 1400, n), list(range(11, 64)), [0])
+        b.reset(1, flags=flags)
+        ctrl = np.zeros(2)
+        for t, c in enumerate(sched):
+            if c is not None:
+                ctrl[:] = c
+                b.set_ctrl_broadcast(ctrl)
+            b.step(7, sens=out[:, t], sens_stride=len(sched) * 12, flags=flags)
+            nbad += int((flags != 0).sum())
+        a = out.cpu().numpy()
+        assert np.isfinite(a).all()
+        h.update(a.tobytes())
+    digests.append(h.hexdigest())
+    print("run %d: %d episodes x %d envs, flagged env-steps %d, max |sensor| %.3g, sha256 %s" % (run, episodes, n, nbad, np.abs(a).max(), digests[-1][:16]))
+    del b
+assert digests[0] == digests[1], "runs differ"
+print("deterministic: the two runs agree bit for bit")
