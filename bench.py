@@ -184,7 +184,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[2]: %d envs/GPU, %s scene (nv=%d), stiffness ~ U(300,1400)%s, reference 200-step squeeze "
-                                   "schedule from reset, 7 substeps per env step" % (n, args.scene, nm.nq, " split in per-rank bins" if world > 1 else ""),
+                                   "schedule from reset, 7 substeps per env step; %d equality rows (composite neighbour equalities %s: DESIGN.md 2, U2)" % (
+                                       n, args.scene, nm.nq, " split in per-rank bins" if world > 1 else "", model.neq,
+                                       "on" if (model.eq_obj2id >= 0).any() else "off"),
                        "envs_per_gpu": n, "substeps_per_step": sim_step, "physics_substeps_per_s": value * sim_step,
                        "envs_flagged_bad": nbad, "launches_timed": launches,
                        "timed_region": ("%d whole episode(s) from reset" % (args.steps // T)) if args.steps % T == 0 else
