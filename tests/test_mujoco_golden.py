@@ -36,6 +36,9 @@ def test_oracle_matches_mujoco_capture(path):
     meta = json.loads(str(d["meta"]))
     scene = meta["xml"].replace("soft_experiments_", "").replace("_adjusted_for_2_fingers.xml", "")
     m = sg.load_model(model_path(scene))
+    if meta["counts"].get("neq") == sg.load_model(model_path(scene + "_nb")).neq:
+        m = sg.load_model(model_path(scene + "_nb"))   # the capture's neq settles SURVEY U2: MuJoCo created the neighbour equalities
+        # (with them the squeeze amplifies round-off, DESIGN 2: expect agreement at TOL over the first ~60 env steps only)
     for k, v in meta["counts"].items():
         assert getattr(m, k, v) == v, "compiled model differs from MuJoCo's in %s" % k
     assert abs(float(np.sum(m.body_mass)) - meta["total_mass"]) < 1e-9
