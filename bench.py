@@ -1,27 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the batched soft-gripper simulator (BASELINE.json metric).
 
-A "step" is one ManEnv.step() (7 mj_step substeps + 12-channel sensor read-out, reference
-environment/manenv.py:44-53) for every env of the batch.  Workload at N GPUs: 4096 envs per
-GPU of the softbox scene, stiffness drawn from U(300,1400) (BASELINE.json configs[2]; with
-N > 1 each rank draws from its own stiffness bin, configs[3]), following the reference's
-200-step squeeze schedule (create_dataset.py:41-60) from a fresh reset, state resident in HBM.
-Prints ONE JSON line on rank 0.
+A "step" is the device work of one ManEnv.step() (reference environment/manenv.py:44-53) for every env of the batch: one
+sg_step call = 7 mj_step substeps + the 12-channel sensor read-out, written straight into the [n, 200, 12] episode block --
+the loop ManEnv.rollout() / create_dataset run.  (ManEnv.step() itself adds a host sync per step for its return value; the
+dataset path does not take it, so it is not in the metric.)  Workload at N GPUs: 4096 envs per GPU of the softbox scene as
+MuJoCo's composite documentation describes it (fix rows + neighbour equalities), stiffness drawn from
+U(300,1400) (BASELINE.json configs[2]; with N > 1 each rank draws from its own stiffness bin, configs[3]), following the
+reference's 200-step squeeze schedule (create_dataset.py:41-60) from a fresh reset, state resident in HBM.
+
+Timed region: --steps S a multiple of 200 = S/200 whole episodes (resets included).  Any other S: one episode is run from
+reset and S of its 200 steps, spread evenly over it, are timed one by one (sync + timer around each) -- an estimate of the
+episode average, not of an episode prefix (the first 40 steps have no contacts and cost a third of the average).
+
+`python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run as a child process, before this
+process touches a GPU).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # the CPU baseline's OpenMP threads must not spin between steps
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+device_sync = None   # torch.cuda.synchronize (set in main)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PROFILE_TAG = "r02"    # profiles/<tag>_<scene>_{hbm_traffic,sq_totals}.json: the committed rocprofv3 PMC passes of this workload
 
 
 def algorithmic_bytes_per_env_step(nq, nv, na, nu, nsens):
@@ -72,150 +85,268 @@ def cpu_baseline(model, ks, sim_step, sched, budget_envs, threads):
     return budget_envs * len(sched) / dt, dt
 
 
+def stratified_steps(S, T):
+    """S step indices spread evenly over an episode of T steps (the midpoints of S equal strata)"""
+    return sorted({min(T - 1, int((i + 0.5) * T / S)) for i in range(S)})
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without a launcher: start N ranks with torch.distributed.run as a CHILD process (this process has not
+    touched a GPU and never does) and pass its output through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+class Runner:
+    """one batch + its episode block; runs schedule steps and keeps the flags"""
+
+    def __init__(self, scene, n, local, rank, world):
+        import torch
+        import softgrip_amd as sg
+        from softgrip_amd import native
+        from softgrip_amd.create_dataset import episode_schedule, stiffness_bin
+        self.torch = torch
+        self.model = sg.load_model(os.path.join(ROOT, "models", scene + ".sgmodel"))
+        self.nm = native.NativeModel(self.model)
+        self.n = n
+        self.batch = native.NativeBatch(self.nm, n, local)
+        dev = self.batch.device
+        # stiffness: full paper range on one GPU, one bin per rank on several (no collective on the data path)
+        if world == 1:
+            self.ks = np.random.RandomState(0).uniform(300, 1400, n)
+        else:
+            lo, hi = stiffness_bin(rank, world)
+            self.ks = np.random.RandomState(1000 + rank).uniform(lo, hi, n)
+        self.batch.set_stiffness(self.ks, list(range(11, 64)), [0])
+        self.sched = episode_schedule()
+        self.T = len(self.sched)
+        self.sim_step, self.sim_start = 7, 1
+        self.nsd = self.nm.nsensordata
+        self.out = torch.zeros(n, self.T, self.nsd, dtype=torch.float64, device=dev)
+        self.flags = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.flags_or = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.ctrl = np.zeros(self.nm.nu)
+
+    def step(self, t):
+        """env step t of the episode loop (t % T == 0: reset first)"""
+        T = self.T
+        if t % T == 0:
+            self.batch.reset(self.sim_start, flags=self.flags)
+            self.ctrl[:] = 0
+        if self.sched[t % T] is not None:
+            self.ctrl[:] = self.sched[t % T]
+            self.batch.set_ctrl_broadcast(self.ctrl)
+        self.batch.step(self.sim_step, sens=self.out[:, t % T], sens_stride=T * self.nsd, flags=self.flags)
+        self.flags_or.bitwise_or_(self.flags)
+
+    def timed(self, steps, barrier, after_episode=None):
+        """-> (seconds, avg kernel ms per sg_step call over the timed steps, launches timed, description)"""
+        torch, T, b = self.torch, self.T, self.batch
+        b.profile_enable(False)
+        b.profile_read(reset=True)
+        if steps % T == 0:
+            barrier()
+            b.profile_enable(True)
+            t0 = time.perf_counter()
+            for t in range(steps):
+                self.step(t)
+                if after_episode is not None and (t + 1) % T == 0:
+                    after_episode(self)
+            barrier()
+            dt = time.perf_counter() - t0
+            desc = "%d whole episode(s) from reset (resets included)" % (steps // T)
+        else:
+            pick = set(stratified_steps(steps, T))
+            barrier()
+            dt = 0.0
+            for t in range(T):
+                if t in pick:
+                    device_sync()
+                    b.profile_enable(True)
+                    t0 = time.perf_counter()
+                    self.step(t)
+                    device_sync()
+                    dt += time.perf_counter() - t0
+                    b.profile_enable(False)
+                else:
+                    self.step(t)
+            barrier()
+            desc = ("stratified over the episode: %d of the 200 env steps of one episode from reset, evenly spaced (steps %s), "
+                    "each timed on its own between device syncs; the other steps run untimed" % (len(pick), ",".join(map(str, sorted(pick)))))
+            steps = len(pick)
+        kernel_ms, launches = b.profile_read(reset=True)
+        b.profile_enable(False)
+        return dt, kernel_ms, launches, desc, steps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--scene", default="softbox")
+    ap.add_argument("--scene", default="softbox", help="softbox (default: MuJoCo's documented composite) | softbox_fix | softball | softcylinder ...")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fix-variant", action="store_true", help="skip the labelled secondary measurement on the fix-rows-only model")
+    ap.add_argument("--with-regressor", action="store_true", help="BASELINE configs[4]: ConvNet forward + one Adam step on every finished [n,200,12] block, inside the timed region (needs --steps a multiple of 200)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL over xGMI) or gloo (for testing the multi-process path)")
     ap.add_argument("--force-device", type=int, default=-1, help="testing only: put every rank on this GPU")
+    ap.add_argument("--fake-native-for-tests", action="store_true",
+                    help="testing only (tests/test_dist_gloo.py): a fake batch from tests/fake_native.py replaces the HIP library so the rank "
+                         "plumbing runs without a GPU; the JSON line is then labelled FAKE and is not a measurement")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.with_regressor and args.steps % 200 != 0:
+        raise SystemExit("--with-regressor needs --steps as a multiple of 200 (whole episodes)")
+
     import torch
-    import softgrip_amd as sg
-    from softgrip_amd import native
-    from softgrip_amd.create_dataset import episode_schedule, stiffness_bin
+
+    global device_sync
+    if args.fake_native_for_tests:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import fake_native
+        from softgrip_amd import native
+        native.NativeModel, native.NativeBatch = fake_native.FakeModel, fake_native.FakeBatch
+        device_sync = lambda: None  # noqa: E731
+    else:
+        device_sync = torch.cuda.synchronize
 
     rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if args.force_device >= 0:
         local = args.force_device
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
+        if not args.fake_native_for_tests:
+            torch.cuda.set_device(local)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.dist_backend)
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-
-    model = sg.load_model(os.path.join(ROOT, "models", args.scene + ".sgmodel"))
-    nm = native.NativeModel(model)
-    n = args.envs
-    batch = native.NativeBatch(nm, n, local)
-    dev = batch.device
-    # stiffness: full paper range on one GPU, one bin per rank on several (no collective on the data path)
-    if world == 1:
-        ks = np.random.RandomState(0).uniform(300, 1400, n)
-    else:
-        lo, hi = stiffness_bin(rank, world)
-        ks = np.random.RandomState(1000 + rank).uniform(lo, hi, n)
-    jids, tids = list(range(11, 64)), [0]
-    batch.set_stiffness(ks, jids, tids)
-    sched = episode_schedule()
-    T = len(sched)
-    sim_step, sim_start = 7, 1
-    nsd = nm.nsensordata
-    out = torch.zeros(n, T, nsd, dtype=torch.float64, device=dev)
-    flags = torch.zeros(n, dtype=torch.int32, device=dev)
-    flags_or = torch.zeros(n, dtype=torch.int32, device=dev)
-    ctrl = np.zeros(nm.nu)
-
-    def run(nsteps, t_begin):
-        """nsteps env steps following the episode schedule from position t_begin (reset at every episode start)"""
-        t = t_begin
-        for _ in range(nsteps):
-            if t % T == 0:
-                batch.reset(sim_start, flags=flags)
-                ctrl[:] = 0
-            if sched[t % T] is not None:
-                ctrl[:] = sched[t % T]
-                batch.set_ctrl_broadcast(ctrl)
-            batch.step(sim_step, sens=out[:, t % T], sens_stride=T * nsd, flags=flags)
-            flags_or.bitwise_or_(flags)
-            t += 1
-        return t
 
     def barrier():
-        torch.cuda.synchronize()
+        device_sync()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            device_sync()
 
-    # warmup: first W steps of an episode, then start the timed region at a fresh episode
-    run(args.warmup, 0)
+    R = Runner(args.scene, args.envs, local, rank, world)
+    n, T, nm, model = R.n, R.T, R.nm, R.model
+    dev = R.batch.device
+
+    after_episode = None
+    reg = None
+    if args.with_regressor:
+        from softgrip_amd import convnet
+        torch.manual_seed(0)
+        net = convnet.ConvNet().to(dev)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        y = torch.tensor(R.ks, device=dev)
+        reg = {"loss": []}
+
+        def after_episode(r):
+            mean, std = convnet.channel_stats(r.out)
+            loss, _ = convnet.train_step(net, opt, r.out, y, mean, std, add_noise=True)
+            reg["loss"].append(loss)
+
+    # warm-up: W steps of the episode loop (kernels loaded, workspace touched); the timed region starts at a fresh reset
+    for t in range(args.warmup):
+        R.step(t)
+    if after_episode is not None:
+        after_episode(R)
+        reg["loss"].clear()
     barrier()
-    flags_or.zero_()
-    batch.profile_enable(True)
-    batch.profile_read(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps, 0)
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms, launches = batch.profile_read(reset=True)
-    batch.profile_enable(False)
-    if dist is not None:  # the only collectives of the run: a barrier per side and this MAX (timing, not data path)
+    R.flags_or.zero_()
+    dt, kernel_ms, launches, desc, nsteps = R.timed(args.steps, barrier, after_episode)
+    if dist is not None:  # the only collectives of the run: barriers and this MAX (timing, not data path)
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    nbad = int((flags_or != 0).sum().item())
+    nbad = int((R.flags_or != 0).sum().item())
 
     if rank == 0:
-        value = world * n * args.steps / dt
-        abytes = algorithmic_bytes_per_env_step(nm.nq, nm.nq, nm.nu, nm.nu, nsd)
+        value = world * n * nsteps / dt
+        abytes = algorithmic_bytes_per_env_step(nm.nq, nm.nq, nm.nu, nm.nu, R.nsd)
         ach = abytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic, traffic_src = None, None
         pipe = os.environ.get("SG_PIPELINE", "rows")
-        tp = os.path.join(ROOT, "profiles", {"rows": "r01_v12_rows_hbm_traffic.json", "split": "r01_v4_hbm_traffic.json"}.get(pipe, "none"))
-        if os.path.exists(tp) and args.scene == "softbox" and n == 4096:
-            # HBM-side bytes per sg_step call from the committed rocprofv3 PMC passes of this very workload (not re-measured here)
-            traffic = json.load(open(tp))["per_sg_step_call_bytes"]
-            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; gfx950 x2 correction on the 16-B-per-lane reads of the PGS kernel; fabric-side: Infinity-Cache hits included)" % os.path.basename(tp)
+        nb_on = bool((model.eq_obj2id >= 0).any())
         res = {
             "metric": "env steps/sec (whole node) at batch=4096",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[2]: %d envs/GPU, %s scene (nv=%d), stiffness ~ U(300,1400)%s, reference 200-step squeeze "
-                                   "schedule from reset, 7 substeps per env step; %d equality rows (composite neighbour equalities %s: DESIGN.md 2, U2)" % (
-                                       n, args.scene, nm.nq, " split in per-rank bins" if world > 1 else "", model.neq,
-                                       "on" if (model.eq_obj2id >= 0).any() else "off"),
-                       "envs_per_gpu": n, "substeps_per_step": sim_step, "physics_substeps_per_s": value * sim_step,
-                       "envs_flagged_bad": nbad, "launches_timed": launches,
-                       "timed_region": ("%d whole episode(s) from reset" % (args.steps // T)) if args.steps % T == 0 else
-                                       ("the first %d env steps of the episode loop -- NOT the episode average (use --steps as a multiple of %d)" % (args.steps, T))},
+            "ms_per_step": dt / nsteps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic" if not args.fake_native_for_tests else "FAKE native batch (plumbing test, not a measurement)",
+            "config": {"workload": "configs[%d]: %d envs/GPU, %s scene (nv=%d), stiffness ~ U(300,1400)%s, reference 200-step squeeze "
+                                   "schedule from reset, 7 substeps per env step; %d equality rows (composite neighbour equalities %s: DESIGN.md 2, U2)%s" % (
+                                       4 if args.with_regressor else (3 if world > 1 else 2), n, args.scene, nm.nq,
+                                       " split in per-rank bins" if world > 1 else "", model.neq, "on" if nb_on else "off",
+                                       "; + ConvNet regressor: channel stats, noise augmentation, forward and one Adam step on every finished [n,200,12] block, on device, inside the timed region" if args.with_regressor else ""),
+                       "envs_per_gpu": n, "substeps_per_step": R.sim_step, "physics_substeps_per_s": value * R.sim_step,
+                       "envs_flagged_bad": nbad, "launches_timed": launches, "steps_timed": nsteps, "timed_region": desc},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": {"rows": "sg_chain_kernel + sg_phase_kernel + sg_pgs_rows_kernel chain of one sg_step call (rows pipeline; dominant: sg_pgs_rows_kernel)", "split": "sg_chain_kernel + sg_phase_kernel + sg_pgs_kernel chain of one sg_step call (split pipeline)"}.get(pipe, "sg_step_kernel"),
+                         "traffic": None, "traffic_source": None,
+                         "kernel": {"rows": "sg_chain_kernel + sg_phase_kernel + sg_pgs_rows_kernel chain of one sg_step call (rows pipeline; dominant: sg_pgs_rows_kernel)", "split": "sg_chain_kernel + sg_phase_kernel + sg_pgs_kernel chain of one sg_step call (split pipeline)"}.get(pipe, "sg_step_kernel"),
                          "avg_kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": abytes,
-                         "note": "one 'launch' = the kernel chain of one sg_step call (7 substeps); the path is instruction-issue-bound (serial Gauss-Seidel per finger), not HBM-bound; traffic is mostly contact blocks re-read from L2/Infinity Cache by each sweep (DESIGN.md 4.3)"},
+                         "note": "one 'launch' = the kernel chain of one sg_step call (7 substeps), HIP events on the launch stream over the timed steps only; "
+                                 "the path is instruction-issue-bound (serial Gauss-Seidel per finger), not HBM-bound; traffic is mostly contact blocks "
+                                 "re-read from L2/Infinity Cache by each sweep (DESIGN.md 4.3)"},
         }
-        # secondary roofline (SURVEY 8(d): the binding limit is instruction issue, not HBM): VALU wavefront-instructions per env
-        # step from the committed SQ-counter pass of this very command, times the measured rate, against what the chip's 1024
-        # SIMDs can issue (one fp64 wavefront instruction per 4 cycles each)
-        sp = os.path.join(ROOT, "profiles", "r01_v12_sq_totals.json")
-        if os.path.exists(sp) and args.scene == "softbox" and n == 4096 and pipe == "rows":
+        if reg is not None:
+            res["config"]["regressor_loss_first_last"] = [float(reg["loss"][0]), float(reg["loss"][-1])] if reg["loss"] else None
+        # Episode-average counters of this very workload from committed rocprofv3 PMC passes (profiles/<tag>_<scene>_*.json).  They
+        # describe the whole 200-step episode, which is what both kinds of timed region measure or estimate; they are attached
+        # only for the workload they were collected on.
+        attach = n == 4096 and pipe == "rows" and not args.with_regressor
+        tp = os.path.join(ROOT, "profiles", "%s_%s_hbm_traffic.json" % (PROFILE_TAG, args.scene))
+        if attach and os.path.exists(tp):
+            res["roofline"]["traffic"] = json.load(open(tp))["per_sg_step_call_bytes"]
+            res["roofline"]["traffic_source"] = ("profiles/%s: episode average per sg_step call (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; gfx950 x2 "
+                                                 "correction on the 16-B-per-lane reads of the PGS kernel; fabric-side: Infinity-Cache hits included)" % os.path.basename(tp))
+        sp = os.path.join(ROOT, "profiles", "%s_%s_sq_totals.json" % (PROFILE_TAG, args.scene))
+        if attach and os.path.exists(sp):
+            # secondary roofline (SURVEY 8(d): the binding limit is instruction issue, not HBM): VALU wavefront-instructions per env
+            # step (episode average) x the measured episode-average rate, against what 1024 SIMDs can issue
             sq = json.load(open(sp))["per_env_step"]
             peak = 1024 * 2.4e9 / 4.0
-            ach = sq["SQ_INSTS_VALU"] * value / world   # per GPU
+            a2 = sq["SQ_INSTS_VALU"] * value / world   # per GPU
             res["roofline"]["secondary"] = {
-                "bound": "fp64 VALU issue", "unit": "wavefront-instructions/s", "achieved": ach, "peak": peak, "frac": ach / peak,
+                "bound": "fp64 VALU issue", "unit": "wavefront-instructions/s", "achieved": a2, "peak": peak, "frac": a2 / peak,
                 "valu_insts_per_env_step": sq["SQ_INSTS_VALU"], "salu_insts_per_env_step": sq["SQ_INSTS_SALU"],
                 "lds_insts_per_env_step": sq["SQ_INSTS_LDS"],
-                "source": "profiles/r01_v12_sq_totals.json (rocprofv3 --pmc SQ_INSTS_*, own pass); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per "
-                          "fp64 wavefront instruction; the PGS kernel, 70 % of the time, can only put wavefronts on 512 SIMDs at 4096 envs"}
-        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
+                "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_*, own pass, episode average); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per "
+                          "fp64 wavefront instruction; the PGS kernel can only put wavefronts on 512 SIMDs at 4096 envs" % os.path.basename(sp)}
+        if world == 1 and nb_on and not args.fake_native_for_tests and not args.no_fix_variant and not args.with_regressor and args.scene.endswith(("softbox", "softball", "softcylinder")):
+            # labelled secondary: the same workload on the fix-rows-only model (composite_neighbors=False)
+            del R
+            torch.cuda.empty_cache()
+            R2 = Runner(args.scene + "_fix", n, local, rank, world)
+            for t in range(args.warmup):
+                R2.step(t)
+            barrier()
+            dt2, km2, _, desc2, ns2 = R2.timed(args.steps, barrier)
+            res["config"]["fix_only_variant"] = {"value": n * ns2 / dt2, "unit": "env-steps/s", "avg_kernel_ms": km2, "equality_rows": R2.model.neq,
+                                                 "note": "same workload on models/%s_fix.sgmodel (composite without its neighbour equalities) -- NOT the headline" % args.scene}
+            del R2
+        if not args.no_cpu_baseline and world == 1 and not args.fake_native_for_tests:  # reported at N = 1 only
             cores = usable_cores()
-            envs = 16 * cores  # 16 full episodes per core: about 10-20 s of wall time
-            v, cdt = cpu_baseline(model, ks, sim_step, sched, envs, cores)
-            v1, cdt1 = cpu_baseline(model, ks, sim_step, sched, 8, 1)   # SURVEY 8(d): a 1-thread figure beside the all-cores one
+            envs = 8 * cores  # 8 full episodes per core: about 10-20 s of wall time
+            ks = np.random.RandomState(0).uniform(300, 1400, n)
+            from softgrip_amd.create_dataset import episode_schedule
+            sched = episode_schedule()
+            v, cdt = cpu_baseline(model, ks, 7, sched, envs, cores)
+            v1, cdt1 = cpu_baseline(model, ks, 7, sched, 2, 1)   # SURVEY 8(d): a 1-thread figure beside the all-cores one
             probe = []
             for mod in ("mujoco", "mujoco_py"):                          # SURVEY 8(d): time MuJoCo itself iff it exists on the box -- probe, never assume
                 try:
@@ -226,7 +357,7 @@ def main():
             res["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
                                    "sample": "%d envs x one 200-step episode (same scene/schedule/stiffness draws) on the fp64 C oracle, "
                                              "OpenMP over envs, %.1f s" % (envs, cdt),
-                                   "one_thread": {"value": v1, "sample": "8 envs x one episode on 1 thread, %.1f s" % cdt1},
+                                   "one_thread": {"value": v1, "sample": "2 envs x one episode on 1 thread, %.1f s" % cdt1},
                                    "mujoco_probe": "; ".join(probe)}
         print(json.dumps(res))
     if dist is not None:

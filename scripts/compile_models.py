@@ -20,9 +20,9 @@ SCENES = {
 
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "models"), exist_ok=True)
-    # <scene>.sgmodel: the composite as fix rows + tendon row (the default); <scene>_nb.sgmodel: the same scene with
-    # the composite's neighbour equalities switched on -- rows pipeline only
-    for suffix, nb in (("", False), ("_nb", True)):
+    # <scene>.sgmodel: the composite as MuJoCo's documentation describes it -- fix rows, neighbour equalities, tendon row (the
+    # default; rows pipeline only); <scene>_fix.sgmodel: the same scene without the neighbour equalities (opt-in)
+    for suffix, nb in (("", True), ("_fix", False)):
         for name, xml in SCENES.items():
             m = sg.compile_mjcf(os.path.join(REF, xml), composite_neighbors=nb)
             out = os.path.join(ROOT, "models", name + suffix + ".sgmodel")

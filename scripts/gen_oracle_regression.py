@@ -16,7 +16,7 @@ from softgrip_amd.create_dataset import episode_schedule  # noqa: E402
 
 K = 903.6948543200572   # np.random.seed(0); np.random.uniform(300, 1400): the reference's first draw
 out = {"stiffness": np.array(K)}
-for scene, nsteps in (("softbox", 200), ("softbox_nb", 60)):
+for scene, nsteps in (("softbox_fix", 200), ("softbox", 60)):
     s = oracle_sim(sg.load_model(model_path(scene)), K)
     s.reset(); s.forward(); s.step()
     rows, ncon = [], []

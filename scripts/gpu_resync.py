@@ -15,7 +15,7 @@ from oracle import oracle as O  # noqa: E402
 from softgrip_amd import native  # noqa: E402
 from softgrip_amd.create_dataset import episode_schedule  # noqa: E402
 
-scene = sys.argv[1] if len(sys.argv) > 1 else "softbox"
+scene = sys.argv[1] if len(sys.argv) > 1 else "softbox_fix"
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 free = len(sys.argv) > 3 and sys.argv[3] == "free"
 ks = [700.0, 903.6948543200572, 300.0, 1400.0, 512.25, 350.0, 1000.0, 1250.0, 640.0]

@@ -9,7 +9,7 @@ import softgrip_amd as sg
 from softgrip_amd import native
 from softgrip_amd.create_dataset import episode_schedule
 
-scene = sys.argv[1] if len(sys.argv) > 1 else "softball"
+scene = sys.argv[1] if len(sys.argv) > 1 else "softball_fix"
 m = sg.load_model("models/%s.sgmodel" % scene)
 nm = native.NativeModel(m)
 n = 64

@@ -14,7 +14,7 @@ import softgrip_amd as sg  # noqa: E402
 from softgrip_amd import native  # noqa: E402
 from softgrip_amd.create_dataset import episode_schedule  # noqa: E402
 
-scene = sys.argv[1] if len(sys.argv) > 1 else "softbox"
+scene = sys.argv[1] if len(sys.argv) > 1 else "softbox_fix"
 episodes = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 n = 4096
 m = sg.load_model(os.path.join(ROOT, "models", scene + ".sgmodel"))

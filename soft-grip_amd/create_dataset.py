@@ -35,63 +35,93 @@ def stiffness_bin(rank, world, lo=300.0, hi=1400.0):
     return lo + w * rank, lo + w * (rank + 1)
 
 
+def _part_path(folder, name, ep):
+    return os.path.join(folder, "{}.part{:05d}.pickle".format(name, ep))
+
+
+def _atomic_pickle(path, obj):
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as file:
+        pickle.dump(obj, file)
+    os.replace(tmp, path)   # a crash never leaves a half-written shard behind
+
+
 def log_into_file(args):
+    """reference create_dataset.py:20-80.  Extensions (all off by default on one GPU with one env, where the function does
+    exactly what the reference does): n_envs > 1 -> every "episode" is a batch of n_envs episodes; several ranks -> each rank
+    draws from its own stiffness bin and writes its own file; --num-batches B -> B episode-batches per model path;
+    --incremental (always on with several ranks) -> every finished episode-batch is written at once as
+    <name>.partNNNNN.pickle, a restarted run skips the parts it finds (the reference pickles once at the
+    very end, create_dataset.py:75-79, and loses everything on a crash) and the final pickle is assembled from the parts."""
     assert type(args.mujoco_model_paths) is list
     num_envs = len(args.mujoco_model_paths)
     current_env = 0
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    num_batches = int(getattr(args, "num_batches", NUM_EPISODES) or NUM_EPISODES)
+    incremental = bool(getattr(args, "incremental", False)) or world > 1
 
     env_spec = ManEnv.get_std_spec(args)
     env_spec["device"] = int(os.environ.get("LOCAL_RANK", getattr(args, "device", 0)))
     env = ManEnv(**env_spec)
     n = env.n_envs
+    lo, hi = stiffness_bin(rank, world) if world > 1 else (300, 1400)   # stiffness sweep sharded by bin (BASELINE.json configs[3])
 
     os.makedirs(args.data_folder, exist_ok=True)
     name = args.data_name if world == 1 else "%s.rank%d" % (args.data_name, rank)
     path = os.path.join(args.data_folder, "{}.pickle".format(name))
     data, stiffness = list(), list()
+    n_skipped = 0
 
-    for ep in range(NUM_EPISODES * num_envs):
-        if world > 1:  # stiffness sweep sharded by bin (BASELINE.json configs[3])
-            lo, hi = stiffness_bin(rank, world)
-            env.set_new_stiffness(lo, hi)
-            env.env.reset(max(env.sim_start, 0), sens=env._sens, flags=env._flags, touch=env._touch)
-            current_stiffness = env.stiffness.copy()
+    for ep in range(num_batches * num_envs):
+        part = _part_path(args.data_folder, name, ep)
+        if incremental and os.path.exists(part):
+            env.rng.uniform(lo, hi, size=n if n > 1 else None)   # consume the draws of the finished batch: the stream stays aligned
+            n_skipped += 1
         else:
-            current_stiffness = env.reset()
+            current_stiffness = np.array(env.reset(lo, hi), dtype=np.float64).reshape(-1).copy()   # the label is the pre-episode draw (reference :35,65)
 
-        samples = list()
-        for _ in range(START_STEP):
-            readings, contact = env.step()
-            readings = _mask(args, readings, contact)
-            samples.append(readings)
-        env.close_hand()
-        for i in range(MAX_ITER_PER_EP):
-            env.render()
-            if i % OPEN_CLOSE_DIV == 0 and i > 0:
-                env.toggle_grip()
-            readings, contact = env.step()
-            readings = _mask(args, readings, contact)
-            samples.append(readings)
+            samples = list()
+            for _ in range(START_STEP):
+                readings, contact = env.step()
+                readings = _mask(args, readings, contact)
+                samples.append(readings)
+            env.close_hand()
+            for i in range(MAX_ITER_PER_EP):
+                env.render()
+                if i % OPEN_CLOSE_DIV == 0 and i > 0:
+                    env.toggle_grip()
+                readings, contact = env.step()
+                readings = _mask(args, readings, contact)
+                samples.append(readings)
 
-        if n == 1:
-            data.append(np.array(samples))
-            stiffness.append(float(np.asarray(current_stiffness).reshape(-1)[0]))
-        else:
-            import torch
-            block = torch.stack(samples, dim=1).cpu().numpy()  # [n, 200, 12]
-            data.extend(np.array(block[e]) for e in range(n))
-            stiffness.extend(float(k) for k in np.asarray(env.stiffness))
+            if n == 1:
+                ep_data, ep_k = [np.array(samples)], [float(current_stiffness[0])]
+            else:
+                import torch
+                block = torch.stack(samples, dim=1).cpu().numpy()  # [n, 200, 12]
+                ep_data, ep_k = [np.array(block[e]) for e in range(n)], [float(k) for k in current_stiffness]
+            if incremental:
+                _atomic_pickle(part, {"data": ep_data, "stiffness": ep_k})
+            else:
+                data.extend(ep_data)
+                stiffness.extend(ep_k)
 
-        if (ep + 1) % NUM_EPISODES == 0 and num_envs > 1:
+        if (ep + 1) % num_batches == 0 and num_envs > 1:
             current_env += 1
             if current_env >= num_envs:
                 current_env = 0
             env.load_env(current_env)
 
-    with open(path, "wb") as file:
-        pickle.dump({"data": data, "stiffness": stiffness}, file)
+    if incremental:   # assemble the final pickle from the parts (the parts stay: they are the resume state)
+        for ep in range(num_batches * num_envs):
+            with open(_part_path(args.data_folder, name, ep), "rb") as file:
+                d = pickle.load(file)
+            data.extend(d["data"])
+            stiffness.extend(d["stiffness"])
+        if n_skipped:
+            print("resumed: {0} finished episode-batch(es) found and skipped".format(n_skipped))
+    _atomic_pickle(path, {"data": data, "stiffness": stiffness})
     print("Total number of samples: {0}".format(len(data)))
     return path
 
@@ -116,6 +146,10 @@ def make_parser():
     parser.add_argument('--n-envs', type=int, default=1)
     parser.add_argument('--device', type=int, default=0)
     parser.add_argument('--seed', type=int, default=None)
+    parser.add_argument('--num-batches', type=int, default=NUM_EPISODES, help="episode-batches per model path (reference: NUM_EPISODES = 1)")
+    parser.add_argument('--incremental', action='store_true', default=False,
+                        help="write every finished episode-batch as <name>.partNNNNN.pickle and skip finished parts on restart")
+    parser.add_argument('--contact-flag-mode', default="intent", choices=["intent", "reference"])
     return parser
 
 

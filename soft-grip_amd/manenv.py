@@ -63,6 +63,7 @@ class ManEnv(Env):
         self._touch = torch.zeros(self.n_envs, dtype=torch.int32, device=dev)
         self._ctrl = np.zeros(self.nmodel.nu)
         self.stiffness = np.full(self.n_envs, np.nan)
+        self._k_range = (300, 1400)  # range of the last set_new_stiffness draw: re-draws after a failure stay inside it
         # which finger boxes (bit 2*chain+box of `touch`) match each name in finger_names
         self._finger_bits = []
         bits = self._chain_geom_bits()
@@ -104,9 +105,10 @@ class ManEnv(Env):
             self._reset_envs(bad)
         return self._result()
 
-    def reset(self):
-        """reference manenv.py:55-63"""
-        current_stiffness = self.set_new_stiffness()
+    def reset(self, range_min=300, range_max=1400):
+        """reference manenv.py:55-63; the stiffness range is an extension (the reference always draws from U(300, 1400)):
+        a rank of a sharded run passes its stiffness bin"""
+        current_stiffness = self.set_new_stiffness(range_min, range_max)
         self.env.reset(max(self.sim_start, 0), sens=self._sens, flags=self._flags, touch=self._touch)
         self._ctrl[:] = 0  # mj_resetData clears ctrl
         bad = (self._flags != 0)
@@ -115,19 +117,24 @@ class ManEnv(Env):
         return current_stiffness
 
     def _reset_envs(self, bad_mask, max_tries=5):
+        """what `except MujocoException: self.reset()` does (reference manenv.py:50-51), for the flagged envs only: a new
+        stiffness from the range of the last draw, mj_resetData (ctrl of those envs stays 0 until the next close / toggle, as in
+        the reference), forward, sim_start steps.  Raises only when envs are still flagged after max_tries resets."""
         import torch
+        lo, hi = self._k_range
         for _ in range(max_tries):
             idx = torch.nonzero(bad_mask).flatten().cpu().numpy()
             if idx.size == 0:
                 return
-            self.stiffness[idx] = self.rng.uniform(300, 1400, size=idx.size) if idx.size > 1 else self.rng.uniform(300, 1400)
+            self.stiffness[idx] = self.rng.uniform(lo, hi, size=idx.size) if idx.size > 1 else self.rng.uniform(lo, hi)
             self.env.set_stiffness(self.stiffness, self.joint_ids, self.tendon_ids)
             mask = bad_mask.to(torch.uint8).contiguous()
             flags = torch.zeros_like(self._flags)
             self.env.reset(max(self.sim_start, 0), sens=self._sens, flags=flags, touch=self._touch, mask=mask)
-            self.env.set_ctrl_broadcast(self._ctrl)  # the reference's ctrl survives only via is_closing; keep the schedule's ctrl
             bad_mask = bad_mask & (flags != 0)
-        raise SimulationError("envs keep failing after %d resets: %s" % (max_tries, idx))
+        idx = torch.nonzero(bad_mask).flatten().cpu().numpy()
+        if idx.size:
+            raise SimulationError("envs keep failing after %d resets: %s" % (max_tries, idx))
 
     def _contact_flags(self):
         import torch
@@ -178,6 +185,7 @@ class ManEnv(Env):
     def set_new_stiffness(self, range_min=300, range_max=1400):
         """reference manenv.py:103-109: one draw per env from the global NumPy RNG, written to
         jnt_stiffness[joint_ids] and tendon_stiffness[tendon_ids]"""
+        self._k_range = (range_min, range_max)
         if self.n_envs == 1:
             new_value = self.rng.uniform(range_min, range_max)
             self.stiffness[0] = new_value
@@ -232,7 +240,7 @@ class ManEnv(Env):
             "env_paths": args.mujoco_model_paths,
             "is_vis": args.vis,
         }
-        for extra in ("n_envs", "device"):
+        for extra in ("n_envs", "device", "contact_flag_mode"):
             if hasattr(args, extra):
                 spec[extra] = getattr(args, extra)
         return spec

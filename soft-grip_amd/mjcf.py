@@ -257,7 +257,7 @@ def _bool(s, default=False):
 
 
 class _Compiler:
-    def __init__(self, path: str, composite_neighbors: bool = False):
+    def __init__(self, path: str, composite_neighbors: bool = True):
         self.root = _load_xml(path)
         self.composite_neighbors = composite_neighbors
         self.defaults = _Defaults()
@@ -973,12 +973,13 @@ class Model:
         return "\n".join(out)
 
 
-def compile_mjcf(path: str, composite_neighbors: bool = False) -> Model:
+def compile_mjcf(path: str, composite_neighbors: bool = True) -> Model:
     """Counterpart of ``mujoco_py.load_model_from_path`` (reference environment/manenv.py:27).
 
-    ``composite_neighbors=True`` adds the neighbour equalities of box / ellipsoid / cylinder composites (SURVEY.md App. A.2,
-    unknown U2: "each joint is equality-constrained to remain equal to its neighbor joints") -- a switch, off by default,
-    because no MuJoCo is available to confirm that the shipped compiler creates them."""
+    ``composite_neighbors`` (default True) adds the neighbour equalities of box / ellipsoid / cylinder composites as MuJoCo's
+    composite documentation describes them ("each joint is equality-constrained to remain equal to its
+    neighbor joints").  ``False`` compiles the fix-rows-only variant (``models/*_fix.sgmodel``); a MuJoCo capture whose ``neq``
+    is 111 instead of 327 would be the evidence to flip the default back (tests/test_mujoco_golden.py)."""
     return _Compiler(path, composite_neighbors).run()
 
 

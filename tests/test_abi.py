@@ -21,7 +21,7 @@ def test_header_symbols_exported():
 
 
 def test_model_create_and_errors():
-    m = sg.load_model(model_path("softbox"))
+    m = sg.load_model(model_path("softbox_fix"))
     nm = native.NativeModel(m)
     assert (nm.nq, nm.nu, nm.nsensordata, nm.ntendon, nm.nelem) == (118, 2, 12, 3, 110)
     p = C.c_void_p()
@@ -34,7 +34,7 @@ def test_model_create_and_errors():
     assert ei.value.code == native.SG_ERR_MODEL
 
 
-@pytest.mark.parametrize("scene,nelem", [("softbox_nb", 110), ("softcylinder_nb", 192), ("softball_nb", 218)])
+@pytest.mark.parametrize("scene,nelem", [("softbox", 110), ("softcylinder", 192), ("softball", 218)])
 def test_neighbour_row_models_are_accepted(scene, nelem):
     """the plan builder takes the composite's neighbour equalities (two-joint rows, right after their element's fix row) and
     refuses what it cannot schedule: a neighbour row with a polynomial other than q1 = q2"""
@@ -55,7 +55,7 @@ def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present")
-    nm = native.NativeModel(sg.load_model(model_path("softbox")))
+    nm = native.NativeModel(sg.load_model(model_path("softbox_fix")))
     with pytest.raises(native.SoftgripError) as ei:
         native.NativeBatch(nm, 4, 0)
     assert ei.value.code == native.SG_ERR_NO_DEVICE

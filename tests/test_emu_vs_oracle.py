@@ -21,7 +21,7 @@ def _pair(scene, k):
 
 @pytest.mark.parametrize("k", [903.6948543200572, 300.0])
 def test_softbox_full_episode(k):
-    m, e, s = _pair("softbox", k)
+    m, e, s = _pair("softbox_fix", k)
     worst = 0.0
     for t, c in enumerate(episode_schedule()):
         if c is not None:
@@ -37,7 +37,7 @@ def test_softbox_full_episode(k):
     np.testing.assert_allclose(a, s.act, atol=1e-14)
 
 
-@pytest.mark.parametrize("scene", ["softcylinder", "softball"])
+@pytest.mark.parametrize("scene", ["softcylinder_fix", "softball_fix"])
 def test_penetrating_scenes_first_steps(scene):
     """these scenes start in deep penetration and are chaotic; the two implementations agree until the first tie-break"""
     m, e, s = _pair(scene, 700.0)

@@ -30,10 +30,51 @@ def _bufs(b, n):
             torch.zeros(n, dtype=torch.int32, device=b.device))
 
 
+def _touch_bit_of_geom(m):
+    """geom id -> bit of `touch_out` (include/softgrip.h: bit 2*chain + box), from the model alone: the moving boxes, grouped by the
+    root moving body of their finger, in body order"""
+    chains = {}
+    for g in range(m.ngeom):
+        b = m.geom_bodyid[g]
+        if m.body_weldid[b] == 0 or m.geom_type[g] != 6:
+            continue
+        while m.body_weldid[m.body_parentid[b]] != 0:
+            b = m.body_parentid[b]
+        chains.setdefault(b, []).append(g)
+    return {g: 2 * c + k for c, root in enumerate(sorted(chains)) for k, g in enumerate(chains[root])}
+
+
+def _expected_touch(m, contacts, bit_of):
+    """the set of (finger box, OBJ* geom) pairs in the oracle's contact list, as touch bits (what manenv.py:71-83 looks at)"""
+    t = 0
+    for c in contacts:
+        for a, b in ((c["geom1"], c["geom2"]), (c["geom2"], c["geom1"])):
+            if a in bit_of and m.geom_names[b].startswith("OBJ"):
+                t |= 1 << bit_of[a]
+    return t
+
+
+def _reference_flag(m, contacts, fingers_left, obj_name="OBJ"):
+    """replay of reference environment/manenv.py:65-85 on a contact list; `fingers_left` is the list the reference aliases
+    (pass a fresh copy of finger_names for the intended semantics, a persistent list for the reference's actual behaviour)"""
+    flag = False
+    for c in contacts:
+        n1, n2 = m.geom_names[c["geom1"]] or None, m.geom_names[c["geom2"]] or None
+        if n1 is not None and n2 is not None:
+            if obj_name in n1 or obj_name in n2:
+                for f in fingers_left:
+                    if f in n1 or f in n2:
+                        fingers_left.remove(f)
+        if len(fingers_left) == 0:
+            flag = True
+            break
+    return flag
+
+
 FREE_RUN_STEPS = 47  # env steps over which the neighbour-row scene is also compared free-running (contact starts at ~45; the error grows 10x every 5 steps from there: 1e-10 at 47, 7e-10 at 50, 3e-8 at 60)
 
 
-@pytest.mark.parametrize("scene,pipeline", [("softbox", "rows"), ("softbox", "split"), ("softbox", "fused"), ("softbox_nb", "rows")])
+@pytest.mark.parametrize("scene,pipeline", [("softbox_fix", "rows"), ("softbox_fix", "split"), ("softbox_fix", "fused"), ("softbox", "rows")])
 def test_softbox_episode_matches_oracle(scene, pipeline):
     """every kernel pipeline against the oracle over the whole reference episode, 9 envs so that the PGS kernel runs a full
     and a partial wavefront.  softbox = the scene as compiled by default (all three pipelines); softbox_nb = the same scene with
@@ -46,7 +87,7 @@ def test_softbox_episode_matches_oracle(scene, pipeline):
     the kernels add in one env step (7 substeps) -- every step of the episode, contact sets and iteration counts exactly."""
     import torch
     ks = [700.0, 903.6948543200572, 300.0, 1400.0, 512.25, 350.0, 1000.0, 1250.0, 640.0]
-    reseat = scene == "softbox_nb"
+    reseat = scene == "softbox"
     m, nm, b = _gpu_batch(scene, ks, pipeline)
     sens, flags, touch = _bufs(b, len(ks))
     sims = [oracle_sim(m, k) for k in ks]
@@ -56,6 +97,8 @@ def test_softbox_episode_matches_oracle(scene, pipeline):
     np.testing.assert_allclose(sens.cpu().numpy(), np.stack([s.sensordata for s in sims]), atol=1e-12)
     ctrl = np.zeros(2)
     worst = 0.0
+    bit_of = _touch_bit_of_geom(m)
+    touched = 0
     for t, c in enumerate(episode_schedule()):
         if c is not None:
             ctrl[:] = c
@@ -70,6 +113,11 @@ def test_softbox_episode_matches_oracle(scene, pipeline):
         worst = max(worst, np.abs(got - np.stack([s.sensordata for s in sims])).max())
         assert worst < TOL_SENSOR, (t, worst)
         assert int(flags.abs().sum()) == 0
+        # the contact read-out (reference manenv.py:65-85 reads data.contact after the 7 substeps): touch_out == the (finger box,
+        # OBJ*) pairs of the oracle's contact list, every step
+        want = [_expected_touch(m, s.contacts(), bit_of) for s in sims]
+        assert touch.cpu().tolist() == want, (t, touch.cpu().tolist(), want)
+        touched |= want[0]
         if t % 20 == 0 or reseat:
             st = b.solver_stats()
             assert st["ncon"].cpu().tolist() == [s.ncon for s in sims]
@@ -84,6 +132,7 @@ def test_softbox_episode_matches_oracle(scene, pipeline):
             b.set_state(qpos=T([s.qpos for s in sims]), qvel=T([s.qvel for s in sims]), act=T([s.act for s in sims]),
                         qacc_warmstart=T([s.qacc_warmstart for s in sims]))
     assert worst < TOL_SENSOR, worst
+    assert (touched & 0b0011) and (touched & 0b1100), touched   # both fingers did touch the object during the squeeze
     st = b.get_state()
     for e, s in enumerate(sims):
         np.testing.assert_allclose(st["qpos"][e].cpu().numpy(), s.qpos, atol=1e-9)
@@ -91,9 +140,9 @@ def test_softbox_episode_matches_oracle(scene, pipeline):
         np.testing.assert_allclose(st["act"][e].cpu().numpy(), s.act, atol=1e-13)
 
 
-@pytest.mark.parametrize("scene,pipeline", [("softcylinder", "rows"), ("softball", "rows"), ("softcylinder", "split"), ("softball", "split"),
-                                            ("softcylinder", "fused"), ("softball", "fused"),
-                                            ("softcylinder_nb", "rows"), ("softball_nb", "rows")])
+@pytest.mark.parametrize("scene,pipeline", [("softcylinder_fix", "rows"), ("softball_fix", "rows"), ("softcylinder_fix", "split"), ("softball_fix", "split"),
+                                            ("softcylinder_fix", "fused"), ("softball_fix", "fused"),
+                                            ("softcylinder", "rows"), ("softball", "rows")])
 def test_other_scenes_first_substeps(scene, pipeline):
     """R = 3 / 4 kernel instantiations; these scenes start in deep penetration (chaotic), so only the first substeps
     are compared point-wise"""
@@ -124,8 +173,8 @@ def test_full_size_properties():
     ks = rng.uniform(300, 1400, n)
     ks[1::2] = ks[0::2]                        # pairs of identical envs
     perm = rng.permutation(n)
-    m, nm, b = _gpu_batch("softbox", ks)
-    _, _, b2 = _gpu_batch("softbox", ks[perm])
+    m, nm, b = _gpu_batch("softbox_fix", ks)
+    _, _, b2 = _gpu_batch("softbox_fix", ks[perm])
     outs = []
     for batch in (b, b2):
         sens, flags, touch = _bufs(batch, n)
@@ -151,7 +200,7 @@ def test_pipelines_agree_at_full_size():
     ks = np.random.RandomState(0).uniform(300, 1400, n)
     outs = []
     for pipeline in ("rows", "fused"):
-        _, _, b = _gpu_batch("softbox", ks, pipeline)
+        _, _, b = _gpu_batch("softbox_fix", ks, pipeline)
         sens, flags, touch = _bufs(b, n)
         b.reset(1, sens=sens, flags=flags, touch=touch)
         b.set_ctrl_broadcast(np.array([-0.2, -0.2]))
@@ -163,7 +212,7 @@ def test_pipelines_agree_at_full_size():
 
 def test_neighbour_row_model_refuses_other_pipelines():
     from softgrip_amd import native
-    m, nm, b = _gpu_batch("softbox_nb", [700.0])
+    m, nm, b = _gpu_batch("softbox", [700.0])
     with pytest.raises(native.SoftgripError):
         b.set_pipeline("fused")
 
@@ -172,7 +221,7 @@ def test_cfg2_uniform_stiffness_batch_is_bit_identical_across_envs():
     """SURVEY 8(d) cfg 2: B = 1024, every env k = 700 (the XML value).  Identical envs must give bit-identical trajectories
     whatever lane, quad or wavefront they sit in; env 0 is checked against the oracle."""
     n = 1024
-    m, nm, b = _gpu_batch("softbox", np.full(n, 700.0))
+    m, nm, b = _gpu_batch("softbox_fix", np.full(n, 700.0))
     sens, flags, touch = _bufs(b, n)
     s0 = oracle_sim(m, 700.0)
     s0.reset(); s0.forward(); s0.step()
@@ -198,7 +247,7 @@ def test_cfg2_uniform_stiffness_batch_is_bit_identical_across_envs():
 def test_state_roundtrip_and_masked_reset():
     import torch
     ks = [700.0, 800.0, 900.0]
-    m, nm, b = _gpu_batch("softbox", ks)
+    m, nm, b = _gpu_batch("softbox_fix", ks)
     sens, flags, touch = _bufs(b, 3)
     b.reset(1, sens=sens, flags=flags, touch=touch)
     b.set_ctrl_broadcast(np.array([-0.2, -0.2]))
@@ -227,12 +276,12 @@ def test_manenv_and_dataset_on_gpu(tmp_path):
     import types
     from softgrip_amd import create_dataset as cd
     np.random.seed(0)
-    args = types.SimpleNamespace(mujoco_model_paths=[model_path("softbox")], sim_start=1, sim_step=7, vis=False, mask_contact=False,
+    args = types.SimpleNamespace(mujoco_model_paths=[model_path("softbox_fix")], sim_start=1, sim_step=7, vis=False, mask_contact=False,
                                  data_folder=str(tmp_path), data_name="ds", n_envs=3, device=0)
     path = cd.log_into_file(args)
     d = pickle.load(open(path, "rb"))
     assert len(d["data"]) == 3 and np.array(d["data"][0]).shape == (200, 12)
-    s = oracle_sim(sg.load_model(model_path("softbox")), d["stiffness"][1])
+    s = oracle_sim(sg.load_model(model_path("softbox_fix")), d["stiffness"][1])
     s.reset(); s.forward(); s.step()
     ref = []
     for c in episode_schedule():
@@ -249,7 +298,7 @@ def test_bad_env_is_reset_like_mujoco_exception():
     import torch
     from softgrip_amd import ManEnv
     np.random.seed(0)
-    env = ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=4)
+    env = ManEnv(1, 7, [model_path("softbox_fix")], is_vis=False, n_envs=4)
     k0 = env.reset().copy()
     env.close_hand()
     for _ in range(20):
@@ -277,7 +326,7 @@ def test_config5_online_regressor():
     from softgrip_amd import ManEnv, convnet
     from softgrip_amd.create_dataset import episode_schedule
     np.random.seed(1)
-    env = ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=64)
+    env = ManEnv(1, 7, [model_path("softbox_fix")], is_vis=False, n_envs=64)
     env.set_new_stiffness()
     out, flags = env.rollout(episode_schedule())
     assert out.shape == (64, 200, 12) and out.is_cuda and int((flags != 0).sum()) == 0
@@ -293,7 +342,7 @@ def test_config5_online_regressor():
     assert float(l1) < float(l0) * 1.5
 
 
-@pytest.mark.parametrize("scene,n", [("softbox", 1), ("softbox", 65), ("softbox_nb", 1), ("softbox_nb", 13)])
+@pytest.mark.parametrize("scene,n", [("softbox_fix", 1), ("softbox_fix", 65), ("softbox", 1), ("softbox", 13)])
 def test_ragged_batches(scene, n):
     """batch sizes that fill neither a PGS wavefront (8 envs) nor a chain wavefront (64 chains): every env against the oracle
     through reset, the idle phase and the first contacts (45 env steps)"""
@@ -320,7 +369,7 @@ def test_ragged_batches(scene, n):
     assert b.solver_stats()["ncon"].cpu().tolist() == [s.ncon for s in sims]
 
 
-@pytest.mark.parametrize("scene", ["softbox", "softbox_nb"])
+@pytest.mark.parametrize("scene", ["softbox_fix", "softbox"])
 def test_runs_are_bit_reproducible_and_flag_free(scene):
     """two runs from scratch of two consecutive episodes (fresh stiffness draws, reset in between) at 1024 envs: no flag, all finite, and
     the same bits -- nothing on the path depends on scheduling (scripts/soak.py does this at 4096 envs and more episodes)"""
@@ -353,7 +402,7 @@ def test_stiffness_far_outside_the_paper_range():
     """k = 1 ... 1e4 (the reference draws 300 ... 1400): same parity as inside the range; k = 1e5 makes the explicit element springs
     unstable at h = 5 ms -- MuJoCo would raise its bad-qacc warning, the oracle and the kernels both flag the env (data, not an error)"""
     ks = [1.0, 10.0, 100.0, 1e4, 1e5]
-    m, nm, b = _gpu_batch("softbox", ks)
+    m, nm, b = _gpu_batch("softbox_fix", ks)
     sens, flags, touch = _bufs(b, len(ks))
     sims = [oracle_sim(m, k) for k in ks]
     for s in sims:
@@ -378,3 +427,76 @@ def test_stiffness_far_outside_the_paper_range():
         worst[ok] = np.maximum(worst[ok], d[ok])
     assert (gflag[:4] == 0).all() and (oflag[:4] == 0).all() and worst[:4].max() < TOL_SENSOR
     assert gflag[4] != 0 and oflag[4] != 0
+
+
+def _oracle_episode_with_flags(m, k, mode):
+    """(sensor rows [200,12], contact flag per step) of one episode on the oracle, the flag by replaying the reference's own logic
+    (manenv.py:65-85) on the oracle's contact list: "intent" = a fresh finger list per call, "reference" = the list the reference
+    aliases and never refills (one list per env, as in a fresh process per env)"""
+    s = oracle_sim(m, k)
+    s.reset(); s.forward(); s.step()
+    left = ['g12', 'g2']
+    _reference_flag(m, s.contacts(), left if mode == "reference" else list(left))   # reset() ends in step() -> get_sensor_sensordata()
+    rows, fl = [], []
+    for c in episode_schedule():
+        if c is not None:
+            s.ctrl[:] = c
+        for _ in range(7):
+            assert s.step() == 0
+        rows.append(s.sensordata.copy())
+        fl.append(_reference_flag(m, s.contacts(), left if mode == "reference" else ['g12', 'g2']))
+    return np.array(rows), np.array(fl)
+
+
+@pytest.mark.parametrize("mode", ["intent", "reference"])
+def test_contact_flag_and_masked_dataset_match_reference_logic(tmp_path, mode):
+    """a5 / f3: ManEnv's contact flag in both modes == the reference's get_sensor_sensordata logic replayed on the oracle's contacts,
+    at every step of the episode; and a --mask-contact dataset written on the GPU == the oracle's rows masked by that flag
+    (reference create_dataset.py:43-44,57-58).  softbox_fix: the variant that can be compared free-running over 200 steps."""
+    import pickle
+    import types
+    from softgrip_amd import create_dataset as cd
+    np.random.seed(11)
+    args = types.SimpleNamespace(mujoco_model_paths=[model_path("softbox_fix")], sim_start=1, sim_step=7, vis=False, mask_contact=True,
+                                 data_folder=str(tmp_path), data_name="masked_" + mode, n_envs=3, device=0, contact_flag_mode=mode)
+    d = pickle.load(open(cd.log_into_file(args), "rb"))
+    m = sg.load_model(model_path("softbox_fix"))
+    nmasked = 0
+    for e in range(3):
+        rows, fl = _oracle_episode_with_flags(m, d["stiffness"][e], mode)
+        want = rows * fl[:, None]
+        got = np.array(d["data"][e])
+        assert np.array_equal(np.abs(got).sum(1) == 0, ~fl), "env %d: masked steps differ" % e
+        assert np.abs(got - want).max() < TOL_SENSOR
+        nmasked += int((~fl).sum())
+        assert fl.any() and not fl.all()
+    if mode == "reference":   # the aliased list is never refilled: once both fingers have touched, any contact keeps the flag up
+        rows, fl_i = _oracle_episode_with_flags(m, d["stiffness"][0], "intent")
+        rows, fl_r = _oracle_episode_with_flags(m, d["stiffness"][0], "reference")
+        assert fl_r.sum() >= fl_i.sum()
+
+
+def test_default_scene_dataset_first_steps(tmp_path):
+    """the dataset path on the DEFAULT model (composite with its neighbour equalities): rows 0..46 of every env against the oracle
+    (beyond, the restated system amplifies round-off), the stored labels are the draws"""
+    import pickle
+    import types
+    from softgrip_amd import create_dataset as cd
+    np.random.seed(0)
+    draws = np.random.uniform(300, 1400, size=3)
+    np.random.seed(0)
+    args = types.SimpleNamespace(mujoco_model_paths=[model_path("softbox")], sim_start=1, sim_step=7, vis=False, mask_contact=False,
+                                 data_folder=str(tmp_path), data_name="ds", n_envs=3, device=0)
+    d = pickle.load(open(cd.log_into_file(args), "rb"))
+    assert d["stiffness"] == draws.tolist()
+    m = sg.load_model(model_path("softbox"))
+    assert m.neq == 327
+    for e in range(3):
+        s = oracle_sim(m, d["stiffness"][e])
+        s.reset(); s.forward(); s.step()
+        for t, c in enumerate(episode_schedule()[:FREE_RUN_STEPS]):
+            if c is not None:
+                s.ctrl[:] = c
+            for _ in range(7):
+                s.step()
+            assert np.abs(np.array(d["data"][e])[t] - s.sensordata).max() < TOL_SENSOR, (e, t)

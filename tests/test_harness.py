@@ -18,50 +18,7 @@ from softgrip_amd import manenv, native
 FX = json.load(open(os.path.join(ROOT, "tests", "golden", "harness_fixture.json")))
 
 
-class FakeModel:
-    def __init__(self, model):
-        self.model, self.nq, self.nu, self.nsensordata, self.ntendon, self.nelem = model, model.nv, model.nu, 12, 3, 110
-
-
-class FakeBatch:
-    """records every physics call; sensordata = running substep count (like the stub simulator of the fixture)"""
-    log = []
-
-    def __init__(self, nmodel, n_envs, device=0):
-        self.n, self.nmodel, self.device = n_envs, nmodel, torch.device("cpu")
-        self.ctrl = np.zeros(2)
-        self.nsub = 0
-        self.k = None
-
-    def set_stiffness(self, k, jids, tids):
-        self.k = np.array(k, copy=True)
-        FakeBatch.log.append(("stiffness", list(jids), list(tids), self.k.copy()))
-
-    def set_ctrl_broadcast(self, c):
-        self.ctrl[:] = c
-
-    def reset(self, sim_start, sens=None, flags=None, touch=None, mask=None):
-        FakeBatch.log.append(("reset", sim_start))
-        self.ctrl[:] = 0
-        self.nsub = 0
-        self._advance(sim_start, sens, flags, touch)
-
-    def step(self, n, sens=None, sens_stride=0, flags=None, touch=None):
-        self._advance(n, sens, flags, touch)
-
-    def _advance(self, n, sens, flags, touch):
-        for _ in range(n):
-            self.nsub += 1
-            FakeBatch.log.append(("substep", float(self.ctrl[0]), float(self.ctrl[1])))
-        if sens is not None:
-            sens[:] = self.nsub
-        if flags is not None:
-            flags.zero_()
-        if touch is not None:
-            touch.zero_()
-
-    def solver_stats(self):
-        return dict(ncon=torch.zeros(self.n, dtype=torch.int32))
+from fake_native import FakeBatch, FakeModel  # noqa: E402
 
 
 @pytest.fixture
@@ -73,7 +30,7 @@ def fake_native(monkeypatch):
 
 
 def _args(tmp, n_envs=1):
-    return types.SimpleNamespace(mujoco_model_paths=[model_path("softbox")], sim_start=1, sim_step=7, vis=False, mask_contact=False,
+    return types.SimpleNamespace(mujoco_model_paths=[model_path("softbox_fix")], sim_start=1, sim_step=7, vis=False, mask_contact=False,
                                  data_folder=str(tmp), data_name="fx", n_envs=n_envs, device=0)
 
 
@@ -133,7 +90,7 @@ def test_batched_dataset_schema(fake_native, tmp_path):
 
 def test_manenv_single_env_return_types(fake_native):
     np.random.seed(0)
-    env = manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False)
+    env = manenv.ManEnv(1, 7, [model_path("softbox_fix")], is_vis=False)
     k = env.reset()
     assert isinstance(k, float) and k == FX["stiffness_seed0"][0]
     r, c = env.step()
@@ -146,7 +103,7 @@ def test_manenv_single_env_return_types(fake_native):
 
 
 def test_contact_flag_modes(fake_native):
-    env = manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=3)
+    env = manenv.ManEnv(1, 7, [model_path("softbox_fix")], is_vis=False, n_envs=3)
     bits = env._chain_geom_bits()
     assert bits == {0: "g122", 1: "g123", 2: "g22", 3: "g23"}
     assert env._finger_bits == [0b0011, 0b1100]                    # 'g12' -> left boxes, 'g2' -> right boxes
@@ -154,7 +111,7 @@ def test_contact_flag_modes(fake_native):
     assert env._contact_flags().tolist() == [False, True, False]
     # reference mode: the per-env list is never refilled (manenv.py:70-83 aliasing) -> after both fingers touched once,
     # the flag follows ncon > 0
-    env2 = manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=1, contact_flag_mode="reference")
+    env2 = manenv.ManEnv(1, 7, [model_path("softbox_fix")], is_vis=False, n_envs=1, contact_flag_mode="reference")
     env2.env.solver_stats = lambda: dict(ncon=torch.tensor([3], dtype=torch.int32))
     env2._touch[:] = 0b0001
     assert env2._contact_flags().tolist() == [False]
@@ -178,3 +135,67 @@ def test_sharded_dataset_by_stiffness_bin(fake_native, tmp_path, monkeypatch):
     k1 = pickle.load(open(paths[1], "rb"))["stiffness"]
     assert len(k0) == 8 and len(k1) == 8
     assert all(300 <= k < 850 for k in k0) and all(850 <= k < 1400 for k in k1)
+
+
+def test_incremental_shards_and_resume(fake_native, tmp_path):
+    """every finished episode-batch is on disk at once; a restarted run skips finished parts, keeps the RNG
+    stream aligned and ends with the same dataset as an uninterrupted run"""
+    def args(folder):
+        a = _args(folder, n_envs=4)
+        a.num_batches, a.incremental = 3, True
+        return a
+    full = tmp_path / "full"; part = tmp_path / "part"
+    np.random.seed(5)
+    ref = pickle.load(open(cd.log_into_file(args(full)), "rb"))
+    assert len(ref["data"]) == 12 and sorted(os.listdir(full)) == ["fx.part00000.pickle", "fx.part00001.pickle", "fx.part00002.pickle", "fx.pickle"]
+    # interrupted run: only the first part exists (as after a crash during batch 1)
+    os.makedirs(part)
+    import shutil
+    shutil.copy(full / "fx.part00000.pickle", part / "fx.part00000.pickle")
+    fake_native.log.clear()
+    np.random.seed(5)
+    got = pickle.load(open(cd.log_into_file(args(part)), "rb"))
+    assert got["stiffness"] == ref["stiffness"]
+    assert all(np.array_equal(a, b) for a, b in zip(got["data"], ref["data"]))
+    assert sum(1 for e in fake_native.log if e[0] == "reset") == 2        # only the two missing batches were simulated
+
+
+def test_labels_are_the_pre_episode_draw_after_a_mid_episode_failure(fake_native, tmp_path, monkeypatch):
+    """reference create_dataset.py:35,65: the stored label is what reset() returned, also when an env failed and was re-drawn
+    mid-episode (manenv.py:50-51) -- for one env and for a batch alike; the re-draw stays inside the range of the last draw"""
+    calls = {"n": 0}
+    orig = fake_native._advance
+
+    def failing(self, n, sens, flags, touch):
+        orig(self, n, sens, flags, touch)
+        calls["n"] += 1
+        if calls["n"] == 30 and flags is not None:   # env 1 raises a warning once, mid-episode
+            flags[1] = 4
+    monkeypatch.setattr(fake_native, "_advance", failing)
+    np.random.seed(3)
+    draws = np.random.uniform(300, 1400, size=4).tolist()
+    np.random.seed(3)
+    a = _args(tmp_path, n_envs=4)
+    d = pickle.load(open(cd.log_into_file(a), "rb"))
+    assert d["stiffness"] == draws
+    st = [e for e in fake_native.log if e[0] == "stiffness"]
+    assert len(st) == 2 and st[1][3][1] != draws[1] and np.array_equal(np.delete(st[1][3], 1), np.delete(np.array(draws), 1))
+
+
+def test_reset_envs_returns_after_the_last_successful_retry(fake_native):
+    env = manenv.ManEnv(1, 7, [model_path("softbox_fix")], is_vis=False, n_envs=2)
+    env.set_new_stiffness(400, 500)
+    tries = {"n": 0}
+    orig = env.env.reset
+
+    def flaky(sim_start, sens=None, flags=None, touch=None, mask=None):
+        orig(sim_start, sens=sens, flags=flags, touch=touch, mask=mask)
+        tries["n"] += 1
+        if tries["n"] < 5:
+            flags[0] = 32
+    env.env.reset = flaky
+    env._reset_envs(torch.tensor([True, False]))       # succeeds on the 5th (= last allowed) retry: no exception
+    assert tries["n"] == 5 and 400 <= env.stiffness[0] < 500
+    tries["n"] = -100
+    with pytest.raises(manenv.SimulationError):
+        env._reset_envs(torch.tensor([True, False]))

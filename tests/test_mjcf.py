@@ -12,12 +12,12 @@ SIZES = {"softbox": (121, 118, 120, 110), "softcylinder": (203, 200, 202, 192), 
 
 @pytest.mark.parametrize("scene", list(SIZES))
 def test_blob_sizes_and_mass(scene):
-    m = sg.load_model(model_path(scene))
+    m = sg.load_model(model_path(scene + "_fix"))   # the composite without its neighbour equalities (opt-in variant)
     nbody, nv, ngeom, nelem = SIZES[scene]
     assert (m.nbody, m.nv, m.ngeom) == (nbody, nv, ngeom)
     assert m.neq == nelem + 1 and m.ntendon == 3 and (m.eq_obj2id < 0).all()
-    nnb = {"softbox": 216, "softcylinder": 380, "softball": 432}[scene]   # the neighbour-equality variant
-    mn = sg.load_model(model_path(scene + "_nb"))
+    nnb = {"softbox": 216, "softcylinder": 380, "softball": 432}[scene]   # the documented composite, the DEFAULT model
+    mn = sg.load_model(model_path(scene))
     assert mn.neq == nelem + nnb + 1 and (mn.eq_obj2id >= 0).sum() == nnb and mn.eq_type[-1] == 3 and mn.eq_obj2id[0] == -1
     assert mn.nv == nv and np.array_equal(mn.body_mass, m.body_mass) and m.nu == 2 and m.nsensordata == 12
     assert abs(m.body_mass.sum() - 0.45) < 1e-14              # settotalmass
@@ -36,7 +36,7 @@ def test_blob_sizes_and_mass(scene):
 
 
 def test_softbox_element_mass_and_ids():
-    m = sg.load_model(model_path("softbox"))
+    m = sg.load_model(model_path("softbox_fix"))
     np.testing.assert_allclose(m.body_mass[11], 1.9458618e-4, rtol=1e-7)
     assert m.geom_names[:10] == ["ground", "", "", "g121", "g122", "g123", "g21", "g22", "g23", "OBJGcenter"]
     assert m.jnt_names[8] == "OBJJ0_0_0" and m.body_names[10] == "" and m.body_names[11] == "OBJB0_0_0"
@@ -49,13 +49,16 @@ def test_softbox_element_mass_and_ids():
 @pytest.mark.skipif(not os.path.exists(REF_XML % "softbox"), reason="reference MJCF only exists in the build container")
 @pytest.mark.parametrize("scene", list(SIZES))
 def test_committed_blob_matches_reference_mjcf(scene):
-    fresh = sg.compile_mjcf(REF_XML % scene).to_blob()
+    fresh = sg.compile_mjcf(REF_XML % scene).to_blob()           # default: with the composite's neighbour equalities
     with open(model_path(scene), "rb") as f:
+        assert f.read() == fresh
+    fresh = sg.compile_mjcf(REF_XML % scene, composite_neighbors=False).to_blob()
+    with open(model_path(scene + "_fix"), "rb") as f:
         assert f.read() == fresh
 
 
 def test_blob_roundtrip():
-    m = sg.load_model(model_path("softbox"))
+    m = sg.load_model(model_path("softbox_fix"))
     m2 = sg.Model.from_blob(m.to_blob())
     assert m2.to_blob() == m.to_blob()
 

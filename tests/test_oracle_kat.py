@@ -10,7 +10,7 @@ from helpers import ROOT, model_path, oracle_sim
 
 
 def test_rest_sensors_read_gravity():
-    s = oracle_sim(sg.load_model(model_path("softbox")))
+    s = oracle_sim(sg.load_model(model_path("softbox_fix")))
     s.reset()
     assert s.forward() == 0
     np.testing.assert_allclose(s.sensordata, [0, 0, 9.81, 0, 0, 9.81, 0, 0, 0, 0, 0, 0], atol=1e-12)
@@ -19,7 +19,7 @@ def test_rest_sensors_read_gravity():
 
 def test_cylinder_actuator_filter():
     """act_{n} = c (1 - (1-h)^n) for constant ctrl c (dyntype filter, timeconst 1)"""
-    s = oracle_sim(sg.load_model(model_path("softbox")))
+    s = oracle_sim(sg.load_model(model_path("softbox_fix")))
     s.reset()
     s.ctrl[:] = -0.2
     h = 0.005
@@ -43,7 +43,7 @@ def test_single_slider_implicit_damping():
 
 
 def test_mass_matrix_blocks_and_symmetry():
-    m = sg.load_model(model_path("softbox"))
+    m = sg.load_model(model_path("softbox_fix"))
     s = oracle_sim(m)
     s.reset()
     s.qpos[:8] = [-0.2, 0.005, 0.1, -0.003, 0.004, 0.2, -0.1, 0.002]
@@ -59,7 +59,7 @@ def test_mass_matrix_blocks_and_symmetry():
 
 def test_energy_decays_without_actuation_or_contact():
     """heavily damped sliders released from a stretch: kinetic + elastic energy of the object decays"""
-    m = sg.load_model(model_path("softbox"))
+    m = sg.load_model(model_path("softbox_fix"))
     s = oracle_sim(m)
     s.reset()
     rng = np.random.RandomState(3)
@@ -79,7 +79,7 @@ def test_energy_decays_without_actuation_or_contact():
 
 
 def test_joint_limit_pushes_back():
-    m = sg.load_model(model_path("softbox"))
+    m = sg.load_model(model_path("softbox_fix"))
     s = oracle_sim(m)
     s.reset()
     s.qpos[1] = 0.05   # twist joint, range +-0.01
@@ -90,7 +90,7 @@ def test_joint_limit_pushes_back():
 
 
 def test_contact_appears_when_finger_closes():
-    m = sg.load_model(model_path("softbox"))
+    m = sg.load_model(model_path("softbox_fix"))
     s = oracle_sim(m)
     s.reset()
     s.ctrl[:] = -0.2
@@ -110,7 +110,7 @@ def test_neighbour_equality_rows_known_answers():
     """the composite's neighbour equalities (models/*_nb): row q couples sliders (j1, j2) with J = (+1, -1), so against the other
     rows A = J M^-1 J' has 1/m1 + 1/m2 on its diagonal, +1/m1 / -1/m2 towards the fix rows of its two sliders, and R =
     (1 - d)/d (invweight(j1) + invweight(j2)) with d = solimp[0] at zero violation; the rows follow their element's fix row"""
-    m = sg.load_model(model_path("softbox_nb"))
+    m = sg.load_model(model_path("softbox"))
     s = oracle_sim(m, 700.0)
     s.reset()
     assert s.forward() == 0 and s.ncon == 0 and s.nefc == m.neq == 327
@@ -148,7 +148,7 @@ def test_neighbour_equality_rows_known_answers():
     np.testing.assert_allclose(b2[others], b0[others], atol=1e-9)
 
 
-@pytest.mark.parametrize("scene,n_eq_rows,sweeps", [("softbox", 111, 3000), ("softbox_nb", 327, 30000)])
+@pytest.mark.parametrize("scene,n_eq_rows,sweeps", [("softbox_fix", 111, 3000), ("softbox", 327, 30000)])
 def test_pgs_fixed_point_satisfies_the_cone_qp_kkt_conditions(scene, n_eq_rows, sweeps):
     """Independent check of the solver math (row projections, elliptic cone handling, QCQP): run to the fixed point (3000
     sweeps instead of 30), the PGS force must solve  min 1/2 f'(A+R)f + f'b  over  equality rows free, limit rows f >= 0,
@@ -209,7 +209,7 @@ def test_gyro_reads_the_hinge_rate_of_its_own_finger_only():
     """a gyro on a finger site measures the body's angular velocity in the site frame: with a single hinge turning at rate w
     the reading has norm w if that hinge is an ancestor of the sensor's body and 0 otherwise (rotation frames do not change
     norms); sliders of the object never reach a finger gyro"""
-    m = sg.load_model(model_path("softbox"))
+    m = sg.load_model(model_path("softbox_fix"))
     s = oracle_sim(m, 700.0)
     hinges = [j for j in range(m.nv) if not m.jnt_names[j].startswith("OBJ")]
     assert len(hinges) == 8
@@ -236,7 +236,7 @@ def test_oracle_regression_fixture():
     from softgrip_amd.create_dataset import episode_schedule
     g = np.load(os.path.join(ROOT, "tests", "golden", "oracle_regression.npz"))
     k = float(g["stiffness"])
-    for scene, nsteps in (("softbox", 200), ("softbox_nb", 47)):
+    for scene, nsteps in (("softbox_fix", 200), ("softbox", 47)):
         s = oracle_sim(sg.load_model(model_path(scene)), k)
         s.reset(); s.forward(); s.step()
         for t, c in enumerate(episode_schedule()[:nsteps]):
@@ -246,8 +246,8 @@ def test_oracle_regression_fixture():
                 assert s.step() == 0
             np.testing.assert_allclose(s.sensordata, g[scene + "_sens"][t], atol=1e-7, err_msg="%s step %d" % (scene, t))
             assert s.ncon == g[scene + "_ncon"][t]
-        if scene == "softbox":
-            np.testing.assert_allclose(s.qpos, g["softbox_qpos_end"], atol=1e-9)
+        if scene == "softbox_fix":
+            np.testing.assert_allclose(s.qpos, g["softbox_fix_qpos_end"], atol=1e-9)
 
 
 def test_capsule_box_narrowphase_known_answers():

@@ -24,7 +24,7 @@ def _schedule(scene):
     return np.array(out[:4 * ns]).reshape(ns, 4), nelem.value, nnb.value
 
 
-@pytest.mark.parametrize("scene,bound", [("softbox_nb", 53), ("softcylinder_nb", 69), ("softball_nb", 73)])
+@pytest.mark.parametrize("scene,bound", [("softbox", 53), ("softcylinder", 69), ("softball", 73)])
 def test_schedule_is_the_sequential_sweep(scene, bound):
     m = sg.load_model(model_path(scene))
     S, N, nnb = _schedule(scene)
