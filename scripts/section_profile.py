@@ -25,7 +25,7 @@ CHAIN_NAMES = {17: "load state", 18: "FINISH", 19: "kinematics", 20: "dynamics (
 
 
 def main():
-    m = sg.load_model("models/%s.sgmodel" % (sys.argv[1] if len(sys.argv) > 1 else "softbox_fix"))
+    m = sg.load_model("models/%s.sgmodel" % (sys.argv[1] if len(sys.argv) > 1 else "softbox"))
     nm = native.NativeModel(m)
     n = 4096
     b = native.NativeBatch(nm, n, 0)
@@ -54,7 +54,9 @@ def main():
                 print("   %-26s %8.0f  %5.1f %%" % (name, v[k], 100 * v[k] / (v.sum() + v24)))
             print("   %-26s %8.0f  %5.1f %%" % ("24 contact rows (build)", v24, 100 * v24 / (v.sum() + v24)))
             print("   broadphase survivors per env and launch: %.1f pairs, %.2f dense narrowphase passes" % (buf[30] / (n * 8.0), buf[31] / (n * 8.0)))
-            w = np.array(buf[:32], dtype=np.float64) / ((n // 8) * 7)  # 7 PGS launches per sg_step call, 8 envs per wavefront
+            epw = int(os.environ.get("SG_PGS_EPW", "8" if n >= 8192 else "4"))  # envs per PGS wavefront (sg_api.hip launch_split)
+            nwave = n // epw
+            w = np.array(buf[:32], dtype=np.float64) / (nwave * 7)  # 7 PGS launches per sg_step call
             tot = sum(w[k] for k in PGS_NAMES)
             print("   sg_pgs_rows_kernel: %.0f cycles per wavefront and launch (after the prologue)" % tot)
             print("   contact passes per wavefront and launch: %.1f, contact slots swept: %.0f" % (w[29], w[28]))
@@ -62,7 +64,7 @@ def main():
                 print("   contact updates per stream and launch: %.0f, of which outside the friction cone (Newton / QCQP path): %.0f" % (
                     buf[26] / (2.0 * n * 7), buf[27] / (2.0 * n * 7)))
                 print("   QCQP fallback per wavefront and launch: entered on %.0f slots, %.0f further Newton evaluations" % (
-                    buf[32] / ((n // 8) * 7.0), buf[33] / ((n // 8) * 7.0)))
+                    buf[32] / (nwave * 7.0), buf[33] / (nwave * 7.0)))
             for k, name in PGS_NAMES.items():
                 print("   %-26s %8.0f  %5.1f %%" % (name, w[k], 100 * w[k] / max(tot, 1)))
             cw = np.array(buf[:32], dtype=np.float64) / ((n // 64) * 2 * 8)  # 8 chain launches per sg_step call, 64 chains per wavefront

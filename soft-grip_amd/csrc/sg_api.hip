@@ -82,7 +82,7 @@ int sg_model_create(const void* blob, size_t nbytes, sg_model** out) {
   }
   if (m->plan.h.nnb > 0) {  // the rows PGS kernel keeps every equality row of 8 envs in LDS (launch_split)
     const size_t na = 8 * (size_t)((m->plan.h.nelem + 7) / 8) + 8 + 48, neqp = (size_t)m->plan.h.nelem + m->plan.h.nnb + 1;
-    if (sizeof(double) * (10 * na + 24 * neqp + 72) > 160 * 1024) {
+    if (sizeof(double) * SG_ROWS_LDS_NB(4, na, neqp, m->plan.h.eq_rounds) > 160 * 1024) {
       delete m;
       return fail(SG_ERR_MODEL, "sg_model_create: too many neighbour equality rows for the PGS kernel's LDS");
     }
@@ -149,6 +149,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
     };
     bool ok = walloc((void**)&b->w.secprof, sizeof(unsigned long long) * 48) && walloc((void**)&b->w.crec, sizeof(double) * SG_CAP * ((n + SG_EPW - 1) / SG_EPW + 1) * SG_RF * SG_SPW) && walloc((void**)&b->w.ns, sizeof(int) * S) &&
               walloc((void**)&b->w.crow, sizeof(double) * (SG_CAP + 2) * ((n + 7) / 8 + 2) * SG_RK * 64) &&
+              walloc((void**)&b->w.cdummy, sizeof(double) * ((n + 3) / 4) * SG_RK * 64) &&
               walloc((void**)&b->w.envh, sizeof(double) * 4 * n) && walloc((void**)&b->w.shared, sizeof(int) * n) &&
               walloc((void**)&b->w.pending, sizeof(int) * n) && walloc((void**)&b->w.status, sizeof(int) * n) &&
               walloc((void**)&b->w.iters, sizeof(int) * n) && walloc((void**)&b->w.ncon, sizeof(int) * n) &&
@@ -269,15 +270,18 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     if (v * 8 >= H.nelem) { nsl = v; break; }
   const bool nbm = H.nnb > 0;
   const size_t na = 8 * (size_t)nsl + 8, neqp = (size_t)H.nelem + H.nnb + 1;
-  const size_t lds_rows = nbm ? sizeof(double) * (10 * na + 24 * neqp + 72)
-                              : sizeof(double) * ((size_t)(5 * 8 + 2) * 8 * nsl + 16 * 4 * SG_MAXLIM + 72);
+  // envs per PGS wavefront: 8 when that already gives every SIMD of the chip a wavefront, else 4 (sg_pgs_rows_kernel); SG_PGS_EPW overrides
+  int epw = (b->n + 7) / 8 >= 1024 ? 8 : 4;
+  if (const char* pe = getenv("SG_PGS_EPW")) epw = atoi(pe) == 4 ? 4 : 8;
+  if (nbm && sizeof(double) * SG_ROWS_LDS_NB(8, na, neqp, H.eq_rounds) > 160 * 1024) epw = 4;  // the rows of 8 envs do not fit the LDS
+  const size_t lds_rows = sizeof(double) * (nbm ? SG_ROWS_LDS_NB(epw, na, neqp, H.eq_rounds) : SG_ROWS_LDS_FIX(epw, 8 * (size_t)nsl));
   if (!b->lds_attr_set) {  // per device: a batch on another GPU of the same process needs its own call
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#define SG_ATTR(v)                                                                                                                    \
-  HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<v, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-  HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<v, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+#define SG_ATTR1(v, nb, e) HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<v, nb, e>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+#define SG_ATTR(v) SG_ATTR1(v, false, 8); SG_ATTR1(v, true, 8); SG_ATTR1(v, false, 4); SG_ATTR1(v, true, 4)
     SG_ATTR(8); SG_ATTR(14); SG_ATTR(20); SG_ATTR(26); SG_ATTR(29); SG_ATTR(32);
 #undef SG_ATTR
+#undef SG_ATTR1
     b->lds_attr_set = true;
   }
   // forward passes to run: (mode 1: one non-integrating forward first) + nsub integrating ones
@@ -315,20 +319,20 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     HIPCHK(hipGetLastError());
     if (k < nfwd) {
       if (b->pipeline == 2) {
-        const dim3 grid((b->n + 7) / 8);
-#define SG_ROWS(v)                                                                                       \
-  case v:                                                                                                \
-    if (nbm) hipLaunchKernelGGL((sg_pgs_rows_kernel<v, true>), grid, dim3(64), lds_rows, s, ga);         \
-    else hipLaunchKernelGGL((sg_pgs_rows_kernel<v, false>), grid, dim3(64), lds_rows, s, ga);            \
+        const dim3 grid((b->n + epw - 1) / epw);
+#define SG_ROWS1(v, nb, e) hipLaunchKernelGGL((sg_pgs_rows_kernel<v, nb, e>), grid, dim3(64), lds_rows, s, ga)
+#define SG_ROWS(v)                                                                    \
+  case v:                                                                             \
+    if (nbm) { if (epw == 8) SG_ROWS1(v, true, 8); else SG_ROWS1(v, true, 4); }       \
+    else { if (epw == 8) SG_ROWS1(v, false, 8); else SG_ROWS1(v, false, 4); }         \
     break
         switch (nsl) {
           SG_ROWS(8); SG_ROWS(14); SG_ROWS(20); SG_ROWS(26); SG_ROWS(29);
           default:
-            if (nbm) hipLaunchKernelGGL((sg_pgs_rows_kernel<32, true>), grid, dim3(64), lds_rows, s, ga);
-            else hipLaunchKernelGGL((sg_pgs_rows_kernel<32, false>), grid, dim3(64), lds_rows, s, ga);
-            break;
+          SG_ROWS(32);
         }
 #undef SG_ROWS
+#undef SG_ROWS1
       }
       else hipLaunchKernelGGL(sg_pgs_kernel, dim3((b->n + SG_EPW - 1) / SG_EPW), dim3(64), lds, s, ga);
       HIPCHK(hipGetLastError());

@@ -382,20 +382,27 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
         if (ok) ready.push_back(q);
       }
       std::stable_sort(ready.begin(), ready.end(), [&](int a, int b) { return height[a] > height[b]; });
-      for (int g = 0; g < 8; g++) {
-        SgEqSlot s;
-        s.e1 = N; s.e2 = N; s.row = N + nnb; s.pad = 0; s.im1 = 0; s.im2 = 0;
-        if (g < (int)ready.size()) {
-          const int q = ready[g];
-          round_of[q] = rnd; left--;
-          s.e1 = row_e1[q]; s.row = unified[q]; s.im1 = invm(row_e1[q]);
-          if (row_e2[q] >= 0) { s.e2 = row_e2[q]; s.im2 = invm(row_e2[q]); }
-        }
-        P.sched.push_back(s);
+      // the lanes of a group are typed: slots 0 .. SG_EQ_FIXLANES-1 take joint-fix rows only, the others neighbour rows only, so
+      // that "1 / m of the second slider" (0 for a fix row) is a per-lane constant in the solver (sg_pgs_rows_kernel)
+      SgEqSlot slots[8];
+      for (int g = 0; g < 8; g++) { slots[g].e1 = N; slots[g].e2 = N; slots[g].row = N + nnb; slots[g].pad = 0; slots[g].im1 = 0; slots[g].im2 = 0; }
+      int nf = 0, nn = 0;
+      for (int q : ready) {
+        const bool fix = row_e2[q] < 0;
+        int g;
+        if (fix) { if (nf >= SG_EQ_FIXLANES) continue; g = nf++; }
+        else { if (nn >= 8 - SG_EQ_FIXLANES) continue; g = SG_EQ_FIXLANES + nn++; }
+        round_of[q] = rnd; left--;
+        SgEqSlot& sl = slots[g];
+        sl.e1 = row_e1[q]; sl.row = unified[q]; sl.im1 = invm(row_e1[q]);
+        if (!fix) { sl.e2 = row_e2[q]; sl.im2 = invm(row_e2[q]); }
       }
+      for (int g = 0; g < 8; g++) P.sched.push_back(slots[g]);
       rnd++;
     }
     H.eq_rounds = rnd;
+    for (int e = 1; e < N; e++)
+      if (invm(e) != invm(0)) FAIL("neighbour-row models need elements of equal mass (the solver keeps 1 / m as a constant)");
   }
   kb(eq_solref, eq_solimp, &H.eqj_K, &H.eqj_B);
   memcpy(H.eqj_solimp, eq_solimp, 40);

@@ -24,6 +24,7 @@
 #define SG_CG 2     // box geoms per chain
 #define SG_CS 2     // sensor sites per chain
 #define SG_MAXSTATIC 8
+#define SG_EQ_FIXLANES 3  // lanes of a group of 8 that take joint-fix rows in the equality schedule (the other 5: neighbour rows)
 
 struct SgChain {
   int nbody, ndof, ngeom, nsite, dof0, pad0[3];

@@ -38,6 +38,7 @@ struct SgWork {          // device workspace of one batch (all pointers device m
   double* crec;          // [SG_CAP][nwb + 1][SG_RF][16]   nwb = ceil(nenv / 8) PGS wavefronts (+1 dummy block)
   unsigned long long* secprof;  // [32] cycle sums per kernel section (only written when built with -DSG_SECTION_PROF)
   double* crow;          // [SG_CAP + 2][nwb + 2][SG_RK / 2][64][2]   row layout (sg_pgs_rows_kernel), +2 dummy blocks
+  double* cdummy;        // [ceil(nenv / 4)][SG_RK / 2][64][2]  one private all-zero block per PGS wavefront for its lanes without an env
   int* ns;               // [S]
   double* envh;          // [4][nenv]: tb, tR, tA, tf
   int *shared, *pending, *status, *iters, *ncon, *nefc, *touch;  // [nenv]
@@ -1245,11 +1246,20 @@ __device__ __forceinline__ double sg_gsum8(double x) {
 // holds g = b + R f (instead of f), R and 1 / (A + R); the update is res = g + a1 - a2, t = res / (A + R), a1 -= t / m1,
 // a2 += t / m2, g -= R t.  The slider accelerations are kept incrementally (every update is applied to them as it happens),
 // so the final "fresh M^-1 J' f" pass only concerns the finger chains.
-template <int NSL, bool NB>  // NSL >= ceil(nelem / 8): joint-fix rows per lane, unrolled and padded (straight-line code, LDS reads issue back to back)
+// LDS of sg_pgs_rows_kernel in doubles (kernel and host use the same expressions): EPW envs per wavefront
+#define SG_ROWS_LDS_FIX(EPW, NR) ((size_t)(5 * (EPW) + 2) * (NR) + 72)
+#define SG_ROWS_LDS_NB(EPW, NA, NEQP, ROUNDS) ((size_t)((EPW) + 2) * (NA) + (size_t)2 * (EPW) * (NEQP) + (size_t)8 * ((ROUNDS) + 4) + 72)
+// EPW: envs per wavefront, 8 lanes each: 8 fills the wavefront (16 finger streams advance per instruction); 4 leaves lanes 32 .. 63 idle
+// but spreads a batch of 4096 envs over 1024 wavefronts -- one per SIMD of the whole chip instead of half of it -- and a wavefront
+// then runs the QCQP fallback (entered when ANY of its streams slides, for as many Newton evaluations as its slowest stream needs)
+// for 8 streams instead of 16.  The wavefront's instruction stream is what a launch waits for, not its lane count.
+template <int NSL, bool NB, int EPW>  // NSL >= ceil(nelem / 8): joint-fix rows per lane, unrolled and padded (straight-line code, LDS reads issue back to back)
 __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x, le = lane >> 3, g = lane & 7, c = g >> 2, r = g & 3;
-  const int env = blockIdx.x * 8 + le;
+  const bool in_wave = le < EPW;             // lanes beyond the wavefront's envs stay idle (they own no LDS)
+  const int lec = in_wave ? le : 0;
+  const int env = blockIdx.x * EPW + le;
   const SgPlanHeader& H = *a.H;
   const int N = H.nelem;
   const size_t S = 2 * (size_t)a.nenv;
@@ -1259,31 +1269,35 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   const double mur = r == 1 ? mu0 : mu1;
   const double rsel0 = r == 0 ? 1.0 : 0.0, rsel1 = r == 1 ? 1.0 : 0.0, rsel2 = r == 2 ? 1.0 : 0.0;
   const int max_iter = H.iterations;
-  const bool valid = env < a.nenv && W.pending[env] != 0;
+  const bool valid = in_wave && env < a.nenv && W.pending[env < a.nenv ? env : 0] != 0;
   if (!__ballot(valid)) return;
   // LDS: joint-fix rows padded to NR = 8 * NSL per env (padding rows are neutral: b = 0, R = 1, 1/(A+R) = 0, so their update
   // is a no-op and the row loop needs no bound test).  Per env: AF[j] = (a_s, f) [the only pair written], BR[j] = (b, R),
-  // RI[j] = 1 / (A_jj + R_j); shared by the 8 envs: IC[j] = (1/m, tendon coefficient).  A row is three 16-byte reads + one 8-byte.
+  // RI[j] = 1 / (A_jj + R_j); shared by the wavefront's envs: IC[j] = (1/m, tendon coefficient).  A row is three 16-byte reads + one 8-byte.
   constexpr int NR = 8 * NSL;
   // NB layout: Ae[NA] slider accelerations per env (word N is a dummy that stays 0: "no second slider"), IC[NA] shared,
   // Ge[NEQP] / RRe[NEQP] per env: g and (R, 1 / (A + R)) of fix row e at e, of neighbour row k at N + k, dummy record at N + nnb
   constexpr int NA = NR + 8;
   const int nnb = NB ? H.nnb : 0, NEQP = N + nnb + 1;
-  double2* const AF = (double2*)lds + (size_t)le * NR;
-  double2* const BR = (double2*)lds + (size_t)8 * NR + (size_t)le * NR;
-  double* const RI = lds + (size_t)32 * NR + (size_t)le * NR;
-  double2* const IC = NB ? (double2*)(lds + (size_t)8 * NA) : (double2*)(lds + (size_t)40 * NR);
-  double* const Ae = lds + (size_t)le * NA;
-  double* const Ge = lds + (size_t)10 * NA + (size_t)le * NEQP;
-  double2* const RRe = (double2*)(lds + (size_t)10 * NA + (size_t)8 * NEQP) + (size_t)le * NEQP;
-  double* Lzero = NB ? lds + (size_t)10 * NA + (size_t)24 * NEQP
-                     : lds + (size_t)42 * NR + (size_t)16 * 4 * SG_MAXLIM;  // [0]: a word that stays 0 (reads of "no slider"), [1 + lane]: write sink
+  double2* const AF = (double2*)lds + (size_t)lec * NR;
+  double2* const BR = (double2*)lds + (size_t)EPW * NR + (size_t)lec * NR;
+  double* const RI = lds + (size_t)4 * EPW * NR + (size_t)lec * NR;
+  double2* const IC = NB ? (double2*)(lds + (size_t)EPW * NA) : (double2*)(lds + (size_t)5 * EPW * NR);
+  double* const Ae = lds + (size_t)lec * NA;
+  // equality rows of an env (NB): REC[u] = (g, 1 / (A + R)), g = b + R f, of fix row e at u = e, of neighbour row k at u = N + k,
+  // a dummy record (0, 0) at N + nnb; TAB (shared by the wavefront's envs): the plan's schedule as LDS byte offsets,
+  // (a1 | a2 << 16, record) per slot
+  double2* const REC = (double2*)(lds + (size_t)(EPW + 2) * NA) + (size_t)lec * NEQP;
+  uint2* const TAB = (uint2*)(lds + (size_t)(EPW + 2) * NA + (size_t)2 * EPW * NEQP);
+  double* Lzero = NB ? lds + (size_t)(EPW + 2) * NA + (size_t)2 * EPW * NEQP + (size_t)8 * (H.eq_rounds + 4)
+                     : lds + (size_t)(5 * EPW + 2) * NR;  // [0]: a word that stays 0 (reads of "no slider"), [1 + lane]: write sink
   double* const ASb = NB ? Ae : (double*)AF;  // slider acceleration of element j: ASb[ASS * j]
   constexpr int ASS = NB ? 1 : 2;
   if (lane == 0) Lzero[0] = 0.0;
   for (int j = lane; j < (NB ? NA : NR); j += 64)
     IC[j] = j < N ? make_double2(1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]), a.elem[(size_t)SGE_COEF * N + j]) : make_double2(0.0, 0.0);
   if constexpr (!NB) {
+  if (in_wave)
   for (int j = g; j < NR; j += 8) {
     double2 af = make_double2(0.0, 0.0), br = make_double2(0.0, 1.0);
     double ri = 0.0;
@@ -1295,12 +1309,11 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     }
     AF[j] = af; BR[j] = br; RI[j] = ri;
   }
-  } else {
+  } else if (in_wave) {
     auto EIM = [&](int e) { return 1.0 / (a.elem[(size_t)SGE_MASS * N + e] + a.elem[(size_t)SGE_ARMATURE * N + e]); };
     for (int j = g; j < NA; j += 8) Ae[j] = (valid && j < N) ? W.as[(size_t)env * N + j] : 0.0;
     for (int u = g; u < NEQP; u += 8) {
-      double gg = 0.0;
-      double2 rr = make_double2(0.0, 0.0);
+      double2 rec = make_double2(0.0, 0.0);
       if (valid && u < N + nnb) {
         double bb, Rr, ff, ims;
         if (u < N) {
@@ -1312,13 +1325,18 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           bb = W.nbb[o]; Rr = W.nbR[o]; ff = W.nbf[o];
           ims = EIM(a.nbtab[9 * N + k]) + EIM(a.nbtab[9 * N + nnb + k]);
         }
-        gg = bb + Rr * ff;
-        rr = make_double2(Rr, sg_div(1.0, ims + Rr));
+        rec = make_double2(bb + Rr * ff, sg_div(1.0, ims + Rr));
       }
-      Ge[u] = gg; RRe[u] = rr;
+      REC[u] = rec;
     }
   }
-  const size_t st = 2 * (size_t)(env < a.nenv ? env : 0) + c;
+  if constexpr (NB) {  // the schedule (plus four idle rounds for the look-ahead) as LDS byte offsets
+    for (int i = lane; i < 8 * (H.eq_rounds + 4); i += 64) {
+      const SgEqSlot sl = a.sched[i];
+      TAB[i] = make_uint2((unsigned)(8 * sl.e1) | ((unsigned)(8 * sl.e2) << 16), (unsigned)(16 * sl.row));
+    }
+  }
+  const size_t st = 2 * (size_t)(valid ? env : 0) + c;
   int ns = 0, lim_active = 0, shared = 0;
   // lane r of the quad owns finger acceleration aF[r]; of M^-1 it needs row r (its share of a limit row's push) and the diagonal
   double Mrow[SG_CD] = {0, 0, 0, 0}, Mdiag[SG_CD] = {0, 0, 0, 0}, aFo = 0;
@@ -1349,12 +1367,16 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
 
   bool running = valid;
   int iters = 0;
-  // my column in the wave's block, biased by 4 field pairs (immediate offsets -4096 .. 3072).  Lanes of envs that do not exist
-  // read the all-zero dummy block and write to the sink block
+  // my column in the wave's block, biased by 4 field pairs (immediate offsets -4096 .. 3072).  Lanes without an env (idle half of
+  // an EPW = 4 wavefront, ragged tail, env not pending) read and write a block of their own wavefront that holds zeros and
+  // never advance: a dummy block shared by all wavefronts made every idle lane of the chip hammer the same 8 KB
+  // (profiles/r02: 1024 wavefronts x 32 idle lanes, contact rows 2.3x slower than with 16 streams per wavefront).
+  // (the phase kernel writes blocks of 8 envs: env e sits in block e >> 3 at lanes 8 (e & 7) .. + 7, whatever EPW is)
   const bool has_row = valid;
-  const double2* const row0 = (const double2*)(W.crow + SG_ROW_INDEX(0, has_row ? (int)blockIdx.x : nwb, 8, lane, nwb));
-  const ptrdiff_t sink_off = has_row ? 0 : (ptrdiff_t)(SG_RK / 2) * 64;  // in double2 units: block nwb -> block nwb + 1
-  const size_t slot_stride = (size_t)(nwb + 2) * (SG_RK / 2) * 64;        // in double2 units
+  const double2* const row0 = has_row ? (const double2*)(W.crow + SG_ROW_INDEX(0, env >> 3, 8, 8 * (env & 7) + g, nwb))
+                                      : (const double2*)(W.cdummy + ((size_t)blockIdx.x * (SG_RK / 2) + 4) * 128 + 2 * lane);
+  const size_t slot_stride = has_row ? (size_t)(nwb + 2) * (SG_RK / 2) * 64 : 0;  // in double2 units (per lane: idle lanes stay put)
+  constexpr ptrdiff_t sink_off = 0;
 
   SG_T0();
   for (int it = 0; it < max_iter; it++) {
@@ -1362,35 +1384,42 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     SG_T(10);
     double imp_acc = 0, tJap = 0;
     if constexpr (NB) {
-      // equality block as the plan's schedule.  The slot of round k + 4 is requested when round k is computed (four register
-      // sets in flight: with one round of look-ahead every round waited ~300 cycles for its slot, profiles/r01_v11); the table
-      // ends with four spare rounds of idle slots, so the look-ahead needs no bound check
-      const SgEqSlot* sp = a.sched + g;
-      int4 sa[4];
-      double2 sb[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) { sa[q] = *(const int4*)(sp + 8 * q); sb[q] = *(const double2*)&(sp + 8 * q)->im1; }
-      sp += 32;
-      auto eq_round = [&](const int4& ia, const double2& im) {
-        if (running) {
-          const double a1 = Ae[ia.x], a2 = Ae[ia.y], gg = Ge[ia.z];
-          const double2 rr = RRe[ia.z];
-          const double res = (gg + a1) - a2, t = res * rr.y;
-          Ae[ia.x] = a1 - im.x * t;
-          Ae[ia.y] = a2 + im.y * t;
-          Ge[ia.z] = gg - rr.x * t;
-          imp_acc += 0.5 * res * t;
+      // equality block as the plan's schedule: H.eq_rounds rounds, one row per lane of the env's group.  A row's state is
+      // g = b + R f; with res = g + a1 - a2 and t = res / (A + R) the update is a1 -= t / m1, a2 += t / m2 and g -= R t, which is
+      // g' = a2' - a1' (the row's residual is zero after its update), so R is not needed in the sweep.  The plan types the lanes:
+      // lanes 0 .. 2 of a group only get joint-fix rows (second slider = the group's zero word, 1 / m2 = 0), lanes 3 .. 7 only
+      // neighbour rows, and all elements have the same mass (sg_plan_build checks both), so 1 / m1 and 1 / m2 are per-lane
+      // constants.  A round: one 8-byte table read (two rounds ahead), three LDS reads, seven fp64 operations, three LDS writes
+      // (until r02: slots streamed from global memory with their own 1 / m, R kept per row: ~30 instructions per round).
+      if (running) {
+        const double imA = IC[0].x, imB = g < 3 ? 0.0 : imA;
+        char* const Ab = (char*)Ae;
+        char* const Rb = (char*)REC;
+        const uint2* tp = TAB + g;
+        uint2 ta = tp[0], tb = tp[8];
+        double q2 = 0.0;
+        auto eq_round = [&](const uint2 tt) {
+          double* const p1 = (double*)(Ab + (tt.x & 0xffffu));
+          double* const p2 = (double*)(Ab + (tt.x >> 16));
+          double2* const pr = (double2*)(Rb + tt.y);
+          const double a1 = *p1, a2 = *p2;
+          const double2 rec = *pr;
+          const double res = (rec.x + a1) - a2, t = res * rec.y;
+          const double a1n = a1 - imA * t, a2n = a2 + imB * t;
+          *p1 = a1n;
+          *p2 = a2n;
+          pr->x = a2n - a1n;
+          q2 += res * t;
+        };
+        const int nrounds = H.eq_rounds;
+        for (int k = 0; k < nrounds; k += 2) {  // an odd count runs one idle round (the table ends with two)
+          const uint2 t0 = ta, t1 = tb;
+          tp += 16;
+          ta = tp[0]; tb = tp[8];
+          eq_round(t0);
+          eq_round(t1);
         }
-      };
-      for (int k = 0; k < H.eq_rounds; k += 4) {  // rounds past eq_rounds are idle slots (no-ops)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int4 ia = sa[q];
-          const double2 im = sb[q];
-          sa[q] = *(const int4*)(sp + 8 * q); sb[q] = *(const double2*)&(sp + 8 * q)->im1;
-          eq_round(ia, im);
-        }
-        sp += 32;
+        imp_acc += 0.5 * q2;
       }
       SG_T(11);
       // tendon row over the current slider accelerations, then its push on every slider
@@ -1475,6 +1504,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
       }
       SG_T(13);
       const int nsl = mine ? ns : 0;
+      if (nsmax == 0) { SG_T(14); continue; }  // no contacts anywhere in the wavefront: no look-ahead loads to wait for, no barrier
       struct Row { double2 j01, j23, jsb, fw, a01, a2s, p12, p3i; };
       auto load_row = [&](Row& w, const double2* p) {
         w.j01 = p[-4 * 64]; w.j23 = p[-3 * 64]; w.jsb = p[-2 * 64]; w.fw = p[-1 * 64];

@@ -57,5 +57,11 @@ def test_schedule_is_the_sequential_sweep(scene, bound):
             if e in last:
                 assert round_of[rec[last[e]]] < round_of[rec[i]], (last[e], i, e)
             last[e] = i
+    for i, r in enumerate(S):                                                                # typed lanes: slots 0..2 joint-fix rows, 3..7 neighbour rows
+        assert int(r[0]) == i // 8
+        if r[3] < N:
+            assert i % 8 < 3
+        elif r[3] < N + nnb:
+            assert i % 8 >= 3
     nrounds = int(S[:, 0].max()) + 1
     assert bound <= nrounds <= int(1.35 * bound)      # the critical path bounds it from below; list scheduling stays close
