@@ -46,4 +46,8 @@ def _compile(out, extra, verbose):
 
 if __name__ == "__main__":
     import sys
+    if "--ko" in sys.argv:  # knock-out / experiment builds: --ko NAME -DFLAG ... -> libsoftgrip_NAME.so
+        i = sys.argv.index("--ko")
+        print(_compile(os.path.join(_HERE, "libsoftgrip_%s.so" % sys.argv[i + 1]), sys.argv[i + 2:], False))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, prof="--prof" in sys.argv, count="--count" in sys.argv))

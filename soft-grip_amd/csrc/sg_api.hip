@@ -81,8 +81,8 @@ int sg_model_create(const void* blob, size_t nbytes, sg_model** out) {
     return fail(SG_ERR_MODEL, "sg_model_create: more than 256 composite elements");
   }
   if (m->plan.h.nnb > 0) {  // the rows PGS kernel keeps every equality row of 8 envs in LDS (launch_split)
-    const size_t na = 8 * (size_t)((m->plan.h.nelem + 7) / 8) + 8 + 48, neqp = (size_t)m->plan.h.nelem + m->plan.h.nnb + 1;
-    if (sizeof(double) * SG_ROWS_LDS_NB(4, na, neqp, m->plan.h.eq_rounds) > 160 * 1024) {
+    const size_t na = 8 * (size_t)((m->plan.h.nelem + 7) / 8) + 8 + 48, neqp = 4 * (size_t)m->plan.h.nelem + 1;
+    if (sizeof(double) * SG_ROWS_LDS_NB(4, na, m->plan.h.nelem, m->plan.h.eq_rounds) > 160 * 1024) {
       delete m;
       return fail(SG_ERR_MODEL, "sg_model_create: too many neighbour equality rows for the PGS kernel's LDS");
     }
@@ -170,8 +170,8 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   if (H.nnb > 0) {
     std::vector<SgEqSlot> sch = m->plan.sched;
     SgEqSlot idle;
-    idle.e1 = idle.e2 = H.nelem; idle.row = H.nelem + H.nnb; idle.pad = 0; idle.im1 = idle.im2 = 0;
-    for (int g = 0; g < 8 * 8; g++) sch.push_back(idle);  // the kernel works in groups of four rounds and requests slots four rounds ahead
+    idle.e = idle.p[0] = idle.p[1] = idle.p[2] = H.nelem;
+    for (int g = 0; g < 8 * SG_EQ_SLOTS; g++) sch.push_back(idle);  // the kernel fetches slots a few rounds ahead
     ALLOC(b->dnbtab, sizeof(int) * m->plan.nbtab.size());
     ALLOC(b->dsched, sizeof(SgEqSlot) * sch.size());
     HIPCHK(hipMemcpy(b->dnbtab, m->plan.nbtab.data(), sizeof(int) * m->plan.nbtab.size(), hipMemcpyHostToDevice));
@@ -269,16 +269,16 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   for (int v : nsl_set)
     if (v * 8 >= H.nelem) { nsl = v; break; }
   const bool nbm = H.nnb > 0;
-  const size_t na = 8 * (size_t)nsl + 8, neqp = (size_t)H.nelem + H.nnb + 1;
+  const size_t na = 8 * (size_t)nsl + 8, neqp = 4 * (size_t)H.nelem + 1;
   // envs per PGS wavefront: 8 when that already gives every SIMD of the chip a wavefront, else 4 (sg_pgs_rows_kernel); SG_PGS_EPW overrides
   int epw = (b->n + 7) / 8 >= 1024 ? 8 : 4;
   if (const char* pe = getenv("SG_PGS_EPW")) epw = atoi(pe) == 4 ? 4 : 8;
-  if (nbm && sizeof(double) * SG_ROWS_LDS_NB(8, na, neqp, H.eq_rounds) > 160 * 1024) epw = 4;  // the rows of 8 envs do not fit the LDS
-  const size_t lds_rows = sizeof(double) * (nbm ? SG_ROWS_LDS_NB(epw, na, neqp, H.eq_rounds) : SG_ROWS_LDS_FIX(epw, 8 * (size_t)nsl));
+  if (nbm) epw = 4;  // neighbour-row models: 16 lanes per env
+  const size_t lds_rows = sizeof(double) * (nbm ? SG_ROWS_LDS_NB(epw, na, H.nelem, H.eq_rounds) : SG_ROWS_LDS_FIX(epw, 8 * (size_t)nsl));
   if (!b->lds_attr_set) {  // per device: a batch on another GPU of the same process needs its own call
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define SG_ATTR1(v, nb, e) HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<v, nb, e>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-#define SG_ATTR(v) SG_ATTR1(v, false, 8); SG_ATTR1(v, true, 8); SG_ATTR1(v, false, 4); SG_ATTR1(v, true, 4)
+#define SG_ATTR(v) SG_ATTR1(v, false, 8); SG_ATTR1(v, false, 4); SG_ATTR1(v, true, 4)
     SG_ATTR(8); SG_ATTR(14); SG_ATTR(20); SG_ATTR(26); SG_ATTR(29); SG_ATTR(32);
 #undef SG_ATTR
 #undef SG_ATTR1
@@ -323,7 +323,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
 #define SG_ROWS1(v, nb, e) hipLaunchKernelGGL((sg_pgs_rows_kernel<v, nb, e>), grid, dim3(64), lds_rows, s, ga)
 #define SG_ROWS(v)                                                                    \
   case v:                                                                             \
-    if (nbm) { if (epw == 8) SG_ROWS1(v, true, 8); else SG_ROWS1(v, true, 4); }       \
+    if (nbm) SG_ROWS1(v, true, 4);                                                    \
     else { if (epw == 8) SG_ROWS1(v, false, 8); else SG_ROWS1(v, false, 4); }         \
     break
         switch (nsl) {

@@ -340,69 +340,77 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
     P.nbtab.assign((size_t)9 * N + 3 * nnb, -1);
     int* out_e2 = P.nbtab.data(); int* out_id = out_e2 + 3 * N; int* in_id = out_id + 3 * N; int* r_e1 = in_id + 3 * N; int* r_e2 = r_e1 + nnb;
     int* r_slot = r_e2 + nnb;
-    std::vector<int> nout(N, 0), nin(N, 0), unified(row_e1.size());
+    std::vector<int> nout(N, 0), nin(N, 0);
     int k = 0;
     for (size_t q = 0; q < row_e1.size(); q++) {
       const int e1 = row_e1[q], e2 = row_e2[q];
-      if (e2 < 0) { unified[q] = e1; continue; }
+      if (e2 < 0) continue;
       if (nout[e1] >= 3 || nin[e2] >= 3) FAIL("more than three neighbour equalities on one side of an element");
       const int slot = nout[e1] * N + e1;  // workspace slot of the row: (its rank among e1's rows, e1) -- lanes = elements store coalesced
       out_e2[slot] = e2; out_id[slot] = slot; nout[e1]++;
       in_id[nin[e2] * N + e2] = slot; nin[e2]++;
       r_e1[k] = e1; r_e2[k] = e2; r_slot[k] = slot;
-      unified[q] = N + k;
       k++;
     }
-    // list scheduling, longest remaining dependency chain first
-    const int nr = (int)row_e1.size();
-    std::vector<std::vector<int>> pred(nr), succ(nr);
+    // The equality rows in MuJoCo's order are [fix_e, e's neighbour rows (up to three: slots d = 0, 1, 2)] for e = 0, 1, ...: one BLOCK
+    // per element, all of whose rows act on slider e.  Blocks that share no slider commute exactly; blocks that share one must
+    // keep their order.  List scheduling of the blocks (longest remaining dependency chain first) into rounds of SG_EQ_SLOTS (one block per
+    // lane quad of an env's group in the solver): every block sits in a later round than the blocks it depends on, so the rounds in
+    // order, all slots of a round at once, ARE the sequential sweep.  A lane runs its block's rows one after the other with slider
+    // e's acceleration in a register (until r02 the unit was the row: 53 rounds of one LDS round trip each for softbox; now 24).
+    std::vector<int> part((size_t)3 * N, N);  // partner slider of block e's d-th neighbour row, N (the zero word) = no such row
+    for (int d = 0; d < 3; d++)
+      for (int e = 0; e < N; e++)
+        if (out_e2[d * N + e] >= 0) part[(size_t)d * N + e] = out_e2[d * N + e];
+    std::vector<std::vector<int>> pred(N), succ(N);
     {
       std::vector<int> last(N, -1);
-      for (int q = 0; q < nr; q++) {
-        const int sl[2] = {row_e1[q], row_e2[q]};
-        for (int t = 0; t < 2; t++) {
-          if (sl[t] < 0) continue;
+      for (int e = 0; e < N; e++) {
+        const int sl[4] = {e, part[e], part[N + e], part[2 * N + e]};
+        for (int t = 0; t < 4; t++) {
+          if (sl[t] >= N) continue;
           const int p = last[sl[t]];
-          if (p >= 0 && (pred[q].empty() || pred[q].back() != p)) { pred[q].push_back(p); succ[p].push_back(q); }
-          last[sl[t]] = q;
+          if (p >= 0 && p != e) {
+            bool dup = false;
+            for (int x : pred[e]) dup = dup || x == p;
+            if (!dup) { pred[e].push_back(p); succ[p].push_back(e); }
+          }
+          last[sl[t]] = e;
         }
       }
     }
-    std::vector<int> height(nr, 1), round_of(nr, -1);
-    for (int q = nr - 1; q >= 0; q--)
-      for (int t : succ[q]) height[q] = height[q] > 1 + height[t] ? height[q] : 1 + height[t];
-    int left = nr, rnd = 0;
+    std::vector<int> height(N, 1), round_of(N, -1);
+    for (int e = N - 1; e >= 0; e--)
+      for (int t : succ[e]) height[e] = height[e] > 1 + height[t] ? height[e] : 1 + height[t];
+    int left = N, rnd = 0;
     auto invm = [&](int e) { return 1.0 / (P.elem[(size_t)SGE_MASS * N + e] + P.elem[(size_t)SGE_ARMATURE * N + e]); };
     while (left > 0) {
       std::vector<int> ready;
-      for (int q = 0; q < nr; q++) {
-        if (round_of[q] >= 0) continue;
+      for (int e = 0; e < N; e++) {
+        if (round_of[e] >= 0) continue;
         bool ok = true;
-        for (int p : pred[q]) ok = ok && round_of[p] >= 0 && round_of[p] < rnd;
-        if (ok) ready.push_back(q);
+        for (int p : pred[e]) ok = ok && round_of[p] >= 0 && round_of[p] < rnd;
+        if (ok) ready.push_back(e);
       }
       std::stable_sort(ready.begin(), ready.end(), [&](int a, int b) { return height[a] > height[b]; });
-      // the lanes of a group are typed: slots 0 .. SG_EQ_FIXLANES-1 take joint-fix rows only, the others neighbour rows only, so
-      // that "1 / m of the second slider" (0 for a fix row) is a per-lane constant in the solver (sg_pgs_rows_kernel)
-      SgEqSlot slots[8];
-      for (int g = 0; g < 8; g++) { slots[g].e1 = N; slots[g].e2 = N; slots[g].row = N + nnb; slots[g].pad = 0; slots[g].im1 = 0; slots[g].im2 = 0; }
-      int nf = 0, nn = 0;
-      for (int q : ready) {
-        const bool fix = row_e2[q] < 0;
-        int g;
-        if (fix) { if (nf >= SG_EQ_FIXLANES) continue; g = nf++; }
-        else { if (nn >= 8 - SG_EQ_FIXLANES) continue; g = SG_EQ_FIXLANES + nn++; }
-        round_of[q] = rnd; left--;
-        SgEqSlot& sl = slots[g];
-        sl.e1 = row_e1[q]; sl.row = unified[q]; sl.im1 = invm(row_e1[q]);
-        if (!fix) { sl.e2 = row_e2[q]; sl.im2 = invm(row_e2[q]); }
+      for (int g = 0; g < SG_EQ_SLOTS; g++) {
+        SgEqSlot sl;
+        sl.e = sl.p[0] = sl.p[1] = sl.p[2] = N;  // idle slot: the zero word and the dummy records
+        if (g < (int)ready.size()) {
+          const int e = ready[g];
+          round_of[e] = rnd; left--;
+          sl.e = e;
+          for (int d = 0; d < 3; d++) sl.p[d] = part[(size_t)d * N + e];
+        }
+        P.sched.push_back(sl);
       }
-      for (int g = 0; g < 8; g++) P.sched.push_back(slots[g]);
       rnd++;
     }
     H.eq_rounds = rnd;
     for (int e = 1; e < N; e++)
       if (invm(e) != invm(0)) FAIL("neighbour-row models need elements of equal mass (the solver keeps 1 / m as a constant)");
+    for (int e = 0; e < N; e++)
+      if (P.elem[(size_t)SGE_COEF * N + e] != 1.0) FAIL("neighbour-row models need the element tendon with coefficients 1 (the solver tracks the sum of the slider accelerations)");
   }
   kb(eq_solref, eq_solimp, &H.eqj_K, &H.eqj_B);
   memcpy(H.eqj_solimp, eq_solimp, 40);

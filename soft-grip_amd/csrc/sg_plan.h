@@ -24,7 +24,7 @@
 #define SG_CG 2     // box geoms per chain
 #define SG_CS 2     // sensor sites per chain
 #define SG_MAXSTATIC 8
-#define SG_EQ_FIXLANES 3  // lanes of a group of 8 that take joint-fix rows in the equality schedule (the other 5: neighbour rows)
+#define SG_EQ_SLOTS 4   // blocks per round of the equality schedule: one per lane quad of an env's 16-lane group in the solver
 
 struct SgChain {
   int nbody, ndof, ngeom, nsite, dof0, pad0[3];
@@ -83,15 +83,13 @@ struct SgPlanHeader {
 };
 
 // One slot of the equality-row schedule (neighbour-row models).  MuJoCo sweeps the equality rows in id order
-// [fix_0, nb_0.., fix_1, nb_1.., ...]; two rows that share a slider must keep that order, rows that share none commute
-// exactly.  The plan list-schedules the rows into rounds of 8 (one per lane of an env's group in the PGS kernel): every
-// row sits in a later round than the rows it depends on, so executing the rounds in order, all slots of a round at once,
-// IS the sequential sweep.
+// [fix_0, nb_0.., fix_1, nb_1.., ...]: one block of rows per element e, all acting on slider e.  Two blocks that share a
+// slider must keep that order, blocks that share none commute exactly.  The plan list-schedules the BLOCKS into rounds of SG_EQ_SLOTS
+// (one per lane quad of an env's group in the PGS kernel): every block sits in a later round than the blocks it depends on, so
+// executing the rounds in order, all slots of a round at once, IS the sequential sweep.
 struct SgEqSlot {
-  int e1, e2;   // sliders of the row (element indices); e2 = nelem (a per-env dummy word that stays 0) for a fix row
-  int row;      // record index: fix row of element e -> e, neighbour row k -> nelem + k, idle slot -> nelem + nnb (dummy)
-  int pad;
-  double im1, im2;  // 1 / (mass + armature) of the two sliders (im2 = 0 for a fix row, both 0 for an idle slot)
+  int e;     // the block's element (slider); nelem (a per-env word that stays 0, with all-zero records) for an idle slot
+  int p[3];  // partner slider of the block's d-th neighbour row (workspace slot d * nelem + e); nelem = no such row
 };
 
 struct SgPlan {
@@ -101,7 +99,7 @@ struct SgPlan {
   //   workspace arrays nbf / nbb / nbR have 3 * nelem slots, so the phase kernel's lanes (= elements) store them coalesced
   //   out_*: the (up to 3) neighbour rows of element e: partner element / slot, -1 = none; in_slot: the (up to 3) rows that have e as second joint
   std::vector<int> nbtab;
-  std::vector<SgEqSlot> sched;     // eq_rounds x 8
+  std::vector<SgEqSlot> sched;     // eq_rounds x SG_EQ_SLOTS
   std::vector<double> elem;        // SGE_NFIELD x nelem
   std::vector<int> elem_geom;      // geom id of each element's capsule
   std::vector<int> elem_dofmap;    // (informational) global dof of element e = elem_dof0 + e

@@ -1239,6 +1239,13 @@ __device__ __forceinline__ double sg_gsum8(double x) {
   return x;
 }
 
+// sum over the 16 lanes of a DPP row, result in all 16
+__device__ __forceinline__ double sg_gsum16(double x) {
+  x = sg_gsum8(x);
+  x += sg_dpp<0x140>(x);  // row_mirror: lane i <-> 15 - i, i.e. the other half row (whose lanes all hold its sum)
+  return x;
+}
+
 // NB = true: the model has neighbour equality rows (slider e = slider e2).  The joint-fix rows are then no longer mutually
 // independent, and the equality block of a sweep -- MuJoCo's order [fix_0, nb_0.., fix_1, nb_1.., ...] -- runs as the plan's
 // list schedule (SgEqSlot): H.eq_rounds rounds, one row per lane of the env's group and round, rows of a round share no
@@ -1248,7 +1255,7 @@ __device__ __forceinline__ double sg_gsum8(double x) {
 // so the final "fresh M^-1 J' f" pass only concerns the finger chains.
 // LDS of sg_pgs_rows_kernel in doubles (kernel and host use the same expressions): EPW envs per wavefront
 #define SG_ROWS_LDS_FIX(EPW, NR) ((size_t)(5 * (EPW) + 2) * (NR) + 72)
-#define SG_ROWS_LDS_NB(EPW, NA, NEQP, ROUNDS) ((size_t)((EPW) + 2) * (NA) + (size_t)2 * (EPW) * (NEQP) + (size_t)8 * ((ROUNDS) + 4) + 72)
+#define SG_ROWS_LDS_NB(EPW, NA, N, ROUNDS) ((size_t)(EPW) * (NA) + (size_t)8 * (EPW) * ((N) + 1) + (size_t)8 * ((ROUNDS) + 4) + 72 + 2 * (EPW))  // table: 16 lanes x 4 B per round
 // EPW: envs per wavefront, 8 lanes each: 8 fills the wavefront (16 finger streams advance per instruction); 4 leaves lanes 32 .. 63 idle
 // but spreads a batch of 4096 envs over 1024 wavefronts -- one per SIMD of the whole chip instead of half of it -- and a wavefront
 // then runs the QCQP fallback (entered when ANY of its streams slides, for as many Newton evaluations as its slowest stream needs)
@@ -1256,7 +1263,11 @@ __device__ __forceinline__ double sg_gsum8(double x) {
 template <int NSL, bool NB, int EPW>  // NSL >= ceil(nelem / 8): joint-fix rows per lane, unrolled and padded (straight-line code, LDS reads issue back to back)
 __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   extern __shared__ double lds[];
-  const int lane = threadIdx.x, le = lane >> 3, g = lane & 7, c = g >> 2, r = g & 3;
+  // an env's lane group: 8 lanes (fix-only models: two finger quads); 16 lanes for neighbour-row models (EPW = 4): the two finger
+  // quads (g < 8) plus two more quads that only work in the equality block (one block of rows per quad and round)
+  static_assert(!NB || EPW == 4, "neighbour-row models: four envs of 16 lanes per wavefront");
+  constexpr int LSH = NB ? 4 : 3, LPE = 1 << LSH;
+  const int lane = threadIdx.x, le = lane >> LSH, g = lane & (LPE - 1), c = g >> 2, r = g & 3;
   const bool in_wave = le < EPW;             // lanes beyond the wavefront's envs stay idle (they own no LDS)
   const int lec = in_wave ? le : 0;
   const int env = blockIdx.x * EPW + le;
@@ -1276,67 +1287,91 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   // RI[j] = 1 / (A_jj + R_j); shared by the wavefront's envs: IC[j] = (1/m, tendon coefficient).  A row is three 16-byte reads + one 8-byte.
   constexpr int NR = 8 * NSL;
   // NB layout: Ae[NA] slider accelerations per env (word N is a dummy that stays 0: "no second slider"), IC[NA] shared,
-  // Ge[NEQP] / RRe[NEQP] per env: g and (R, 1 / (A + R)) of fix row e at e, of neighbour row k at N + k, dummy record at N + nnb
   constexpr int NA = NR + 8;
-  const int nnb = NB ? H.nnb : 0, NEQP = N + nnb + 1;
+  const int RECW = 8 * (N + 1);  // doubles of an env's equality records: (N + 1) groups of four (g, 1 / (A + R)) pairs
   double2* const AF = (double2*)lds + (size_t)lec * NR;
   double2* const BR = (double2*)lds + (size_t)EPW * NR + (size_t)lec * NR;
   double* const RI = lds + (size_t)4 * EPW * NR + (size_t)lec * NR;
-  double2* const IC = NB ? (double2*)(lds + (size_t)EPW * NA) : (double2*)(lds + (size_t)5 * EPW * NR);
+  double2* const IC = (double2*)(lds + (size_t)5 * EPW * NR);  // fix-only models: (1/m, tendon coefficient) per element
+  // NB layout: Ae[NA] per env: slider accelerations MINUS the env's offset aoff (below); word N is a zero word ("no partner").
+  // REC per env: group e = the four rows of element e's block -- its fix row, then its up to three neighbour rows -- each
+  // (g, c) with g = b + R f, c = (1/m) / (A + R); rows that do not exist and group N (idle slots) hold (0, 0).  TAB (shared by the
+  // wavefront's envs): the plan's block schedule as LDS byte offsets per lane of a 16-lane group: lane 4 q + k holds
+  // (e | v << 16) of quad q's block e, v = e for k = 0 (the fix row's own slider), the k-th neighbour row's partner for k > 0.
   double* const Ae = lds + (size_t)lec * NA;
-  // equality rows of an env (NB): REC[u] = (g, 1 / (A + R)), g = b + R f, of fix row e at u = e, of neighbour row k at u = N + k,
-  // a dummy record (0, 0) at N + nnb; TAB (shared by the wavefront's envs): the plan's schedule as LDS byte offsets,
-  // (a1 | a2 << 16, record) per slot
-  double2* const REC = (double2*)(lds + (size_t)(EPW + 2) * NA) + (size_t)lec * NEQP;
-  uint2* const TAB = (uint2*)(lds + (size_t)(EPW + 2) * NA + (size_t)2 * EPW * NEQP);
-  double* Lzero = NB ? lds + (size_t)(EPW + 2) * NA + (size_t)2 * EPW * NEQP + (size_t)8 * (H.eq_rounds + 4)
-                     : lds + (size_t)(5 * EPW + 2) * NR;  // [0]: a word that stays 0 (reads of "no slider"), [1 + lane]: write sink
+  double2* const REC = (double2*)(lds + (size_t)EPW * NA + (size_t)lec * RECW);
+  unsigned* const TAB = (unsigned*)(lds + (size_t)EPW * NA + (size_t)EPW * RECW);
+  double* const Lnb = lds + (size_t)EPW * NA + (size_t)EPW * RECW + (size_t)8 * (H.eq_rounds + 4);  // [72 + 2 EPW]
+  double* Lzero = NB ? Lnb : lds + (size_t)(5 * EPW + 2) * NR;  // [0]: a word that stays 0 (reads of "no slider"), [1 + lane]: write sink
+  double* const Lenv = Lnb + 72;  // NB: [e2] sum of the env's slider accelerations at the start, [EPW + e2] its final offset aoff
   double* const ASb = NB ? Ae : (double*)AF;  // slider acceleration of element j: ASb[ASS * j]
   constexpr int ASS = NB ? 1 : 2;
   if (lane == 0) Lzero[0] = 0.0;
-  for (int j = lane; j < (NB ? NA : NR); j += 64)
+  if constexpr (!NB)
+  for (int j = lane; j < NR; j += 64)
     IC[j] = j < N ? make_double2(1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]), a.elem[(size_t)SGE_COEF * N + j]) : make_double2(0.0, 0.0);
-  if constexpr (!NB) {
-  if (in_wave)
-  for (int j = g; j < NR; j += 8) {
-    double2 af = make_double2(0.0, 0.0), br = make_double2(0.0, 1.0);
-    double ri = 0.0;
-    if (valid && j < N) {
-      const size_t o = (size_t)env * N + j;
-      const double Rr = W.eqR[o], im = 1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]);
-      af = make_double2(W.as[o], W.eqf[o]); br = make_double2(W.eqb[o], Rr);
-      ri = sg_div(1.0, im + Rr);  // 1 / (A_jj + R_j): sg_div(res, A_jj + R_j) == res * this
-    }
-    AF[j] = af; BR[j] = br; RI[j] = ri;
-  }
-  } else if (in_wave) {
-    auto EIM = [&](int e) { return 1.0 / (a.elem[(size_t)SGE_MASS * N + e] + a.elem[(size_t)SGE_ARMATURE * N + e]); };
-    for (int j = g; j < NA; j += 8) Ae[j] = (valid && j < N) ? W.as[(size_t)env * N + j] : 0.0;
-    for (int u = g; u < NEQP; u += 8) {
-      double2 rec = make_double2(0.0, 0.0);
-      if (valid && u < N + nnb) {
-        double bb, Rr, ff, ims;
-        if (u < N) {
-          const size_t o = (size_t)env * N + u;
-          bb = W.eqb[o]; Rr = W.eqR[o]; ff = W.eqf[o]; ims = EIM(u);
-        } else {
-          const int k = u - N;
-          const size_t o = (size_t)env * 3 * N + a.nbtab[9 * N + 2 * nnb + k];
-          bb = W.nbb[o]; Rr = W.nbR[o]; ff = W.nbf[o];
-          ims = EIM(a.nbtab[9 * N + k]) + EIM(a.nbtab[9 * N + nnb + k]);
+  // Staging of the envs' rows: all 64 lanes take one env after the other, lane = row, so every load instruction reads 512
+  // contiguous bytes and the loads of an env are independent of each other (until r02 every lane strode through its own env 8
+  // rows apart, 41 trips with two dependent loads each: ~100 us per launch for the neighbour-row models, more than the 30 sweeps
+  // of a contact-free substep).
+#pragma unroll 1
+  for (int e2 = 0; e2 < EPW; e2++) {
+    const int env2 = blockIdx.x * EPW + e2;
+    const bool v2 = env2 < a.nenv && W.pending[env2 < a.nenv ? env2 : 0] != 0;  // uniform
+    if constexpr (!NB) {
+      double2* const AF2 = (double2*)lds + (size_t)e2 * NR;
+      double2* const BR2 = (double2*)lds + (size_t)EPW * NR + (size_t)e2 * NR;
+      double* const RI2 = lds + (size_t)4 * EPW * NR + (size_t)e2 * NR;
+#pragma unroll
+      for (int j0 = 0; j0 < NR; j0 += 64) {
+        const int j = j0 + lane;
+        double2 af = make_double2(0.0, 0.0), br = make_double2(0.0, 1.0);
+        double ri = 0.0;
+        if (v2 && j < N) {
+          const size_t o = (size_t)env2 * N + j;
+          const double Rr = W.eqR[o], im = 1.0 / (a.elem[(size_t)SGE_MASS * N + j] + a.elem[(size_t)SGE_ARMATURE * N + j]);
+          af = make_double2(W.as[o], W.eqf[o]); br = make_double2(W.eqb[o], Rr);
+          ri = sg_div(1.0, im + Rr);  // 1 / (A_jj + R_j): sg_div(res, A_jj + R_j) == res * this
         }
-        rec = make_double2(bb + Rr * ff, sg_div(1.0, ims + Rr));
+        if (j < NR) { AF2[j] = af; BR2[j] = br; RI2[j] = ri; }
       }
-      REC[u] = rec;
+    } else {
+      double* const A2 = lds + (size_t)e2 * NA;
+      double2* const REC2 = (double2*)(lds + (size_t)EPW * NA + (size_t)e2 * RECW);
+      const double im0 = 1.0 / (a.elem[(size_t)SGE_MASS * N] + a.elem[(size_t)SGE_ARMATURE * N]);  // equal for all elements (sg_plan_build)
+      double ssum = 0.0;
+#pragma unroll
+      for (int j0 = 0; j0 < NA; j0 += 64) {
+        const int j = j0 + lane;
+        const double av = (v2 && j < N) ? W.as[(size_t)env2 * N + j] : 0.0;
+        if (j < NA) A2[j] = av;
+        ssum += av;
+      }
+      ssum = wave_sum2(ssum);
+      if (lane == 0) { Lenv[e2] = ssum; Lenv[EPW + e2] = 0.0; }
+      for (int u = lane; u < 4 * (N + 1); u += 64) {  // row u = 4 e + d: d = 0 the fix row of e, d = 1 .. 3 its neighbour row in workspace slot (d - 1) N + e
+        const int e = u >> 2, d = u & 3;
+        double gg = 0.0, cc = 0.0;
+        if (v2 && e < N) {
+          const bool fix = d == 0;
+          const bool have = fix || a.nbtab[(fix ? 0 : d - 1) * N + e] >= 0;
+          const size_t o = fix ? (size_t)env2 * N + e : (size_t)env2 * 3 * N + (size_t)(d - 1) * N + e;
+          const double bb = (fix ? W.eqb : W.nbb)[o], Rr = (fix ? W.eqR : W.nbR)[o], ff = (fix ? W.eqf : W.nbf)[o];
+          if (have) { gg = bb + Rr * ff; cc = sg_div(im0, (fix ? im0 : 2.0 * im0) + Rr); }
+        }
+        REC2[u] = make_double2(gg, cc);  // group e = rows 4 e .. 4 e + 3
+      }
     }
   }
   if constexpr (NB) {  // the schedule (plus four idle rounds for the look-ahead) as LDS byte offsets
-    for (int i = lane; i < 8 * (H.eq_rounds + 4); i += 64) {
-      const SgEqSlot sl = a.sched[i];
-      TAB[i] = make_uint2((unsigned)(8 * sl.e1) | ((unsigned)(8 * sl.e2) << 16), (unsigned)(16 * sl.row));
+    for (int i = lane; i < 16 * (H.eq_rounds + 4); i += 64) {
+      const SgEqSlot sl = a.sched[i >> 2];  // slot (round, quad)
+      const int k = i & 3;
+      TAB[i] = (unsigned)(8 * sl.e) | ((unsigned)(8 * (k == 0 ? sl.e : sl.p[k - 1])) << 16);
     }
   }
-  const size_t st = 2 * (size_t)(valid ? env : 0) + c;
+  const bool sv = valid && g < 8;  // lanes of the env's two finger quads
+  const size_t st = 2 * (size_t)(sv ? env : 0) + (sv ? c : 0);
   int ns = 0, lim_active = 0, shared = 0;
   // lane r of the quad owns finger acceleration aF[r]; of M^-1 it needs row r (its share of a limit row's push) and the diagonal
   double Mrow[SG_CD] = {0, 0, 0, 0}, Mdiag[SG_CD] = {0, 0, 0, 0}, aFo = 0;
@@ -1348,6 +1383,8 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     tb = W.envh[(size_t)0 * a.nenv + env]; tR = W.envh[(size_t)1 * a.nenv + env];
     tA = W.envh[(size_t)2 * a.nenv + env]; tf = W.envh[(size_t)3 * a.nenv + env];
     shared = W.shared[env];
+  }
+  if (sv) {
     ns = W.ns[st];
     lim_active = W.lim_active[st];
 #pragma unroll
@@ -1367,12 +1404,15 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
 
   bool running = valid;
   int iters = 0;
+  // NB: the env's acceleration offset, the tracked sum of its slider accelerations and this lane's not yet reduced share of it
+  double aoff = 0.0, Ssum = NB ? Lenv[lec] : 0.0, dS = 0.0;
+  const double im0 = NB ? 1.0 / (a.elem[(size_t)SGE_MASS * N] + a.elem[(size_t)SGE_ARMATURE * N]) : 0.0;
   // my column in the wave's block, biased by 4 field pairs (immediate offsets -4096 .. 3072).  Lanes without an env (idle half of
   // an EPW = 4 wavefront, ragged tail, env not pending) read and write a block of their own wavefront that holds zeros and
   // never advance: a dummy block shared by all wavefronts made every idle lane of the chip hammer the same 8 KB
   // (profiles/r02: 1024 wavefronts x 32 idle lanes, contact rows 2.3x slower than with 16 streams per wavefront).
   // (the phase kernel writes blocks of 8 envs: env e sits in block e >> 3 at lanes 8 (e & 7) .. + 7, whatever EPW is)
-  const bool has_row = valid;
+  const bool has_row = sv;
   const double2* const row0 = has_row ? (const double2*)(W.crow + SG_ROW_INDEX(0, env >> 3, 8, 8 * (env & 7) + g, nwb))
                                       : (const double2*)(W.cdummy + ((size_t)blockIdx.x * (SG_RK / 2) + 4) * 128 + 2 * lane);
   const size_t slot_stride = has_row ? (size_t)(nwb + 2) * (SG_RK / 2) * 64 : 0;  // in double2 units (per lane: idle lanes stay put)
@@ -1384,60 +1424,94 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     SG_T(10);
     double imp_acc = 0, tJap = 0;
     if constexpr (NB) {
-      // equality block as the plan's schedule: H.eq_rounds rounds, one row per lane of the env's group.  A row's state is
-      // g = b + R f; with res = g + a1 - a2 and t = res / (A + R) the update is a1 -= t / m1, a2 += t / m2 and g -= R t, which is
-      // g' = a2' - a1' (the row's residual is zero after its update), so R is not needed in the sweep.  The plan types the lanes:
-      // lanes 0 .. 2 of a group only get joint-fix rows (second slider = the group's zero word, 1 / m2 = 0), lanes 3 .. 7 only
-      // neighbour rows, and all elements have the same mass (sg_plan_build checks both), so 1 / m1 and 1 / m2 are per-lane
-      // constants.  A round: one 8-byte table read (two rounds ahead), three LDS reads, seven fp64 operations, three LDS writes
-      // (until r02: slots streamed from global memory with their own 1 / m, R kept per row: ~30 instructions per round).
+      // Equality block as the plan's block schedule: H.eq_rounds rounds, one BLOCK per lane of the env's group -- element e's fix
+      // row and its up to three neighbour rows, in MuJoCo's order, with slider e's acceleration carried in a register.  A row's
+      // state is g = b + R f; with res = g + a1 - a2 and t = res / (A + R) the update is a1 -= t / m, a2 += t / m and g -= R t,
+      // which is g' = a2' - a1' (the row's residual is zero after its update), so R is not needed in the sweep.  All elements
+      // have the same mass and tendon coefficient 1 (sg_plan_build), hence:
+      //  * the tendon row's push is the same for every slider: it goes into ONE per-env offset, aoff (true a_e = A[e] + aoff),
+      //    instead of a pass over all sliders; neighbour rows see differences of sliders (offset-free), fix rows and contacts add it;
+      //  * the tendon row's J a = sum of the slider accelerations is TRACKED (Ssum): a neighbour row leaves it unchanged, a fix row
+      //    changes it by -t / m, a contact by its push on its slider, the tendon row by sum(1/m) dft -- no pass over the sliders.
+      // The sweep is bound by LDS round trips (profiles/r02: ~290 cycles per dependent round), so what counts is their number:
+      // 24 block rounds for softbox instead of 53 row rounds, and none for the tendon row.
       if (running) {
-        const double imA = IC[0].x, imB = g < 3 ? 0.0 : imA;
+        // One block per QUAD and round: lane k of the quad holds row k of the block (k = 0 the fix row, k = 1 .. 3 the neighbour
+        // rows) -- its state g_k, its step factor c_k = (1/m) / (A + R) and its partner's acceleration P_k (k = 0: the constant
+        // -aoff, a "partner" that is never pushed).  With d_k = g_k - P_k the block's sequential sweep over slider e's acceleration is
+        //   e_{k+1} = e_k (1 - c_k) - c_k d_k,   k = 0 .. 3,   e_0 = a_e:
+        // four dependent multiply-adds handed from lane to lane by DPP; residual s_k = d_k + e_k, push w_k = c_k s_k on the partner,
+        // new state g_k' = P_k' - e_{k+1} are one instruction each for the four rows.  Per round and lane: one table word, one
+        // slider word and one record read, one slider word and one state written.
         char* const Ab = (char*)Ae;
-        char* const Rb = (char*)REC;
-        const uint2* tp = TAB + g;
-        uint2 ta = tp[0], tb = tp[8];
-        double q2 = 0.0;
-        auto eq_round = [&](const uint2 tt) {
-          double* const p1 = (double*)(Ab + (tt.x & 0xffffu));
-          double* const p2 = (double*)(Ab + (tt.x >> 16));
-          double2* const pr = (double2*)(Rb + tt.y);
-          const double a1 = *p1, a2 = *p2;
-          const double2 rec = *pr;
-          const double res = (rec.x + a1) - a2, t = res * rec.y;
-          const double a1n = a1 - imA * t, a2n = a2 + imB * t;
-          *p1 = a1n;
-          *p2 = a2n;
-          pr->x = a2n - a1n;
-          q2 += res * t;
-        };
+        char* const Rbk = (char*)REC + 16 * r;  // my row's record inside a group
+        const unsigned* tp = TAB + g;
+        const double km = r == 0 ? 0.0 : 1.0, k0 = 1.0 - km, k1 = r == 1 ? 1.0 : 0.0, k2 = r == 2 ? 1.0 : 0.0, k3 = r == 3 ? 1.0 : 0.0;
+        const double Pfix = k0 * -aoff;  // P_0 = -aoff on lane 0, 0 elsewhere (added to km * V)
+        double qc = 0.0, sc = 0.0;
+#ifdef SG_KO_EQ  // knock-out builds (scripts/phase_time.py): timing only, results are wrong
+        const int nrounds = 0;
+#else
         const int nrounds = H.eq_rounds;
-        for (int k = 0; k < nrounds; k += 2) {  // an odd count runs one idle round (the table ends with two)
-          const uint2 t0 = ta, t1 = tb;
-          tp += 16;
-          ta = tp[0]; tb = tp[8];
-          eq_round(t0);
-          eq_round(t1);
+#endif
+        struct Pend { double* p; double g; };
+        auto round = [&](const unsigned tt, const double2 rec, Pend& out) {
+          double* const pv = (double*)(Ab + (tt >> 16));
+          const double V = *pv;
+          const double cc = rec.y, mm = 1.0 - cc;
+          const double P = fma(V, km, Pfix), d = rec.x - P, nu = -(cc * d);
+          const double v0 = fma(V, mm, nu);                                   // lane 0: e1
+          const double x1 = sg_dpp<0x90>(v0), v1 = fma(x1, mm, nu);           // quad_perm [0,0,1,2]: lane k gets lane k - 1; lane 1: e2
+          const double x2 = sg_dpp<0x90>(v1), v2 = fma(x2, mm, nu);           // lane 2: e3
+          const double x3 = sg_dpp<0x90>(v2), v3 = fma(x3, mm, nu);           // lane 3: e4
+          const double ein = (V * k0 + x1 * k1) + (x2 * k2 + x3 * k3);        // my row's e_k: exact (one term, the others are zeros)
+          const double eout = fma(ein, mm, nu);
+          const double sres = d + ein, w = cc * sres, Pn = fma(w, km, P);
+          const double e4 = sg_qb<3>(v3);
+          *pv = r == 0 ? e4 : Pn;                                             // lane 0 stores the block's result a_e' = e4, the others their partner
+          qc += sres * w;
+          sc += w * k0;
+          out.p = (double*)(Rbk + 8 * (tt & 0xffffu));
+          out.g = Pn - eout;
+        };
+        auto ld_rec = [&](const unsigned tt) { return *(const double2*)(Rbk + 8 * (tt & 0xffffu)); };
+        // two rounds per trip; table words are fetched two rounds ahead, records one round ahead (no row of a round writes the
+        // records of another block), and a round's new states are written after the NEXT round has issued its slider read
+        unsigned tA = tp[0], tB = tp[16];
+        double2 rA = ld_rec(tA), rB;
+        Pend pend;
+        pend.p = (double*)(Rbk + 64 * N); pend.g = 0.0;  // first "pending" store: zero into the idle group
+        for (int k = 0; k < nrounds; k += 2) {  // an odd count runs one idle round (the table ends with four)
+          tp += 32;
+          const unsigned tC = tp[0], tD = tp[16];
+          Pend pa, pb;
+          rB = ld_rec(tB);
+          round(tA, rA, pa);
+          *pend.p = pend.g;
+          rA = ld_rec(tC);
+          round(tB, rB, pb);
+          *pa.p = pa.g;
+          pend = pb;
+          tA = tC; tB = tD;
         }
-        imp_acc += 0.5 * q2;
+        *pend.p = pend.g;
+        imp_acc += 0.5 * qc * (1.0 / im0);
+        dS -= sc;
       }
       SG_T(11);
-      // tendon row over the current slider accelerations, then its push on every slider
-      if (running) {
-#pragma unroll
-        for (int t = 0; t < NSL + 1; t++) tJap += IC[g + 8 * t].y * Ae[g + 8 * t];
-      }
-      double Ja = sg_gsum8(tJap);
-      double old = tf, tfn = tf;
-      double ch = scalar_update(tfn, tb, Ja, tR, tA, false);
-      if (running) {
-        if (g == 0) imp_acc -= ch;
-        tf = tfn;
-      }
-      const double dft = tf - old;
-      if (running) {
-#pragma unroll
-        for (int t = 0; t < NSL + 1; t++) { const double2 ic = IC[g + 8 * t]; Ae[g + 8 * t] += ic.x * ic.y * dft; }
+      // tendon row: J a = the tracked sum (+ what this group's lanes and contact quads have added since the last tendon row)
+      {
+        const double Ja = Ssum + sg_gsum16(dS);
+        double old = tf, tfn = tf;
+        double ch = scalar_update(tfn, tb, Ja, tR, tA, false);
+        if (running) {
+          if (g == 0) imp_acc -= ch;
+          tf = tfn;
+          const double dft = tf - old;
+          aoff += im0 * dft;
+          Ssum = Ja + (tA - tR) * dft;  // tA - tR = sum over the sliders of coef^2 / m
+          dS = 0.0;
+        }
       }
     } else {
     double ael[NSL], fnw[NSL], imc[NSL];
@@ -1484,8 +1558,11 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     }
     __syncthreads();
     SG_T(12);
+#ifdef SG_KO_SWEEPS
+    if (it >= SG_KO_SWEEPS) running = false;
+#endif
     for (int pass = 0; pass < 2; pass++) {
-      const bool mine = running && ((c == 0 || !shared) ? pass == 0 : pass == 1);
+      const bool mine = running && g < 8 && ((c == 0 || !shared) ? pass == 0 : pass == 1);
       if (!__ballot(mine)) continue;
       auto qbd = [&](double x, int d) { return d == 0 ? sg_qb<0>(x) : (d == 1 ? sg_qb<1>(x) : (d == 2 ? sg_qb<2>(x) : sg_qb<3>(x))); };  // d is a constant after unrolling
       if (any_lim) {  // limit rows: every lane of the quad computes the same scalars, lane 0 records the force
@@ -1518,7 +1595,8 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           const double Rr = w.p3i.y;  // R: replicated on the row lanes (field 15), 0 on lane 3
           const double P11 = sg_qb<3>(J0), P12 = sg_qb<3>(J1), P22 = sg_qb<3>(J2);  // early: off the update's dependency chain
           const int sl = __double2loint(sg_qb<3>(Js));
-          const double as_ = *(sl >= 0 ? (const double*)(ASb + ASS * sl) : &Lzero[0]);  // branch-free: "no slider" reads a zero word
+          const double araw = *(sl >= 0 ? (const double*)(ASb + ASS * sl) : &Lzero[0]);  // branch-free: "no slider" reads a zero word
+          const double as_ = NB ? araw + aoff : araw;  // (a contact without a slider has J_s = 0: the offset it then sees is inert)
           const double f0_ = sg_qb<0>(aFo), f1_ = sg_qb<1>(aFo), f2_ = sg_qb<2>(aFo), f3_ = sg_qb<3>(aFo);  // the finger's four accelerations
           const double res = ((bb + Js * as_) + (J0 * f0_ + J1 * f1_)) + ((Rr * fo + J2 * f2_) + J3 * f3_);  // unused on lane 3
           const double o0 = sg_qb<0>(fo);
@@ -1610,7 +1688,8 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           imp_acc -= (reject || r != 0) ? 0.0 : change;
           // the slider's share: one quad sum (invm J_s' df); the finger's: lane q adds its column of M^-1 J_F' df
           const double jsdf = sg_qsum(JsI * dr);
-          *((sl >= 0 && r == 0) ? (double*)(ASb + ASS * sl) : &Lzero[1 + lane]) = as_ + jsdf;  // other lanes write to their sink word
+          *((sl >= 0 && r == 0) ? (double*)(ASb + ASS * sl) : &Lzero[1 + lane]) = araw + jsdf;  // other lanes write to their sink word
+          if constexpr (NB) dS += 0.25 * jsdf;  // the four lanes of the quad hold the same push: the group sum counts it once
           aFo += (W0 * sg_qb<0>(dr) + W1 * sg_qb<1>(dr)) + W2 * sg_qb<2>(dr);
           w.fw = make_double2(fn, wn);
         }
@@ -1635,7 +1714,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
       SG_T(14);
     }
     double imp = imp_acc;
-    imp = sg_gsum8(imp);
+    imp = NB ? sg_gsum16(imp) : sg_gsum8(imp);
     if (running) {
       iters = it + 1;
       if (imp * pgs_scale < tolerance) running = false;
@@ -1648,10 +1727,20 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   //      ~10^3 additions (parity against the oracle, which multiplies out the final forces: 9e-12 over the episode).  Recomputing
   //      them from the forces cost one more pass over all contact rows, 3.3 % of the kernel (until r01 v11)
   __syncthreads();
-  if (valid) W.saF[(size_t)r * S + st] = aFo;
-  if (valid) {
-    for (int j = g; j < N; j += 8) W.as[(size_t)env * N + j] = ASb[ASS * j];
-    if (g == 0) W.iters[env] = iters;
+  if (sv) W.saF[(size_t)r * S + st] = aFo;
+  if (valid && g == 0) W.iters[env] = iters;
+  if constexpr (NB) {
+    if (valid && g == 0) Lenv[EPW + le] = aoff;
+    __syncthreads();
+  }
+#pragma unroll 1
+  for (int e2 = 0; e2 < EPW; e2++) {  // slider accelerations back to the workspace, lane = element
+    const int env2 = blockIdx.x * EPW + e2;
+    if (env2 < a.nenv && W.pending[env2] != 0) {
+      const double* const AS2 = NB ? lds + (size_t)e2 * NA : lds + (size_t)2 * e2 * NR;
+      const double off2 = NB ? Lenv[EPW + e2] : 0.0;
+      for (int j = lane; j < N; j += 64) W.as[(size_t)env2 * N + j] = AS2[ASS * j] + off2;
+    }
   }
   SG_T(16);
   SG_TEND();

@@ -42,9 +42,9 @@ int emu_plan_schedule(const void* blob, size_t n, int* out, int cap, int* nelem,
   }
   *nelem = P.h.nelem; *nnb = P.h.nnb;
   const int ns = (int)P.sched.size();
-  if (ns != 8 * P.h.eq_rounds || ns > cap) return -1;
+  if (ns != SG_EQ_SLOTS * P.h.eq_rounds || ns > cap) return -1;
   for (int i = 0; i < ns; i++) {
-    out[4 * i] = i / 8; out[4 * i + 1] = P.sched[i].e1; out[4 * i + 2] = P.sched[i].e2; out[4 * i + 3] = P.sched[i].row;
+    out[4 * i] = P.sched[i].e; out[4 * i + 1] = P.sched[i].p[0]; out[4 * i + 2] = P.sched[i].p[1]; out[4 * i + 3] = P.sched[i].p[2];
   }
   return ns;
 }
