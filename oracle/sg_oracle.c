@@ -683,28 +683,127 @@ static int capsule_box(const sgo_model* m, sgo_data* d, int g1, int g2, double m
   return n;
 }
 
-/* separating-axis overlap test for two boxes (detection only, deviation D2) */
-static int box_box_overlap(const sgo_model* m, const sgo_data* d, int g1, int g2, double margin) {
+/* Box-box narrowphase (deviation D2': NOT a transcription of MuJoCo's mjc_BoxBox, which is not available here; the classic
+ * separating-axis + face-clipping construction that box-box routines of this family share):
+ *  1. 15 candidate axes (3 face normals of each box, 9 edge x edge cross products); separation s = |T.L| - (rA + rB); any
+ *     s > margin -> no contact.  The axis of least penetration wins; an edge axis must beat the best face axis by more than
+ *     BB_FUDGE (relative) to be chosen, so near-ties go to faces (stable manifolds).
+ *  2. face axis: the reference box owns it; of the other ("incident") box take the face most anti-parallel to the normal, clip
+ *     its 4 corners against the 4 side planes of the reference face (Sutherland-Hodgman), keep the points whose distance to
+ *     the reference face is <= margin: up to 8 contacts, in clip order; position = midway between point and reference face.
+ *  3. edge axis: one contact midway between the closest points of the two edges.
+ * Normal: from geom1 towards geom2; dist < 0 = penetration. */
+#define BB_FUDGE 1.05
+static int box_box(const sgo_model* m, sgo_data* d, int g1, int g2, double margin) {
   const double *p1 = d->geom_xpos + 3 * g1, *R1 = d->geom_xmat + 9 * g1, *s1 = m->geom_size + 3 * g1;
   const double *p2 = d->geom_xpos + 3 * g2, *R2 = d->geom_xmat + 9 * g2, *s2 = m->geom_size + 3 * g2;
-  double T[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, ax[15][3];
-  int na = 0;
-  for (int k = 0; k < 3; k++) { ax[na][0] = R1[k]; ax[na][1] = R1[3 + k]; ax[na][2] = R1[6 + k]; na++; }
-  for (int k = 0; k < 3; k++) { ax[na][0] = R2[k]; ax[na][1] = R2[3 + k]; ax[na][2] = R2[6 + k]; na++; }
+  double T[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, A[3][3], B[3][3];
+  for (int k = 0; k < 3; k++) { A[k][0] = R1[k]; A[k][1] = R1[3 + k]; A[k][2] = R1[6 + k]; B[k][0] = R2[k]; B[k][1] = R2[3 + k]; B[k][2] = R2[6 + k]; }
+  double C[3][3], Q[3][3]; /* C = A' B, Q = |C| */
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { C[i][j] = dot3(A[i], B[j]); Q[i][j] = fabs(C[i][j]); }
+  double best = -1e300, bn[3] = {0, 0, 0};
+  int code = -1; /* 0..2 face of box 1, 3..5 face of box 2, 6 + 3 i + j edge i x edge j */
+  for (int k = 0; k < 3; k++) { /* faces of box 1 */
+    double t = dot3(T, A[k]), sep = fabs(t) - (s1[k] + s2[0] * Q[k][0] + s2[1] * Q[k][1] + s2[2] * Q[k][2]);
+    if (sep > margin) return 0;
+    if (sep > best) { best = sep; code = k; double sg = t < 0 ? -1 : 1; for (int c = 0; c < 3; c++) bn[c] = sg * A[k][c]; }
+  }
+  for (int k = 0; k < 3; k++) { /* faces of box 2 */
+    double t = dot3(T, B[k]), sep = fabs(t) - (s2[k] + s1[0] * Q[0][k] + s1[1] * Q[1][k] + s1[2] * Q[2][k]);
+    if (sep > margin) return 0;
+    if (sep > best) { best = sep; code = 3 + k; double sg = t < 0 ? -1 : 1; for (int c = 0; c < 3; c++) bn[c] = sg * B[k][c]; }
+  }
+  double ebest = -1e300, en[3] = {0, 0, 0};
+  int ecode = -1;
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) {
-      cross3(ax[na], ax[i], ax[3 + j]);
-      double n = sqrt(dot3(ax[na], ax[na]));
-      if (n < 1e-9) continue;
-      ax[na][0] /= n; ax[na][1] /= n; ax[na][2] /= n;
-      na++;
+      double L[3];
+      cross3(L, A[i], B[j]);
+      double n = sqrt(dot3(L, L));
+      if (n < 1e-6) continue; /* parallel edges: covered by the face axes */
+      for (int c = 0; c < 3; c++) L[c] /= n;
+      double ra = 0, rb = 0;
+      for (int k = 0; k < 3; k++) { ra += s1[k] * fabs(dot3(L, A[k])); rb += s2[k] * fabs(dot3(L, B[k])); }
+      double t = dot3(T, L), sep = fabs(t) - (ra + rb);
+      if (sep > margin) return 0;
+      if (sep > ebest) { ebest = sep; ecode = 6 + 3 * i + j; double sg = t < 0 ? -1 : 1; for (int c = 0; c < 3; c++) en[c] = sg * L[c]; }
     }
-  for (int a = 0; a < na; a++) {
-    double ra = 0, rb = 0;
-    for (int k = 0; k < 3; k++) { ra += s1[k] * fabs(dot3(ax[a], ax[k])); rb += s2[k] * fabs(dot3(ax[a], ax[3 + k])); }
-    if (fabs(dot3(T, ax[a])) > ra + rb + margin) return 0;
+  if (ecode >= 0 && ebest > best + (BB_FUDGE - 1.0) * fabs(best) + 1e-9) { best = ebest; code = ecode; memcpy(bn, en, 24); }
+  if (code >= 6) { /* edge-edge: closest points of the two supporting edges */
+    int i = (code - 6) / 3, j = (code - 6) % 3;
+    double pa[3], pb[3];
+    for (int c = 0; c < 3; c++) { pa[c] = p1[c]; pb[c] = p2[c]; }
+    for (int k = 0; k < 3; k++) {
+      if (k != i) { double sg = dot3(bn, A[k]) > 0 ? 1 : -1; addscl3(pa, A[k], sg * s1[k]); }
+      if (k != j) { double sg = dot3(bn, B[k]) > 0 ? -1 : 1; addscl3(pb, B[k], sg * s2[k]); }
+    }
+    /* lines pa + a A[i], pb + b B[j] */
+    double r[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]}, uv = C[i][j], den = 1 - uv * uv;
+    double ta = 0, tb = 0;
+    if (den > 1e-12) { double q1 = dot3(A[i], r), q2 = dot3(B[j], r); ta = (q1 - uv * q2) / den; tb = (uv * q1 - q2) / den; }
+    ta = ta > s1[i] ? s1[i] : ta < -s1[i] ? -s1[i] : ta;
+    tb = tb > s2[j] ? s2[j] : tb < -s2[j] ? -s2[j] : tb;
+    double pos[3];
+    for (int c = 0; c < 3; c++) pos[c] = 0.5 * ((pa[c] + ta * A[i][c]) + (pb[c] + tb * B[j][c]));
+    return add_contact(m, d, g1, g2, best, pos, bn, NULL) != NULL;
   }
-  return 1;
+  /* face contact: reference box owns the axis */
+  const int ref1 = code < 3, ka = ref1 ? code : code - 3;
+  const double (*Ra)[3] = ref1 ? A : B, (*Rb)[3] = ref1 ? B : A;
+  const double *pa = ref1 ? p1 : p2, *pb = ref1 ? p2 : p1, *sa = ref1 ? s1 : s2, *sb = ref1 ? s2 : s1;
+  double nrm[3]; /* outward normal of the reference face (towards the incident box) */
+  for (int c = 0; c < 3; c++) nrm[c] = ref1 ? bn[c] : -bn[c];
+  /* incident face: axis of the incident box most aligned with nrm; its face on the side facing the reference box */
+  int kb = 0; double mx = -1;
+  for (int k = 0; k < 3; k++) { double v = fabs(dot3(nrm, Rb[k])); if (v > mx + 1e-12) { mx = v; kb = k; } }
+  double sgb = dot3(nrm, Rb[kb]) > 0 ? -1 : 1, cen[3];
+  for (int c = 0; c < 3; c++) cen[c] = pb[c] + sgb * sb[kb] * Rb[kb][c];
+  int u = (kb + 1) % 3, v = (kb + 2) % 3, ua = (ka + 1) % 3, va = (ka + 2) % 3;
+  double poly[16][3], tmp[16][3];
+  int np = 4;
+  const double cs[4][2] = {{1, 1}, {-1, 1}, {-1, -1}, {1, -1}};
+  for (int q = 0; q < 4; q++)
+    for (int c = 0; c < 3; c++) poly[q][c] = cen[c] + cs[q][0] * sb[u] * Rb[u][c] + cs[q][1] * sb[v] * Rb[v][c];
+  /* clip against the four side planes of the reference face: |(x - pa).Ra[ua]| <= sa[ua], same for va */
+  for (int pl = 0; pl < 4 && np > 0; pl++) {
+    const int ax = pl < 2 ? ua : va; const double sg = (pl & 1) ? -1 : 1, lim = sa[ax];
+    int nq = 0;
+    for (int q = 0; q < np; q++) {
+      const double *x0 = poly[q], *x1 = poly[(q + 1) % np];
+      double e0[3] = {x0[0] - pa[0], x0[1] - pa[1], x0[2] - pa[2]}, e1[3] = {x1[0] - pa[0], x1[1] - pa[1], x1[2] - pa[2]};
+      double d0 = sg * dot3(e0, Ra[ax]) - lim, d1 = sg * dot3(e1, Ra[ax]) - lim;
+      if (d0 <= 0) { memcpy(tmp[nq++], x0, 24); }
+      if ((d0 <= 0) != (d1 <= 0)) { double w = d0 / (d0 - d1); for (int c = 0; c < 3; c++) tmp[nq][c] = x0[c] + w * (x1[c] - x0[c]); nq++; }
+    }
+    np = nq;
+    memcpy(poly, tmp, sizeof(double) * 3 * np);
+  }
+  int n = 0;
+  for (int q = 0; q < np && n < 8; q++) {
+    double e[3] = {poly[q][0] - pa[0], poly[q][1] - pa[1], poly[q][2] - pa[2]}, dist = dot3(e, nrm) - sa[ka], pos[3];
+    if (dist > margin) continue;
+    for (int c = 0; c < 3; c++) pos[c] = poly[q][c] - 0.5 * dist * nrm[c];
+    if (add_contact(m, d, g1, g2, dist, pos, bn, NULL)) n++;
+  }
+  return n;
+}
+
+/* plane (geom g1) against box g2: the box corners within the margin of the plane, in corner order (x fastest), at most 4 */
+static int plane_box(const sgo_model* m, sgo_data* d, int g1, int g2, double margin) {
+  const double *p1 = d->geom_xpos + 3 * g1, *M1 = d->geom_xmat + 9 * g1;
+  const double *p2 = d->geom_xpos + 3 * g2, *M2 = d->geom_xmat + 9 * g2, *sz = m->geom_size + 3 * g2;
+  double nrm[3] = {M1[2], M1[5], M1[8]};
+  int n = 0;
+  for (int q = 0; q < 8 && n < 4; q++) {
+    double loc[3] = {(q & 1 ? 1 : -1) * sz[0], (q & 2 ? 1 : -1) * sz[1], (q & 4 ? 1 : -1) * sz[2]}, w[3], pos[3];
+    mulmat3(w, M2, loc);
+    for (int c = 0; c < 3; c++) w[c] += p2[c] - p1[c];
+    double dist = dot3(w, nrm);
+    if (dist > margin) continue;
+    for (int c = 0; c < 3; c++) pos[c] = w[c] + p1[c] - 0.5 * dist * nrm[c];
+    if (add_contact(m, d, g1, g2, dist, pos, nrm, NULL)) n++;
+  }
+  return n;
 }
 
 static void collision(const sgo_model* m, sgo_data* d) {
@@ -732,11 +831,8 @@ static void collision(const sgo_model* m, sgo_data* d) {
           for (int q = 0; q < 3; q++) pos[q] = c[q] - nrm[q] * (r + 0.5 * dist);
           add_contact(m, d, g1, g2, dist, pos, nrm, ax);
         }
-      } else { /* plane-box: detect only (D2) */
-        const double *M2 = d->geom_xmat + 9 * g2, *sz = m->geom_size + 3 * g2;
-        double ext = 0;
-        for (int c = 0; c < 3; c++) ext += sz[c] * fabs(nrm[0] * M2[c] + nrm[1] * M2[3 + c] + nrm[2] * M2[6 + c]);
-        if (dot3(dif, nrm) - ext <= margin) d->warnings |= SGO_WARN_UNSUPPORTED_PAIR;
+      } else {
+        plane_box(m, d, g1, g2, margin);
       }
       continue;
     }
@@ -744,7 +840,10 @@ static void collision(const sgo_model* m, sgo_data* d) {
     if (dot3(dif, dif) > bound * bound) continue; /* bounding spheres */
     if (t1 == SG_GEOM_SPHERE) sphere_box(m, d, g1, g2, p1, m->geom_size[3 * g1], margin);
     else if (t1 == SG_GEOM_CAPSULE) capsule_box(m, d, g1, g2, margin);
-    else if (box_box_overlap(m, d, g1, g2, margin)) d->warnings |= SGO_WARN_UNSUPPORTED_PAIR;
+    else {
+      int nb = box_box(m, d, g1, g2, margin);
+      if (nb > 0 && getenv("SGO_DEBUG_PAIR")) fprintf(stderr, "box-box %d %d: %d contacts t=%g\n", g1, g2, nb, d->time);
+    }
   }
 }
 

@@ -38,10 +38,11 @@ class ManEnv(Env):
     finger_names = ['g12', 'g2']
     obj_name = 'OBJ'
 
-    def __init__(self, sim_start, sim_step, env_paths, is_vis=True, n_envs=1, device=0, contact_flag_mode="intent"):
+    def __init__(self, sim_start, sim_step, env_paths, is_vis=True, n_envs=1, device=0, contact_flag_mode="intent", check_scene=True):
         super().__init__(sim_start, sim_step)
         assert len(env_paths) > 0
         assert contact_flag_mode in ("intent", "reference")
+        self.check_scene = check_scene
         self.is_vis = is_vis  # no viewer exists; kept for signature parity (render() is a no-op)
         self.env_paths = env_paths
         self.n_envs = int(n_envs)
@@ -71,6 +72,30 @@ class ManEnv(Env):
             self._finger_bits.append(sum(1 << b for b, gname in bits.items() if name in gname))
         self._finger_bits_names = list(self.finger_names)
         self._fingers_left = [list(self.finger_names) for _ in range(self.n_envs)]  # "reference" mode state
+        if self.check_scene:
+            self._check_scene(path)
+
+    def _check_scene(self, path, n_steps=40):
+        """Fail loudly at load time for a scene that cannot produce data: the idle phase of an episode (reset + 40 env steps at
+        ctrl = 0, the model's own stiffness) must run without a simulation warning.  The reference's soft ball / cylinder scenes
+        start with the shell 0.14 / 0.30 deep inside the fingers; under the restated physics that start throws the fingers
+        through their joint limits into each other within a few env steps, and every reset starts there again --
+        the reference's `except MujocoException: self.reset()` (manenv.py:50-51) would loop forever."""
+        import torch
+        flags = torch.zeros_like(self._flags)
+        bad = torch.zeros_like(self._flags)
+        self.env.reset(max(self.sim_start, 0), flags=flags)
+        bad |= flags
+        for _ in range(n_steps):
+            self.env.step(self.sim_step, flags=flags)
+            bad |= flags
+        if bool((bad != 0).any()):
+            names = {1: "BADQPOS", 2: "BADQVEL", 4: "BADQACC", 8: "CONTACTFULL", 16: "CNSTRFULL", 32: "UNSUPPORTED_PAIR"}
+            f = int(bad.max())
+            raise SimulationError("scene %s does not survive its own idle phase (flags %s within %d env steps at ctrl = 0): its start pose "
+                                  "is in deep penetration; no dataset can be generated from it (pass check_scene=False to load it anyway)"
+                                  % (path, "|".join(v for k, v in names.items() if f & k), n_steps))
+        self.env.reset(0, flags=flags)   # back to the state after mj_resetData
 
     def _chain_geom_bits(self):
         """bit index -> geom name for the moving finger boxes, in the kernels' (chain, box) order"""
@@ -240,7 +265,7 @@ class ManEnv(Env):
             "env_paths": args.mujoco_model_paths,
             "is_vis": args.vis,
         }
-        for extra in ("n_envs", "device", "contact_flag_mode"):
+        for extra in ("n_envs", "device", "contact_flag_mode", "check_scene"):
             if hasattr(args, extra):
                 spec[extra] = getattr(args, extra)
         return spec

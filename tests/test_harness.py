@@ -31,7 +31,8 @@ def fake_native(monkeypatch):
 
 def _args(tmp, n_envs=1):
     return types.SimpleNamespace(mujoco_model_paths=[model_path("softbox_fix")], sim_start=1, sim_step=7, vis=False, mask_contact=False,
-                                 data_folder=str(tmp), data_name="fx", n_envs=n_envs, device=0)
+                                 data_folder=str(tmp), data_name="fx", n_envs=n_envs, device=0,
+                                 check_scene=False)   # the load-time dry run (an extension) would add its steps to the call log
 
 
 def test_constants_and_class_attrs():
@@ -199,3 +200,22 @@ def test_reset_envs_returns_after_the_last_successful_retry(fake_native):
     tries["n"] = -100
     with pytest.raises(manenv.SimulationError):
         env._reset_envs(torch.tensor([True, False]))
+
+
+def test_scene_check_refuses_a_scene_that_flags_in_its_idle_phase(fake_native, monkeypatch):
+    """load-time dry run: reset + 40 idle env steps must raise no simulation warning, else ManEnv refuses the scene loudly"""
+    env = manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2)          # the fake never flags: loads
+    assert sum(1 for e in fake_native.log if e[0] == "reset") == 2                        # dry run, then back to the reset state
+    calls = {"n": 0}
+    orig = fake_native._advance
+
+    def failing(self, n, sens, flags, touch):
+        orig(self, n, sens, flags, touch)
+        calls["n"] += 1
+        if calls["n"] == 12 and flags is not None:
+            flags[1] = 32
+    monkeypatch.setattr(fake_native, "_advance", failing)
+    with pytest.raises(manenv.SimulationError, match="UNSUPPORTED_PAIR"):
+        manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2)
+    calls["n"] = 0
+    manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2, check_scene=False)

@@ -414,3 +414,84 @@ def test_two_link_arm_mass_matrix_coriolis_gravity_closed_form():
         G = np.array([(m1 * lc + m2 * l) * g * np.cos(q1) + m2 * lc * g * np.cos(q1 + q2), m2 * lc * g * np.cos(q1 + q2)])
         np.testing.assert_allclose(s.qfrc_bias, c + G, rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(s.qacc, -np.linalg.solve(M, c + G), rtol=1e-11, atol=1e-11)
+
+
+def _boxbox(q):
+    m = sg.compile_mjcf(os.path.join(ROOT, "tests", "data", "boxbox.xml"))
+    s = oracle_sim(m)
+    s.reset()
+    s.qpos[:] = q
+    s.forward()
+    names = m.geom_names
+    return m, s, [(names[c["geom1"]], names[c["geom2"]], c["dist"], c["pos"], c["frame"][:3]) for c in s.contacts()]
+
+
+def test_box_box_narrowphase_known_answers():
+    """tests/data/boxbox.xml: a brick (half sizes .2 .3 .4) above a static slab whose top face is z = 0.1.  Face-face: the brick's
+    bottom face (z = 1 + qz - 0.4) 0.02 inside the slab -> its four corners, each at depth 0.02, midway between the two faces, normal
+    from the slab (geom1) up into the brick.  Rotated by 45 degrees about z the same four corners (the face still lies inside the
+    slab's 1 x 1 top).  Shifted so that it overhangs the slab's edge, the incident face is clipped at x = 0.5.  Tilted about x, one
+    edge of the brick's bottom face is lowest: two contacts on it.  Edge-edge: the brick, rotated about z and x, crossing the slab's
+    rim with an edge -> one contact between the two closest edge points."""
+    # face-face, aligned: bottom at z = 0.08
+    m, s, cs = _boxbox([0, 0, -0.52, 0, 0])
+    assert len(cs) == 4 and all(c[0] == "slab" and c[1] == "brick" for c in cs)
+    for _, _, dist, pos, n in cs:
+        assert abs(dist + 0.02) < 1e-12 and abs(pos[2] - 0.09) < 1e-12 and np.allclose(n, [0, 0, 1], atol=1e-12)
+    assert sorted((round(c[3][0], 9), round(c[3][1], 9)) for c in cs) == [(-0.2, -0.3), (-0.2, 0.3), (0.2, -0.3), (0.2, 0.3)]
+    # rotated 45 degrees about z: same depth, corners rotated
+    m, s, cs = _boxbox([0, 0, -0.52, np.pi / 4, 0])
+    assert len(cs) == 4
+    want = sorted((round(x * np.cos(np.pi / 4) - y * np.sin(np.pi / 4), 9), round(x * np.sin(np.pi / 4) + y * np.cos(np.pi / 4), 9))
+                  for x in (-0.2, 0.2) for y in (-0.3, 0.3))
+    assert sorted((round(c[3][0], 9), round(c[3][1], 9)) for c in cs) == want and all(abs(c[2] + 0.02) < 1e-12 for c in cs)
+    # overhang: brick centre at x = 0.45 -> its face spans x in [0.25, 0.65], clipped by the slab's side plane x = 0.5
+    m, s, cs = _boxbox([0.45, 0, -0.52, 0, 0])
+    assert len(cs) == 4 and sorted(round(c[3][0], 9) for c in cs) == [0.25, 0.25, 0.5, 0.5] and all(abs(c[2] + 0.02) < 1e-12 for c in cs)
+    # tilted by 0.2 rad about x: the bottom edge at local y = -0.3 ... (y = +0.3 for positive rotation about x is raised) is lowest
+    a = 0.2
+    zc = 0.1 + 0.3 * np.sin(a) + 0.4 * np.cos(a) - 0.01          # lowest edge 0.01 inside the slab
+    m, s, cs = _boxbox([0, 0, zc - 1.0, 0, a])
+    low = [c for c in cs if abs(c[2] + 0.01) < 1e-9]
+    assert len(low) == 2 and all(np.allclose(c[4], [0, 0, 1], atol=1e-12) for c in cs)
+    assert sorted(round(c[3][0], 9) for c in low) == [-0.2, 0.2]
+    yl = -0.3 * np.cos(a) + 0.4 * np.sin(a)
+    assert all(abs(c[3][1] - yl) < 1e-9 for c in low)
+    # separated by more than the margin: nothing
+    m, s, cs = _boxbox([0, 0, -0.49, 0, 0])
+    assert cs == []
+    # edge-edge: yawed by psi and tilted by phi about its own x axis, the brick hangs over the slab's rim (the edge along y at x = 0.5,
+    # z = 0.1) and crosses it with one of its local-y edges: exactly one contact, normal perpendicular to both edges, i.e. along
+    # y x e with e = Rz(psi) Rx(phi) (0, 1, 0), pointing up and away from the slab
+    psi, phi = np.pi / 2 - 0.4, np.pi / 4
+    m, s, cs = _boxbox([0.7, 0, -0.5, psi, phi])
+    assert len(cs) == 1
+    _, _, dist, pos, n = cs[0]
+    e = np.array([-np.sin(psi) * np.cos(phi), np.cos(psi) * np.cos(phi), np.sin(phi)])
+    want = np.cross([0, 1, 0], e)
+    want /= np.linalg.norm(want)
+    assert dist < 0 and np.allclose(n, want, atol=1e-12) and n[0] > 0 and n[2] > 0
+    assert abs(pos[0] - 0.5) < abs(dist) and abs(pos[2] - 0.1) < abs(dist)          # midway between the two edges' closest points
+    # the same pose with the brick's edges parallel to the rim (psi = 90 degrees): no edge axis, the brick's face normal wins -> two contacts along the rim
+    m, s, cs = _boxbox([0.62, 0, -0.5, np.pi / 2, np.pi / 4])
+    assert len(cs) == 2 and all(np.allclose(c[4], [np.sqrt(0.5), 0, np.sqrt(0.5)], atol=1e-9) for c in cs)
+
+
+def test_plane_box_known_answers():
+    """the brick over the floor plane (z = -2): flat, its four bottom corners touch together (depth 0.03 each, midway positions, normal
+    +z, corner order x fastest); tilted, only the lowest corners within the margin"""
+    m, s, cs = _boxbox([2.0, 0, -2.57, 0, 0])                  # away from the slab; bottom face at z = -1.97 - ... = 1 - 2.57 - 0.4 = -1.97?  no: -2.03 + ... see below
+    cs = [c for c in cs if c[0] == "floor"]
+    zb = 1.0 - 2.57 - 0.4                                      # = -1.97: above the floor -> no contact
+    assert zb > -2.0 and cs == []
+    m, s, cs = _boxbox([2.0, 0, -2.63, 0, 0])                  # bottom at z = -2.03: 0.03 inside
+    cs = [c for c in cs if c[0] == "floor"]
+    assert len(cs) == 4 and all(c[1] == "brick" for c in cs)
+    assert [(round(c[3][0] - 2.0, 9), round(c[3][1], 9)) for c in cs] == [(-0.2, -0.3), (0.2, -0.3), (-0.2, 0.3), (0.2, 0.3)]
+    for _, _, dist, pos, n in cs:
+        assert abs(dist + 0.03) < 1e-12 and abs(pos[2] + 2.015) < 1e-12 and np.allclose(n, [0, 0, 1], atol=1e-12)
+    a = 0.3
+    zc = -2.0 + 0.3 * np.sin(a) + 0.4 * np.cos(a) - 0.02
+    m, s, cs = _boxbox([2.0, 0, zc - 1.0, 0, a])
+    cs = [c for c in cs if c[0] == "floor"]
+    assert len(cs) == 2 and all(abs(c[2] + 0.02) < 1e-9 for c in cs)
