@@ -3,7 +3,7 @@ for BASELINE.json configs[4]: it consumes the simulator's on-device ``[n, 200, 1
 
 Layer by layer: Conv1D(128,3,s2,SAME)+BN+ReLU, Conv1D(256,3,s2,SAME)+BN+ReLU, Conv1D(512,3,s2,SAME),
 GlobalAveragePooling1D, Dense 512/256/128 (+BN+ReLU each), Dense 64, Dense 1.  Keras defaults are mirrored:
-Glorot-uniform kernels, zero bias, BatchNorm momentum 0.99 (torch momentum 0.01) and eps 1e-3; TF's SAME padding for
+Glorot-uniform kernels, zero bias, BatchNorm momentum 0.99 and eps 1e-3 with Keras' update rule (KerasBatchNorm); TF's SAME padding for
 kernel 3 / stride 2 on an even length pads (0, 1).  Head: ``1100 * sigmoid(y) + 300`` (functions/optimization.py:17-19).
 Input normalisation ``(x - mean) / std`` over axes (0, 1) (functions/utils.py:40-41); noise augmentation sigma 0.7 on the
 accelerometer channels 0:6 and 0.06 on the gyro channels 6:12 (functions/optimization.py:6-14).
@@ -13,16 +13,44 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class KerasBatchNorm(nn.Module):
+    """tf.keras.layers.BatchNormalization with its defaults (net/layers.py:27,46: momentum 0.99, epsilon 1e-3, gamma 1, beta 0) over
+    the channel axis 1 of ``[B, C]`` or ``[B, C, T]``.  Training: normalise with the batch mean and the POPULATION variance and
+    move the statistics by ``moving = 0.99 moving + 0.01 batch`` -- the moving variance too takes the population variance
+    (torch.nn.BatchNorm1d feeds it the unbiased one: a 1 % difference at the reference's batch size 100 on the dense layers).
+    Inference: the moving statistics."""
+
+    def __init__(self, channels, momentum=0.99, eps=1e-3):
+        super().__init__()
+        self.momentum, self.eps = momentum, eps
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self.register_buffer("running_mean", torch.zeros(channels))
+        self.register_buffer("running_var", torch.ones(channels))
+
+    def forward(self, x):
+        dims = (0,) if x.dim() == 2 else (0, 2)
+        shape = (1, -1) if x.dim() == 2 else (1, -1, 1)
+        if self.training:
+            mean = x.mean(dim=dims)
+            var = x.var(dim=dims, unbiased=False)
+            with torch.no_grad():
+                self.running_mean.mul_(self.momentum).add_(mean.detach(), alpha=1 - self.momentum)
+                self.running_var.mul_(self.momentum).add_(var.detach(), alpha=1 - self.momentum)
+        else:
+            mean, var = self.running_mean, self.running_var
+        return (x - mean.view(shape)) * torch.rsqrt(var.view(shape) + self.eps) * self.weight.view(shape) + self.bias.view(shape)
+
+
 class ConvNet(nn.Module):
     def __init__(self, in_channels=12):
         super().__init__()
-        bn = dict(momentum=0.01, eps=1e-3)
-        self.conv1, self.bn1 = nn.Conv1d(in_channels, 128, 3, stride=2), nn.BatchNorm1d(128, **bn)
-        self.conv2, self.bn2 = nn.Conv1d(128, 256, 3, stride=2), nn.BatchNorm1d(256, **bn)
+        self.conv1, self.bn1 = nn.Conv1d(in_channels, 128, 3, stride=2), KerasBatchNorm(128)
+        self.conv2, self.bn2 = nn.Conv1d(128, 256, 3, stride=2), KerasBatchNorm(256)
         self.conv3 = nn.Conv1d(256, 512, 3, stride=2)
-        self.fc1, self.fbn1 = nn.Linear(512, 512), nn.BatchNorm1d(512, **bn)
-        self.fc2, self.fbn2 = nn.Linear(512, 256), nn.BatchNorm1d(256, **bn)
-        self.fc3, self.fbn3 = nn.Linear(256, 128), nn.BatchNorm1d(128, **bn)
+        self.fc1, self.fbn1 = nn.Linear(512, 512), KerasBatchNorm(512)
+        self.fc2, self.fbn2 = nn.Linear(512, 256), KerasBatchNorm(256)
+        self.fc3, self.fbn3 = nn.Linear(256, 128), KerasBatchNorm(128)
         self.fc4 = nn.Linear(128, 64)
         self.out = nn.Linear(64, 1)
         for m in self.modules():

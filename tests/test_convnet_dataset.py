@@ -63,3 +63,42 @@ def test_dataset_roundtrip_and_stats(tmp_path):
     assert tx.shape == (4, 200, 12) and vx.shape == (2, 200, 12) and mean.shape == (1, 1, 12)
     np.testing.assert_allclose(mean[0, 0], np.concatenate(data[:4]).mean(0), atol=1e-12)
     np.testing.assert_allclose(std[0, 0], np.concatenate(data[:4]).std(0), atol=1e-12)
+
+
+def test_conv1_bn_relu_hand_computed_train_and_eval():
+    """Pin of the first block (net/layers.py:24-29: Conv1D(k 3, s 2, SAME) -> BatchNormalization -> ReLU) against a computation by
+    hand in NumPy -- Keras outputs cannot be captured here (TensorFlow absent): 2 samples, 8 steps, 12 channels, float64.
+    Training mode: batch statistics over (batch, time) with the population variance; the moving statistics take one 0.99 / 0.01 step.
+    Inference mode: the moving statistics.  TF SAME on an even length pads one zero on the right."""
+    torch.manual_seed(3)
+    rng = np.random.RandomState(3)
+    net = cn.ConvNet().double()
+    x = rng.randn(2, 8, 12)
+    W = net.conv1.weight.detach().numpy()        # [128, 12, 3]
+    b = rng.randn(128) * 0.1
+    with torch.no_grad():
+        net.conv1.bias[:] = torch.tensor(b)
+    xp = np.concatenate([x, np.zeros((2, 1, 12))], axis=1)                       # SAME: (0, 1)
+    conv = np.zeros((2, 4, 128))
+    for n in range(2):
+        for t in range(4):
+            win = xp[n, 2 * t:2 * t + 3]                                          # [3, 12]: inputs 2t, 2t+1, 2t+2
+            conv[n, t] = np.einsum("kc,ock->o", win, W) + b
+    mean, var = conv.mean(axis=(0, 1)), conv.var(axis=(0, 1))                    # population variance
+    want_train = np.maximum((conv - mean) / np.sqrt(var + 1e-3), 0.0)
+
+    def block(xx):
+        h = net.conv1(cn.ConvNet._same(torch.tensor(xx).transpose(1, 2)))
+        return torch.relu(net.bn1(h)).transpose(1, 2).detach().numpy()
+    net.train()
+    np.testing.assert_allclose(block(x), want_train, atol=1e-12)
+    np.testing.assert_allclose(net.bn1.running_mean.numpy(), 0.01 * mean, atol=1e-14)
+    np.testing.assert_allclose(net.bn1.running_var.numpy(), 0.99 + 0.01 * var, atol=1e-14)
+    net.eval()
+    want_eval = np.maximum((conv - 0.01 * mean) / np.sqrt(0.99 + 0.01 * var + 1e-3), 0.0)
+    np.testing.assert_allclose(block(x), want_eval, atol=1e-12)
+    # dense block (layers.py:43-47): batch statistics over the batch axis only
+    bn = cn.KerasBatchNorm(5).double().train()
+    z = rng.randn(7, 5)
+    np.testing.assert_allclose(bn(torch.tensor(z)).detach().numpy(), (z - z.mean(0)) / np.sqrt(z.var(0) + 1e-3), atol=1e-12)
+    np.testing.assert_allclose(bn.running_var.numpy(), 0.99 + 0.01 * z.var(0), atol=1e-14)
