@@ -264,9 +264,12 @@ def main():
     # warm-up: W steps of the episode loop (kernels loaded, workspace touched); the timed region starts at a fresh reset
     for t in range(args.warmup):
         R.step(t)
-    if after_episode is not None:
-        after_episode(R)
-        reg["loss"].clear()
+    if after_episode is not None:  # warm the regressor's kernels on a throw-away copy (the episode block is not filled yet)
+        import copy
+        wnet = copy.deepcopy(net)
+        wx = torch.randn(n, T, R.nsd, dtype=torch.float64, device=dev)
+        convnet.train_step(wnet, torch.optim.Adam(wnet.parameters(), lr=1e-3), wx, y, *convnet.channel_stats(wx), add_noise=True)
+        del wnet, wx
     barrier()
     R.flags_or.zero_()
     dt, kernel_ms, launches, desc, nsteps = R.timed(args.steps, barrier, after_episode)
