@@ -75,6 +75,17 @@ SG_HD double sg_div(double a, double b) {
 #endif
 }
 
+// a / b for Newton corrections whose last bits do not matter (the next evaluation absorbs them): one Newton step on v_rcp_f64
+SG_HD double sg_div_fast(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  return a * r;
+#else
+  return a / b;
+#endif
+}
+
 // "some lane of the wavefront has x": a wavefront-uniform condition, so the guarded block is a real (scalar) branch that the
 // compiler cannot flatten into predicated code executed by everyone.  Host (lane-serial emulation): just x.
 SG_HD bool sg_any(bool x) {

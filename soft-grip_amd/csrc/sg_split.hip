@@ -189,20 +189,56 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
       ke[r] = a.kmask_jnt[e0 + e] ? kenv : EL(SGE_K0, e);
     }
   }
+  // the loads of FINISH (solver result, smooth acceleration and force of the previous substep) and the import of the chain
+  // hand-off record are issued here, together with the state: one memory latency instead of three in a row (the kernel waits for
+  // memory two thirds of its time, profiles/r02)
+  const bool fin = a.do_finish && W.pending[env];
+  double ase[R], asme_p[R], fsm_p[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int e = r * 64 + lane;
+    ase[r] = asme_p[r] = fsm_p[r] = 0;
+    if (fin && e < N) {
+      ase[r] = W.as[(size_t)env * N + e]; asme_p[r] = W.asme[(size_t)env * N + e];
+      if (a.finish_integrate) fsm_p[r] = W.fsm[(size_t)env * N + e];
+    }
+  }
+  if (a.do_begin && half < nchain) {  // the chain stage ran in sg_chain_kernel: import its hand-off record, the 32 lanes of a half sharing the loads
+    const double* ch = W.chh + ((size_t)env * 2 + half) * SG_CHW;
+    double* const kd = (double*)&Sm.K[half];
+    double* const box = &Sm.boxp[half * SG_CG][0];
+    double* const boxm = &Sm.boxm[half * SG_CG][0];
+    double* const lim = CS.lim_sign;  // lim_sign, lim_R, lim_b, lim_f are contiguous, as SGH_LIMSIGN .. SGH_LIMF are
+#pragma unroll
+    for (int j0 = 0; j0 < SG_CHW; j0 += 32) {
+      const int j = j0 + (lane & 31);
+      const double v = j < SG_CHW ? ch[j] : 0.0;
+      if (j >= SGH_QSM && j < SGH_QSM + SG_CD) CS.qacc_smooth[j - SGH_QSM] = v;
+      else if (j >= SGH_K && j < SGH_K + 48) kd[j - SGH_K] = v;
+      else if (j >= SGH_MINV && j < SGH_MINV + 16) CS.Minv[j - SGH_MINV] = v;
+      else if (j >= SGH_V && j < SGH_V + SG_CD) CS.v[j - SGH_V] = v;
+      else if (j >= SGH_W && j < SGH_W + SG_CD) CS.w[j - SGH_W] = v;
+      else if (j >= SGH_BOX && j < SGH_BOX + 12 * SG_CG) {
+        const int g = (j - SGH_BOX) / 12, k = (j - SGH_BOX) % 12;
+        if (k < 3) box[3 * g + k] = v; else boxm[9 * g + k - 3] = v;
+      }
+      else if (j == SGH_LIMACT) CS.lim_active = (int)v;
+      else if (j >= SGH_LIMSIGN && j < SGH_LIMSIGN + 4 * SG_MAXLIM) lim[j - SGH_LIMSIGN] = v;
+    }
+  }
   __syncthreads();
 
   SG_T(0);
   // =============================== FINISH the previous substep ===============================
-  if (a.do_finish && W.pending[env]) {
+  if (fin) {
     int badacc = 0;
-    double qacc_e[R], ase[R];
+    double qacc_e[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
       int e = r * 64 + lane;
-      qacc_e[r] = ase[r] = 0;
+      qacc_e[r] = 0;
       if (e < N) {
-        ase[r] = W.as[(size_t)env * N + e];
-        qacc_e[r] = W.asme[(size_t)env * N + e] + ase[r];
+        qacc_e[r] = asme_p[r] + ase[r];
         if (isbad(qacc_e[r])) badacc = 1;
       }
     }
@@ -216,7 +252,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         we[r] = qacc_e[r];
         if (e < N && a.finish_integrate) {
           double m = EL(SGE_MASS, e) + EL(SGE_ARMATURE, e);
-          double qa = (W.fsm[(size_t)env * N + e] + m * ase[r]) / (m + h * EL(SGE_DAMPING, e));
+          double qa = (fsm_p[r] + m * ase[r]) / (m + h * EL(SGE_DAMPING, e));
           ve[r] += h * qa;
           qe[r] += h * ve[r];
         }
@@ -236,32 +272,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
     if (__ballot(bad != 0)) {
       flags |= (__ballot(bad & 1) ? 1 : 0) | (__ballot(bad & 2) ? 2 : 0);
     } else {
-      // ---- chains ----
-      {  // the chain stage ran in sg_chain_kernel: import its hand-off record, the 32 lanes of a half sharing the loads
-        if (half < nchain) {
-          const double* ch = W.chh + ((size_t)env * 2 + half) * SG_CHW;
-          double* const kd = (double*)&Sm.K[half];
-          double* const box = &Sm.boxp[half * SG_CG][0];
-          double* const boxm = &Sm.boxm[half * SG_CG][0];
-          double* const lim = CS.lim_sign;  // lim_sign, lim_R, lim_b, lim_f are contiguous, as SGH_LIMSIGN .. SGH_LIMF are
-#pragma unroll
-          for (int j0 = 0; j0 < SG_CHW; j0 += 32) {
-            const int j = j0 + (lane & 31);
-            const double v = j < SG_CHW ? ch[j] : 0.0;
-            if (j >= SGH_QSM && j < SGH_QSM + SG_CD) CS.qacc_smooth[j - SGH_QSM] = v;
-            else if (j >= SGH_K && j < SGH_K + 48) kd[j - SGH_K] = v;
-            else if (j >= SGH_MINV && j < SGH_MINV + 16) CS.Minv[j - SGH_MINV] = v;
-            else if (j >= SGH_V && j < SGH_V + SG_CD) CS.v[j - SGH_V] = v;
-            else if (j >= SGH_W && j < SGH_W + SG_CD) CS.w[j - SGH_W] = v;
-            else if (j >= SGH_BOX && j < SGH_BOX + 12 * SG_CG) {
-              const int g = (j - SGH_BOX) / 12, k = (j - SGH_BOX) % 12;
-              if (k < 3) box[3 * g + k] = v; else boxm[9 * g + k - 3] = v;
-            }
-            else if (j == SGH_LIMACT) CS.lim_active = (int)v;
-            else if (j >= SGH_LIMSIGN && j < SGH_LIMSIGN + 4 * SG_MAXLIM) lim[j - SGH_LIMSIGN] = v;
-          }
-        }
-      }
+      // ---- chains: imported at the top of the kernel ----
       // ---- elements ----
       double invm[R], asme[R], coef[R];
       double L0p = 0, Ldp = 0;
@@ -1349,16 +1360,31 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
       }
       ssum = wave_sum2(ssum);
       if (lane == 0) { Lenv[e2] = ssum; Lenv[EPW + e2] = 0.0; }
-      for (int u = lane; u < 4 * (N + 1); u += 64) {  // row u = 4 e + d: d = 0 the fix row of e, d = 1 .. 3 its neighbour row in workspace slot (d - 1) N + e
-        const int e = u >> 2, d = u & 3;
+    }
+  }
+  if constexpr (NB) {
+    // equality records of all the wavefront's envs, lane = row: the loads of a row (one table word, three values per env) are
+    // independent of each other and of the other rows' -- they are issued together, not one memory round trip after the other
+    const double im0s = 1.0 / (a.elem[(size_t)SGE_MASS * N] + a.elem[(size_t)SGE_ARMATURE * N]);
+#pragma unroll 2
+    for (int u = lane; u < 4 * (N + 1); u += 64) {  // row u = 4 e + d: d = 0 the fix row of e, d = 1 .. 3 its neighbour row in workspace slot (d - 1) N + e
+      const int e = u >> 2, d = u & 3, ec = e < N ? e : 0;
+      const bool fix = d == 0;
+      const bool have = e < N && (fix || a.nbtab[(fix ? 0 : d - 1) * N + ec] >= 0);
+      double bb[EPW], Rr[EPW], ff[EPW];
+#pragma unroll
+      for (int e2 = 0; e2 < EPW; e2++) {
+        const int env2 = blockIdx.x * EPW + e2, envc = env2 < a.nenv ? env2 : 0;
+        const size_t o = fix ? (size_t)envc * N + ec : (size_t)envc * 3 * N + (size_t)(d - 1) * N + ec;
+        bb[e2] = (fix ? W.eqb : W.nbb)[o]; Rr[e2] = (fix ? W.eqR : W.nbR)[o]; ff[e2] = (fix ? W.eqf : W.nbf)[o];
+      }
+#pragma unroll
+      for (int e2 = 0; e2 < EPW; e2++) {
+        const int env2 = blockIdx.x * EPW + e2;
+        const bool v2 = env2 < a.nenv && W.pending[env2 < a.nenv ? env2 : 0] != 0;  // uniform
+        double2* const REC2 = (double2*)(lds + (size_t)EPW * NA + (size_t)e2 * RECW);
         double gg = 0.0, cc = 0.0;
-        if (v2 && e < N) {
-          const bool fix = d == 0;
-          const bool have = fix || a.nbtab[(fix ? 0 : d - 1) * N + e] >= 0;
-          const size_t o = fix ? (size_t)env2 * N + e : (size_t)env2 * 3 * N + (size_t)(d - 1) * N + e;
-          const double bb = (fix ? W.eqb : W.nbb)[o], Rr = (fix ? W.eqR : W.nbR)[o], ff = (fix ? W.eqf : W.nbf)[o];
-          if (have) { gg = bb + Rr * ff; cc = sg_div(im0, (fix ? im0 : 2.0 * im0) + Rr); }
-        }
+        if (v2 && have) { gg = bb[e2] + Rr[e2] * ff[e2]; cc = sg_div(im0s, (fix ? im0s : 2.0 * im0s) + Rr[e2]); }
         REC2[u] = make_double2(gg, cc);  // group e = rows 4 e .. 4 e + 3
       }
     }
@@ -1459,7 +1485,9 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           double* const pv = (double*)(Ab + (tt >> 16));
           const double V = *pv;
           const double cc = rec.y, mm = 1.0 - cc;
-          const double P = fma(V, km, Pfix), d = rec.x - P, nu = -(cc * d);
+          // nu = -c d = (c km) V + c (Pfix - g): one operation behind the slider read instead of three
+          const double nu = fma(cc * km, V, cc * (Pfix - rec.x));
+          const double P = fma(V, km, Pfix), d = rec.x - P;
           const double v0 = fma(V, mm, nu);                                   // lane 0: e1
           const double x1 = sg_dpp<0x90>(v0), v1 = fma(x1, mm, nu);           // quad_perm [0,0,1,2]: lane k gets lane k - 1; lane 1: e2
           const double x2 = sg_dpp<0x90>(v1), v2 = fma(x2, mm, nu);           // lane 2: e3
@@ -1660,7 +1688,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
               t1 = S12 * b2 - cc * b1; t2 = S12 * b1 - ca * b2;                    // -adj(S + la) b
               const double d2 = det * det, num = (t1 * t1 + t2 * t2) - r2 * d2;    // val det^2
               const double qf = (cc * t1 * t1 + ca * t2 * t2) - 2.0 * S12 * t1 * t2;  // w' adj w
-              const double delta = sg_div(num * det, 2.0 * qf);
+              const double delta = sg_div_fast(num * det, 2.0 * qf);  // a Newton step: its last bits are absorbed by the next evaluation
               const bool go = run && !(det < 1e-10 || num < 1e-10 * d2 || delta < 1e-10);
               la = go ? la + delta : la;
               run = go;
