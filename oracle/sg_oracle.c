@@ -1096,6 +1096,7 @@ static void rne_bias(const sgo_model* m, sgo_data* d) {
 
 /* ------------------------------------------------------------------ PGS (mj_solPGS) */
 long long sgo_dbg_counters[8];
+long long sgo_dbg_qcqp_hist[24]; /* debug: calls of qcqp2 by the number of Newton evaluations they ran (index 21: singular, 22: ran out of its 20) */
 static int qcqp2(double* res, const double* Ain, const double* bin, const double* dd, double r) {
   double b1 = bin[0] * dd[0], b2 = bin[1] * dd[1];
   double A11 = Ain[0] * dd[0] * dd[0], A22 = Ain[3] * dd[1] * dd[1], A12 = Ain[1] * dd[0] * dd[1];
@@ -1104,14 +1105,15 @@ static int qcqp2(double* res, const double* Ain, const double* bin, const double
   for (int it = 0; it < 20; it++) {
     sgo_dbg_counters[1]++;
     double det = (A11 + la) * (A22 + la) - A12 * A12;
-    if (det < 1e-10) { res[0] = res[1] = 0; return 0; }
+    if (det < 1e-10) { res[0] = res[1] = 0; sgo_dbg_qcqp_hist[21]++; return 0; }
     double di = 1 / det, P11 = (A22 + la) * di, P22 = (A11 + la) * di, P12 = -A12 * di;
     v1 = -P11 * b1 - P12 * b2; v2 = -P12 * b1 - P22 * b2;
     double val = v1 * v1 + v2 * v2 - r * r;
-    if (val < 1e-10) break;
+    if (val < 1e-10) { sgo_dbg_qcqp_hist[it + 1]++; break; }
     double deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2), delta = -val / deriv;
-    if (delta < 1e-10) break;
+    if (delta < 1e-10) { sgo_dbg_qcqp_hist[it + 1]++; break; }
     la += delta;
+    if (it == 19) sgo_dbg_qcqp_hist[22]++;
   }
   res[0] = v1 * dd[0]; res[1] = v2 * dd[1];
   return la != 0;
