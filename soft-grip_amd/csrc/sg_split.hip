@@ -104,9 +104,9 @@ struct Smem2 {
   double boxp[SG_MAXCH * SG_CG][3], boxm[SG_MAXCH * SG_CG][9];
   double ve[R * 64], asme[R * 64], we[R * 64], as[R * 64];
   StageRec2 stage[SG_MAXCH][32 * CPL];
-  int owner[R * 64];                                  // bit c set: chain c has a contact on this element's slider
+  unsigned char owner[SG_MAXCH][R * 64];              // [c][e] != 0: chain c has a contact on this element's slider (plain stores of 1)
   unsigned short pairs[SG_MAXCH * SG_CG * (R * 64 + 2)];  // broadphase survivors, (box << 12) | element, in contact order
-  unsigned short eslot[R * 64][SG_MAXCH * SG_CG];         // per element and box: first contact slot | (contact count << 8)
+  unsigned char eslot[R * 64][SG_MAXCH * SG_CG];          // per element and box: first contact slot (< 64) | (contact count << 6)
   double cval[SG_MAXCH][32 * CPL];                        // per contact slot: invm * Js' f (its push on the slider)
   double nbf[NB ? 3 * R * 64 : 1];                        // neighbour equality rows: warmstart force, by row id
 };
@@ -303,8 +303,8 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             cpos[r][0] = EL(SGE_GX, e) + ax[0] * dq; cpos[r][1] = EL(SGE_GY, e) + ax[1] * dq; cpos[r][2] = EL(SGE_GZ, e) + ax[2] * dq;
             if (!(qe[r] > EL(SGE_QLO, e) && qe[r] < EL(SGE_QHI, e))) unsupported = 1;
             Sm.ve[e] = ve[r]; Sm.asme[e] = asme[r]; Sm.we[e] = we[r];
-            Sm.owner[e] = 0;
-            *(unsigned long long*)&Sm.eslot[e][0] = 0ull;
+            Sm.owner[0][e] = 0; Sm.owner[1][e] = 0;
+            *(unsigned int*)&Sm.eslot[e][0] = 0u;
             Sm.as[e] = qe[r];  // scratch until recompute_a: the dense narrowphase below reads other lanes' slider positions
           }
         }
@@ -402,12 +402,13 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             }
             if (mine && n > 0 && !is_center) {
               const int room = 32 * CPL - base, nst = n < room ? n : (room > 0 ? room : 0);
-              Sm.eslot[e][b] = (unsigned short)(base | (nst << 8));
+              static_assert(32 * CPL <= 64, "a contact slot index must fit 6 bits");
+              Sm.eslot[e][b] = nst ? (unsigned char)(base | (nst << 6)) : (unsigned char)0;
             }
             nsc[cc] += __popcll(m1) + __popcll(m2);
             if (nsc[cc] > 32 * CPL) { nsc[cc] = 32 * CPL; overflow = 1; }
           }
-          if (n > 0 && !is_center) atomicOr(&Sm.owner[e], 1 << c);
+          if (n > 0 && !is_center) Sm.owner[c][e] = 1;
 #pragma unroll
           for (int bb = 0; bb < SG_MAXCH * SG_CG; bb++)
             if (__ballot(n > 0 && b == bb)) touch |= 1 << bb;
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 #pragma unroll
       for (int r = 0; r < R; r++) {
         int e = r * 64 + lane;
-        if (e < N && Sm.owner[e] == 3) shared_slider = 1;
+        if (e < N && Sm.owner[0][e] && Sm.owner[1][e]) shared_slider = 1;
       }
       shared_slider = __ballot(shared_slider) != 0;
 
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             double as_ = invm[r] * fe;
 #pragma unroll
             for (int cb = 0; cb < SG_MAXCH * SG_CG; cb++) {
-              const int u = Sm.eslot[e][cb], i0 = u & 0xFF, nst = u >> 8;
+              const int u = Sm.eslot[e][cb], i0 = u & 0x3F, nst = u >> 6;
               if (nst >= 1) as_ += Sm.cval[cb / SG_CG][i0];
               if (nst >= 2) as_ += Sm.cval[cb / SG_CG][i0 + 1];
             }
