@@ -150,6 +150,7 @@ class Runner:
         torch, T, b = self.torch, self.T, self.batch
         b.profile_enable(False)
         b.profile_read(reset=True)
+        b.profile_read_solver(reset=True)
         if steps % T == 0:
             barrier()
             b.profile_enable(True)
@@ -181,6 +182,7 @@ class Runner:
                     "each timed on its own between device syncs; the other steps run untimed" % (len(pick), ",".join(map(str, sorted(pick)))))
             steps = len(pick)
         kernel_ms, launches = b.profile_read(reset=True)
+        self.solver_ms, self.solver_launches = b.profile_read_solver(reset=True)
         b.profile_enable(False)
         return dt, kernel_ms, launches, desc, steps
 
@@ -306,6 +308,15 @@ def main():
                                  "the path is instruction-issue-bound (serial Gauss-Seidel per finger), not HBM-bound; traffic is mostly contact blocks "
                                  "re-read from L2/Infinity Cache by each sweep (DESIGN.md 4.3)"},
         }
+        if R.solver_launches:
+            # the dominant kernel on its own: its average launch (HIP events around every launch of it in the timed steps; the committed
+            # rocprofv3 --stats summary's AverageNs for the same kernel agrees) against the algorithmic bytes of one substep of one call
+            sub = abytes * n / R.sim_step
+            res["roofline"]["dominant_kernel"] = {
+                "name": "sg_pgs_rows_kernel (one launch per physics substep)", "avg_launch_ms": R.solver_ms, "launches_timed": R.solver_launches,
+                "algorithmic_bytes_per_launch": sub, "achieved": sub / (R.solver_ms * 1e-3) / 1e9, "unit": "GB/s",
+                "frac": sub / (R.solver_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "share_of_call_time": R.sim_step * R.solver_ms / kernel_ms if kernel_ms else None}
         if reg is not None:
             res["config"]["regressor_loss_first_last"] = [float(reg["loss"][0]), float(reg["loss"][-1])] if reg["loss"] else None
         # Episode-average counters of this very workload from committed rocprofv3 PMC passes (profiles/<tag>_<scene>_*.json).  They

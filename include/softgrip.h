@@ -117,6 +117,9 @@ int sg_set_pipeline(sg_batch* b, int pipeline);
  * stream.  Synchronises the host. */
 int sg_profile_enable(sg_batch* b, int enable);
 int sg_profile_read(sg_batch* b, int reset, double* avg_ms, long long* launches);
+/* the same for the dominant kernel alone: average device time (ms) of one solver-kernel launch (sg_pgs_rows_kernel / sg_pgs_kernel;
+ * one per substep) over the calls since the last reset; the split and rows pipelines only (0 launches otherwise) */
+int sg_profile_read_solver(sg_batch* b, int reset, double* avg_ms, long long* launches);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,9 @@ struct sg_batch {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   double prof_ms;
   long long prof_n;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pgs;  // around every solver-kernel launch (the dominant kernel)
+  double prof_pgs_ms;
+  long long prof_pgs_n;
 };
 
 extern "C" {
@@ -107,6 +110,7 @@ void sg_batch_destroy(sg_batch* b) {
   for (void* p : b->wbufs)
     if (p) (void)hipFree(p);
   for (auto& e : b->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : b->ev_pgs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete b;
 }
 
@@ -117,7 +121,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   if (device < 0 || device >= ndev) return fail(SG_ERR_NO_DEVICE, "sg_batch_create: device index out of range");
   HIPCHK(hipSetDevice(device));
   sg_batch* b = new sg_batch();
-  b->m = m; b->n = n_envs; b->device = device; b->lds_attr_set = false; b->prof = false; b->prof_ms = 0; b->prof_n = 0;
+  b->m = m; b->n = n_envs; b->device = device; b->lds_attr_set = false; b->prof = false; b->prof_ms = 0; b->prof_n = 0; b->prof_pgs_ms = 0; b->prof_pgs_n = 0;
   b->dnbtab = nullptr; b->dsched = nullptr;
   b->dH = nullptr; b->delem = b->qpos = b->qvel = b->warm = b->act = b->ctrl = b->kenv = b->ctrl_row = nullptr;
   b->kmask_jnt = b->kmask_ten = b->flags = b->touch = b->ncon = b->nefc = b->iters = nullptr;
@@ -318,6 +322,8 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     phase(p);
     HIPCHK(hipGetLastError());
     if (k < nfwd) {
+      hipEvent_t p0 = nullptr, p1 = nullptr;
+      if (b->prof) { HIPCHK(hipEventCreate(&p0)); HIPCHK(hipEventCreate(&p1)); HIPCHK(hipEventRecord(p0, s)); }
       if (b->pipeline == 2) {
         const dim3 grid((b->n + epw - 1) / epw);
 #define SG_ROWS1(v, nb, e) hipLaunchKernelGGL((sg_pgs_rows_kernel<v, nb, e>), grid, dim3(64), lds_rows, s, ga)
@@ -336,6 +342,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
       }
       else hipLaunchKernelGGL(sg_pgs_kernel, dim3((b->n + SG_EPW - 1) / SG_EPW), dim3(64), lds, s, ga);
       HIPCHK(hipGetLastError());
+      if (b->prof) { HIPCHK(hipEventRecord(p1, s)); b->ev_pgs.emplace_back(p0, p1); }
     }
   }
   if (b->prof) {
@@ -455,6 +462,23 @@ int sg_debug_sections(sg_batch* b, unsigned long long* out32) {
 int sg_profile_enable(sg_batch* b, int enable) {
   if (!b) return fail(SG_ERR_INVALID, "sg_profile_enable: bad argument");
   b->prof = enable != 0;
+  return SG_OK;
+}
+
+int sg_profile_read_solver(sg_batch* b, int reset, double* avg_ms, long long* launches) {
+  if (!b) return fail(SG_ERR_INVALID, "sg_profile_read_solver: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  for (auto& e : b->ev_pgs) {
+    HIPCHK(hipEventSynchronize(e.second));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+    b->prof_pgs_ms += ms; b->prof_pgs_n++;
+    (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+  }
+  b->ev_pgs.clear();
+  if (avg_ms) *avg_ms = b->prof_pgs_n ? b->prof_pgs_ms / b->prof_pgs_n : 0.0;
+  if (launches) *launches = b->prof_pgs_n;
+  if (reset) { b->prof_pgs_ms = 0; b->prof_pgs_n = 0; }
   return SG_OK;
 }
 

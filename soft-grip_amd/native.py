@@ -17,7 +17,7 @@ SYMBOLS = [
     "sg_last_error", "sg_version", "sg_model_create", "sg_model_destroy", "sg_model_nq", "sg_model_nu",
     "sg_model_nsensordata", "sg_model_ntendon", "sg_model_nelem", "sg_batch_create", "sg_batch_destroy",
     "sg_batch_nenvs", "sg_batch_device", "sg_set_stiffness", "sg_set_ctrl", "sg_reset", "sg_step", "sg_get_state",
-    "sg_set_state", "sg_get_solver_stats", "sg_set_pipeline", "sg_profile_enable", "sg_profile_read",
+    "sg_set_state", "sg_get_solver_stats", "sg_set_pipeline", "sg_profile_enable", "sg_profile_read", "sg_profile_read_solver",
 ]
 
 
@@ -61,6 +61,7 @@ def lib():
     L.sg_set_pipeline.argtypes = [vp, C.c_int]
     L.sg_profile_enable.argtypes = [vp, C.c_int]
     L.sg_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    L.sg_profile_read_solver.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     _LIB = L
     return L
 
@@ -165,4 +166,9 @@ class NativeBatch:
     def profile_read(self, reset=True):
         ms, n = C.c_double(), C.c_longlong()
         check(lib().sg_profile_read(self.ptr, int(reset), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def profile_read_solver(self, reset=True):
+        ms, n = C.c_double(), C.c_longlong()
+        check(lib().sg_profile_read_solver(self.ptr, int(reset), C.byref(ms), C.byref(n)))
         return ms.value, n.value

@@ -54,3 +54,6 @@ class FakeBatch:
 
     def profile_read(self, reset=True):
         return 0.0, 0
+
+    def profile_read_solver(self, reset=True):
+        return 0.0, 0
