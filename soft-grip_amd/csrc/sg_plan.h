@@ -24,7 +24,7 @@
 #define SG_CG 2     // box geoms per chain
 #define SG_CS 2     // sensor sites per chain
 #define SG_MAXSTATIC 8
-#define SG_EQ_SLOTS 4   // blocks per round of the equality schedule: one per lane quad of an env's 16-lane group in the solver
+#define SG_EQ_SLOTS 8   // blocks per round of the equality schedule: one per lane pair of an env's 16-lane group in the solver
 
 struct SgChain {
   int nbody, ndof, ngeom, nsite, dof0, pad0[3];

@@ -1267,7 +1267,7 @@ __device__ __forceinline__ double sg_gsum16(double x) {
 // so the final "fresh M^-1 J' f" pass only concerns the finger chains.
 // LDS of sg_pgs_rows_kernel in doubles (kernel and host use the same expressions): EPW envs per wavefront
 #define SG_ROWS_LDS_FIX(EPW, NR) ((size_t)(5 * (EPW) + 2) * (NR) + 72)
-#define SG_ROWS_LDS_NB(EPW, NA, N, ROUNDS) ((size_t)(EPW) * (NA) + (size_t)8 * (EPW) * ((N) + 1) + (size_t)8 * ((ROUNDS) + 4) + 72 + 2 * (EPW))  // table: 16 lanes x 4 B per round
+#define SG_ROWS_LDS_NB(EPW, NA, N, ROUNDS) ((size_t)(EPW) * (NA) + (size_t)8 * (EPW) * ((N) + 1) + (size_t)16 * ((ROUNDS) + 4) + 72 + 2 * (EPW))  // table: 16 lanes x 8 B per round
 // EPW: envs per wavefront, 8 lanes each: 8 fills the wavefront (16 finger streams advance per instruction); 4 leaves lanes 32 .. 63 idle
 // but spreads a batch of 4096 envs over 1024 wavefronts -- one per SIMD of the whole chip instead of half of it -- and a wavefront
 // then runs the QCQP fallback (entered when ANY of its streams slides, for as many Newton evaluations as its slowest stream needs)
@@ -1308,12 +1308,12 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   // NB layout: Ae[NA] per env: slider accelerations MINUS the env's offset aoff (below); word N is a zero word ("no partner").
   // REC per env: group e = the four rows of element e's block -- its fix row, then its up to three neighbour rows -- each
   // (g, c) with g = b + R f, c = (1/m) / (A + R); rows that do not exist and group N (idle slots) hold (0, 0).  TAB (shared by the
-  // wavefront's envs): the plan's block schedule as LDS byte offsets per lane of a 16-lane group: lane 4 q + k holds
-  // (e | v << 16) of quad q's block e, v = e for k = 0 (the fix row's own slider), the k-th neighbour row's partner for k > 0.
+  // wavefront's envs): the plan's block schedule as LDS byte offsets per lane of a 16-lane group: lane 2 b + h holds, for the block e
+  // in slot b of the round, (x | y << 16, record offset) with (x, y) = (e, p0) for h = 0 and (p1, p2) for h = 1.
   double* const Ae = lds + (size_t)lec * NA;
   double2* const REC = (double2*)(lds + (size_t)EPW * NA + (size_t)lec * RECW);
   unsigned* const TAB = (unsigned*)(lds + (size_t)EPW * NA + (size_t)EPW * RECW);
-  double* const Lnb = lds + (size_t)EPW * NA + (size_t)EPW * RECW + (size_t)8 * (H.eq_rounds + 4);  // [72 + 2 EPW]
+  double* const Lnb = lds + (size_t)EPW * NA + (size_t)EPW * RECW + (size_t)16 * (H.eq_rounds + 4);  // [72 + 2 EPW]
   double* Lzero = NB ? Lnb : lds + (size_t)(5 * EPW + 2) * NR;  // [0]: a word that stays 0 (reads of "no slider"), [1 + lane]: write sink
   double* const Lenv = Lnb + 72;  // NB: [e2] sum of the env's slider accelerations at the start, [EPW + e2] its final offset aoff
   double* const ASb = NB ? Ae : (double*)AF;  // slider acceleration of element j: ASb[ASS * j]
@@ -1390,11 +1390,12 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
       }
     }
   }
-  if constexpr (NB) {  // the schedule (plus four idle rounds for the look-ahead) as LDS byte offsets
+  if constexpr (NB) {  // the schedule (plus four idle rounds for the look-ahead) as LDS byte offsets: lane 2 b + h of a group, block slot b
     for (int i = lane; i < 16 * (H.eq_rounds + 4); i += 64) {
-      const SgEqSlot sl = a.sched[i >> 2];  // slot (round, quad)
-      const int k = i & 3;
-      TAB[i] = (unsigned)(8 * sl.e) | ((unsigned)(8 * (k == 0 ? sl.e : sl.p[k - 1])) << 16);
+      const SgEqSlot sl = a.sched[i >> 1];  // slot (round, pair)
+      const int h = i & 1;
+      const unsigned x = h ? sl.p[1] : sl.e, y = h ? sl.p[2] : sl.p[0];
+      ((uint2*)TAB)[i] = make_uint2((8u * x) | ((8u * y) << 16), 64u * (unsigned)sl.e + 32u * (unsigned)h);
     }
   }
   const bool sv = valid && g < 8;  // lanes of the env's two finger quads
@@ -1463,67 +1464,71 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
       // The sweep is bound by LDS round trips (profiles/r02: ~290 cycles per dependent round), so what counts is their number:
       // 24 block rounds for softbox instead of 53 row rounds, and none for the tendon row.
       if (running) {
-        // One block per QUAD and round: lane k of the quad holds row k of the block (k = 0 the fix row, k = 1 .. 3 the neighbour
-        // rows) -- its state g_k, its step factor c_k = (1/m) / (A + R) and its partner's acceleration P_k (k = 0: the constant
-        // -aoff, a "partner" that is never pushed).  With d_k = g_k - P_k the block's sequential sweep over slider e's acceleration is
-        //   e_{k+1} = e_k (1 - c_k) - c_k d_k,   k = 0 .. 3,   e_0 = a_e:
-        // four dependent multiply-adds handed from lane to lane by DPP; residual s_k = d_k + e_k, push w_k = c_k s_k on the partner,
-        // new state g_k' = P_k' - e_{k+1} are one instruction each for the four rows.  Per round and lane: one table word, one
-        // slider word and one record read, one slider word and one state written.
+        // One block per lane PAIR and round: lane h = 0 holds rows 0, 1 of the block (the fix row and the first neighbour row), lane
+        // h = 1 rows 2, 3 -- per row its state g_k, its step factor c_k = (1/m) / (A + R) and its partner's acceleration P_k (row 0: the
+        // constant -aoff, a "partner" that is never pushed).  With d_k = g_k - P_k the block's sequential sweep over slider e's
+        // acceleration is   e_{k+1} = e_k (1 - c_k) - c_k d_k,   k = 0 .. 3,   e_0 = a_e:
+        // two dependent multiply-adds on lane 0, one DPP hand-over, two on lane 1; each row's residual s_k = d_k + e_k, push
+        // w_k = c_k s_k on its partner and new state g_k' = P_k' - e_{k+1} follow.  A wavefront alone on its SIMD issues one
+        // instruction per ~7 cycles whatever it is, so rounds x instructions per round is the cost: 24 x ~47 here; one row per lane
+        // (a quad per block) was 32 x 48, a block per lane 24 x 80.
         char* const Ab = (char*)Ae;
-        char* const Rbk = (char*)REC + 16 * r;  // my row's record inside a group
-        const unsigned* tp = TAB + g;
-        const double km = r == 0 ? 0.0 : 1.0, k0 = 1.0 - km, k1 = r == 1 ? 1.0 : 0.0, k2 = r == 2 ? 1.0 : 0.0, k3 = r == 3 ? 1.0 : 0.0;
-        const double Pfix = k0 * -aoff;  // P_0 = -aoff on lane 0, 0 elsewhere (added to km * V)
+        char* const Rb = (char*)REC;
+        const uint2* tp = (const uint2*)TAB + g;
+        const int hh = g & 1;
+        const double hm = hh ? 1.0 : 0.0, h0 = 1.0 - hm;
+        const double Pfix = h0 * -aoff;  // row 0's "partner" -aoff on lane 0 (added to hm * X)
         double qc = 0.0, sc = 0.0;
 #ifdef SG_KO_EQ  // knock-out builds (scripts/phase_time.py): timing only, results are wrong
         const int nrounds = 0;
 #else
         const int nrounds = H.eq_rounds;
 #endif
-        struct Pend { double* p; double g; };
-        auto round = [&](const unsigned tt, const double2 rec, Pend& out) {
-          double* const pv = (double*)(Ab + (tt >> 16));
-          const double V = *pv;
-          const double cc = rec.y, mm = 1.0 - cc;
-          // nu = -c d = (c km) V + c (Pfix - g): one operation behind the slider read instead of three
-          const double nu = fma(cc * km, V, cc * (Pfix - rec.x));
-          const double P = fma(V, km, Pfix), d = rec.x - P;
-          const double v0 = fma(V, mm, nu);                                   // lane 0: e1
-          const double x1 = sg_dpp<0x90>(v0), v1 = fma(x1, mm, nu);           // quad_perm [0,0,1,2]: lane k gets lane k - 1; lane 1: e2
-          const double x2 = sg_dpp<0x90>(v1), v2 = fma(x2, mm, nu);           // lane 2: e3
-          const double x3 = sg_dpp<0x90>(v2), v3 = fma(x3, mm, nu);           // lane 3: e4
-          const double ein = (V * k0 + x1 * k1) + (x2 * k2 + x3 * k3);        // my row's e_k: exact (one term, the others are zeros)
-          const double eout = fma(ein, mm, nu);
-          const double sres = d + ein, w = cc * sres, Pn = fma(w, km, P);
-          const double e4 = sg_qb<3>(v3);
-          *pv = r == 0 ? e4 : Pn;                                             // lane 0 stores the block's result a_e' = e4, the others their partner
-          qc += sres * w;
-          sc += w * k0;
-          out.p = (double*)(Rbk + 8 * (tt & 0xffffu));
-          out.g = Pn - eout;
+        struct Pend { double2* p; double ga, gb; };
+        struct Rec { double2 a, b; };  // (g, c) of my two rows
+        auto ld_rec = [&](const uint2 tt) { const double2* p = (const double2*)(Rb + (tt.y & 0xffffu)); Rec rc; rc.a = p[0]; rc.b = p[1]; return rc; };
+        auto round = [&](const uint2 tt, const Rec rc, Pend& out) {
+          double* const px = (double*)(Ab + (tt.x & 0xffffu));   // lane 0: slider e itself; lane 1: partner of row 2
+          double* const py = (double*)(Ab + (tt.x >> 16));       // partner of row 1 / row 3
+          const double X = *px, Y = *py;
+          const double cA = rc.a.y, cB = rc.b.y, mA = 1.0 - cA, mB = 1.0 - cB;
+          const double PA = fma(X, hm, Pfix), dA = rc.a.x - PA, dB = rc.b.x - Y;
+          // nu = -c d, written so that it is ONE operation behind the slider reads: (c hm) X + c (Pfix - g) and c Y - c g
+          const double nuA = fma(cA * hm, X, cA * (Pfix - rc.a.x)), nuB = fma(cB, Y, -(cB * rc.b.x));
+          const double e2 = fma(fma(X, mA, nuA), mB, nuB);       // lane 0: e after rows 0, 1
+          const double T = sg_dpp<0xB1>(e2);                     // quad_perm [1,0,3,2]: the pair's other lane
+          const double I = hh ? T : X;                           // my first row's e_k
+          const double O1 = fma(I, mA, nuA), O2 = fma(O1, mB, nuB);
+          const double sA = dA + I, sB = dB + O1, wA = cA * sA, wB = cB * sB;
+          const double PAn = fma(wA, hm, PA), Yn = Y + wB;
+          const double e4 = sg_dpp<0xB1>(O2);                    // lane 0 receives the block's result from lane 1
+          *px = hh ? PAn : e4;
+          *py = Yn;
+          qc += sA * wA + sB * wB;
+          sc += wA * h0;
+          out.p = (double2*)(Rb + (tt.y & 0xffffu));
+          out.ga = PAn - O1; out.gb = Yn - O2;
         };
-        auto ld_rec = [&](const unsigned tt) { return *(const double2*)(Rbk + 8 * (tt & 0xffffu)); };
         // two rounds per trip; table words are fetched two rounds ahead, records one round ahead (no row of a round writes the
-        // records of another block), and a round's new states are written after the NEXT round has issued its slider read
-        unsigned tA = tp[0], tB = tp[16];
-        double2 rA = ld_rec(tA), rB;
+        // records of another block), and a round's new states are written after the NEXT round has issued its slider reads
+        uint2 tA = tp[0], tB = tp[16];
+        Rec rA = ld_rec(tA), rB;
         Pend pend;
-        pend.p = (double*)(Rbk + 64 * N); pend.g = 0.0;  // first "pending" store: zero into the idle group
+        pend.p = (double2*)(Rb + 64 * N); pend.ga = pend.gb = 0.0;  // first "pending" store: zeros into the idle group
         for (int k = 0; k < nrounds; k += 2) {  // an odd count runs one idle round (the table ends with four)
           tp += 32;
-          const unsigned tC = tp[0], tD = tp[16];
+          const uint2 tC = tp[0], tD = tp[16];
           Pend pa, pb;
           rB = ld_rec(tB);
           round(tA, rA, pa);
-          *pend.p = pend.g;
+          pend.p[0].x = pend.ga; pend.p[1].x = pend.gb;
           rA = ld_rec(tC);
           round(tB, rB, pb);
-          *pa.p = pa.g;
+          pa.p[0].x = pa.ga; pa.p[1].x = pa.gb;
           pend = pb;
           tA = tC; tB = tD;
         }
-        *pend.p = pend.g;
+        pend.p[0].x = pend.ga; pend.p[1].x = pend.gb;
         imp_acc += 0.5 * qc * (1.0 / im0);
         dS -= sc;
       }
