@@ -1260,11 +1260,11 @@ __device__ __forceinline__ double sg_gsum16(double x) {
 
 // NB = true: the model has neighbour equality rows (slider e = slider e2).  The joint-fix rows are then no longer mutually
 // independent, and the equality block of a sweep -- MuJoCo's order [fix_0, nb_0.., fix_1, nb_1.., ...] -- runs as the plan's
-// list schedule (SgEqSlot): H.eq_rounds rounds, one row per lane of the env's group and round, rows of a round share no
-// slider and every row comes after the rows it depends on, so the rounds in order ARE the sequential sweep.  Per row the LDS
-// holds g = b + R f (instead of f), R and 1 / (A + R); the update is res = g + a1 - a2, t = res / (A + R), a1 -= t / m1,
-// a2 += t / m2, g -= R t.  The slider accelerations are kept incrementally (every update is applied to them as it happens),
-// so the final "fresh M^-1 J' f" pass only concerns the finger chains.
+// list schedule of BLOCKS (SgEqSlot: element e's fix row and its neighbour rows): H.eq_rounds rounds, one block per lane pair
+// of the env's 16-lane group and round; the blocks of a round share no slider and every block comes after the blocks it
+// depends on, so the rounds in order ARE the sequential sweep (details at the equality block below).  The slider
+// accelerations are kept incrementally (every update is applied to them as it happens), so there is no closing
+// "fresh M^-1 J' f" pass.
 // LDS of sg_pgs_rows_kernel in doubles (kernel and host use the same expressions): EPW envs per wavefront
 #define SG_ROWS_LDS_FIX(EPW, NR) ((size_t)(5 * (EPW) + 2) * (NR) + 72)
 #define SG_ROWS_LDS_NB(EPW, NA, N, ROUNDS) ((size_t)(EPW) * (NA) + (size_t)8 * (EPW) * ((N) + 1) + (size_t)16 * ((ROUNDS) + 4) + 72 + 2 * (EPW))  // table: 16 lanes x 8 B per round
@@ -1450,7 +1450,8 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   for (int it = 0; it < max_iter; it++) {
     if (!__ballot(running)) break;
     SG_T(10);
-    double imp_acc = 0, tJap = 0;
+    double imp_acc = 0;
+    [[maybe_unused]] double tJap = 0;
     if constexpr (NB) {
       // Equality block as the plan's block schedule: H.eq_rounds rounds, one BLOCK per lane of the env's group -- element e's fix
       // row and its up to three neighbour rows, in MuJoCo's order, with slider e's acceleration carried in a register.  A row's
@@ -1461,8 +1462,8 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
       //    instead of a pass over all sliders; neighbour rows see differences of sliders (offset-free), fix rows and contacts add it;
       //  * the tendon row's J a = sum of the slider accelerations is TRACKED (Ssum): a neighbour row leaves it unchanged, a fix row
       //    changes it by -t / m, a contact by its push on its slider, the tendon row by sum(1/m) dft -- no pass over the sliders.
-      // The sweep is bound by LDS round trips (profiles/r02: ~290 cycles per dependent round), so what counts is their number:
-      // 24 block rounds for softbox instead of 53 row rounds, and none for the tendon row.
+      // What counts is rounds x (instructions per round x ~7 cycles + one LDS round trip): 24 block rounds for softbox instead of
+      // 53 row rounds, and no pass for the tendon row.
       if (running) {
         // One block per lane PAIR and round: lane h = 0 holds rows 0, 1 of the block (the fix row and the first neighbour row), lane
         // h = 1 rows 2, 3 -- per row its state g_k, its step factor c_k = (1/m) / (A + R) and its partner's acceleration P_k (row 0: the
