@@ -529,3 +529,35 @@ def test_ball_and_cylinder_scenes_are_refused_at_load(scene):
     for _ in range(70):
         w |= s.step()
     assert w != 0
+
+
+def test_default_scene_far_outside_the_paper_range_reseated():
+    """the default model (neighbour rows; the solver tracks the tendon row's sum and offset instead of recomputing them) at k = 1, 10 and
+    1e4, through reset, idle phase, contact onset and the first 40 steps of the squeeze: per-step parity along the oracle's trajectory
+    (re-seated after every env step, as in test_softbox_episode_matches_oracle), contact and sweep counts exactly"""
+    import torch
+    ks = [1.0, 10.0, 1e4]
+    m, nm, b = _gpu_batch("softbox", ks)
+    sens, flags, touch = _bufs(b, len(ks))
+    sims = [oracle_sim(m, k) for k in ks]
+    for s in sims:
+        s.reset(); s.forward(); s.step()
+    b.reset(1, sens=sens, flags=flags, touch=touch)
+    ctrl = np.zeros(2)
+    T = lambda a: torch.tensor(np.stack(a), dtype=torch.float64, device=b.device).contiguous()  # noqa: E731
+    for t, c in enumerate(episode_schedule()[:80]):
+        if c is not None:
+            ctrl[:] = c
+            b.set_ctrl_broadcast(ctrl)
+            for s in sims:
+                s.ctrl[:] = c
+        b.step(7, sens=sens, flags=flags, touch=touch)
+        for s in sims:
+            for _ in range(7):
+                assert s.step() == 0
+        assert np.abs(sens.cpu().numpy() - np.stack([s.sensordata for s in sims])).max() < TOL_SENSOR, t
+        assert int(flags.abs().sum()) == 0
+        st = b.solver_stats()
+        assert st["ncon"].cpu().tolist() == [s.ncon for s in sims] and st["iters"].cpu().tolist() == [s.solver_iter for s in sims]
+        b.set_state(qpos=T([s.qpos for s in sims]), qvel=T([s.qvel for s in sims]), act=T([s.act for s in sims]),
+                    qacc_warmstart=T([s.qacc_warmstart for s in sims]))
