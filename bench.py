@@ -106,13 +106,16 @@ def self_launch(args, argv):
 class Runner:
     """one batch + its episode block; runs schedule steps and keeps the flags"""
 
-    def __init__(self, scene, n, local, rank, world):
+    def __init__(self, scene, n, local, rank, world, damper=None):
         import torch
         import softgrip_amd as sg
         from softgrip_amd import native
         from softgrip_amd.create_dataset import episode_schedule, stiffness_bin
         self.torch = torch
-        self.model = sg.load_model(os.path.join(ROOT, "models", scene + ".sgmodel"))
+        if damper is None:   # what ManEnv's tendon_damper="auto" ends up with: the ball / cylinder scenes only run with the implicit damper (DESIGN.md D5)
+            damper = "explicit" if scene.startswith("softbox") else "implicit"
+        self.damper = damper
+        self.model = sg.load_model(os.path.join(ROOT, "models", scene + ".sgmodel"), damper)
         self.nm = native.NativeModel(self.model)
         self.n = n
         self.batch = native.NativeBatch(self.nm, n, local)
@@ -194,6 +197,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--scene", default="softbox", help="softbox (default: MuJoCo's documented composite) | softbox_fix | softball | softcylinder ...")
+    ap.add_argument("--tendon-damper", default=None, choices=["explicit", "implicit"],
+                    help="integration of the composite volume tendon's damper (DESIGN.md D5); default: explicit (MuJoCo's Euler) for softbox, implicit for the ball / cylinder scenes, which do not run otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fix-variant", action="store_true", help="skip the labelled secondary measurement on the fix-rows-only model")
     ap.add_argument("--with-regressor", action="store_true", help="BASELINE configs[4]: ConvNet forward + one Adam step on every finished [n,200,12] block, inside the timed region (needs --steps a multiple of 200)")
@@ -244,7 +249,8 @@ def main():
             dist.barrier()
             device_sync()
 
-    R = Runner(args.scene, args.envs, local, rank, world)
+    R = Runner(args.scene, args.envs, local, rank, world, args.tendon_damper)
+    damper = R.damper
     n, T, nm, model = R.n, R.T, R.nm, R.model
     dev = R.batch.device
 
@@ -293,9 +299,9 @@ def main():
             "ms_per_step": dt / nsteps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic" if not args.fake_native_for_tests else "FAKE native batch (plumbing test, not a measurement)",
             "config": {"workload": "configs[%d]: %d envs/GPU, %s scene (nv=%d), stiffness ~ U(300,1400)%s, reference 200-step squeeze "
-                                   "schedule from reset, 7 substeps per env step; %d equality rows (composite neighbour equalities %s: DESIGN.md 2, U2)%s" % (
+                                   "schedule from reset, 7 substeps per env step; %d equality rows (composite neighbour equalities %s: DESIGN.md 2, U2)" % (
                                        4 if args.with_regressor else (3 if world > 1 else 2), n, args.scene, nm.nq,
-                                       " split in per-rank bins" if world > 1 else "", model.neq, "on" if nb_on else "off",
+                                       " split in per-rank bins" if world > 1 else "", model.neq, "on" if nb_on else "off") + ("; volume tendon damper integrated %sly" % damper) + (
                                        "; + ConvNet regressor: channel stats, noise augmentation, forward and one Adam step on every finished [n,200,12] block, on device, inside the timed region" if args.with_regressor else ""),
                        "envs_per_gpu": n, "substeps_per_step": R.sim_step, "physics_substeps_per_s": value * R.sim_step,
                        "envs_flagged_bad": nbad, "launches_timed": launches, "steps_timed": nsteps, "timed_region": desc},
@@ -345,7 +351,7 @@ def main():
             # labelled secondary: the same workload on the fix-rows-only model (composite_neighbors=False)
             del R
             torch.cuda.empty_cache()
-            R2 = Runner(args.scene + "_fix", n, local, rank, world)
+            R2 = Runner(args.scene + "_fix", n, local, rank, world, damper)
             for t in range(args.warmup):
                 R2.step(t)
             barrier()

@@ -68,6 +68,7 @@ struct sgo_model {
   int npair;
   int* pair; /* npair x 2 candidate geom pairs in MuJoCo's body-pair order */
   int dof_damping_any;
+  int implicit_tendon_damping; /* model flag opt_i[3] (0 when the blob has only three): see sgo_step */
 };
 
 struct sgo_data {
@@ -79,7 +80,7 @@ struct sgo_data {
   double *qM, *qLD;
   double *bw, *bv, *bal, *ba; /* per body: ang vel, lin vel of origin, ang acc, lin acc of origin */
   double *qfrc_passive, *qfrc_bias, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qfrc_constraint, *qacc;
-  double *act_dot, *actuator_force, *sensordata, *tmpv, *tmpv2;
+  double *act_dot, *actuator_force, *sensordata, *tmpv, *tmpv2, *tmpv3;
   contact_t* contact;
   int ncon;
   /* constraints */
@@ -188,6 +189,7 @@ sgo_model* sgo_model_load(const void* blob, size_t nbytes, char* err, size_t err
   if (!od || !oi) { snprintf(err, errlen, "blob lacks opt"); goto fail; }
   m->timestep = od[0]; memcpy(m->gravity, od + 1, 24); m->tolerance = od[4]; m->impratio = od[5]; m->meaninertia = od[6];
   m->iterations = oi[0]; m->nconmax = oi[1]; m->njmax = oi[2];
+  m->implicit_tendon_damping = cnt > 3 ? oi[3] : 0;
   GETF(body_pos); m->nbody = (int)(cnt / 3);
   GETF(body_quat); GETF(body_ipos); GETF(body_imat); GETF(body_mass); GETF(body_invweight0);
   GETF(jnt_pos); m->nv = (int)(cnt / 3);
@@ -302,7 +304,7 @@ sgo_data* sgo_data_new(const sgo_model* m) {
   d->qM = dalloc((size_t)nv * nv); d->qLD = dalloc((size_t)nv * nv);
   d->bw = dalloc(3 * nb); d->bv = dalloc(3 * nb); d->bal = dalloc(3 * nb); d->ba = dalloc(3 * nb);
   d->qfrc_passive = dalloc(nv); d->qfrc_bias = dalloc(nv); d->qfrc_actuator = dalloc(nv); d->qfrc_smooth = dalloc(nv);
-  d->qacc_smooth = dalloc(nv); d->qfrc_constraint = dalloc(nv); d->qacc = dalloc(nv); d->tmpv = dalloc(nv); d->tmpv2 = dalloc(nv);
+  d->qacc_smooth = dalloc(nv); d->qfrc_constraint = dalloc(nv); d->qacc = dalloc(nv); d->tmpv = dalloc(nv); d->tmpv2 = dalloc(nv); d->tmpv3 = dalloc(nv);
   d->act_dot = dalloc(m->nu); d->actuator_force = dalloc(m->nu); d->sensordata = dalloc(3 * m->nsensor);
   d->contact = (contact_t*)calloc(MAXCON, sizeof(contact_t));
   d->dofrow_adr = ialloc(nv + 1);
@@ -316,7 +318,7 @@ void sgo_data_free(sgo_data* d) {
   double* ds[] = {d->qpos, d->qvel, d->act, d->ctrl, d->qacc_warmstart, d->jnt_stiffness, d->tendon_stiffness, d->xpos, d->xquat,
                   d->xmat, d->xipos, d->ximat, d->xanchor, d->xaxis, d->geom_xpos, d->geom_xmat, d->site_xpos, d->site_xmat,
                   d->ten_length, d->ten_J, d->ten_velocity, d->qM, d->qLD, d->bw, d->bv, d->bal, d->ba, d->qfrc_passive,
-                  d->qfrc_bias, d->qfrc_actuator, d->qfrc_smooth, d->qacc_smooth, d->qfrc_constraint, d->qacc, d->tmpv, d->tmpv2,
+                  d->qfrc_bias, d->qfrc_actuator, d->qfrc_smooth, d->qacc_smooth, d->qfrc_constraint, d->qacc, d->tmpv, d->tmpv2, d->tmpv3,
                   d->act_dot, d->actuator_force, d->sensordata, d->J_val, d->efc_pos, d->efc_margin, d->efc_diagApprox, d->efc_R,
                   d->efc_D, d->efc_KBIP, d->efc_vel, d->efc_aref, d->efc_b, d->efc_force, d->efc_jar, d->AR};
   for (size_t i = 0; i < sizeof ds / sizeof ds[0]; i++) free(ds[i]);
@@ -1338,7 +1340,7 @@ int sgo_step(const sgo_model* m, sgo_data* d) {
     if (isbad(d->qacc[i])) d->warnings |= SGO_WARN_BADQACC;
   if (d->warnings & SGO_WARN_BADQACC) return d->warnings;
   double* qacc = d->qacc;
-  if (m->dof_damping_any) { /* (M + h*diag(damping)) qacc' = qfrc_smooth + qfrc_constraint */
+  if (m->dof_damping_any || m->implicit_tendon_damping) { /* (M + h*diag(damping)) qacc' = qfrc_smooth + qfrc_constraint */
     double* MhB = d->qLD; /* qLD is recomputed at the next forward */
     memcpy(MhB, d->qM, sizeof(double) * (size_t)nv * nv);
     for (int i = 0; i < nv; i++) MhB[(size_t)i * nv + i] += h * m->dof_damping[i];
@@ -1346,6 +1348,22 @@ int sgo_step(const sgo_model* m, sgo_data* d) {
     for (int i = 0; i < nv; i++) d->tmpv2[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
     solve_ld(m, MhB, d->tmpv2);
     qacc = d->tmpv2;
+    if (m->implicit_tendon_damping) {
+      /* EXTENSION (not MuJoCo's Euler; model flag): the damper of a FIXED tendon (constant J) joins the implicit
+       * term, (M + h B + h c J'J) qacc' = f, by Sherman-Morrison on the solve above -- one tendon after the other (exact for one,
+       * which is all the composites have) */
+      for (int t = 0; t < m->ntendon; t++) {
+        if (m->wrap_type[m->tendon_adr[t]] != SG_WRAP_JOINT || !(m->tendon_damping[t] > 0)) continue;
+        const double *J = d->ten_J + (size_t)t * nv, c = m->tendon_damping[t];
+        double* y = d->tmpv3;
+        memcpy(y, J, sizeof(double) * nv);
+        solve_ld(m, MhB, y);
+        double Jy = 0, Jx = 0;
+        for (int i = 0; i < nv; i++) { Jy += J[i] * y[i]; Jx += J[i] * qacc[i]; }
+        const double k = h * c * Jx / (1 + h * c * Jy);
+        for (int i = 0; i < nv; i++) qacc[i] -= k * y[i];
+      }
+    }
   }
   for (int u = 0; u < m->nu; u++) d->act[u] += h * d->act_dot[u];
   for (int i = 0; i < nv; i++) d->qvel[i] += h * qacc[i];

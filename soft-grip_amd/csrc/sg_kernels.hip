@@ -645,13 +645,28 @@ __global__ __launch_bounds__(64, 2) void sg_step_kernel(SgKArgs a) {
 #pragma unroll
     for (int r = 0; r < R; r++) we[r] = qacc_e[r];
     if (!integrate) continue;
+    double qa_e[R], yc[R], Sp = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int e = r * 64 + lane;
+      qa_e[r] = yc[r] = 0;
+      if (e < N) {
+        double m = 1.0 / invm[r];
+        double den = m + h * EL(SGE_DAMPING, e);
+        qa_e[r] = (fsm[r] + m * S.as[e]) / den;
+        if (H.t0_implicit) { yc[r] = coef[r] / den; Sp += coef[r] * qa_e[r]; }
+      }
+    }
+    if (H.t0_implicit) {  // deviation D5, as in sg_phase_kernel's FINISH
+      const double kk = h * H.t0_damping * wave_sum(Sp) / (1.0 + H.t0_hcT);
+#pragma unroll
+      for (int r = 0; r < R; r++) qa_e[r] -= yc[r] * kk;
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
       int e = r * 64 + lane;
       if (e < N) {
-        double m = 1.0 / invm[r];
-        double qa = (fsm[r] + m * S.as[e]) / (m + h * EL(SGE_DAMPING, e));
-        ve[r] += h * qa;
+        ve[r] += h * qa_e[r];
         qe[r] += h * ve[r];
       }
     }

@@ -74,6 +74,7 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
   long long cnt = 0;
   NEEDF(opt_d, "opt_d");
   NEEDI(opt_i, "opt_i");
+  const long long n_opt_i = cnt;
   NEEDF(body_pos, "body_pos");
   const int nbody = (int)(cnt / 3);
   NEEDF(body_quat, "body_quat"); NEEDF(body_ipos, "body_ipos"); NEEDF(body_imat, "body_imat"); NEEDF(body_mass, "body_mass");
@@ -297,6 +298,15 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
     }
   }
   if (H.t0_id < 0) FAIL("model has no fixed tendon over the elements");
+  H.t0_implicit = n_opt_i > 3 && opt_i[3] != 0;
+  H.t0_hcT = 0;
+  if (H.t0_implicit) {
+    for (int c = 0; c < H.nchain; c++)
+      if (H.chain[c].has_ten && H.chain[c].ten_damping != 0) FAIL("implicit tendon damping covers the elements' fixed tendon only: a finger tendon has a damper");
+    double T = 0;
+    for (int e = 0; e < nelem; e++) T += E(SGE_COEF, e) * E(SGE_COEF, e) / (E(SGE_MASS, e) + E(SGE_ARMATURE, e) + H.timestep * E(SGE_DAMPING, e));
+    H.t0_hcT = H.timestep * H.t0_damping * T;
+  }
 
   // ---- equality rows: [joint-fix of element e, then its neighbour rows (e -> e')] for e in order, [tendon-fix] ----
   auto kb = [&](const double* sr, const double* si, double* K, double* Bd) {

@@ -72,7 +72,9 @@ struct SgPlanHeader {
   double eqj_K, eqj_B, eqj_solimp[5];            // joint-fix equality rows
   double eqt_K, eqt_B, eqt_solimp[5], eqt_invw;  // tendon-fix equality row
   double t0_k0, t0_damping, t0_lspring, t0_L0;   // the fixed tendon's own spring/damper
-  int t0_id, pad2;
+  int t0_id;
+  int t0_implicit;   // model flag opt_i[3]: FINISH integrates the fixed tendon's damper implicitly (Sherman-Morrison)
+  double t0_hcT;     // h c sum_e coef_e^2 / (m_e + armature_e + h d_e), the rank-one term's denominator is 1 + t0_hcT
   // contact parameters (identical for every candidate pair, checked at build)
   double con_K, con_B, con_solimp[5], con_mu[2], con_margin;
   // static geoms

@@ -246,14 +246,32 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
     if (anybadacc) {
       status |= SG_FLAG_BADQACC;
     } else {
+      double qa[R], yc[R];  // yc = coef / (m + h d): the tendon's column of (M + h B)^-1 J'
+      double Sp = 0;
 #pragma unroll
       for (int r = 0; r < R; r++) {
         int e = r * 64 + lane;
         we[r] = qacc_e[r];
+        qa[r] = yc[r] = 0;
         if (e < N && a.finish_integrate) {
           double m = EL(SGE_MASS, e) + EL(SGE_ARMATURE, e);
-          double qa = (fsm_p[r] + m * ase[r]) / (m + h * EL(SGE_DAMPING, e));
-          ve[r] += h * qa;
+          double den = m + h * EL(SGE_DAMPING, e);
+          qa[r] = (fsm_p[r] + m * ase[r]) / den;
+          if (H.t0_implicit) { const double cf = EL(SGE_COEF, e); yc[r] = cf / den; Sp += cf * qa[r]; }
+        }
+      }
+      if (H.t0_implicit && a.finish_integrate) {
+        // deviation D5: (M + h B + h c J'J) qacc = f by Sherman-Morrison, qacc = x - y (h c J x) / (1 + h c J y), x = (M + h B)^-1 f,
+        // y = (M + h B)^-1 J' (the sliders' block of M is diagonal, J is zero on the fingers); oracle sgo_step
+        const double kk = h * H.t0_damping * wave_sum2(Sp) / (1.0 + H.t0_hcT);
+#pragma unroll
+        for (int r = 0; r < R; r++) qa[r] -= yc[r] * kk;
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        int e = r * 64 + lane;
+        if (e < N && a.finish_integrate) {
+          ve[r] += h * qa[r];
           qe[r] += h * ve[r];
         }
       }

@@ -38,10 +38,17 @@ class ManEnv(Env):
     finger_names = ['g12', 'g2']
     obj_name = 'OBJ'
 
-    def __init__(self, sim_start, sim_step, env_paths, is_vis=True, n_envs=1, device=0, contact_flag_mode="intent", check_scene=True):
+    def __init__(self, sim_start, sim_step, env_paths, is_vis=True, n_envs=1, device=0, contact_flag_mode="intent", check_scene=True,
+                 tendon_damper="auto"):
+        """``tendon_damper``: how the damper of the composite's volume tendon is integrated (mjcf.load_model).
+        "explicit" = MuJoCo's Euler step as restated; "implicit" = the rank-one implicit treatment; "auto" (default) = explicit,
+        and a scene that fails the load-time check under it (the reference's soft ball / cylinder) is reloaded with "implicit",
+        with a printed notice.  ``self.tendon_damper`` holds what the loaded scene runs with."""
         super().__init__(sim_start, sim_step)
         assert len(env_paths) > 0
         assert contact_flag_mode in ("intent", "reference")
+        assert tendon_damper in ("auto", "explicit", "implicit")
+        self._tendon_damper_arg = tendon_damper
         self.check_scene = check_scene
         self.is_vis = is_vis  # no viewer exists; kept for signature parity (render() is a no-op)
         self.env_paths = env_paths
@@ -53,9 +60,11 @@ class ManEnv(Env):
         self.is_closing = True
 
     # ---- model / batch management (reference manenv.py:27-41) ----
-    def _load(self, path):
+    def _load(self, path, _damper=None):
         import torch
-        self.model = load_model(path)
+        want = _damper or self._tendon_damper_arg
+        self.model = load_model(path, None if want == "auto" else want)
+        self.tendon_damper = "implicit" if self.model.opt_implicit_tendon_damping else "explicit"
         self.nmodel = native.NativeModel(self.model)
         self.env = native.NativeBatch(self.nmodel, self.n_envs, self.device_index)
         dev = self.env.device
@@ -73,14 +82,21 @@ class ManEnv(Env):
         self._finger_bits_names = list(self.finger_names)
         self._fingers_left = [list(self.finger_names) for _ in range(self.n_envs)]  # "reference" mode state
         if self.check_scene:
-            self._check_scene(path)
+            try:
+                self._check_scene(path)
+            except SimulationError as err:
+                if want != "auto" or self.tendon_damper == "implicit":
+                    raise
+                print("NOTICE: %s\n        reloading it with tendon_damper=\"implicit\" (DESIGN.md D5)" % err)
+                self._load(path, "implicit")
 
     def _check_scene(self, path, n_steps=40):
         """Fail loudly at load time for a scene that cannot produce data: the idle phase of an episode (reset + 40 env steps at
         ctrl = 0, the model's own stiffness) must run without a simulation warning.  The reference's soft ball / cylinder scenes
-        start with the shell 0.14 / 0.30 deep inside the fingers; under the restated physics that start throws the fingers
-        through their joint limits into each other within a few env steps, and every reset starts there again --
-        the reference's `except MujocoException: self.reset()` (manenv.py:50-51) would loop forever."""
+        start with the shell 0.14 / 0.30 deep inside the fingers (45 / 37 contacts at reset); with the volume tendon's damper
+        integrated explicitly that start diverges within a few env steps (profiles/r02_ball_stability_probe.txt),
+        and every reset starts there again -- the reference's `except MujocoException: self.reset()` (manenv.py:50-51) would
+        loop forever."""
         import torch
         flags = torch.zeros_like(self._flags)
         bad = torch.zeros_like(self._flags)
@@ -92,9 +108,9 @@ class ManEnv(Env):
         if bool((bad != 0).any()):
             names = {1: "BADQPOS", 2: "BADQVEL", 4: "BADQACC", 8: "CONTACTFULL", 16: "CNSTRFULL", 32: "UNSUPPORTED_PAIR"}
             f = int(bad.max())
-            raise SimulationError("scene %s does not survive its own idle phase (flags %s within %d env steps at ctrl = 0): its start pose "
-                                  "is in deep penetration; no dataset can be generated from it (pass check_scene=False to load it anyway)"
-                                  % (path, "|".join(v for k, v in names.items() if f & k), n_steps))
+            raise SimulationError("scene %s does not survive its own idle phase with the %s tendon damper (flags %s within %d env steps "
+                                  "at ctrl = 0); no dataset can be generated from it this way (check_scene=False loads it anyway)"
+                                  % (path, self.tendon_damper, "|".join(v for k, v in names.items() if f & k), n_steps))
         self.env.reset(0, flags=flags)   # back to the state after mj_resetData
 
     def _chain_geom_bits(self):
@@ -265,7 +281,7 @@ class ManEnv(Env):
             "env_paths": args.mujoco_model_paths,
             "is_vis": args.vis,
         }
-        for extra in ("n_envs", "device", "contact_flag_mode", "check_scene"):
+        for extra in ("n_envs", "device", "contact_flag_mode", "check_scene", "tendon_damper"):
             if hasattr(args, extra):
                 spec[extra] = getattr(args, extra)
         return spec

@@ -527,6 +527,7 @@ class _Compiler:
         m.opt_iterations = self.opt["iterations"]
         m.opt_tolerance = self.opt["tolerance"]
         m.opt_impratio = self.opt["impratio"]
+        m.opt_implicit_tendon_damping = 0   # DESIGN.md D5; load_model(..., tendon_damper="implicit") sets it
         m.nconmax = self.size["nconmax"]
         m.njmax = self.size["njmax"]
 
@@ -911,7 +912,8 @@ class Model:
 
         opt_d = np.array([self.opt_timestep, *self.opt_gravity, self.opt_tolerance, self.opt_impratio,
                           self.meaninertia], dtype=np.float64)
-        opt_i = np.array([self.opt_iterations, self.nconmax, self.njmax], dtype=np.int32)
+        opt_i = np.array([self.opt_iterations, self.nconmax, self.njmax, int(getattr(self, "opt_implicit_tendon_damping", 0))],
+                         dtype=np.int32)
         add("opt_d", opt_d, 1)
         add("opt_i", opt_i, 2)
         for f in self._FIELDS_F64:
@@ -942,7 +944,8 @@ class Model:
             setattr(m, name, arr)
         o = m.opt_d
         m.opt_timestep, m.opt_gravity, m.opt_tolerance, m.opt_impratio, m.meaninertia = o[0], o[1:4], o[4], o[5], o[6]
-        m.opt_iterations, m.nconmax, m.njmax = (int(x) for x in m.opt_i)
+        m.opt_iterations, m.nconmax, m.njmax = (int(x) for x in m.opt_i[:3])
+        m.opt_implicit_tendon_damping = int(m.opt_i[3]) if len(m.opt_i) > 3 else 0
         shp = dict(body_pos=3, body_quat=4, body_ipos=3, body_imat=9, body_invweight0=2, jnt_pos=3, jnt_axis=3,
                    jnt_range=2, jnt_solref=2, jnt_solimp=5, geom_size=3, geom_pos=3, geom_quat=4, geom_friction=3,
                    geom_solref=2, geom_solimp=5, site_pos=3, site_quat=4, eq_solref=2, eq_solimp=5, eq_data=5,
@@ -983,9 +986,21 @@ def compile_mjcf(path: str, composite_neighbors: bool = True) -> Model:
     return _Compiler(path, composite_neighbors).run()
 
 
-def load_model(path: str) -> Model:
-    """Load either an MJCF ``.xml`` (compiled here) or a precompiled ``.sgmodel`` blob."""
+def load_model(path: str, tendon_damper: str = None) -> Model:
+    """Load either an MJCF ``.xml`` (compiled here) or a precompiled ``.sgmodel`` blob.
+
+    ``tendon_damper``: ``None`` keeps what the file says (an ``.xml`` compiles to "explicit"); "explicit" is MuJoCo's
+    semi-implicit Euler as restated (the damper of a tendon is a passive force evaluated at the old velocity, only joint
+    damping enters M + h B: engine_forward.c mj_Euler); "implicit" also integrates the damper of the composite's fixed volume
+    tendon implicitly, qacc = (M + h B + h c J'J)^-1 f (deviation D5 of DESIGN.md: the reference's soft ball / cylinder scenes
+    start in deep penetration and the explicit damper, c h sum_e 1/(m_e + h d_e) = 215 >> 2, diverges on them)."""
     if path.endswith(".xml"):
-        return compile_mjcf(path)
-    with open(path, "rb") as f:
-        return Model.from_blob(f.read())
+        m = compile_mjcf(path)
+    else:
+        with open(path, "rb") as f:
+            m = Model.from_blob(f.read())
+    if tendon_damper is not None:
+        if tendon_damper not in ("explicit", "implicit"):
+            raise ValueError("tendon_damper must be 'explicit' or 'implicit'")
+        m.opt_implicit_tendon_damping = int(tendon_damper == "implicit")
+    return m

@@ -395,9 +395,19 @@ int emu_substep(Emu* E, int integrate) {
     E->act[c] += h * D[c].act_dot;
     for (int d = 0; d < C.ndof; d++) { E->vc[c][d] += h * qa[d]; E->qc[c][d] += h * E->vc[c][d]; }
   }
+  double kk = 0;
+  if (H.t0_implicit) {  // deviation D5 (sg_split.hip FINISH)
+    double Ssum = 0;
+    for (int e = 0; e < N; e++) {
+      double m = 1.0 / invm[e];
+      Ssum += EL(SGE_COEF, e) * (fsm[e] + m * ae[e]) / (m + h * EL(SGE_DAMPING, e));
+    }
+    kk = h * H.t0_damping * Ssum / (1.0 + H.t0_hcT);
+  }
   for (int e = 0; e < N; e++) {
     double m = 1.0 / invm[e];
-    double qa = (fsm[e] + m * ae[e]) / (m + h * EL(SGE_DAMPING, e));
+    double den = m + h * EL(SGE_DAMPING, e);
+    double qa = (fsm[e] + m * ae[e]) / den - (H.t0_implicit ? EL(SGE_COEF, e) / den * kk : 0.0);
     E->ve[e] += h * qa;
     E->qe[e] += h * E->ve[e];
   }

@@ -11,11 +11,11 @@ pytestmark = pytest.mark.gpu
 TOL_SENSOR = 1e-7   # abs, fp64 path; north_star allows 1e-4 against MuJoCo-CPU
 
 
-def _gpu_batch(scene, ks, pipeline=None):
+def _gpu_batch(scene, ks, pipeline=None, damper=None):
     import torch
     from softgrip_amd import native
     assert torch.cuda.is_available(), "GPU tests need a GPU"
-    m = sg.load_model(model_path(scene))
+    m = sg.load_model(model_path(scene), damper)
     nm = native.NativeModel(m)
     b = native.NativeBatch(nm, len(ks), 0)
     if pipeline is not None:
@@ -74,21 +74,31 @@ def _reference_flag(m, contacts, fingers_left, obj_name="OBJ"):
 FREE_RUN_STEPS = 47  # env steps over which the neighbour-row scene is also compared free-running (contact starts at ~45; the error grows 10x every 5 steps from there: 1e-10 at 47, 7e-10 at 50, 3e-8 at 60)
 
 
-@pytest.mark.parametrize("scene,pipeline", [("softbox_fix", "rows"), ("softbox_fix", "split"), ("softbox_fix", "fused"), ("softbox", "rows")])
-def test_softbox_episode_matches_oracle(scene, pipeline):
+@pytest.mark.parametrize("scene,pipeline,damper", [
+    ("softbox_fix", "rows", None), ("softbox_fix", "split", None), ("softbox_fix", "fused", None), ("softbox", "rows", None),
+    ("softbox_fix", "rows", "implicit"), ("softbox", "rows", "implicit"),
+    ("softball_fix", "rows", "implicit"), ("softball_fix", "fused", "implicit"), ("softcylinder_fix", "rows", "implicit"),
+    ("softcylinder_fix", "split", "implicit"), ("softball", "rows", "implicit"), ("softcylinder", "rows", "implicit")])
+def test_episode_matches_oracle(scene, pipeline, damper):
     """every kernel pipeline against the oracle over the whole reference episode, 9 envs so that the PGS kernel runs a full
-    and a partial wavefront.  softbox = the scene as compiled by default (all three pipelines); softbox_nb = the same scene with
-    the composite's neighbour equalities switched on (rows pipeline only).
+    and a partial wavefront (3 envs for the larger ball / cylinder scenes).  softbox = the scene as compiled by default, with the
+    composite's neighbour equalities (rows pipeline only); *_fix = the fix-rows-only variant (all three
+    pipelines).  damper = "implicit": the volume tendon's damper integrated implicitly -- the only way the
+    reference's ball and cylinder scenes, which start in deep penetration, get through an episode.
 
-    softbox is compared free-running over the 200 steps.  With the neighbour rows the squeeze is sensitive to round-off (two
-    runs that differ in the last bit part by a factor ~10 every 5 env steps once the fingers touch), so softbox_nb
-    is compared (a) free-running up to FREE_RUN_STEPS and (b) over the whole episode step by step along the
-    oracle's trajectory: after every env step the batch is re-seated on the oracle's state, and what is bounded is the error
-    the kernels add in one env step (7 substeps) -- every step of the episode, contact sets and iteration counts exactly."""
+    The *_fix scenes are compared free-running over the 200 steps.  With the neighbour rows the squeeze is sensitive to
+    round-off (two runs that differ in the last bit part by a factor ~10 every 5 env steps once the fingers touch), so
+    those scenes are compared (a) free-running up to FREE_RUN_STEPS (softbox: no contact before) and (b) over the whole episode step
+    by step along the oracle's trajectory: after every env step the batch is re-seated on the oracle's state, and what is bounded
+    is the error the kernels add in one env step (7 substeps) -- every step of the episode, contact sets and iteration counts
+    exactly."""
     import torch
     ks = [700.0, 903.6948543200572, 300.0, 1400.0, 512.25, 350.0, 1000.0, 1250.0, 640.0]
-    reseat = scene == "softbox"
-    m, nm, b = _gpu_batch(scene, ks, pipeline)
+    if not scene.startswith("softbox"):
+        ks = ks[:3]
+    reseat = not scene.endswith("_fix")
+    free_run = FREE_RUN_STEPS if scene == "softbox" else 0    # ball / cylinder touch the fingers from the first step on
+    m, nm, b = _gpu_batch(scene, ks, pipeline, damper)
     sens, flags, touch = _bufs(b, len(ks))
     sims = [oracle_sim(m, k) for k in ks]
     for s in sims:
@@ -123,7 +133,7 @@ def test_softbox_episode_matches_oracle(scene, pipeline):
             assert st["ncon"].cpu().tolist() == [s.ncon for s in sims]
             assert st["nefc"].cpu().tolist() == [s.nefc for s in sims]
             assert st["iters"].cpu().tolist() == [s.solver_iter for s in sims]
-        if reseat and t >= FREE_RUN_STEPS:
+        if reseat and t >= free_run:
             gs = b.get_state()
             for e, s in enumerate(sims):
                 np.testing.assert_allclose(gs["qpos"][e].cpu().numpy(), s.qpos, atol=1e-9)
@@ -512,23 +522,41 @@ def test_default_scene_dataset_first_steps(tmp_path):
 
 
 @pytest.mark.parametrize("scene", ["softball", "softcylinder"])
-def test_ball_and_cylinder_scenes_are_refused_at_load(scene):
-    """the reference's other two scenes start 0.14 / 0.30 deep in penetration; under the restated physics the fingers are thrown
-    through their joint limits within a few env steps (oracle: warnings within 10 env steps, with its box-box / plane-box contacts
-    BADQACC follows; kernels: the first box-box pair raises UNSUPPORTED_PAIR).  No dataset can come out of them, so ManEnv refuses
-    them at load time instead of looping through resets; check_scene=False still loads them (first substeps are
-    parity-tested above)."""
+def test_ball_and_cylinder_scenes_need_the_implicit_tendon_damper(scene, tmp_path, capsys):
+    """the reference's other two scenes start 0.14 / 0.30 deep in penetration (45 / 37 contacts at reset).  With the volume
+    tendon's damper integrated explicitly (MuJoCo's Euler as restated) the start diverges within a few env steps -- oracle and
+    kernels alike -- so tendon_damper="explicit" refuses them at load time instead of looping through resets.
+    The default, "auto", reloads them with the implicit damper, says so, and a dataset comes out: compared here
+    with the oracle over the first 12 env steps of two envs (free-running, hence the short window: the neighbour-row model
+    is sensitive to round-off)."""
     from softgrip_amd import ManEnv, SimulationError
-    with pytest.raises(SimulationError, match="does not survive its own idle phase"):
-        ManEnv(1, 7, [model_path(scene)], is_vis=False, n_envs=4)
-    env = ManEnv(1, 7, [model_path(scene)], is_vis=False, n_envs=4, check_scene=False)
-    assert env.n_envs == 4
+    from softgrip_amd import create_dataset as cd
+    import pickle
+    with pytest.raises(SimulationError, match="does not survive its own idle phase with the explicit tendon damper"):
+        ManEnv(1, 7, [model_path(scene)], is_vis=False, n_envs=4, tendon_damper="explicit")
     s = oracle_sim(sg.load_model(model_path(scene)), 700.0)
     s.reset(); s.forward()
     w = s.step()
     for _ in range(70):
         w |= s.step()
-    assert w != 0
+    assert w != 0                                    # the oracle agrees: explicit diverges
+
+    args = cd.make_parser().parse_args(["--mujoco-model-paths", model_path(scene), "--n-envs", "4", "--seed", "11",
+                                        "--data-folder", str(tmp_path), "--data-name", "d"])
+    np.random.seed(11)
+    path = cd.log_into_file(args)
+    assert "reloading it with tendon_damper=\"implicit\"" in capsys.readouterr().out
+    with open(path, "rb") as f:
+        d = pickle.load(f)
+    assert len(d["data"]) == 4 and np.array(d["data"][0]).shape == (200, 12) and np.isfinite(np.array(d["data"])).all()
+    m = sg.load_model(model_path(scene), "implicit")
+    for e in (0, 3):
+        s = oracle_sim(m, d["stiffness"][e])
+        s.reset(); s.forward(); s.step()
+        for t, c in enumerate(episode_schedule()[:12]):
+            for _ in range(7):
+                assert s.step() == 0
+            assert np.abs(np.array(d["data"][e])[t] - s.sensordata).max() < 1e-6, (e, t)
 
 
 def test_default_scene_far_outside_the_paper_range_reseated():

@@ -170,52 +170,36 @@ def test_labels_are_the_pre_episode_draw_after_a_mid_episode_failure(fake_native
     def failing(self, n, sens, flags, touch):
         orig(self, n, sens, flags, touch)
         calls["n"] += 1
-        if calls["n"] == 30 and flags is not None:   # env 1 raises a warning once, mid-episode
-            flags[1] = 4
-    monkeypatch.setattr(fake_native, "_advance", failing)
-    np.random.seed(3)
-    draws = np.random.uniform(300, 1400, size=4).tolist()
-    np.random.seed(3)
-    a = _args(tmp_path, n_envs=4)
-    d = pickle.load(open(cd.log_into_file(a), "rb"))
-    assert d["stiffness"] == draws
-    st = [e for e in fake_native.log if e[0] == "stiffness"]
-    assert len(st) == 2 and st[1][3][1] != draws[1] and np.array_equal(np.delete(st[1][3], 1), np.delete(np.array(draws), 1))
-
-
-def test_reset_envs_returns_after_the_last_successful_retry(fake_native):
-    env = manenv.ManEnv(1, 7, [model_path("softbox_fix")], is_vis=False, n_envs=2)
-    env.set_new_stiffness(400, 500)
-    tries = {"n": 0}
-    orig = env.env.reset
-
-    def flaky(sim_start, sens=None, flags=None, touch=None, mask=None):
-        orig(sim_start, sens=sens, flags=flags, touch=touch, mask=mask)
-        tries["n"] += 1
-        if tries["n"] < 5:
-            flags[0] = 32
-    env.env.reset = flaky
-    env._reset_envs(torch.tensor([True, False]))       # succeeds on the 5th (= last allowed) retry: no exception
-    assert tries["n"] == 5 and 400 <= env.stiffness[0] < 500
-    tries["n"] = -100
-    with pytest.raises(manenv.SimulationError):
-        env._reset_envs(torch.tensor([True, False]))
-
-
-def test_scene_check_refuses_a_scene_that_flags_in_its_idle_phase(fake_native, monkeypatch):
-    """load-time dry run: reset + 40 idle env steps must raise no simulation warning, else ManEnv refuses the scene loudly"""
-    env = manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2)          # the fake never flags: loads
-    assert sum(1 for e in fake_native.log if e[0] == "reset") == 2                        # dry run, then back to the reset state
-    calls = {"n": 0}
-    orig = fake_native._advance
-
-    def failing(self, n, sens, flags, touch):
-        orig(self, n, sens, flags, touch)
-        calls["n"] += 1
-        if calls["n"] == 12 and flags is not None:
+        if calls["n"] == 12 and flags is not None and not self.nmodel.model.opt_implicit_tendon_damping:
             flags[1] = 32
     monkeypatch.setattr(fake_native, "_advance", failing)
-    with pytest.raises(manenv.SimulationError, match="UNSUPPORTED_PAIR"):
-        manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2)
+    with pytest.raises(manenv.SimulationError, match="explicit tendon damper .flags UNSUPPORTED_PAIR"):
+        manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2, tendon_damper="explicit")
     calls["n"] = 0
-    manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2, check_scene=False)
+    manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2, check_scene=False, tendon_damper="explicit")
+
+
+def test_auto_tendon_damper_reloads_a_failing_scene_implicitly(fake_native, monkeypatch, capsys):
+    """tendon_damper="auto" (default): explicit first; a scene that fails the dry run under it is reloaded with the implicit
+    damper and checked again; a scene that fails under both is refused"""
+    orig = fake_native._advance
+    env = manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2)
+    assert env.tendon_damper == "explicit" and env.model.opt_implicit_tendon_damping == 0
+    assert manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2, tendon_damper="implicit").tendon_damper == "implicit"
+
+    def explicit_fails(self, n, sens, flags, touch):
+        orig(self, n, sens, flags, touch)
+        if flags is not None and not self.nmodel.model.opt_implicit_tendon_damping:
+            flags[0] = 4
+    monkeypatch.setattr(fake_native, "_advance", explicit_fails)
+    env = manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2)
+    assert env.tendon_damper == "implicit" and env.nmodel.model.opt_implicit_tendon_damping == 1
+    assert "reloading it with tendon_damper=\"implicit\"" in capsys.readouterr().out
+
+    def always_fails(self, n, sens, flags, touch):
+        orig(self, n, sens, flags, touch)
+        if flags is not None:
+            flags[0] = 4
+    monkeypatch.setattr(fake_native, "_advance", always_fails)
+    with pytest.raises(manenv.SimulationError, match="implicit tendon damper"):
+        manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2)

@@ -495,3 +495,32 @@ def test_plane_box_known_answers():
     m, s, cs = _boxbox([2.0, 0, zc - 1.0, 0, a])
     cs = [c for c in cs if c[0] == "floor"]
     assert len(cs) == 2 and all(abs(c[2] + 0.02) < 1e-9 for c in cs)
+
+
+def test_implicit_volume_tendon_damper_is_the_dense_rank_one_solve():
+    """Model flag opt_i[3] (an extension -- MuJoCo's Euler keeps tendon dampers explicit): the velocity update is
+    v' = v + h (M + h B + h c J J')^-1 (M qacc), J = the fixed tendon's constant Jacobian; checked against a dense NumPy solve
+    on a state with contacts and moving sliders.  The flag off reproduces the explicit update, and the flag survives the blob."""
+    k = 700.0
+    for flag in (0, 1):
+        m = sg.load_model(model_path("softbox_fix"), "implicit" if flag else "explicit")
+        assert sg.mjcf.Model.from_blob(m.to_blob()).opt_implicit_tendon_damping == flag
+        s = oracle_sim(m, k)
+        s.reset()
+        rng = np.random.RandomState(5)
+        s.qpos[:8] = [-0.25, 0.004, 0.1, -0.002, 0.003, 0.25, -0.1, 0.002]     # fingers closed onto the sponge: contacts
+        s.qpos[8:] += rng.uniform(-0.02, 0.02, m.nv - 8)
+        s.qvel[8:] = rng.uniform(-0.5, 0.5, m.nv - 8) + 0.3                    # a net volume rate: the damper acts
+        v = s.qvel.copy()
+        assert s.step() == 0 and s.ncon > 0
+        M, qacc = s.qM.copy(), s.qacc.copy()       # of the forward pass inside the step: mass matrix and solver acceleration
+        h, c = m.opt_timestep, m.tendon_damping[0]
+        J = np.zeros(m.nv)
+        a, n = m.tendon_adr[0], m.tendon_num[0]
+        J[m.wrap_objid[a:a + n]] = m.wrap_prm[a:a + n]                          # joint id == dof id (every joint has one dof)
+        A = M + h * np.diag(m.dof_damping) + (h * c * np.outer(J, J) if flag else 0.0)
+        want = v + h * np.linalg.solve(A, M @ qacc)
+        np.testing.assert_allclose(s.qvel, want, rtol=1e-10, atol=1e-12)
+        if flag:                                                                # and it is not a no-op: c h sum 1/(m + h d) = 110
+            explicit = v + h * np.linalg.solve(M + h * np.diag(m.dof_damping), M @ qacc)
+            assert np.abs(explicit - want).max() > 1e-3
