@@ -50,7 +50,9 @@ enum { SG_WRAP_JOINT = 1, SG_WRAP_SITE = 3 };
 enum { SG_SENS_ACCELEROMETER = 1, SG_SENS_GYRO = 3 };
 
 /* opt_d = { timestep, gravity[3], tolerance, impratio, meaninertia }
- * opt_i = { iterations, nconmax, njmax } */
+ * opt_i = { iterations, nconmax, njmax, implicit_tendon_damping }
+ *   implicit_tendon_damping (optional 4th entry, 0 when absent): 1 = the damper of the elements' fixed (volume) tendon is
+ *   integrated implicitly, (M + h B + h c J'J) qacc' = f, instead of as MuJoCo's explicit passive force */
 
 #ifdef __cplusplus
 }
