@@ -47,9 +47,20 @@ enum {
 const char* sg_last_error(void);
 const char* sg_version(void);
 
-/* ---- model: replaces mujoco_py.load_model_from_path (manenv.py:27,36).  The MJCF is
- * compiled by the Python host (soft-grip_amd/mjcf.py) into the blob of softgrip_model.h;
- * this call validates it and derives the kernel plan.  Host pointers. */
+/* ---- model: replaces mujoco_py.load_model_from_path (manenv.py:27,36).
+ * sg_model_compile: MJCF file -> model: the native compiler of the MJCF subset the soft-gripper scenes use
+ *   (csrc/sg_mjcf.cpp; <include>s resolved relative to the file's directory), then sg_model_create.  flags: SG_COMPILE_*.
+ * sg_mjcf_compile: the same compiler, returning the blob of softgrip_model.h (malloc'd: release with sg_blob_free) -- e.g. to
+ *   store a compiled scene.  The Python host has its own implementation of the same compiler (soft-grip_amd/mjcf.py);
+ *   tests/test_mjcf.py holds the two against each other.
+ * sg_model_create: validates a blob and derives the kernel plan.  Host pointers throughout. */
+enum {
+  SG_COMPILE_NO_NEIGHBORS = 1,            /* leave out the composite's neighbour equalities (models/<scene>_fix) */
+  SG_COMPILE_IMPLICIT_TENDON_DAMPER = 2   /* opt_i[3] = 1: implicit volume-tendon damper */
+};
+int sg_model_compile(const char* xml_path, int flags, sg_model** out);
+int sg_mjcf_compile(const char* xml_path, int flags, void** blob, size_t* nbytes);
+void sg_blob_free(void* blob);
 int sg_model_create(const void* blob, size_t nbytes, sg_model** out);
 void sg_model_destroy(sg_model* m);
 int sg_model_nq(const sg_model* m);           /* == nv */

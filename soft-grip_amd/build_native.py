@@ -6,8 +6,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libsoftgrip.so")
-SOURCES = ["sg_api.hip", "sg_plan.cpp"]
-DEPS = SOURCES + ["sg_kernels.hip", "sg_split.hip", "sg_math.h", "sg_plan.h", "../../include/softgrip.h", "../../include/softgrip_model.h"]
+SOURCES = ["sg_api.hip", "sg_plan.cpp", "sg_mjcf.cpp"]
+DEPS = SOURCES + ["sg_kernels.hip", "sg_split.hip", "sg_math.h", "sg_plan.h", "sg_mjcf.h", "../../include/softgrip.h", "../../include/softgrip_model.h"]
 
 
 def needs_build():

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "sg_kernels.hip"
+#include "sg_mjcf.h"
 #include "sg_split.hip"
 
 namespace {
@@ -94,6 +95,29 @@ int sg_model_create(const void* blob, size_t nbytes, sg_model** out) {
   return SG_OK;
 }
 void sg_model_destroy(sg_model* m) { delete m; }
+
+int sg_mjcf_compile(const char* xml_path, int flags, void** blob, size_t* nbytes) {
+  if (!xml_path || !blob || !nbytes) return fail(SG_ERR_INVALID, "sg_mjcf_compile: null argument");
+  std::string out, err;
+  if (!sg_mjcf_compile_file(xml_path, !(flags & SG_COMPILE_NO_NEIGHBORS), (flags & SG_COMPILE_IMPLICIT_TENDON_DAMPER) != 0, &out, &err))
+    return fail(SG_ERR_MODEL, "sg_mjcf_compile: " + err);
+  void* p = malloc(out.size());
+  if (!p) return fail(SG_ERR_INVALID, "sg_mjcf_compile: out of memory");
+  memcpy(p, out.data(), out.size());
+  *blob = p; *nbytes = out.size();
+  return SG_OK;
+}
+void sg_blob_free(void* blob) { free(blob); }
+
+int sg_model_compile(const char* xml_path, int flags, sg_model** out) {
+  void* blob = nullptr;
+  size_t nbytes = 0;
+  int rc = sg_mjcf_compile(xml_path, flags, &blob, &nbytes);
+  if (rc != SG_OK) return rc;
+  rc = sg_model_create(blob, nbytes, out);
+  free(blob);
+  return rc;
+}
 int sg_model_nq(const sg_model* m) { return m->plan.h.nv; }
 int sg_model_nu(const sg_model* m) { return m->plan.h.nu; }
 int sg_model_nsensordata(const sg_model* m) { return m->plan.h.nsensordata; }

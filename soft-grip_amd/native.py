@@ -18,7 +18,9 @@ SYMBOLS = [
     "sg_model_nsensordata", "sg_model_ntendon", "sg_model_nelem", "sg_batch_create", "sg_batch_destroy",
     "sg_batch_nenvs", "sg_batch_device", "sg_set_stiffness", "sg_set_ctrl", "sg_reset", "sg_step", "sg_get_state",
     "sg_set_state", "sg_get_solver_stats", "sg_set_pipeline", "sg_profile_enable", "sg_profile_read", "sg_profile_read_solver",
+    "sg_model_compile", "sg_mjcf_compile", "sg_blob_free",
 ]
+SG_COMPILE_NO_NEIGHBORS, SG_COMPILE_IMPLICIT_TENDON_DAMPER = 1, 2
 
 
 class SoftgripError(RuntimeError):
@@ -44,6 +46,10 @@ def lib():
     L.sg_model_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
     L.sg_model_destroy.argtypes = [vp]
     L.sg_model_destroy.restype = None
+    L.sg_model_compile.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.sg_mjcf_compile.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.sg_blob_free.argtypes = [vp]
+    L.sg_blob_free.restype = None
     for f in ("sg_model_nq", "sg_model_nu", "sg_model_nsensordata", "sg_model_ntendon", "sg_model_nelem"):
         getattr(L, f).argtypes = [vp]
     L.sg_batch_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
@@ -69,6 +75,18 @@ def lib():
 def check(code):
     if code != SG_OK:
         raise SoftgripError(code, lib().sg_last_error().decode())
+
+
+def compile_mjcf_native(xml_path, composite_neighbors=True, implicit_tendon_damping=False):
+    """The library's own MJCF compiler (csrc/sg_mjcf.cpp, ``sg_mjcf_compile``): XML file -> blob bytes.  The Python host uses
+    mjcf.py; this is what a caller without Python gets from ``sg_model_compile`` (tests/test_mjcf.py compares the two)."""
+    flags = (0 if composite_neighbors else SG_COMPILE_NO_NEIGHBORS) | (SG_COMPILE_IMPLICIT_TENDON_DAMPER if implicit_tendon_damping else 0)
+    blob, n = C.c_void_p(), C.c_size_t()
+    check(lib().sg_mjcf_compile(os.fsencode(xml_path), flags, C.byref(blob), C.byref(n)))
+    try:
+        return C.string_at(blob, n.value)
+    finally:
+        lib().sg_blob_free(blob)
 
 
 class NativeModel:
