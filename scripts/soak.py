@@ -1,5 +1,5 @@
 """Soak / determinism check on the GPU box: E episodes of the reference schedule at 4096 envs, twice from scratch; no env may raise
-a flag, every sample must be finite, and the two runs must agree bit for bit.  usage: soak.py [scene] [episodes]"""
+a flag, every sample must be finite, and the two runs must agree bit for bit.  usage: soak.py [scene] [episodes] [explicit|implicit]   (tendon damper; default: what bench.py uses for the scene)"""
 import hashlib
 import os
 import sys
@@ -17,7 +17,8 @@ from softgrip_amd.create_dataset import episode_schedule  # noqa: E402
 scene = sys.argv[1] if len(sys.argv) > 1 else "softbox_fix"
 episodes = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 n = 4096
-m = sg.load_model(os.path.join(ROOT, "models", scene + ".sgmodel"))
+damper = sys.argv[3] if len(sys.argv) > 3 else ("explicit" if scene.startswith("softbox") else "implicit")
+m = sg.load_model(os.path.join(ROOT, "models", scene + ".sgmodel"), damper)
 nm = native.NativeModel(m)
 sched = episode_schedule()
 digests = []
