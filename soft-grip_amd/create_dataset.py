@@ -8,6 +8,7 @@ its own GPU and writes its own shard file -- no collective.
 import os
 import pickle
 from argparse import ArgumentParser
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -72,6 +73,7 @@ def log_into_file(args):
     path = os.path.join(args.data_folder, "{}.pickle".format(name))
     data, stiffness = list(), list()
     n_skipped = 0
+    writer, pending = None, None
 
     for ep in range(num_batches * num_envs):
         part = _part_path(args.data_folder, name, ep)
@@ -102,7 +104,13 @@ def log_into_file(args):
                 block = torch.stack(samples, dim=1).cpu().numpy()  # [n, 200, 12]
                 ep_data, ep_k = [np.array(block[e]) for e in range(n)], [float(k) for k in current_stiffness]
             if incremental:
-                _atomic_pickle(part, {"data": ep_data, "stiffness": ep_k})
+                # the part is pickled and written by a worker thread while the next episode-batch simulates (the host is idle
+                # then, waiting for the GPU); one write in flight bounds the memory, a failed write surfaces at the next hand-over
+                if writer is None:
+                    writer = ThreadPoolExecutor(max_workers=1)
+                if pending is not None:
+                    pending.result()
+                pending = writer.submit(_atomic_pickle, part, {"data": ep_data, "stiffness": ep_k})
             else:
                 data.extend(ep_data)
                 stiffness.extend(ep_k)
@@ -113,6 +121,10 @@ def log_into_file(args):
                 current_env = 0
             env.load_env(current_env)
 
+    if pending is not None:
+        pending.result()
+    if writer is not None:
+        writer.shutdown()
     if incremental:   # assemble the final pickle from the parts (the parts stay: they are the resume state)
         for ep in range(num_batches * num_envs):
             with open(_part_path(args.data_folder, name, ep), "rb") as file:
