@@ -346,7 +346,7 @@ def main():
                 "valu_insts_per_env_step": sq["SQ_INSTS_VALU"], "salu_insts_per_env_step": sq["SQ_INSTS_SALU"],
                 "lds_insts_per_env_step": sq["SQ_INSTS_LDS"],
                 "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_*, own pass, episode average); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per "
-                          "fp64 wavefront instruction; the PGS kernel can only put wavefronts on 512 SIMDs at 4096 envs" % os.path.basename(sp)}
+                          "fp64 wavefront instruction; the PGS kernel runs one wavefront per SIMD (1024 at 4096 envs: 4 envs per wavefront) and a wavefront alone on its SIMD issues one instruction per ~7-8 cycles, so ~0.5 is this design's ceiling for it" % os.path.basename(sp)}
         if world == 1 and nb_on and not args.fake_native_for_tests and not args.no_fix_variant and not args.with_regressor and args.scene.endswith(("softbox", "softball", "softcylinder")):
             # labelled secondary: the same workload on the fix-rows-only model (composite_neighbors=False)
             del R
