@@ -204,7 +204,7 @@ def test_native_compiler_matches_python_on_own_scene(tmp_path, ctype, count, nei
     np.testing.assert_allclose(nat.actuator_gain[0], np.pi * 0.3 ** 2 / 4, rtol=1e-15)
 
 
-@pytest.mark.parametrize("name", ["arm2", "boxbox", "capbox", "capbox_slide", "hinge_sensor", "limit", "slider", "tendon"])
+@pytest.mark.parametrize("name", ["arm2", "boxbox", "capbox", "capbox_slide", "hinge_sensor", "limit", "slider", "tendon", "volume_tendon"])
 def test_native_compiler_matches_python_on_test_scenes(name):
     from softgrip_amd import native
     from helpers import ROOT

@@ -524,3 +524,30 @@ def test_implicit_volume_tendon_damper_is_the_dense_rank_one_solve():
         if flag:                                                                # and it is not a no-op: c h sum 1/(m + h d) = 110
             explicit = v + h * np.linalg.solve(M + h * np.diag(m.dof_damping), M @ qacc)
             assert np.abs(explicit - want).max() > 1e-3
+
+
+@pytest.mark.parametrize("c,implicit", [(1.0, False), (1.5, False), (1.5, True), (400.0, True)])
+def test_damped_fixed_tendon_stability_threshold_closed_form(c, implicit):
+    """Why D5 exists, in closed form.  N sliders (mass m, joint damping d) under one fixed tendon with damping c and nothing else:
+    with the tendon's damper a passive force at the old velocity and only the joint damping implicit (MuJoCo's Euler), the tendon
+    rate S = sum of the slider rates obeys S' = S (1 - h (c N + d) / (m + h d)) per step -- it alternates and GROWS as soon as
+    h (c N + d) / (m + h d) > 2 (here c > 1.25; the reference's composites have 110 / 192 / 215 on the left), while the differences
+    between sliders just decay.  With the damper in the implicit term the factor is 1 - h (c N + d) / (m + h d + h c N), inside
+    (0, 1) for any c.  The oracle follows both to 1e-10 over 60 steps."""
+    m = sg.compile_mjcf(os.path.join(ROOT, "tests", "data", "volume_tendon.xml"))
+    m.tendon_damping[:] = c
+    m.opt_implicit_tendon_damping = int(implicit)
+    s = oracle_sim(m)
+    s.reset()
+    v0 = np.array([0.3, -0.1, 0.2, 0.4])
+    s.qvel[:] = v0
+    N, mass, d, h = 4, 0.01, 1.0, 0.005
+    fac_sum = 1 - h * (c * N + d) / (mass + h * d + (h * c * N if implicit else 0.0))
+    fac_dif = 1 - h * d / (mass + h * d)
+    assert (abs(fac_sum) > 1) == (c == 1.5 and not implicit)
+    mean, dev = v0.mean(), v0 - v0.mean()
+    for k in range(60):
+        assert s.step() == 0
+        mean, dev = mean * fac_sum, dev * fac_dif
+        np.testing.assert_allclose(s.qvel, mean + dev, rtol=1e-10, atol=1e-12 * max(1.0, abs(mean)))
+    assert (abs(s.qvel.sum()) > abs(v0.sum())) == (abs(fac_sum) > 1)
