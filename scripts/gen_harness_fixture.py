@@ -62,7 +62,11 @@ def make_stub(log):
         def forward(self):
             log["calls"].append("forward")
 
-    mj.load_model_from_path = lambda p: Model(p)
+    def load_model_from_path(p):
+        log["calls"].append("load " + p)
+        return Model(p)
+
+    mj.load_model_from_path = load_model_from_path
     mj.MjSim = MjSim
     mj.MjViewer = lambda sim: None
     sys.modules["mujoco_py"] = mj
@@ -108,7 +112,7 @@ def main():
             runs.append([list(c), 1])
     fixture["mj_step_ctrl_runs"] = runs
     fixture["n_mj_step"] = len(steps)
-    fixture["calls_before_first_step"] = log["calls"][:2]
+    fixture["calls_before_first_step"] = [c for c in log["calls"] if not c.startswith("load ")][:2]
     fixture["pickle_keys"] = sorted(d.keys())
     fixture["sample_shape"] = list(np.array(d["data"][0]).shape)
     fixture["sample_dtype"] = str(np.array(d["data"][0]).dtype)
@@ -125,6 +129,21 @@ def main():
                                     "finger_names": ["g12", "g2"], "obj_name": RefManEnv.obj_name}
     fixture["std_spec_keys"] = sorted(RefManEnv.get_std_spec(
         types.SimpleNamespace(sim_start=1, sim_step=7, mujoco_model_paths=["a"], vis=False)).keys())
+    # the multi-scene loop (reference create_dataset.py:23,68-72): three model paths in one run -- which scene is loaded when, how many
+    # mj_steps each gets, the labels
+    log["steps"].clear()
+    log["calls"].clear()
+    with tempfile.TemporaryDirectory() as td:
+        args = types.SimpleNamespace(mujoco_model_paths=["a.xml", "b.xml", "c.xml"], sim_start=1, sim_step=7, vis=False, mask_contact=False,
+                                     data_folder=td, data_name="fx3")
+        np.random.seed(0)
+        ref_cd.log_into_file(args)
+        with open(os.path.join(td, "fx3.pickle"), "rb") as f:
+            d3 = pickle.load(f)
+    fixture["multi_scene"] = {"loads": [c[5:] for c in log["calls"] if c.startswith("load ")], "n_mj_step": len(log["steps"]),
+                              "n_reset": log["calls"].count("reset"), "n_samples": len(d3["data"]),
+                              "stiffness_seed0": [float(x) for x in d3["stiffness"]],
+                              "first_sensor_of_each_sample": [float(np.array(x)[0, 0]) for x in d3["data"]]}
     with open(OUT, "w") as f:
         json.dump(fixture, f, indent=1)
     print("wrote", OUT)

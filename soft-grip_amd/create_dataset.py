@@ -115,10 +115,10 @@ def log_into_file(args):
                 data.extend(ep_data)
                 stiffness.extend(ep_k)
 
-        if (ep + 1) % num_batches == 0 and num_envs > 1:
+        if (ep + 1) % num_batches == 0 and num_envs > 1 and ep + 1 < num_batches * num_envs:
+            # next scene (reference create_dataset.py:68-72; after the last one the reference asks load_env for an index past the
+            # list, which only prints "Wrong number": nothing is reloaded at the end)
             current_env += 1
-            if current_env >= num_envs:
-                current_env = 0
             env.load_env(current_env)
 
     if pending is not None:

@@ -589,3 +589,30 @@ def test_default_scene_far_outside_the_paper_range_reseated():
         assert st["ncon"].cpu().tolist() == [s.ncon for s in sims] and st["iters"].cpu().tolist() == [s.solver_iter for s in sims]
         b.set_state(qpos=T([s.qpos for s in sims]), qvel=T([s.qvel for s in sims]), act=T([s.act for s in sims]),
                     qacc_warmstart=T([s.qacc_warmstart for s in sims]))
+
+
+def test_three_scene_dataset_like_the_reference_run(tmp_path, capsys):
+    """the reference's own usage: one create_dataset run over the box, cylinder and ball scenes (create_dataset.py:23,68-72).  One
+    episode-batch per scene, in order; the box keeps MuJoCo's explicit tendon damper, the other two are reloaded with the implicit one
+    (announced); every sample finite; each scene's first env reproduces the oracle's first rows for its label."""
+    import pickle
+    from softgrip_amd import create_dataset as cd
+    scenes = ["softbox", "softcylinder", "softball"]
+    args = cd.make_parser().parse_args(["--mujoco-model-paths"] + [model_path(s) for s in scenes] + [
+        "--n-envs", "6", "--data-folder", str(tmp_path), "--data-name", "three"])
+    np.random.seed(5)
+    draws = np.random.uniform(300, 1400, size=18)
+    np.random.seed(5)
+    d = pickle.load(open(cd.log_into_file(args), "rb"))
+    assert capsys.readouterr().out.count("reloading it with tendon_damper=\"implicit\"") == 2
+    assert len(d["data"]) == 18 and d["stiffness"] == draws.tolist()
+    X = np.array(d["data"])
+    assert X.shape == (18, 200, 12) and np.isfinite(X).all()
+    for i, scene in enumerate(scenes):
+        m = sg.load_model(model_path(scene), "explicit" if scene == "softbox" else "implicit")
+        s = oracle_sim(m, d["stiffness"][6 * i])
+        s.reset(); s.forward(); s.step()
+        for t in range(10):
+            for _ in range(7):
+                assert s.step() == 0
+            assert np.abs(X[6 * i, t] - s.sensordata).max() < 1e-6, (scene, t)

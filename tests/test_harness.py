@@ -203,3 +203,28 @@ def test_auto_tendon_damper_reloads_a_failing_scene_implicitly(fake_native, monk
     monkeypatch.setattr(fake_native, "_advance", always_fails)
     with pytest.raises(manenv.SimulationError, match="implicit tendon damper"):
         manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2)
+
+
+def test_multi_scene_loop_matches_reference(fake_native, tmp_path, monkeypatch):
+    """three model paths in one run (reference create_dataset.py:23,68-72), against the fixture generated by the reference's own
+    log_into_file on a stub simulator: which scene is loaded when (each once, in order, nothing reloaded at the end), one reset and
+    1401 mj_steps per scene, one sample per scene, the labels = the first three draws of the seeded stream"""
+    M = FX["multi_scene"]
+    loads = []
+    real = manenv.load_model
+
+    def logging_load(path, tendon_damper=None):
+        loads.append(os.path.basename(path))
+        return real(path, tendon_damper)
+    monkeypatch.setattr(manenv, "load_model", logging_load)
+    paths = [model_path("softbox_fix"), model_path("softcylinder_fix"), model_path("softball_fix")]
+    args = _args(tmp_path)
+    args.mujoco_model_paths = paths
+    np.random.seed(0)
+    path = cd.log_into_file(args)
+    assert loads == [os.path.basename(p) for p in paths] and len(loads) == len(M["loads"])
+    assert sum(1 for e in fake_native.log if e[0] == "substep") == M["n_mj_step"]
+    assert sum(1 for e in fake_native.log if e[0] == "reset") == M["n_reset"]
+    d = pickle.load(open(path, "rb"))
+    assert len(d["data"]) == M["n_samples"] and d["stiffness"] == M["stiffness_seed0"]
+    assert [float(np.array(x)[0, 0]) for x in d["data"]] == M["first_sensor_of_each_sample"]
