@@ -43,10 +43,10 @@ class Emu:
         if getattr(self, "p", None):
             self.L.emu_free(self.p)
 
-    def set_stiffness(self, k):
-        for j in JOINT_IDS:
+    def set_stiffness(self, k, joint_ids=JOINT_IDS, tendon_ids=TENDON_IDS):
+        for j in joint_ids:
             self.L.emu_set_jnt_stiffness(self.p, j, k)
-        for t in TENDON_IDS:
+        for t in tendon_ids:
             self.L.emu_set_tendon_stiffness(self.p, t, k)
 
     def reset(self):

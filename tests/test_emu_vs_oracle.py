@@ -68,3 +68,33 @@ def test_implicit_tendon_damper_episodes(scene, n_steps):
     assert worst < 1e-8
     q, v, w, a = e.state()
     np.testing.assert_allclose(q, s.qpos, atol=1e-9)
+
+
+def test_own_scene_full_episode():
+    """tests/data/mini_gripper.xml (this repo's own scene in the plan class: 34 elements, h = 0.004, 20 sweeps), fix-rows-only
+    variant: the kernels' math lane-serially against the oracle over the whole squeeze schedule, contacts and all"""
+    import os
+    from helpers import ROOT
+    from oracle import oracle as O
+    m = sg.compile_mjcf(os.path.join(ROOT, "tests", "data", "mini_gripper.xml"), composite_neighbors=False)
+    e = Emu(m.to_blob(), m.nv)
+    om = O.OracleModel(m.to_blob())
+    s = O.OracleSim(om)
+    k = 640.0
+    s.jnt_stiffness[8:] = k
+    s.tendon_stiffness[0] = k
+    e.set_stiffness(k, list(range(8, 42)), [0])
+    e.reset(); s.reset()
+    e.substep(False); s.forward()
+    e.substep(True); s.step()
+    worst, most = 0.0, 0
+    for t, c in enumerate(episode_schedule()):
+        if c is not None:
+            e.set_ctrl(c)
+            s.ctrl[:] = c
+        for _ in range(7):
+            assert e.substep(True) == 0 and s.step() == 0
+        worst = max(worst, np.abs(e.sensordata - s.sensordata).max())
+        assert e.ncon == s.ncon
+        most = max(most, s.ncon)
+    assert worst < 1e-8 and most >= 6

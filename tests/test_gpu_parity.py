@@ -616,3 +616,57 @@ def test_three_scene_dataset_like_the_reference_run(tmp_path, capsys):
             for _ in range(7):
                 assert s.step() == 0
             assert np.abs(X[6 * i, t] - s.sensordata).max() < 1e-6, (scene, t)
+
+
+@pytest.mark.parametrize("neighbors,pipeline", [(False, "rows"), (False, "fused"), (False, "split"), (True, "rows")])
+def test_own_scene_through_the_native_compiler(neighbors, pipeline):
+    """tests/data/mini_gripper.xml -- a scene of this repo's own making inside the plan class (34 shell elements, two finger chains,
+    h = 0.004, 20 sweeps; not one of the reference's) -- compiled by the library's own MJCF compiler (sg_mjcf_compile, what
+    sg_model_compile runs), stepped through the squeeze schedule on the GPU (R = 1 / NSL = 8 kernel instantiations) and compared with
+    the oracle built from the same blob: free-running for the fix-rows-only variant, re-seated per step with the neighbour rows."""
+    import os
+    import torch
+    from helpers import ROOT
+    from softgrip_amd import native
+    from oracle import oracle as O
+    path = os.path.join(ROOT, "tests", "data", "mini_gripper.xml")
+    m = sg.Model.from_blob(native.compile_mjcf_native(path, composite_neighbors=neighbors))
+    assert m.nv == 42 and m.neq == (99 if neighbors else 35)
+    jids, tids = list(range(8, 42)), [0]
+    ks = [640.0, 300.0, 1400.0, 905.5, 512.25]
+    nm = native.NativeModel(m)
+    b = native.NativeBatch(nm, len(ks), 0)
+    b.set_pipeline(pipeline)
+    b.set_stiffness(np.asarray(ks), jids, tids)
+    sens, flags, touch = _bufs(b, len(ks))
+    om = O.OracleModel(m.to_blob())
+    sims = [O.OracleSim(om) for _ in ks]
+    for s, k in zip(sims, ks):
+        s.jnt_stiffness[jids] = k
+        s.tendon_stiffness[tids] = k
+        s.reset(); s.forward(); s.step()
+    b.reset(1, sens=sens, flags=flags, touch=touch)
+    ctrl = np.zeros(2)
+    worst, most = 0.0, 0
+    for t, c in enumerate(episode_schedule()):
+        if c is not None:
+            ctrl[:] = c
+            b.set_ctrl_broadcast(ctrl)
+            for s in sims:
+                s.ctrl[:] = c
+        b.step(7, sens=sens, flags=flags, touch=touch)
+        for s in sims:
+            for _ in range(7):
+                assert s.step() == 0
+        worst = max(worst, np.abs(sens.cpu().numpy() - np.stack([s.sensordata for s in sims])).max())
+        assert worst < TOL_SENSOR, (t, worst)
+        assert int(flags.abs().sum()) == 0
+        st = b.solver_stats()
+        assert st["ncon"].cpu().tolist() == [s.ncon for s in sims]
+        assert st["iters"].cpu().tolist() == [s.solver_iter for s in sims]
+        most = max(most, max(s.ncon for s in sims))
+        if neighbors:
+            T = lambda a: torch.tensor(np.stack(a), dtype=torch.float64, device=b.device).contiguous()  # noqa: E731
+            b.set_state(qpos=T([s.qpos for s in sims]), qvel=T([s.qvel for s in sims]), act=T([s.act for s in sims]),
+                        qacc_warmstart=T([s.qacc_warmstart for s in sims]))
+    assert most >= 6

@@ -204,7 +204,7 @@ def test_native_compiler_matches_python_on_own_scene(tmp_path, ctype, count, nei
     np.testing.assert_allclose(nat.actuator_gain[0], np.pi * 0.3 ** 2 / 4, rtol=1e-15)
 
 
-@pytest.mark.parametrize("name", ["arm2", "boxbox", "capbox", "capbox_slide", "hinge_sensor", "limit", "slider", "tendon", "volume_tendon"])
+@pytest.mark.parametrize("name", ["arm2", "boxbox", "capbox", "capbox_slide", "hinge_sensor", "limit", "slider", "tendon", "volume_tendon", "mini_gripper"])
 def test_native_compiler_matches_python_on_test_scenes(name):
     from softgrip_amd import native
     from helpers import ROOT
@@ -246,3 +246,21 @@ def test_native_compiler_errors_are_reported(tmp_path):
         assert ei.value.code == -2
     with pytest.raises(native.SoftgripError, match="cannot open"):
         native.compile_mjcf_native(str(tmp_path / "missing.xml"))
+
+
+def test_own_scene_in_the_plan_class_is_accepted_by_sg_model_compile():
+    """tests/data/mini_gripper.xml: a scene of this repo's own making inside the kernels' plan class (two 4-dof finger chains, a
+    3 x 4 x 3 shell, other dimensions / masses / time step than the reference's) goes XML -> native compiler -> plan on the CPU;
+    the GPU tests run it (the reference's XML files do not exist on the GPU box)."""
+    import ctypes as C
+    from softgrip_amd import native
+    from helpers import ROOT
+    path = os.path.join(ROOT, "tests", "data", "mini_gripper.xml")
+    L = native.lib()
+    for flags, neq in ((0, 34 + 64 + 1), (native.SG_COMPILE_NO_NEIGHBORS, 35), (native.SG_COMPILE_IMPLICIT_TENDON_DAMPER, 99)):
+        ptr = C.c_void_p()
+        native.check(L.sg_model_compile(os.fsencode(path), flags, C.byref(ptr)))
+        assert (L.sg_model_nq(ptr), L.sg_model_nelem(ptr), L.sg_model_nu(ptr), L.sg_model_nsensordata(ptr)) == (42, 34, 2, 12)
+        L.sg_model_destroy(ptr)
+        m = sg.Model.from_blob(native.compile_mjcf_native(path, composite_neighbors=not (flags & 1), implicit_tendon_damping=bool(flags & 2)))
+        assert m.neq == neq and m.opt_timestep == 0.004 and m.opt_iterations == 20
