@@ -670,3 +670,36 @@ def test_own_scene_through_the_native_compiler(neighbors, pipeline):
             b.set_state(qpos=T([s.qpos for s in sims]), qvel=T([s.qvel for s in sims]), act=T([s.act for s in sims]),
                         qacc_warmstart=T([s.qacc_warmstart for s in sims]))
     assert most >= 6
+
+
+def test_c_abi_from_plain_c_matches_the_python_host(tmp_path):
+    """examples/c_rollout.c: the boundary used the way a non-Python caller would -- gcc, include/softgrip.h, libsoftgrip.so and the
+    HIP runtime, nothing else: sg_model_compile on an XML file, sg_batch_create, sg_set_stiffness / sg_reset / sg_set_ctrl / sg_step
+    over the squeeze schedule.  Its sensor rows must be bit-identical to the Python host's on the same inputs."""
+    import os
+    import subprocess
+    from helpers import ROOT
+    from softgrip_amd import native
+    exe = str(tmp_path / "c_rollout")
+    libdir = os.path.join(ROOT, "soft-grip_amd")
+    subprocess.check_call(["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "examples", "c_rollout.c"), "-o", exe, "-L", libdir, "-lsoftgrip", "-L", "/opt/rocm/lib",
+                           "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    xml = os.path.join(ROOT, "tests", "data", "mini_gripper.xml")
+    n = 8
+    out = subprocess.run([exe, xml, str(n)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[-1] == "flagged 0" and len(lines) == 201
+    rows = np.array([[float(x) for x in ln.split()[1:]] for ln in lines[:200]])       # [200, 24]: env 0 and env n - 1
+    m = sg.Model.from_blob(native.compile_mjcf_native(xml))
+    b = native.NativeBatch(native.NativeModel(m), n, 0)
+    b.set_stiffness(np.array([300.0 + 1100.0 * e / (n - 1) for e in range(n)]), list(range(m.nv - 34, m.nv)), [0])
+    sens, flags, touch = _bufs(b, n)
+    b.reset(1, sens=sens, flags=flags, touch=touch)
+    for t, c in enumerate(episode_schedule()):
+        if c is not None:
+            b.set_ctrl_broadcast(np.array([c, c]))
+        b.step(7, sens=sens, flags=flags, touch=touch)
+        got = sens.cpu().numpy()
+        assert np.array_equal(rows[t, :12], got[0]) and np.array_equal(rows[t, 12:], got[n - 1]), t
