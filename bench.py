@@ -234,6 +234,9 @@ def main():
     if args.force_device >= 0:
         local = args.force_device
     dist = None
+    if not args.fake_native_for_tests and torch.cuda.device_count() <= local:
+        # fail at once and on every rank: a rank that dies later would leave the others waiting in the first barrier
+        raise SystemExit("bench.py: rank %d wants GPU %d but this node shows %d GPU(s)" % (rank, local, torch.cuda.device_count()))
     if world > 1:
         import torch.distributed as dist
         if not args.fake_native_for_tests:
