@@ -388,16 +388,17 @@ def test_ragged_batches(scene, n):
     assert b.solver_stats()["ncon"].cpu().tolist() == [s.ncon for s in sims]
 
 
-@pytest.mark.parametrize("scene", ["softbox_fix", "softbox"])
-def test_runs_are_bit_reproducible_and_flag_free(scene):
+@pytest.mark.parametrize("scene,damper", [("softbox_fix", None), ("softbox", None), ("softball", "implicit"), ("softcylinder", "implicit")])
+def test_runs_are_bit_reproducible_and_flag_free(scene, damper):
     """two runs from scratch of two consecutive episodes (fresh stiffness draws, reset in between) at 1024 envs: no flag, all finite, and
-    the same bits -- nothing on the path depends on scheduling (scripts/soak.py does this at 4096 envs and more episodes)"""
+    the same bits -- nothing on the path depends on scheduling (scripts/soak.py does this at 4096 envs and more episodes).  The ball
+    and cylinder scenes with the implicit volume-tendon damper: the whole stiffness range, no env flagged."""
     import torch
     n, outs = 1024, []
     sched = episode_schedule()
     for run in range(2):
         rng = np.random.RandomState(7)
-        m, nm, b = _gpu_batch(scene, rng.uniform(300, 1400, n))
+        m, nm, b = _gpu_batch(scene, rng.uniform(300, 1400, n), damper=damper)
         out = torch.zeros(n, len(sched), 12, dtype=torch.float64, device=b.device)
         flags = torch.zeros(n, dtype=torch.int32, device=b.device)
         acc = []
