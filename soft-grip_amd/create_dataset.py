@@ -164,6 +164,8 @@ def make_parser():
     parser.add_argument('--contact-flag-mode', default="intent", choices=["intent", "reference"])
     parser.add_argument('--tendon-damper', default="auto", choices=["auto", "explicit", "implicit"],
                         help="integration of the composite volume tendon's damper (DESIGN.md D5); auto = explicit, implicit for scenes that need it")
+    parser.add_argument('--joint-ids', type=int, nargs="+", default=None, help="joints whose stiffness is randomised (default: the reference's 11..63)")
+    parser.add_argument('--tendon-ids', type=int, nargs="+", default=None, help="tendons whose stiffness is randomised (default: the reference's 0)")
     parser.add_argument('--no-check-scene', dest="check_scene", action='store_false', default=True,
                         help="skip the load-time dry run that rejects scenes which cannot survive their own idle phase")
     return parser

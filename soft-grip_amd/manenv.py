@@ -39,8 +39,10 @@ class ManEnv(Env):
     obj_name = 'OBJ'
 
     def __init__(self, sim_start, sim_step, env_paths, is_vis=True, n_envs=1, device=0, contact_flag_mode="intent", check_scene=True,
-                 tendon_damper="auto"):
-        """``tendon_damper``: how the damper of the composite's volume tendon is integrated (mjcf.load_model).
+                 tendon_damper="auto", joint_ids=None, tendon_ids=None):
+        """``joint_ids`` / ``tendon_ids``: which model entries ``set_new_stiffness`` writes; default = the reference's class attributes
+        (joints 11..63 and tendon 0: manenv.py:12-13), to be overridden for a scene with another layout (e.g. a smaller shell).
+        ``tendon_damper``: how the damper of the composite's volume tendon is integrated (mjcf.load_model).
         "explicit" = MuJoCo's Euler step as restated; "implicit" = the rank-one implicit treatment; "auto" (default) = explicit,
         and a scene that fails the load-time check under it (the reference's soft ball / cylinder) is reloaded with "implicit",
         with a printed notice.  ``self.tendon_damper`` holds what the loaded scene runs with."""
@@ -49,6 +51,10 @@ class ManEnv(Env):
         assert contact_flag_mode in ("intent", "reference")
         assert tendon_damper in ("auto", "explicit", "implicit")
         self._tendon_damper_arg = tendon_damper
+        if joint_ids is not None:
+            self.joint_ids = [int(j) for j in joint_ids]      # instance attributes shadow the class lists (which stay the reference's)
+        if tendon_ids is not None:
+            self.tendon_ids = [int(t) for t in tendon_ids]
         self.check_scene = check_scene
         self.is_vis = is_vis  # no viewer exists; kept for signature parity (render() is a no-op)
         self.env_paths = env_paths
@@ -65,6 +71,10 @@ class ManEnv(Env):
         want = _damper or self._tendon_damper_arg
         self.model = load_model(path, None if want == "auto" else want)
         self.tendon_damper = "implicit" if self.model.opt_implicit_tendon_damping else "explicit"
+        if max(self.joint_ids) >= self.model.nv or max(self.tendon_ids) >= self.model.ntendon:
+            raise ValueError("scene %s has %d joints and %d tendons: the stiffness ids (joints %d..%d, tendons %s) do not fit it -- pass "
+                             "joint_ids / tendon_ids" % (path, self.model.nv, self.model.ntendon, min(self.joint_ids), max(self.joint_ids),
+                                                         self.tendon_ids))
         self.nmodel = native.NativeModel(self.model)
         self.env = native.NativeBatch(self.nmodel, self.n_envs, self.device_index)
         dev = self.env.device
@@ -281,7 +291,7 @@ class ManEnv(Env):
             "env_paths": args.mujoco_model_paths,
             "is_vis": args.vis,
         }
-        for extra in ("n_envs", "device", "contact_flag_mode", "check_scene", "tendon_damper"):
+        for extra in ("n_envs", "device", "contact_flag_mode", "check_scene", "tendon_damper", "joint_ids", "tendon_ids"):
             if hasattr(args, extra):
                 spec[extra] = getattr(args, extra)
         return spec

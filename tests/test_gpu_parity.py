@@ -704,3 +704,35 @@ def test_c_abi_from_plain_c_matches_the_python_host(tmp_path):
         b.step(7, sens=sens, flags=flags, touch=touch)
         got = sens.cpu().numpy()
         assert np.array_equal(rows[t, :12], got[0]) and np.array_equal(rows[t, 12:], got[n - 1]), t
+
+
+def test_dataset_from_an_xml_scene_with_its_own_id_set(tmp_path):
+    """create_dataset on tests/data/mini_gripper.xml given as an XML path (compiled by mjcf.py at load) with --joint-ids for its
+    34-element shell: labels = the seeded draws, rows = the oracle's for those labels (fix-rows-only is not selectable from the command
+    line, so the default neighbour-row model is compared over its first steps)"""
+    import os
+    import pickle
+    from helpers import ROOT
+    from oracle import oracle as O
+    from softgrip_amd import create_dataset as cd
+    xml = os.path.join(ROOT, "tests", "data", "mini_gripper.xml")
+    args = cd.make_parser().parse_args(["--mujoco-model-paths", xml, "--n-envs", "3", "--data-folder", str(tmp_path), "--data-name", "mini",
+                                        "--joint-ids"] + [str(j) for j in range(8, 42)] + ["--tendon-ids", "0"])
+    np.random.seed(2)
+    draws = np.random.uniform(300, 1400, size=3)
+    np.random.seed(2)
+    d = pickle.load(open(cd.log_into_file(args), "rb"))
+    assert d["stiffness"] == draws.tolist() and np.array(d["data"]).shape == (3, 200, 12) and np.isfinite(np.array(d["data"])).all()
+    m = sg.compile_mjcf(xml)
+    om = O.OracleModel(m.to_blob())
+    for e in range(3):
+        s = O.OracleSim(om)
+        s.jnt_stiffness[8:] = d["stiffness"][e]
+        s.tendon_stiffness[0] = d["stiffness"][e]
+        s.reset(); s.forward(); s.step()
+        for t, c in enumerate(episode_schedule()[:55]):
+            if c is not None:
+                s.ctrl[:] = c
+            for _ in range(7):
+                assert s.step() == 0
+            assert np.abs(np.array(d["data"][e])[t] - s.sensordata).max() < 1e-6, (e, t)

@@ -228,3 +228,15 @@ def test_multi_scene_loop_matches_reference(fake_native, tmp_path, monkeypatch):
     d = pickle.load(open(path, "rb"))
     assert len(d["data"]) == M["n_samples"] and d["stiffness"] == M["stiffness_seed0"]
     assert [float(np.array(x)[0, 0]) for x in d["data"]] == M["first_sensor_of_each_sample"]
+
+
+def test_stiffness_id_sets_can_be_overridden_and_are_checked(fake_native):
+    """the reference hard-codes joints 11..63 and tendon 0 (manenv.py:12-13) -- the defaults; another scene layout passes its own ids,
+    and ids that do not fit the loaded scene are refused at load time instead of failing inside the library"""
+    env = manenv.ManEnv(1, 7, [model_path("softbox_fix")], is_vis=False, n_envs=2, check_scene=False, joint_ids=range(8, 118), tendon_ids=[0])
+    env.reset()
+    st = [e for e in fake_native.log if e[0] == "stiffness"][-1]
+    assert st[1] == list(range(8, 118)) and st[2] == [0]
+    assert manenv.ManEnv.joint_ids == list(range(11, 64))           # the class attributes stay the reference's
+    with pytest.raises(ValueError, match="do not fit"):
+        manenv.ManEnv(1, 7, [model_path("softbox_fix")], is_vis=False, check_scene=False, joint_ids=[5, 118])
