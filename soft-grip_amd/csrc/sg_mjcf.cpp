@@ -530,7 +530,8 @@ struct Compiler {
           } else {  // cylinder
             const double l0 = std::fmax(std::fabs(p[0]), std::fabs(p[1])), n2 = std::sqrt(p[0] * p[0] + p[1] * p[1]);
             V3 q;
-            q[0] = p[0] / n2 * half[0] * l0; q[1] = p[1] / n2 * half[1] * l0; q[2] = p[2] * half[2];
+            if (n2 >= kMinVal) { q[0] = p[0] / n2 * half[0] * l0; q[1] = p[1] / n2 * half[1] * l0; }  // else: an element on the axis (odd counts) stays there
+            q[2] = p[2] * half[2];
             p = q;
           }
           char tag[64];

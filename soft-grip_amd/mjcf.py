@@ -463,7 +463,10 @@ class _Compiler:
                     else:  # cylinder
                         l0 = max(abs(p[0]), abs(p[1]))
                         n2 = np.linalg.norm(p[:2])
-                        p = np.array([p[0] / n2 * half[0] * l0, p[1] / n2 * half[1] * l0, p[2] * half[2]])
+                        if n2 < MJ_MINVAL:  # odd counts put an element on the axis (the centre of a cap): it stays there
+                            p = np.array([0.0, 0.0, p[2] * half[2]])
+                        else:
+                            p = np.array([p[0] / n2 * half[0] * l0, p[1] / n2 * half[1] * l0, p[2] * half[2]])
                     tag = "%d_%d_%d" % (ix, iy, iz)
                     b = _Body(prefix + "B" + tag, p, quat_z2vec(p), bid)
                     g = self._make_geom(gattr, prefix + "G" + tag)

@@ -264,3 +264,81 @@ def test_own_scene_in_the_plan_class_is_accepted_by_sg_model_compile():
         L.sg_model_destroy(ptr)
         m = sg.Model.from_blob(native.compile_mjcf_native(path, composite_neighbors=not (flags & 1), implicit_tendon_damping=bool(flags & 2)))
         assert m.neq == neq and m.opt_timestep == 0.004 and m.opt_iterations == 20
+
+
+def _random_scene(rng):
+    """a random scene inside the MJCF subset: a tree of bodies up to three deep with boxes / capsules / spheres (mass or density),
+    hinges and slides (some limited, damped, with armature / springref), sites, optionally a composite shell, spatial and fixed
+    tendons over what exists, a cylinder actuator and sensors"""
+    f = lambda lo, hi: "%.6g" % rng.uniform(lo, hi)  # noqa: E731
+    names = {"joint": [], "site": [], "hinge": []}
+    out = ["<mujoco>", "<compiler angle=\"radian\" settotalmass=\"%s\"/>" % f(0.2, 3) if rng.rand() < 0.5 else "<compiler angle=\"radian\"/>",
+           "<option timestep=\"%s\" solver=\"PGS\" cone=\"elliptic\" iterations=\"%d\"/>" % (f(0.001, 0.01), rng.randint(5, 50)),
+           "<default><geom friction=\"%s %s\"/><default class=\"c1\"><joint damping=\"%s\"/><geom density=\"%s\"/></default></default>" % (
+               f(0.5, 1.5), f(0.001, 0.01), f(0, 3), f(100, 2000)), "<worldbody>", "<geom type=\"plane\" size=\"1 1 1\"/>"]
+
+    def body(depth):
+        out.append("<body pos=\"%s %s %s\" quat=\"%s %s %s %s\"%s>" % (f(-1, 1), f(-1, 1), f(0, 2), f(0.5, 1), f(-.5, .5), f(-.5, .5), f(-.5, .5),
+                                                                    " childclass=\"c1\"" if rng.rand() < 0.3 else ""))
+        for _ in range(rng.randint(0, 3)):
+            jn = "j%d" % len(names["joint"])
+            typ = "hinge" if rng.rand() < 0.7 else "slide"
+            out.append("<joint name=\"%s\" type=\"%s\" axis=\"%s %s %s\" pos=\"%s 0 0\"%s%s armature=\"%s\" springref=\"%s\" stiffness=\"%s\"/>" % (
+                jn, typ, f(-1, 1), f(-1, 1), f(0.2, 1), f(-.2, .2), " limited=\"true\" range=\"%s %s\"" % (f(-1, 0), f(0, 1)) if rng.rand() < 0.5 else "",
+                " damping=\"%s\"" % f(0, 2) if rng.rand() < 0.5 else "", f(0, 0.05), f(-.1, .1), f(0, 5)))
+            names["joint"].append(jn)
+            if typ == "hinge":
+                names["hinge"].append(jn)
+        for _ in range(rng.randint(1, 3)):
+            typ = ["box", "capsule", "sphere"][rng.randint(3)]
+            size = {"box": "%s %s %s" % (f(.05, .3), f(.05, .3), f(.05, .3)), "capsule": "%s %s" % (f(.03, .1), f(.05, .3)), "sphere": f(.05, .2)}[typ]
+            out.append("<geom type=\"%s\" size=\"%s\" pos=\"%s %s %s\" quat=\"%s %s 0 %s\"%s/>" % (
+                typ, size, f(-.3, .3), f(-.3, .3), f(-.3, .3), f(.5, 1), f(-.5, .5), f(-.5, .5), " mass=\"%s\"" % f(0.01, 0.5) if rng.rand() < 0.5 else ""))
+        for _ in range(rng.randint(0, 2)):
+            sn = "s%d" % len(names["site"])
+            out.append("<site name=\"%s\" pos=\"%s %s %s\"/>" % (sn, f(-.3, .3), f(-.3, .3), f(-.3, .3)))
+            names["site"].append(sn)
+        if depth < 3:
+            for _ in range(rng.randint(0, 2 if depth else 3)):
+                body(depth + 1)
+        out.append("</body>")
+    for _ in range(rng.randint(1, 3)):
+        body(1)
+    if rng.rand() < 0.6:
+        ctype = ["box", "ellipsoid", "cylinder"][rng.randint(3)]
+        out.append("<body pos=\"2 0 1\"><composite prefix=\"S\" type=\"%s\" count=\"%d %d %d\" spacing=\"%s\"><geom type=\"capsule\" size=\".03 .04\" mass=\"%s\"/>"
+                   "<joint kind=\"main\" stiffness=\"%s\" damping=\"%s\" solreffix=\"-100 -10\"/><tendon kind=\"main\" damping=\"%s\" solimpfix=\"0.8 0.9 0.01\"/></composite></body>" % (
+                       ctype, rng.randint(2, 5), rng.randint(2, 5), rng.randint(2, 5), f(.1, .3), f(.001, .01), f(10, 900), f(1, 90), f(0, 5)))
+    out.append("</worldbody>")
+    ten = []
+    if len(names["site"]) >= 2:
+        ten.append("<spatial name=\"sp\" stiffness=\"%s\" damping=\"%s\"><site site=\"%s\"/><site site=\"%s\"/></spatial>" % (f(0, 50), f(0, 2), names["site"][0], names["site"][-1]))
+    if len(names["joint"]) >= 2:
+        ten.append("<fixed name=\"fx\"><joint joint=\"%s\" coef=\"%s\"/><joint joint=\"%s\" coef=\"%s\"/></fixed>" % (names["joint"][0], f(-2, 2), names["joint"][-1], f(-2, 2)))
+    if ten:
+        out.append("<tendon>" + "".join(ten) + "</tendon>")
+        out.append("<actuator><cylinder tendon=\"%s\" timeconst=\"%s\" area=\"%s\"/></actuator>" % ("sp" if len(names["site"]) >= 2 else "fx", f(.1, 2), f(1, 500)))
+    if names["site"]:
+        out.append("<sensor><accelerometer site=\"%s\"/><gyro name=\"g\" site=\"%s\"/></sensor>" % (names["site"][0], names["site"][-1]))
+    out.append("</mujoco>")
+    return "\n".join(out)
+
+
+def test_native_compiler_matches_python_on_random_scenes(tmp_path):
+    """40 random scenes inside the subset (seeded): the two compilers agree field by field on every one, or refuse the same ones
+    (a random scene may have a moving body without mass)"""
+    from softgrip_amd import native
+    rng = np.random.RandomState(20260)
+    compiled = 0
+    for i in range(40):
+        path = tmp_path / ("r%d.xml" % i)
+        path.write_text(_random_scene(rng))
+        try:
+            py = sg.Model.from_blob(sg.compile_mjcf(str(path)).to_blob())
+        except (ValueError, np.linalg.LinAlgError) as e:
+            with pytest.raises(native.SoftgripError):
+                native.compile_mjcf_native(str(path))
+            continue
+        _compare_models(py, sg.Model.from_blob(native.compile_mjcf_native(str(path))), rtol=1e-9)
+        compiled += 1
+    assert compiled >= 25
