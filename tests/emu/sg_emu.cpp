@@ -118,6 +118,17 @@ void emu_get_state(Emu* E, double* qpos, double* qvel, double* warm, double* act
   for (int c = 0; c < H.nchain; c++)
     if (H.chain[c].has_act) act[H.chain[c].act_id] = E->act[c];
 }
+void emu_set_state(Emu* E, const double* qpos, const double* qvel, const double* warm, const double* act) {  // re-seating (tests)
+  const SgPlanHeader& H = E->P.h;
+  for (int c = 0; c < H.nchain; c++)
+    for (int d = 0; d < H.chain[c].ndof; d++) {
+      int j = H.chain[c].dof0 + d;
+      E->qc[c][d] = qpos[j]; E->vc[c][d] = qvel[j]; E->wc[c][d] = warm[j];
+    }
+  for (int e = 0; e < E->N; e++) { E->qe[e] = qpos[H.elem_dof0 + e]; E->ve[e] = qvel[H.elem_dof0 + e]; E->we[e] = warm[H.elem_dof0 + e]; }
+  for (int c = 0; c < H.nchain; c++)
+    if (H.chain[c].has_act) E->act[c] = act[H.chain[c].act_id];
+}
 const double* emu_sensordata(Emu* E) { return E->sens.data(); }
 int emu_ncon(Emu* E) { return E->ncon; }
 int emu_contact(Emu* E, int i, int* chain, int* sl, double* R, double* b3) {

@@ -31,6 +31,7 @@ class Emu:
         L.emu_set_jnt_stiffness.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.emu_set_tendon_stiffness.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.emu_get_state.argtypes = [C.c_void_p] + [np.ctypeslib.ndpointer(np.float64)] * 4
+        L.emu_set_state.argtypes = [C.c_void_p] + [np.ctypeslib.ndpointer(np.float64)] * 4
         for f in ("emu_ncon", "emu_nefc", "emu_iters"):
             getattr(L, f).argtypes = [C.c_void_p]
         err = C.create_string_buffer(256)
@@ -69,6 +70,10 @@ class Emu:
         a = np.zeros(2)
         self.L.emu_get_state(self.p, q, v, w, a)
         return q, v, w, a
+
+    def set_state(self, qpos, qvel, warm, act):
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        self.L.emu_set_state(self.p, c(qpos), c(qvel), c(warm), c(act))
 
     @property
     def ncon(self):

@@ -98,3 +98,63 @@ def test_own_scene_full_episode():
         assert e.ncon == s.ncon
         most = max(most, s.ncon)
     assert worst < 1e-8 and most >= 6
+
+
+def _plan_class_variant(rng):
+    """tests/data/mini_gripper.xml with its link sizes and masses, the shell's type / counts / spacing / spring and damper, the
+    time step, the sweep count and the actuator gain drawn at random: still inside the plan class"""
+    import os
+    import re
+    from helpers import ROOT
+    x = open(os.path.join(ROOT, "tests", "data", "mini_gripper.xml")).read()
+    jit = lambda vals: " ".join("%.4g" % (a * rng.uniform(.9, 1.1)) for a in vals)  # noqa: E731
+    x = re.sub(r'size="0\.3 0\.08 0\.2"', lambda m: 'size="%s"' % jit((0.3, 0.08, 0.2)), x)
+    x = re.sub(r'size="0\.25 0\.08 0\.2"', lambda m: 'size="%s"' % jit((0.25, 0.08, 0.2)), x)
+    x = re.sub(r'mass="0\.1"', lambda m: 'mass="%.4g"' % rng.uniform(.06, .15), x)
+    x = re.sub(r'mass="0\.06"', lambda m: 'mass="%.4g"' % rng.uniform(.04, .09), x)
+    ctype = ["box", "ellipsoid", "cylinder"][rng.randint(3)]
+    x = x.replace('type="box" count="3 4 3" spacing="0.2"', 'type="%s" count="%d %d %d" spacing="%.4g"' % (
+        ctype, rng.randint(3, 5), rng.randint(3, 6), rng.randint(3, 5), rng.uniform(0.14, 0.2)))
+    x = x.replace('stiffness="500" damping="60"', 'stiffness="%.4g" damping="%.4g"' % (rng.uniform(300, 900), rng.uniform(30, 90)))
+    x = x.replace('timestep="0.004"', 'timestep="%.4g"' % rng.uniform(0.003, 0.005))
+    x = x.replace('iterations="20"', 'iterations="%d"' % rng.randint(10, 31))
+    return x.replace('area="300"', 'area="%.4g"' % rng.uniform(200, 400))
+
+
+def test_random_scenes_in_the_plan_class_step_by_step(tmp_path):
+    """Fuzzing the kernels' math against the oracle: 24 seeded variants of the own scene (box / ellipsoid / cylinder shells of 34 - 68
+    elements, other link sizes, masses, time steps, sweep counts), fix-rows-only, 100 env steps each through idle, closing and
+    squeeze.  Some of these scenes amplify round-off (a finger rocking on two capsules: 10x per 3 env steps), so the comparison is
+    step by step along the oracle's trajectory: the emulation is re-seated on the oracle's state after every env step and the error it
+    adds in one env step is bounded; contact and sweep counts equal at every step."""
+    from oracle import oracle as O
+    rng = np.random.RandomState(11)
+    touched = 0
+    for i in range(24):
+        path = tmp_path / ("v%d.xml" % i)
+        path.write_text(_plan_class_variant(rng))
+        m = sg.compile_mjcf(str(path), composite_neighbors=False)
+        e = Emu(m.to_blob(), m.nv)                      # the plan builder accepts every variant
+        s = O.OracleSim(O.OracleModel(m.to_blob()))
+        s._om = s.model
+        k = rng.uniform(300, 1400)
+        s.jnt_stiffness[8:] = k
+        s.tendon_stiffness[0] = k
+        e.set_stiffness(k, list(range(8, m.nv)), [0])
+        e.reset(); s.reset()
+        e.substep(False); s.forward()
+        e.substep(True); s.step()
+        most = 0
+        for t, c in enumerate(episode_schedule()[:100]):
+            if c is not None:
+                e.set_ctrl(c)
+                s.ctrl[:] = c
+            for _ in range(7):
+                assert e.substep(True) == 0 and s.step() == 0, (i, t)
+                assert e.ncon == s.ncon and e.L.emu_iters(e.p) == s.solver_iter, (i, t)
+            q, v, w, a = e.state()
+            assert np.abs(e.sensordata - s.sensordata).max() < 1e-8 and np.abs(q - s.qpos).max() < 1e-10, (i, t)
+            e.set_state(s.qpos, s.qvel, s.qacc_warmstart, s.act)
+            most = max(most, s.ncon)
+        touched += most > 0
+    assert touched >= 18
