@@ -158,3 +158,51 @@ def test_random_scenes_in_the_plan_class_step_by_step(tmp_path):
             most = max(most, s.ncon)
         touched += most > 0
     assert touched >= 18
+
+
+def thin_shell_scene(path):
+    """the own scene with a thin 3 x 2 x 3 shell of fat capsules: the capsules on the shell's x-edges stick out towards BOTH fingers, so
+    from the first touch on one slider carries contacts of both finger streams (the kernels' `shared` path: the two streams of an env
+    are then swept one after the other instead of side by side)"""
+    import os
+    from helpers import ROOT
+    x = open(os.path.join(ROOT, "tests", "data", "mini_gripper.xml")).read()
+    x = x.replace('count="3 4 3" spacing="0.2"', 'count="3 2 3" spacing="0.1"').replace('size=".08 0.06"', 'size=".12 0.04"')
+    with open(path, "w") as f:
+        f.write(x)
+    return str(path)
+
+
+def elements_touching_both_fingers(m, contacts):
+    names, by = m.geom_names, {}
+    for c in contacts:
+        g1, g2 = c["geom1"], c["geom2"]
+        cap, box = (g1, g2) if names[g1].startswith("OBJG") else (g2, g1)
+        by.setdefault(cap, set()).add(names[box][:2])       # "fL" / "fR"
+    return sum(1 for v in by.values() if len(v) > 1)
+
+
+def test_one_slider_under_both_fingers(tmp_path):
+    from oracle import oracle as O
+    m = sg.compile_mjcf(thin_shell_scene(tmp_path / "thin.xml"), composite_neighbors=False)
+    e = Emu(m.to_blob(), m.nv)
+    s = O.OracleSim(O.OracleModel(m.to_blob()))
+    s._om = s.model
+    k = 600.0
+    s.jnt_stiffness[8:] = k
+    s.tendon_stiffness[0] = k
+    e.set_stiffness(k, list(range(8, m.nv)), [0])
+    e.reset(); s.reset()
+    e.substep(False); s.forward()
+    e.substep(True); s.step()
+    shared, worst = 0, 0.0
+    for t, c in enumerate(episode_schedule()[:130]):
+        if c is not None:
+            e.set_ctrl(c)
+            s.ctrl[:] = c
+        for _ in range(7):
+            assert e.substep(True) == 0 and s.step() == 0
+            shared += elements_touching_both_fingers(m, s.contacts()) > 0
+        worst = max(worst, np.abs(e.sensordata - s.sensordata).max())
+        assert e.ncon == s.ncon
+    assert shared > 300 and worst < 1e-8        # free-running: this scene does not amplify round-off

@@ -796,3 +796,50 @@ def test_random_scenes_in_the_plan_class_on_the_gpu(tmp_path, neighbors):
         touched += most > 0
         del b
     assert touched >= 7 and left_envelope <= 3, (touched, left_envelope)
+
+
+@pytest.mark.parametrize("neighbors,pipeline", [(False, "rows"), (False, "split"), (False, "fused"), (True, "rows")])
+def test_one_slider_under_both_fingers_on_the_gpu(tmp_path, neighbors, pipeline):
+    """the solver's `shared` path (tests/test_emu_vs_oracle.py thin_shell_scene: a thin shell whose edge capsules touch BOTH fingers, so the
+    two finger streams of an env meet on one slider and are swept one after the other): 130 env steps, 4 envs, against the oracle --
+    free-running without the neighbour rows, re-seated with them; the oracle's contact list confirms the situation occurs"""
+    import torch
+    from oracle import oracle as O
+    from softgrip_amd import native
+    from test_emu_vs_oracle import elements_touching_both_fingers, thin_shell_scene
+    m = sg.Model.from_blob(native.compile_mjcf_native(thin_shell_scene(tmp_path / "thin.xml"), composite_neighbors=neighbors))
+    jids, tids = list(range(8, m.nv)), [0]
+    ks = [600.0, 300.0, 1400.0, 950.0]
+    b = native.NativeBatch(native.NativeModel(m), len(ks), 0)
+    b.set_pipeline(pipeline)
+    b.set_stiffness(np.asarray(ks), jids, tids)
+    sens, flags, touch = _bufs(b, len(ks))
+    om = O.OracleModel(m.to_blob())
+    sims = [O.OracleSim(om) for _ in ks]
+    for s, k in zip(sims, ks):
+        s.jnt_stiffness[jids] = k
+        s.tendon_stiffness[tids] = k
+        s.reset(); s.forward(); s.step()
+    b.reset(1, sens=sens, flags=flags, touch=touch)
+    ctrl = np.zeros(2)
+    shared = 0
+    T = lambda a: torch.tensor(np.stack(a), dtype=torch.float64, device=b.device).contiguous()  # noqa: E731
+    for t, c in enumerate(episode_schedule()[:130]):
+        if c is not None:
+            ctrl[:] = c
+            b.set_ctrl_broadcast(ctrl)
+            for s in sims:
+                s.ctrl[:] = c
+        b.step(7, sens=sens, flags=flags, touch=touch)
+        for s in sims:
+            for _ in range(7):
+                assert s.step() == 0
+        assert int(flags.abs().sum()) == 0, t
+        assert np.abs(sens.cpu().numpy() - np.stack([s.sensordata for s in sims])).max() < TOL_SENSOR, t
+        st = b.solver_stats()
+        assert st["ncon"].cpu().tolist() == [s.ncon for s in sims] and st["iters"].cpu().tolist() == [s.solver_iter for s in sims], t
+        shared += sum(elements_touching_both_fingers(m, s.contacts()) > 0 for s in sims)
+        if neighbors:
+            b.set_state(qpos=T([s.qpos for s in sims]), qvel=T([s.qvel for s in sims]), act=T([s.act for s in sims]),
+                        qacc_warmstart=T([s.qacc_warmstart for s in sims]))
+    assert shared > 100
