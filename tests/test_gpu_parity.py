@@ -843,3 +843,24 @@ def test_one_slider_under_both_fingers_on_the_gpu(tmp_path, neighbors, pipeline)
             b.set_state(qpos=T([s.qpos for s in sims]), qvel=T([s.qvel for s in sims]), act=T([s.act for s in sims]),
                         qacc_warmstart=T([s.qacc_warmstart for s in sims]))
     assert shared > 100
+
+
+def test_bench_two_ranks_with_the_real_library(tmp_path):
+    """the multi-process path with the real kernels: `bench.py --gpus 2` launches its own two workers (torch.distributed.run as a child
+    process), both placed on this box's one GPU (--force-device 0) with gloo as the rendezvous backend (RCCL refuses two ranks on one
+    device); per-rank stiffness bins, barrier + max-over-ranks timing, one JSON line from rank 0 with the whole-job rate"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs", "512", "--steps", "10", "--warmup", "2",
+                          "--dist-backend", "gloo", "--force-device", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "weak" and d["config"]["envs_per_gpu"] == 512
+    assert d["config"]["envs_flagged_bad"] == 0 and d["value"] > 1e4 and "per-rank bins" in d["config"]["workload"]
+    assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
