@@ -286,6 +286,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   pa.mask = mask; pa.sens = nullptr; pa.sens_stride = stride > 0 ? stride : H.nsensordata;
   pa.w = b->w; pa.nenv = b->n; pa.rowlayout = b->pipeline == 2;
   pa.nbtab = b->dnbtab;
+  pa.nelem = H.nelem; pa.nv = H.nv; pa.nu = H.nu; pa.elem_dof0 = H.elem_dof0; pa.nchain = H.nchain; pa.t0_id = H.t0_id; pa.timestep = H.timestep;
   SgPgsArgs ga;
   ga.sched = b->dsched; ga.nbtab = b->dnbtab;
   ga.H = b->dH; ga.elem = b->delem; ga.w = b->w; ga.nenv = b->n;

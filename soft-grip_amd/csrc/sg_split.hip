@@ -65,6 +65,9 @@ struct SgPhaseArgs {
   int do_reset, do_finish, finish_integrate, do_begin, first;
   int rowlayout;  // 1: export contact records in the row layout of sg_pgs_rows_kernel
   const int* nbtab;  // SgPlan::nbtab (neighbour rows per element), nullptr when H.nnb == 0
+  // copies of the plan header's sizes, by value: the kernels' first addresses then do not wait for a load from *H
+  int nelem, nv, nu, elem_dof0, nchain, t0_id;
+  double timestep;
 };
 
 // chain hand-off record (doubles): written by the chain stage (phase kernel or sg_chain_kernel), read by FINISH and by BEGIN
@@ -153,9 +156,9 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   if (a.mask && !a.mask[env]) return;
   SG_T0();
   const SgPlanHeader& H = *a.H;
-  const int N = H.nelem, nv = H.nv, nu = H.nu, e0 = H.elem_dof0, nchain = H.nchain;
+  const int N = a.nelem, nv = a.nv, nu = a.nu, e0 = a.elem_dof0, nchain = a.nchain;
   const size_t S = 2 * (size_t)a.nenv;
-  const double h = H.timestep;
+  const double h = a.timestep;
   __shared__ Smem2<R, CPL, NB> Sm;
   auto EL = [&](int f, int e) { return a.elem[(size_t)f * N + e]; };
   const int half = lane >> 5;
@@ -167,15 +170,16 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   ChainLds2& CS = Sm.cs[half];
   SgWork& W = a.w;
 
+  // status and pending are LOADED here and TESTED below, after the state loads have been issued: an early return on them would put
+  // one memory round trip in front of every other load of the kernel (a wavefront lives ~30 us, a round trip costs 1 - 2)
   int status = W.status[env];  // sg_chain_kernel, which runs first, resets it at the start of a call
-  const bool dead = (status & (SG_FLAG_BADQPOS | SG_FLAG_BADQVEL | SG_FLAG_BADQACC)) != 0;
-  if (dead) return;  // the env stopped integrating earlier in this call
+  const int pend = W.pending[env];
 
   double* gq = a.qpos + (size_t)env * nv;
   double* gv = a.qvel + (size_t)env * nv;
   double* gw = a.warm + (size_t)env * nv;
   const double kenv = a.kenv[env];
-  const double kt0 = a.kmask_ten[H.t0_id] ? kenv : H.t0_k0;
+  const int kt0_masked = a.kmask_ten[a.t0_id];
 
   // ---------------- load state ----------------
   double qe[R], ve[R], we[R], ke[R];
@@ -192,13 +196,12 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   // the loads of FINISH (solver result, smooth acceleration and force of the previous substep) and the import of the chain
   // hand-off record are issued here, together with the state: one memory latency instead of three in a row (the kernel waits for
   // memory two thirds of its time, profiles/r02)
-  const bool fin = a.do_finish && W.pending[env];
   double ase[R], asme_p[R], fsm_p[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const int e = r * 64 + lane;
     ase[r] = asme_p[r] = fsm_p[r] = 0;
-    if (fin && e < N) {
+    if (a.do_finish && e < N) {  // whether a substep is pending is tested below: the workspace words exist either way
       ase[r] = W.as[(size_t)env * N + e]; asme_p[r] = W.asme[(size_t)env * N + e];
       if (a.finish_integrate) fsm_p[r] = W.fsm[(size_t)env * N + e];
     }
@@ -226,6 +229,10 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
       else if (j >= SGH_LIMSIGN && j < SGH_LIMSIGN + 4 * SG_MAXLIM) lim[j - SGH_LIMSIGN] = v;
     }
   }
+  const bool dead = (status & (SG_FLAG_BADQPOS | SG_FLAG_BADQVEL | SG_FLAG_BADQACC)) != 0;
+  if (dead) return;  // the env stopped integrating earlier in this call
+  const bool fin = a.do_finish && pend;
+  const double kt0 = kt0_masked ? kenv : H.t0_k0;
   __syncthreads();
 
   SG_T(0);
@@ -848,18 +855,19 @@ __global__ __launch_bounds__(64) void sg_chain_kernel(SgPhaseArgs a) {
   const int lane = threadIdx.x, c = blockIdx.x & 1, env = (int)(blockIdx.x >> 1) * 64 + lane;
   SG_T0();
   const SgPlanHeader& H = *a.H;
-  const int nv = H.nv, nu = H.nu;
+  const int nv = a.nv, nu = a.nu;
   const size_t S = 2 * (size_t)a.nenv;
   if (env >= a.nenv) return;
   const size_t st = 2 * (size_t)env + c;
   if (a.mask && !a.mask[env]) return;
   SgWork& W = a.w;
   if (a.first && c == 0) { W.status[env] = 0; if (!a.do_finish) W.pending[env] = 0; }
-  if (c >= H.nchain) return;
+  if (c >= a.nchain) return;
+  // loaded here, tested after the state loads have been issued (an early return would put a memory round trip in front of them)
   const int status = a.first ? 0 : W.status[env];
-  if (status & (SG_FLAG_BADQPOS | SG_FLAG_BADQVEL | SG_FLAG_BADQACC)) return;
+  const int pend = a.do_finish ? W.pending[env] : 0;
   const SgChain& C = H.chain[c];
-  const double h = H.timestep;
+  const double h = a.timestep;
   double* gq = a.qpos + (size_t)env * nv;
   double* gv = a.qvel + (size_t)env * nv;
   double* gw = a.warm + (size_t)env * nv;
@@ -879,9 +887,10 @@ __global__ __launch_bounds__(64) void sg_chain_kernel(SgPhaseArgs a) {
   const double kten = C.has_ten ? (a.kmask_ten[C.ten_id] ? kenv : C.ten_k0) : 0.0;
   double* ch = W.chh + st * SG_CHW;
   bool bad_acc = false;
+  if (status & (SG_FLAG_BADQPOS | SG_FLAG_BADQVEL | SG_FLAG_BADQACC)) return;
 
   SG_T(17);
-  if (a.do_finish && W.pending[env]) {
+  if (a.do_finish && pend) {
     double aF[SG_CD], qacc_c[SG_CD];
 #pragma unroll
     for (int d = 0; d < SG_CD; d++) {
