@@ -149,25 +149,27 @@ std::string dir_of(const std::string& path) {
   return k == std::string::npos ? std::string(".") : path.substr(0, k);
 }
 
-std::unique_ptr<Node> load_xml(const std::string& path, const std::string& base_dir);
+constexpr int kMaxIncludeDepth = 16;   // the reference nests three files deep (experiment -> gripper -> scene)
+std::unique_ptr<Node> load_xml(const std::string& path, const std::string& base_dir, int depth);
 
-void expand_includes(Node* parent, const std::string& base_dir) {
+void expand_includes(Node* parent, const std::string& base_dir, int depth) {
   std::vector<std::unique_ptr<Node>> out;
   for (auto& c : parent->kids) {
     if (c->tag == "include") {
       const std::string* f = c->get("file");
       if (!f) fail("<include> without file");
-      auto inc = load_xml(base_dir + "/" + *f, base_dir);
+      if (depth >= kMaxIncludeDepth) fail("<include file=\"" + *f + "\"> nests deeper than " + std::to_string(kMaxIncludeDepth) + " files (an include cycle?)");
+      auto inc = load_xml(base_dir + "/" + *f, base_dir, depth + 1);
       for (auto& k : inc->kids) out.push_back(std::move(k));
     } else {
-      expand_includes(c.get(), base_dir);
+      expand_includes(c.get(), base_dir, depth);
       out.push_back(std::move(c));
     }
   }
   parent->kids = std::move(out);
 }
 
-std::unique_ptr<Node> load_xml(const std::string& path, const std::string& base_dir) {
+std::unique_ptr<Node> load_xml(const std::string& path, const std::string& base_dir, int depth) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) fail("cannot open " + path);
   std::string src;
@@ -180,7 +182,7 @@ std::unique_ptr<Node> load_xml(const std::string& path, const std::string& base_
   if (P.p >= src.size()) fail(path + ": no root element");
   auto root = P.element();
   if (root->tag != "mujoco") fail(path + ": root element must be <mujoco>");
-  expand_includes(root.get(), base_dir.empty() ? dir_of(path) : base_dir);
+  expand_includes(root.get(), base_dir.empty() ? dir_of(path) : base_dir, depth);
   return root;
 }
 
@@ -470,8 +472,17 @@ struct Compiler {
     const std::string* cs = elem.get("count");
     if (!cs) fail("composite without count");
     auto cv = parse_vec(*cs);
-    if (cv.size() != 3 || cv[0] < 2 || cv[1] < 2 || cv[2] < 2) fail("box/ellipsoid composites need a 3-D count >= 2");
+    // range-checked before the cast (a huge double -> int is undefined) and before the O(count^3) grid walk: the kernels take <= 256
+    // shell elements (sg_model_create), which no axis beyond 64 can stay under
+    if (cv.size() != 3) fail("box/ellipsoid composites need a 3-D count");
+    for (double c : cv)
+      if (!(c >= 2 && c <= 64) || c != std::floor(c)) fail("composite count must be whole numbers in [2, 64] per axis, got \"" + *cs + "\"");
     const int count[3] = {(int)cv[0], (int)cv[1], (int)cv[2]};
+    {
+      const long inner = (long)(count[0] - 2) * (count[1] - 2) * (count[2] - 2);
+      const long shell = (long)count[0] * count[1] * count[2] - (inner > 0 ? inner : 0);
+      if (shell > 256) fail("composite with " + std::to_string(shell) + " shell elements: at most 256 are supported");
+    }
     const std::string* sp = elem.get("spacing");
     if (!sp) fail("composite without spacing");
     const double spacing = parse_vec(*sp)[0];
@@ -611,7 +622,7 @@ struct Compiler {
 
   void run(const std::string& path, bool neighbors) {
     composite_neighbors = neighbors;
-    root = load_xml(path, "");
+    root = load_xml(path, "", 0);
     Body world;
     world.name = "world";
     bodies.push_back(world);

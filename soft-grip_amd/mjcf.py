@@ -103,7 +103,10 @@ def quat_z2vec(vec):
 # ----------------------------------------------------------------------------
 # XML loading with <include>
 # ----------------------------------------------------------------------------
-def _load_xml(path: str, base_dir: Optional[str] = None) -> ET.Element:
+MAX_INCLUDE_DEPTH = 16   # csrc/sg_mjcf.cpp kMaxIncludeDepth
+
+
+def _load_xml(path: str, base_dir: Optional[str] = None, depth: int = 0) -> ET.Element:
     root = ET.parse(path).getroot()
     if root.tag != "mujoco":
         raise ValueError("%s: root element must be <mujoco>" % path)
@@ -113,7 +116,9 @@ def _load_xml(path: str, base_dir: Optional[str] = None) -> ET.Element:
         out = []
         for child in list(parent):
             if child.tag == "include":
-                inc = _load_xml(os.path.join(base_dir, child.attrib["file"]), base_dir)
+                if depth >= MAX_INCLUDE_DEPTH:
+                    raise ValueError("<include file=%r> nests deeper than %d files (an include cycle?)" % (child.attrib["file"], MAX_INCLUDE_DEPTH))
+                inc = _load_xml(os.path.join(base_dir, child.attrib["file"]), base_dir, depth + 1)
                 out.extend(list(inc))
             else:
                 expand(child)
@@ -403,9 +408,15 @@ class _Compiler:
         if ctype not in ("box", "ellipsoid", "cylinder"):
             raise ValueError("unsupported composite type %r" % ctype)
         prefix = elem.attrib.get("prefix", "")
-        count = [int(t) for t in elem.attrib["count"].split()]
-        if len(count) != 3 or min(count) < 2:
-            raise ValueError("box/ellipsoid composites need a 3-D count >= 2")
+        fcount = [float(t) for t in elem.attrib["count"].split()]
+        if len(fcount) != 3:
+            raise ValueError("box/ellipsoid composites need a 3-D count")
+        if any(not (2 <= c <= 64) or c != int(c) for c in fcount):
+            raise ValueError("composite count must be whole numbers in [2, 64] per axis, got %r" % elem.attrib["count"])
+        count = [int(c) for c in fcount]
+        shell = count[0] * count[1] * count[2] - max(0, (count[0] - 2) * (count[1] - 2) * (count[2] - 2))
+        if shell > 256:
+            raise ValueError("composite with %d shell elements: at most 256 are supported" % shell)
         spacing = float(elem.attrib["spacing"])
         gattr = self.defaults.resolve("geom", {}, childclass)
         jattr = self.defaults.resolve("joint", {}, childclass)
@@ -855,6 +866,11 @@ class Model:
         return len(self.jnt_type)
 
     nq = nv
+    njnt = nv      # every joint of the subset is scalar (hinge / slide)
+
+    @property
+    def nsite(self):
+        return len(self.site_bodyid)
 
     @property
     def ngeom(self):

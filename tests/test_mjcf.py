@@ -229,6 +229,11 @@ def test_native_compiler_matches_committed_blobs(scene):
     L.sg_model_destroy(ptr)
 
 
+_COMPOSITE_XML = ("<mujoco><compiler angle='radian'/><option solver='PGS' cone='elliptic'/><worldbody><body pos='0 0 1'>"
+                  "<composite type='box' count='%s' spacing='.3'><geom type='capsule' size='.02 .05' mass='.01'/></composite>"
+                  "</body></worldbody></mujoco>")
+
+
 def test_native_compiler_errors_are_reported(tmp_path):
     """same refusals as mjcf.py, as SG_ERR_MODEL with a message (no exception crosses the C ABI)"""
     from softgrip_amd import native
@@ -238,12 +243,23 @@ def test_native_compiler_errors_are_reported(tmp_path):
              "degree.xml": ("<mujoco><option solver='PGS' cone='elliptic'/><compiler angle='degree'/></mujoco>", "radian"),
              "broken.xml": ("<mujoco><worldbody><body></worldbody></mujoco>", "XML error"),
              "mesh.xml": ("<mujoco><compiler angle='radian'/><option solver='PGS' cone='elliptic'/><worldbody><geom type='mesh'/>"
-                          "</worldbody></mujoco>", "unsupported geom type")}
+                          "</worldbody></mujoco>", "unsupported geom type"),
+             # an include cycle used to recurse until the stack overflowed, a huge composite count hung the compile
+             "cycle.xml": ("<mujoco><include file='cycle.xml'/></mujoco>", "include cycle"),
+             "cycle_a.xml": ("<mujoco><include file='cycle_b.xml'/></mujoco>", "include cycle"),
+             "huge.xml": (_COMPOSITE_XML % "2000 2000 2000", r"whole numbers in \[2, 64\]"),
+             "huge2.xml": (_COMPOSITE_XML % "1e300 4 4", r"whole numbers in \[2, 64\]"),
+             "frac.xml": (_COMPOSITE_XML % "4.5 4 4", r"whole numbers in \[2, 64\]"),
+             "many.xml": (_COMPOSITE_XML % "20 20 20", "at most 256")}
+    (tmp_path / "cycle_b.xml").write_text("<mujoco><include file='cycle_a.xml'/></mujoco>")
     for fn, (xml, what) in cases.items():
         (tmp_path / fn).write_text(xml)
         with pytest.raises(native.SoftgripError, match=what) as ei:
             native.compile_mjcf_native(str(tmp_path / fn))
         assert ei.value.code == -2
+        if fn.startswith(("cycle", "huge", "frac", "many")):   # the Python compiler refuses the same files with the same words
+            with pytest.raises(ValueError, match=what):
+                sg.compile_mjcf(str(tmp_path / fn))
     with pytest.raises(native.SoftgripError, match="cannot open"):
         native.compile_mjcf_native(str(tmp_path / "missing.xml"))
 

@@ -28,28 +28,87 @@ def test_capture_script_schedule_is_the_reference_schedule():
     assert (cap.SIM_START, cap.SIM_STEP, cap.JOINT_IDS, cap.TENDON_IDS) == (1, 7, list(range(11, 64)), [0])
 
 
-@pytest.mark.skipif(not CAPTURES, reason="MuJoCo parity not yet measured: no tests/golden/mujoco_*.npz (run scripts/capture_mujoco_golden.py "
-                                         "on a machine with MuJoCo 2.x / mujoco_py and commit its output)")
-@pytest.mark.parametrize("path", CAPTURES or ["none"])
-def test_oracle_matches_mujoco_capture(path):
+def _scene_of(meta):
+    return meta["xml"].replace("soft_experiments_", "").replace("_adjusted_for_2_fingers.xml", "")
+
+
+def check_capture(path, model_for_scene=None):
+    """the comparison the armed test runs on a capture: model counts, total mass, then every sensor row of every captured episode.
+    models/<scene>.sgmodel is the default (neighbour equalities, 327 / 573 / 651 rows); a capture whose `neq` equals the fix-rows-only
+    variant's (111 / 193 / 219) settles SURVEY U2 the other way and is held against models/<scene>_fix.sgmodel"""
     d = np.load(path)
     meta = json.loads(str(d["meta"]))
-    scene = meta["xml"].replace("soft_experiments_", "").replace("_adjusted_for_2_fingers.xml", "")
-    m = sg.load_model(model_path(scene))
-    if meta["counts"].get("neq") == sg.load_model(model_path(scene + "_nb")).neq:
-        m = sg.load_model(model_path(scene + "_nb"))   # the capture's neq settles SURVEY U2: MuJoCo created the neighbour equalities
+    scene = _scene_of(meta)
+    load = model_for_scene or (lambda name: sg.load_model(model_path(name)))
+    m = load(scene)
+    variant = scene
+    fix = load(scene + "_fix")
+    if meta["counts"].get("neq") == fix.neq:
+        m, variant = fix, scene + "_fix"   # MuJoCo did not create the neighbour equalities
         # (with them the squeeze amplifies round-off, DESIGN 2: expect agreement at TOL over the first ~60 env steps only)
     for k, v in meta["counts"].items():
         assert getattr(m, k, v) == v, "compiled model differs from MuJoCo's in %s" % k
     assert abs(float(np.sum(m.body_mass)) - meta["total_mass"]) < 1e-9
     from softgrip_amd.create_dataset import episode_schedule
+    n_steps = d["sensordata"].shape[1] - 1
     for i, k in enumerate(d["stiffness"]):
         s = oracle_sim(m, float(k))
         s.reset(); s.forward(); s.step()
         np.testing.assert_allclose(s.sensordata, d["sensordata"][i, 0], atol=TOL)
-        for t, c in enumerate(episode_schedule()):
+        for t, c in enumerate(episode_schedule()[:n_steps]):
             if c is not None:
                 s.ctrl[:] = c
             for _ in range(7):
                 s.step()
             np.testing.assert_allclose(s.sensordata, d["sensordata"][i, t + 1], atol=TOL, err_msg="env step %d, k=%g" % (t, k))
+    return variant
+
+
+@pytest.mark.skipif(not CAPTURES, reason="MuJoCo parity not yet measured: no tests/golden/mujoco_*.npz (run scripts/capture_mujoco_golden.py "
+                                         "on a machine with MuJoCo 2.x / mujoco_py and commit its output)")
+@pytest.mark.parametrize("path", CAPTURES or ["none"])
+def test_oracle_matches_mujoco_capture(path):
+    check_capture(path)
+
+
+def _synthetic_capture(path, m, ks, n_steps, perturb=0.0):
+    """a file of exactly the layout scripts/capture_mujoco_golden.py writes, filled by the ORACLE instead of MuJoCo -- it pins nothing
+    about MuJoCo; it exists so that the armed path above is executed before the day a real capture arrives"""
+    from softgrip_amd.create_dataset import episode_schedule
+    sens = np.zeros((len(ks), n_steps + 1, 12))
+    for i, k in enumerate(ks):
+        s = oracle_sim(m, float(k))
+        s.reset(); s.forward(); s.step()
+        sens[i, 0] = s.sensordata
+        for t, c in enumerate(episode_schedule()[:n_steps]):
+            if c is not None:
+                s.ctrl[:] = c
+            for _ in range(7):
+                s.step()
+            sens[i, t + 1] = s.sensordata
+    sens[:, n_steps // 2:, 3] += perturb
+    meta = {"mujoco": "synthetic (oracle)", "xml": "soft_experiments_softbox_adjusted_for_2_fingers.xml",
+            "counts": {k: int(getattr(m, k)) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "ntendon", "neq", "nsensordata")},
+            "total_mass": float(np.sum(m.body_mass))}
+    np.savez_compressed(path, stiffness=np.array(ks, dtype=float), sensordata=sens, meta=json.dumps(meta))
+
+
+@pytest.mark.parametrize("variant", ["softbox", "softbox_fix"])
+def test_armed_path_runs_on_a_synthetic_capture(tmp_path, variant):
+    """the armed comparison must work the day a capture arrives.  Both U2 outcomes: a capture with 327 equality
+    rows is held against the default model, one with 111 against the fix-rows-only variant; a capture that differs from the oracle by
+    more than 1e-4 fails, and one with other model counts fails on the counts."""
+    m = sg.load_model(model_path(variant))
+    p = str(tmp_path / "mujoco_synth.npz")
+    _synthetic_capture(p, m, [700.0, 903.6948543200572], 14)
+    assert check_capture(p) == variant
+    _synthetic_capture(p, m, [700.0], 6, perturb=3e-4)
+    with pytest.raises(AssertionError, match="env step"):
+        check_capture(p)
+    d = dict(np.load(p))
+    meta = json.loads(str(d["meta"]))
+    meta["counts"]["ngeom"] += 1
+    d["meta"] = json.dumps(meta)
+    np.savez_compressed(p, **d)
+    with pytest.raises(AssertionError, match="ngeom"):
+        check_capture(p)
