@@ -263,7 +263,7 @@ def main():
         from softgrip_amd import convnet
         torch.manual_seed(0)
         net = convnet.ConvNet().to(dev)
-        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        opt = convnet.make_optimizer(net)
         y = torch.tensor(R.ks, device=dev)
         reg = {"loss": []}
 
@@ -279,7 +279,7 @@ def main():
         import copy
         wnet = copy.deepcopy(net)
         wx = torch.randn(n, T, R.nsd, dtype=torch.float64, device=dev)
-        convnet.train_step(wnet, torch.optim.Adam(wnet.parameters(), lr=1e-3), wx, y, *convnet.channel_stats(wx), add_noise=True)
+        convnet.train_step(wnet, convnet.make_optimizer(wnet), wx, y, *convnet.channel_stats(wx), add_noise=True)
         del wnet, wx
     barrier()
     R.flags_or.zero_()

@@ -64,7 +64,9 @@ class ConvNet(nn.Module):
 
     def forward(self, x):
         """x: [B, T, 12] (channels last, any float dtype) -> raw output [B, 1]"""
-        x = x.to(torch.float32).transpose(1, 2)            # tf.cast(inputs, tf.float32) (NeuralNets.py:22)
+        # tf.cast(inputs, tf.float32) (NeuralNets.py:22): the network computes in the dtype of its parameters -- float32 as built;
+        # a .double() copy is the fp64 evaluation the numeric tests hold the float32 one against
+        x = x.to(self.conv1.weight.dtype).transpose(1, 2)
         x = F.relu(self.bn1(self.conv1(self._same(x))))
         x = F.relu(self.bn2(self.conv2(self._same(x))))
         x = self.conv3(self._same(x))                       # no BN / activation on the last conv (layers.py:26)
@@ -91,6 +93,12 @@ def noised_modality(x, generator=None):
     noise = torch.randn(x.shape, dtype=x.dtype, device=x.device, generator=generator)
     scale = torch.cat([torch.full((6,), 0.7), torch.full((x.shape[-1] - 6,), 0.06)]).to(x)
     return x + noise * scale
+
+
+def make_optimizer(model, lr=1e-3):
+    """tf.keras.optimizers.Adam(learning_rate) as the reference builds it (training_cross_validate.py:58-61; the ExponentialDecay there is
+    always evaluated at step 0, so the rate is a constant 1e-3): beta 0.9 / 0.999 and Keras' epsilon 1e-7 (torch's default is 1e-8)"""
+    return torch.optim.Adam(model.parameters(), lr=lr, betas=(0.9, 0.999), eps=1e-7)
 
 
 def train_step(model, optimizer, x, y, mean, std, add_noise=False):

@@ -38,7 +38,7 @@ def test_shapes_and_same_padding():
 def test_train_step_decreases_loss():
     torch.manual_seed(0)
     m = cn.ConvNet()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)          # training_cross_validate.py:58-61 (constant 1e-3)
+    opt = cn.make_optimizer(m)          # training_cross_validate.py:58-61 (constant 1e-3)
     x = torch.randn(32, 200, 12, dtype=torch.float64)
     y = 300 + 1100 * torch.rand(32)
     mean, std = cn.channel_stats(x)
@@ -102,3 +102,83 @@ def test_conv1_bn_relu_hand_computed_train_and_eval():
     z = rng.randn(7, 5)
     np.testing.assert_allclose(bn(torch.tensor(z)).detach().numpy(), (z - z.mean(0)) / np.sqrt(z.var(0) + 1e-3), atol=1e-12)
     np.testing.assert_allclose(bn.running_var.numpy(), 0.99 + 0.01 * z.var(0), atol=1e-14)
+
+
+def _state(net):
+    return {k: v.detach().cpu().double().numpy().copy() for k, v in net.state_dict().items()}
+
+
+def _random_net(seed, dtype=torch.float64):
+    """a ConvNet with every parameter and moving statistic away from its initial value (biases, gammas, betas, moving mean / variance)"""
+    torch.manual_seed(seed)
+    net = cn.ConvNet().to(dtype)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if name.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g, dtype=dtype))
+            elif "bn" in name and name.endswith("weight"):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g, dtype=dtype))
+        for name, b in net.named_buffers():
+            b.copy_((0.1 * torch.randn(b.shape, generator=g, dtype=dtype)) if name.endswith("mean") else (0.5 + torch.rand(b.shape, generator=g, dtype=dtype)))
+    return net
+
+
+def test_whole_network_against_the_numpy_restatement_train_and_eval():
+    """The hand-computed pin extended from conv1 + BN to the WHOLE network: conv2 / conv3 (no BN / activation on the
+    last conv), global average pooling, the three dense + BN + ReLU blocks, dense 64, dense 1, the head and the MAE loss -- module
+    (fp64) against tests/np_convnet.py, which shares no code with it, in training mode (batch statistics, moving statistics updated by
+    one 0.99 / 0.01 step) and in inference mode (moving statistics), on an even and on an odd number of time steps."""
+    import np_convnet as npc
+    rng = np.random.RandomState(5)
+    for T in (200, 26, 9):
+        net = _random_net(11 + T)
+        x = rng.randn(6, T, 12)
+        y = rng.uniform(300, 1400, 6)
+        p = _state(net)
+        net.eval()
+        with torch.no_grad():
+            got_eval = net(torch.tensor(x))[:, 0].numpy()
+        np.testing.assert_allclose(got_eval, npc.forward(p, x, training=False), rtol=1e-10, atol=1e-10)
+        net.train()
+        new_stats = {}
+        want_train = npc.forward(p, x, training=True, new_stats=new_stats)
+        with torch.no_grad():
+            got_train = net(torch.tensor(x))[:, 0].numpy()
+        np.testing.assert_allclose(got_train, want_train, rtol=1e-9, atol=1e-9)
+        after = _state(net)
+        assert len(new_stats) == 10
+        for k, v in new_stats.items():
+            np.testing.assert_allclose(after[k], v, rtol=1e-12, atol=1e-12)
+        pred = cn.normalize_predictions(torch.tensor(want_train)[:, None]).numpy()
+        np.testing.assert_allclose(pred, npc.predictions(want_train), rtol=1e-12)
+        assert abs(float(np.abs(pred - y).mean()) - npc.mae_loss(p, x, y)) < 1e-9
+
+
+def test_gradients_against_finite_differences_of_the_numpy_loss_and_adam_step():
+    """every gradient tensor of one training step (autograd, fp64) against central finite differences of the NumPy restatement's loss
+    along a random direction per tensor, and the optimizer step against Adam's first step written out by hand with Keras' epsilon"""
+    import np_convnet as npc
+    rng = np.random.RandomState(7)
+    net = _random_net(3)
+    x = rng.randn(5, 24, 12)
+    y = rng.uniform(300, 1400, 5)
+    one, zero = torch.ones(1, 1, 12, dtype=torch.float64), torch.zeros(1, 1, 12, dtype=torch.float64)
+    p0 = _state(net)
+    opt = cn.make_optimizer(net)
+    loss, _ = cn.train_step(net, opt, torch.tensor(x), torch.tensor(y), zero, one)
+    assert abs(float(loss) - npc.mae_loss(p0, x, y)) < 1e-9
+    grads = {k: v.grad.numpy().copy() for k, v in net.named_parameters()}
+    assert len(grads) == 26
+    for k, g in grads.items():
+        d = rng.randn(*g.shape)
+        d /= np.linalg.norm(d)
+        eps = 1e-6
+        pp, pm = dict(p0), dict(p0)
+        pp[k], pm[k] = p0[k] + eps * d, p0[k] - eps * d
+        fd = (npc.mae_loss(pp, x, y) - npc.mae_loss(pm, x, y)) / (2 * eps)
+        an = float((g * d).sum())
+        assert abs(fd - an) <= 1e-5 * max(1.0, abs(an)), (k, fd, an)
+    after = _state(net)
+    for k, g in grads.items():
+        np.testing.assert_allclose(after[k], npc.adam_first_step(p0[k], g), rtol=0, atol=1e-12, err_msg=k)

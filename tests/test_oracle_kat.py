@@ -551,3 +551,27 @@ def test_damped_fixed_tendon_stability_threshold_closed_form(c, implicit):
         mean, dev = mean * fac_sum, dev * fac_dif
         np.testing.assert_allclose(s.qvel, mean + dev, rtol=1e-10, atol=1e-12 * max(1.0, abs(mean)))
     assert (abs(s.qvel.sum()) > abs(v0.sum())) == (abs(fac_sum) > 1)
+
+
+def test_ensemble_statistic_is_calibrated():
+    """The statistical comparison the GPU suite uses for rows 47 .. 199 of the default model (helpers.assert_ensembles_match) held
+    against the one pair of runs known to be "the same system, other round-off": the oracle, and the oracle with 1e-13 added to one
+    slider position at env step 47 -- they are O(1) apart point-wise by step 120 on the envs that squeeze hard, and must PASS; and
+    against two wrong systems, which must FAIL: the same data one env step late, and accelerometers 15 % off."""
+    import os
+    from helpers import assert_ensembles_match, ensemble_report, oracle_episodes, model_path
+    import softgrip_amd as sg
+    m = sg.load_model(model_path("softbox"))
+    ks = np.linspace(300.0, 1400.0, 32)
+    th = min(8, os.cpu_count() or 1)
+    a, b = oracle_episodes(m, ks, th), oracle_episodes(m, ks, th, perturb=1e-13)
+    assert np.array_equal(a[:, :47], b[:, :47])
+    assert np.abs(a[:, 120:] - b[:, 120:]).max() > 1e-2        # the perturbation did grow: point-wise comparison is impossible here
+    rep = assert_ensembles_match(a, b, ks)
+    assert 0.3 < rep["pointwise_1e-4"] < 1.0
+    late = ensemble_report(a[:, 1:], b[:, :-1], ks)
+    assert late["mean_p99"] > 1.0 and late["quantile_p99"] > 1.0
+    scaled = a.copy()
+    scaled[:, :, :6] *= 1.15
+    off = ensemble_report(scaled, b, ks)
+    assert off["mean_p99"] > 1.0 and off["feat"] > 1.0
