@@ -148,15 +148,19 @@ class Runner:
         self.batch.step(self.sim_step, sens=self.out[:, t % T], sens_stride=T * self.nsd, flags=self.flags)
         self.flags_or.bitwise_or_(self.flags)
 
-    def timed(self, steps, barrier, after_episode=None):
-        """-> (seconds, avg kernel ms per sg_step call over the timed steps, launches timed, description)"""
+    def timed(self, steps, barrier, after_episode=None, profile=False):
+        """-> (seconds, avg kernel ms per sg_step call over the timed steps, launches timed, description, steps timed).
+        profile=False: the headline pass -- nothing but the path itself inside the timed interval.  profile=True: the same region again
+        with HIP events on the launch stream around every sg_step call's kernel chain and around every solver-kernel launch (7 per
+        call): the event records sit in the stream between the kernels, so that pass yields the kernel durations (roofline), not `value`
+        (ADVICE r02)."""
         torch, T, b = self.torch, self.T, self.batch
         b.profile_enable(False)
         b.profile_read(reset=True)
         b.profile_read_solver(reset=True)
         if steps % T == 0:
             barrier()
-            b.profile_enable(True)
+            b.profile_enable(profile)
             t0 = time.perf_counter()
             for t in range(steps):
                 self.step(t)
@@ -172,7 +176,7 @@ class Runner:
             for t in range(T):
                 if t in pick:
                     device_sync()
-                    b.profile_enable(True)
+                    b.profile_enable(profile)
                     t0 = time.perf_counter()
                     self.step(t)
                     device_sync()
@@ -188,6 +192,12 @@ class Runner:
         self.solver_ms, self.solver_launches = b.profile_read_solver(reset=True)
         b.profile_enable(False)
         return dt, kernel_ms, launches, desc, steps
+
+    def measure(self, steps, barrier, after_episode=None):
+        """headline pass (uninstrumented), then the same timed region once more with the HIP events on for the kernel durations"""
+        dt, _, _, desc, nsteps = self.timed(steps, barrier, after_episode, profile=False)
+        dtp, kernel_ms, launches, _, _ = self.timed(steps, barrier, None, profile=True)
+        return dt, kernel_ms, launches, desc, nsteps, dtp
 
 
 def main():
@@ -283,11 +293,16 @@ def main():
         del wnet, wx
     barrier()
     R.flags_or.zero_()
-    dt, kernel_ms, launches, desc, nsteps = R.timed(args.steps, barrier, after_episode)
+    dt, kernel_ms, launches, desc, nsteps, dt_prof = R.measure(args.steps, barrier, after_episode)
     if dist is not None:  # the only collectives of the run: barriers and this MAX (timing, not data path)
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        per_rank = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(per_rank, tt)      # per-rank times next to the MAX: a scaling run shows imbalance between GPUs
+        per_rank_dt = [float(x.item()) for x in per_rank]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    else:
+        per_rank_dt = [dt]
     nbad = int((R.flags_or != 0).sum().item())
 
     if rank == 0:
@@ -299,7 +314,8 @@ def main():
         res = {
             "metric": "env steps/sec (whole node) at batch=4096",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / nsteps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / nsteps * 1e3, "ms_per_step_with_hip_events": dt_prof / nsteps * 1e3,
+            "ms_per_step_per_rank": [d / nsteps * 1e3 for d in per_rank_dt], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic" if not args.fake_native_for_tests else "FAKE native batch (plumbing test, not a measurement)",
             "config": {"workload": "configs[%d]: %d envs/GPU, %s scene (nv=%d), stiffness ~ U(300,1400)%s, reference 200-step squeeze "
                                    "schedule from reset, 7 substeps per env step; %d equality rows (composite neighbour equalities %s: DESIGN.md 2, U2)" % (
@@ -313,7 +329,8 @@ def main():
                          "kernel": {"rows": "sg_chain_kernel + sg_phase_kernel + sg_pgs_rows_kernel chain of one sg_step call (rows pipeline; dominant: sg_pgs_rows_kernel)", "split": "sg_chain_kernel + sg_phase_kernel + sg_pgs_kernel chain of one sg_step call (split pipeline)"}.get(pipe, "sg_step_kernel"),
                          "avg_kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": abytes,
-                         "note": "one 'launch' = the kernel chain of one sg_step call (7 substeps), HIP events on the launch stream over the timed steps only; "
+                         "note": "one 'launch' = the kernel chain of one sg_step call (7 substeps), HIP events on the launch stream over the timed steps only "
+                                 "(a second pass over the same timed region: `value` is measured without the events in the stream); "
                                  "the path is instruction-issue-bound (serial Gauss-Seidel per finger), not HBM-bound; traffic is mostly contact blocks "
                                  "re-read from L2/Infinity Cache by each sweep (DESIGN.md 4.3)"},
         }
@@ -358,7 +375,7 @@ def main():
             for t in range(args.warmup):
                 R2.step(t)
             barrier()
-            dt2, km2, _, desc2, ns2 = R2.timed(args.steps, barrier)
+            dt2, km2, _, desc2, ns2, _ = R2.measure(args.steps, barrier)
             res["config"]["fix_only_variant"] = {"value": n * ns2 / dt2, "unit": "env-steps/s", "avg_kernel_ms": km2, "equality_rows": R2.model.neq,
                                                  "note": "same workload on models/%s_fix.sgmodel (composite without its neighbour equalities) -- NOT the headline" % args.scene}
             del R2

@@ -123,6 +123,13 @@ int sg_get_solver_stats(sg_batch* b, int32_t* ncon, int32_t* nefc, int32_t* iter
  * sg_set_pipeline(b, 0 or 1) returns SG_ERR_MODEL. */
 int sg_set_pipeline(sg_batch* b, int pipeline);
 
+/* envs per wavefront of the rows pipeline's solver kernel: 8 fills the wavefront (fix-rows-only models, chosen automatically from
+ * 8185 envs on, where 8 per wavefront still give every SIMD of the chip a wavefront), 4 spreads a smaller batch over twice as many
+ * wavefronts.  Same results either way (parity-tested in both).  epw: 0 = automatic, 4, 8; SG_ERR_MODEL for 8 on a model with
+ * neighbour equality rows (always 4).  sg_solver_envs_per_wavefront reports what the next sg_step will use. */
+int sg_set_solver_envs_per_wavefront(sg_batch* b, int epw);
+int sg_solver_envs_per_wavefront(const sg_batch* b);
+
 /* kernel timing hook for bench.py: average device time (ms) of one sg_step/sg_reset call's kernels over the
  * calls since the last call with reset != 0, measured with HIP events on the launch
  * stream.  Synchronises the host. */

@@ -17,8 +17,10 @@
  *   D1 capsule-box narrowphase is the exact segment/box closest-point construction, not
  *      MuJoCo's mjc_CapsuleBox case analysis (identical for a single nearest-point contact,
  *      may differ in the choice of a second contact for near-parallel configurations);
- *   D2 box-box / plane-box pairs are detected (SAT) but raise SGO_WARN_UNSUPPORTED_PAIR
- *      instead of producing contacts -- they never touch in the reference scenes.
+ *   D2 box-box and plane-box contacts are generated (since r02) by a separating-axis + face-clipping construction and from the
+ *      box corners within the margin -- written from the published description of such routines, not a transcription of
+ *      mjc_BoxBox / mjc_PlaneBox (their source is not available here); plane-capsule and static-box-capsule likewise.
+ *      SGO_WARN_UNSUPPORTED_PAIR is left for geometry outside the model class.
  */
 #include "sg_oracle.h"
 #include "../include/softgrip_model.h"

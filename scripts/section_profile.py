@@ -54,7 +54,7 @@ def main():
                 print("   %-26s %8.0f  %5.1f %%" % (name, v[k], 100 * v[k] / (v.sum() + v24)))
             print("   %-26s %8.0f  %5.1f %%" % ("24 contact rows (build)", v24, 100 * v24 / (v.sum() + v24)))
             print("   broadphase survivors per env and launch: %.1f pairs, %.2f dense narrowphase passes" % (buf[30] / (n * 8.0), buf[31] / (n * 8.0)))
-            epw = int(os.environ.get("SG_PGS_EPW", "8" if n >= 8192 else "4"))  # envs per PGS wavefront (sg_api.hip launch_split)
+            epw = b.solver_envs_per_wavefront()  # envs per PGS wavefront: the library's own choice (sg_api.hip solver_epw)
             nwave = n // epw
             w = np.array(buf[:32], dtype=np.float64) / (nwave * 7)  # 7 PGS launches per sg_step call
             tot = sum(w[k] for k in PGS_NAMES)

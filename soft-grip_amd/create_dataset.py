@@ -5,8 +5,14 @@ driving batched envs.  Same constants, same schedule, same pickle schema
 Multi-GPU: launched with torch.distributed.run, every rank simulates its own stiffness bin on
 its own GPU and writes its own shard file -- no collective.
 """
+import hashlib
+import json
 import os
 import pickle
+import socket
+import subprocess
+import sys
+import time
 from argparse import ArgumentParser
 from concurrent.futures import ThreadPoolExecutor
 
@@ -47,6 +53,23 @@ def _atomic_pickle(path, obj):
     os.replace(tmp, path)   # a crash never leaves a half-written shard behind
 
 
+def _fingerprint(args, env, rank, world, lo, hi, num_batches):
+    """what a part must have been made with to belong to this run (a resumed run used to merge whatever
+    <name>.partNNNNN.pickle it found): seed, batch shape, scenes (by content), stiffness range, integrator and read-out options"""
+    def digest(path):
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    return {"seed": getattr(args, "seed", None), "n_envs": env.n_envs, "num_batches": num_batches, "rank": rank, "world": world,
+            "scenes": [[os.path.basename(p), digest(p)] for p in args.mujoco_model_paths], "k_range": [float(lo), float(hi)],
+            "sim_start": args.sim_start, "sim_step": args.sim_step, "mask_contact": bool(args.mask_contact),
+            "contact_flag_mode": getattr(args, "contact_flag_mode", "intent"), "tendon_damper": getattr(args, "tendon_damper", "auto"),
+            "joint_ids": list(env.joint_ids), "tendon_ids": list(env.tendon_ids)}
+
+
+class PartMismatch(RuntimeError):
+    """a <name>.partNNNNN.pickle found on resume was written by a run with another configuration"""
+
+
 def log_into_file(args):
     """reference create_dataset.py:20-80.  Extensions (all off by default on one GPU with one env, where the function does
     exactly what the reference does): n_envs > 1 -> every "episode" is a batch of n_envs episodes; several ranks -> each rank
@@ -64,6 +87,8 @@ def log_into_file(args):
 
     env_spec = ManEnv.get_std_spec(args)
     env_spec["device"] = int(os.environ.get("LOCAL_RANK", getattr(args, "device", 0)))
+    if getattr(args, "force_device", -1) >= 0:
+        env_spec["device"] = args.force_device
     env = ManEnv(**env_spec)
     n = env.n_envs
     lo, hi = stiffness_bin(rank, world) if world > 1 else (300, 1400)   # stiffness sweep sharded by bin (BASELINE.json configs[3])
@@ -74,11 +99,22 @@ def log_into_file(args):
     data, stiffness = list(), list()
     n_skipped = 0
     writer, pending = None, None
+    fingerprint = _fingerprint(args, env, rank, world, lo, hi, num_batches)
+    t_start, n_simulated, n_flagged = time.perf_counter(), 0, 0
 
     for ep in range(num_batches * num_envs):
         part = _part_path(args.data_folder, name, ep)
         if incremental and os.path.exists(part):
-            env.rng.uniform(lo, hi, size=n if n > 1 else None)   # consume the draws of the finished batch: the stream stays aligned
+            # a finished batch of an interrupted run: it must be this run's (same configuration), and the RNG continues from the
+            # state stored with it -- a batch that re-drew labels for failed envs consumed more than its n draws, so counting
+            # draws would not reproduce the uninterrupted run
+            with open(part, "rb") as file:
+                d = pickle.load(file)
+            if d.get("config") != fingerprint:
+                diff = sorted(k for k in fingerprint if d["config"].get(k) != fingerprint[k]) if isinstance(d.get("config"), dict) else []
+                raise PartMismatch("%s was written by a run with another configuration (%s); remove the stale parts or use another "
+                                   "--data-name" % (part, "differs in: " + ", ".join(diff) if diff else "no configuration stored with it"))
+            env.rng.set_state(d["rng_state"])
             n_skipped += 1
         else:
             current_stiffness = np.array(env.reset(lo, hi), dtype=np.float64).reshape(-1).copy()   # the label is the pre-episode draw (reference :35,65)
@@ -110,10 +146,13 @@ def log_into_file(args):
                     writer = ThreadPoolExecutor(max_workers=1)
                 if pending is not None:
                     pending.result()
-                pending = writer.submit(_atomic_pickle, part, {"data": ep_data, "stiffness": ep_k})
+                pending = writer.submit(_atomic_pickle, part, {"data": ep_data, "stiffness": ep_k, "config": fingerprint,
+                                                               "rng_state": env.rng.get_state()})
             else:
                 data.extend(ep_data)
                 stiffness.extend(ep_k)
+            n_simulated += n
+            n_flagged = int(getattr(env, "n_resets", 0))
 
         if (ep + 1) % num_batches == 0 and num_envs > 1 and ep + 1 < num_batches * num_envs:
             # next scene (reference create_dataset.py:68-72; after the last one the reference asks load_env for an index past the
@@ -135,6 +174,15 @@ def log_into_file(args):
             print("resumed: {0} finished episode-batch(es) found and skipped".format(n_skipped))
     _atomic_pickle(path, {"data": data, "stiffness": stiffness})
     print("Total number of samples: {0}".format(len(data)))
+    # per-rank summary (no collective: every rank writes its own; the self-launching parent adds them up, main())
+    dt = time.perf_counter() - t_start
+    n_steps = START_STEP + MAX_ITER_PER_EP
+    summary = {"rank": rank, "world": world, "shard": os.path.basename(path), "shard_bytes": os.path.getsize(path), "episodes": len(data),
+               "episodes_simulated": n_simulated, "episodes_resumed": len(data) - n_simulated, "env_steps": n_simulated * n_steps,
+               "seconds": dt, "env_steps_per_s": n_simulated * n_steps / dt if dt > 0 else 0.0, "envs_reset_after_a_warning": n_flagged,
+               "stiffness_bin": [float(lo), float(hi)]}
+    with open(os.path.join(args.data_folder, "{}.summary.json".format(name)), "w") as file:
+        json.dump(summary, file)
     return path
 
 
@@ -168,14 +216,72 @@ def make_parser():
     parser.add_argument('--tendon-ids', type=int, nargs="+", default=None, help="tendons whose stiffness is randomised (default: the reference's 0)")
     parser.add_argument('--no-check-scene', dest="check_scene", action='store_false', default=True,
                         help="skip the load-time dry run that rejects scenes which cannot survive their own idle phase")
+    parser.add_argument('--gpus', type=int, default=1,
+                        help="N > 1 without a launcher: start N ranks (torch.distributed.run as a child process), one per GPU, each with its own "
+                             "stiffness bin and shard file -- BASELINE configs[3]: --gpus 8 --n-envs 4096 --total-episodes 131072")
+    parser.add_argument('--total-episodes', type=int, default=None,
+                        help="fixed dataset size over all ranks and scenes: sets --num-batches to ceil(total / (ranks x n_envs x scenes))")
+    parser.add_argument('--force-device', type=int, default=-1, help="testing only: put every rank on this GPU")
+    parser.add_argument('--fake-native-for-tests', action='store_true',
+                        help="testing only (tests/test_dist_gloo.py): tests/fake_native.py replaces the HIP library so the rank plumbing runs without a GPU")
     return parser
 
 
+def _self_launch(args, argv):
+    """--gpus N > 1 without a launcher: N ranks as a CHILD process tree (this process never touches a GPU), then the ranks' summary
+    files added up into one JSON line"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "softgrip_amd.create_dataset"] + list(argv)
+    t0 = time.perf_counter()
+    rc = subprocess.call(cmd, env=env)
+    if rc == 0:
+        print(json.dumps(job_summary(args.data_folder, args.data_name, args.gpus, time.perf_counter() - t0)))
+    return rc
+
+
+def job_summary(folder, name, world, wall_seconds=None):
+    """the whole job from the ranks' <name>.rank<r>.summary.json files (world == 1: <name>.summary.json)"""
+    ranks = []
+    for r in range(world):
+        with open(os.path.join(folder, "%s.summary.json" % (name if world == 1 else "%s.rank%d" % (name, r)))) as f:
+            ranks.append(json.load(f))
+    slowest = max(r["seconds"] for r in ranks)
+    steps = sum(r["env_steps"] for r in ranks)
+    return {"job": "create_dataset", "n_gpus": world, "episodes": sum(r["episodes"] for r in ranks), "env_steps": steps,
+            "env_steps_per_s": steps / slowest if slowest > 0 else 0.0, "slowest_rank_seconds": slowest, "wall_seconds_with_launch": wall_seconds,
+            "envs_reset_after_a_warning": sum(r["envs_reset_after_a_warning"] for r in ranks),
+            "shard_bytes": [r["shard_bytes"] for r in ranks], "per_rank_env_steps_per_s": [r["env_steps_per_s"] for r in ranks],
+            "note": "end to end on the host: ManEnv.step() with its per-step flag check, device -> host copies, pickling, file writes"}
+
+
 def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     args, _ = make_parser().parse_known_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(_self_launch(args, argv))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.fake_native_for_tests:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        import fake_native
+        from . import native
+        native.NativeModel, native.NativeBatch = fake_native.FakeModel, fake_native.FakeBatch
+    if args.total_episodes is not None:
+        per_round = world * args.n_envs * len(args.mujoco_model_paths)
+        args.num_batches = max(1, -(-args.total_episodes // per_round))
     if args.seed is not None:
         np.random.seed(args.seed + int(os.environ.get("RANK", 0)) * 1000)
     log_into_file(args)
+    if world == 1:
+        print(json.dumps(job_summary(args.data_folder, args.data_name, 1)))
 
 
 if __name__ == '__main__':

@@ -52,6 +52,7 @@ struct sg_batch {
   int* dnbtab;       // SgPlan::nbtab on the device (neighbour-row models)
   SgEqSlot* dsched;  // SgPlan::sched + one spare round of idle slots
   int *kmask_jnt, *kmask_ten, *flags, *touch, *ncon, *nefc, *iters;
+  int epw_override;  // sg_set_solver_envs_per_wavefront: 0 = automatic
   int pipeline;  // 0 fused (one kernel per call), 1 split (chain / phase / pgs kernel chain), 2 split with the row-parallel PGS kernel
   SgWork w;
   std::vector<void*> wbufs;
@@ -62,6 +63,7 @@ struct sg_batch {
   double prof_ms;
   long long prof_n;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pgs;  // around every solver-kernel launch (the dominant kernel)
+  std::vector<hipEvent_t> ev_pool;  // events handed back by sg_profile_read*: a profiled call creates none once the pool is warm
   double prof_pgs_ms;
   long long prof_pgs_n;
 };
@@ -135,6 +137,7 @@ void sg_batch_destroy(sg_batch* b) {
     if (p) (void)hipFree(p);
   for (auto& e : b->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : b->ev_pgs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : b->ev_pool) (void)hipEventDestroy(e);
   delete b;
 }
 
@@ -146,7 +149,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   HIPCHK(hipSetDevice(device));
   sg_batch* b = new sg_batch();
   b->m = m; b->n = n_envs; b->device = device; b->lds_attr_set = false; b->prof = false; b->prof_ms = 0; b->prof_n = 0; b->prof_pgs_ms = 0; b->prof_pgs_n = 0;
-  b->dnbtab = nullptr; b->dsched = nullptr;
+  b->dnbtab = nullptr; b->dsched = nullptr; b->epw_override = 0;
   b->dH = nullptr; b->delem = b->qpos = b->qvel = b->warm = b->act = b->ctrl = b->kenv = b->ctrl_row = nullptr;
   b->kmask_jnt = b->kmask_ten = b->flags = b->touch = b->ncon = b->nefc = b->iters = nullptr;
   const SgPlanHeader& H = m->plan.h;
@@ -275,6 +278,32 @@ int sg_set_ctrl(sg_batch* b, const double* ctrl, int broadcast, void* stream) {
   return SG_OK;
 }
 
+// a pair of events registered in `list` BEFORE anything is recorded (so that a failing HIP call cannot leak them), first one recorded
+static int begin_event_pair(sg_batch* b, std::vector<std::pair<hipEvent_t, hipEvent_t>>& list, hipStream_t s) {
+  hipEvent_t e[2];
+  for (int i = 0; i < 2; i++) {
+    if (!b->ev_pool.empty()) { e[i] = b->ev_pool.back(); b->ev_pool.pop_back(); }
+    else if (hipEventCreate(&e[i]) != hipSuccess) {
+      if (i == 1) b->ev_pool.push_back(e[0]);
+      return fail(SG_ERR_HIP, "hipEventCreate failed");
+    }
+  }
+  list.emplace_back(e[0], e[1]);
+  HIPCHK(hipEventRecord(e[0], s));
+  return SG_OK;
+}
+
+// envs per solver wavefront (sg_pgs_rows_kernel<.., EPW>): 8 when that already gives every SIMD of the chip a wavefront
+// (SG_EPW8_MIN_WAVES wavefronts of 8 envs), else 4; sg_set_solver_envs_per_wavefront / the env var SG_PGS_EPW override;
+// neighbour-row models always run 4 envs of 16 lanes
+#define SG_EPW8_MIN_WAVES 1024
+static int solver_epw(const sg_batch* b) {
+  if (b->m->plan.h.nnb > 0) return 4;
+  if (b->epw_override) return b->epw_override;
+  if (const char* pe = getenv("SG_PGS_EPW")) return atoi(pe) == 4 ? 4 : 8;
+  return (b->n + 7) / 8 >= SG_EPW8_MIN_WAVES ? 8 : 4;
+}
+
 // split pipeline: phase(begin) -> pgs -> [phase(finish+begin) -> pgs]* -> phase(finish)
 static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, double* sens, long long stride, int32_t* flags, int32_t* touch,
                         hipStream_t s) {
@@ -299,10 +328,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     if (v * 8 >= H.nelem) { nsl = v; break; }
   const bool nbm = H.nnb > 0;
   const size_t na = 8 * (size_t)nsl + 8, neqp = 4 * (size_t)H.nelem + 1;
-  // envs per PGS wavefront: 8 when that already gives every SIMD of the chip a wavefront, else 4 (sg_pgs_rows_kernel); SG_PGS_EPW overrides
-  int epw = (b->n + 7) / 8 >= 1024 ? 8 : 4;
-  if (const char* pe = getenv("SG_PGS_EPW")) epw = atoi(pe) == 4 ? 4 : 8;
-  if (nbm) epw = 4;  // neighbour-row models: 16 lanes per env
+  const int epw = solver_epw(b);
   const size_t lds_rows = sizeof(double) * (nbm ? SG_ROWS_LDS_NB(epw, na, H.nelem, H.eq_rounds) : SG_ROWS_LDS_FIX(epw, 8 * (size_t)nsl));
   if (!b->lds_attr_set) {  // per device: a batch on another GPU of the same process needs its own call
     HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -315,10 +341,10 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   }
   // forward passes to run: (mode 1: one non-integrating forward first) + nsub integrating ones
   const int nfwd = nsub + (mode == 1 ? 1 : 0);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  size_t call_ev = 0;
   if (b->prof) {
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, s));
+    if (int rc = begin_event_pair(b, b->ev, s)) return rc;
+    call_ev = b->ev.size() - 1;
   }
   auto phase = [&](const SgPhaseArgs& p) {
 #define SG_PHASE(r)                                                                                   \
@@ -347,8 +373,8 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     phase(p);
     HIPCHK(hipGetLastError());
     if (k < nfwd) {
-      hipEvent_t p0 = nullptr, p1 = nullptr;
-      if (b->prof) { HIPCHK(hipEventCreate(&p0)); HIPCHK(hipEventCreate(&p1)); HIPCHK(hipEventRecord(p0, s)); }
+      if (b->prof)
+        if (int rc = begin_event_pair(b, b->ev_pgs, s)) return rc;
       if (b->pipeline == 2) {
         const dim3 grid((b->n + epw - 1) / epw);
 #define SG_ROWS1(v, nb, e) hipLaunchKernelGGL((sg_pgs_rows_kernel<v, nb, e>), grid, dim3(64), lds_rows, s, ga)
@@ -367,13 +393,10 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
       }
       else hipLaunchKernelGGL(sg_pgs_kernel, dim3((b->n + SG_EPW - 1) / SG_EPW), dim3(64), lds, s, ga);
       HIPCHK(hipGetLastError());
-      if (b->prof) { HIPCHK(hipEventRecord(p1, s)); b->ev_pgs.emplace_back(p0, p1); }
+      if (b->prof) HIPCHK(hipEventRecord(b->ev_pgs.back().second, s));
     }
   }
-  if (b->prof) {
-    HIPCHK(hipEventRecord(e1, s));
-    b->ev.emplace_back(e0, e1);
-  }
+  if (b->prof) HIPCHK(hipEventRecord(b->ev[call_ev].second, s));
   // outputs of the call: one small kernel for the five per-env int arrays (five device-to-device copies cost 1 % of a step);
   // with a mask (masked reset) only the selected envs' entries may change
   hipLaunchKernelGGL(sg_masked_copy_kernel, dim3((b->n + 255) / 256), dim3(256), 0, s, mask, b->n, b->w.status, flags ? flags : b->flags,
@@ -395,11 +418,8 @@ static int launch(sg_batch* b, int mode, const uint8_t* mask, int nsub, double* 
   a.flags = flags ? flags : b->flags; a.touch = touch ? touch : b->touch;
   a.ncon = b->ncon; a.nefc = b->nefc; a.iters = b->iters;
   a.nenv = b->n; a.nsub = nsub; a.mode = mode;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (b->prof) {
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, s));
-  }
+  if (b->prof)
+    if (int rc = begin_event_pair(b, b->ev, s)) return rc;
   dim3 grid(b->n), block(64);
   switch (b->m->rounds) {
     case 1: hipLaunchKernelGGL((sg_step_kernel<1, 2>), grid, block, 0, s, a); break;
@@ -408,10 +428,7 @@ static int launch(sg_batch* b, int mode, const uint8_t* mask, int nsub, double* 
     default: hipLaunchKernelGGL((sg_step_kernel<4, 2>), grid, block, 0, s, a); break;
   }
   HIPCHK(hipGetLastError());
-  if (b->prof) {
-    HIPCHK(hipEventRecord(e1, s));
-    b->ev.emplace_back(e0, e1);
-  }
+  if (b->prof) HIPCHK(hipEventRecord(b->ev.back().second, s));
   return SG_OK;
 }
 
@@ -472,6 +489,15 @@ int sg_set_pipeline(sg_batch* b, int pipeline) {
   return SG_OK;
 }
 
+int sg_set_solver_envs_per_wavefront(sg_batch* b, int epw) {
+  if (!b || (epw != 0 && epw != 4 && epw != 8)) return fail(SG_ERR_INVALID, "sg_set_solver_envs_per_wavefront: 0 (automatic), 4 or 8");
+  if (b->m->plan.h.nnb > 0 && epw == 8)
+    return fail(SG_ERR_MODEL, "sg_set_solver_envs_per_wavefront: a model with neighbour equality rows runs 4 envs of 16 lanes per wavefront");
+  b->epw_override = epw;
+  return SG_OK;
+}
+int sg_solver_envs_per_wavefront(const sg_batch* b) { return b ? solver_epw(b) : 0; }
+
 #ifdef SG_SECTION_PROF
 // profiling build only (build_native.py --prof, scripts/section_profile.py): read and clear the per-section cycle sums
 int sg_debug_sections(sg_batch* b, unsigned long long* out32) {
@@ -498,7 +524,7 @@ int sg_profile_read_solver(sg_batch* b, int reset, double* avg_ms, long long* la
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
     b->prof_pgs_ms += ms; b->prof_pgs_n++;
-    (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+    b->ev_pool.push_back(e.first); b->ev_pool.push_back(e.second);
   }
   b->ev_pgs.clear();
   if (avg_ms) *avg_ms = b->prof_pgs_n ? b->prof_pgs_ms / b->prof_pgs_n : 0.0;
@@ -515,7 +541,7 @@ int sg_profile_read(sg_batch* b, int reset, double* avg_ms, long long* launches)
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
     b->prof_ms += ms; b->prof_n++;
-    (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+    b->ev_pool.push_back(e.first); b->ev_pool.push_back(e.second);
   }
   b->ev.clear();
   if (avg_ms) *avg_ms = b->prof_n ? b->prof_ms / b->prof_n : 0.0;

@@ -1507,11 +1507,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         const double hm = hh ? 1.0 : 0.0, h0 = 1.0 - hm;
         const double Pfix = h0 * -aoff;  // row 0's "partner" -aoff on lane 0 (added to hm * X)
         double qc = 0.0, sc = 0.0;
-#ifdef SG_KO_EQ  // knock-out builds (scripts/phase_time.py): timing only, results are wrong
-        const int nrounds = 0;
-#else
         const int nrounds = H.eq_rounds;
-#endif
         struct Pend { double2* p; double ga, gb; };
         struct Rec { double2 a, b; };  // (g, c) of my two rows
         auto ld_rec = [&](const uint2 tt) { const double2* p = (const double2*)(Rb + (tt.y & 0xffffu)); Rec rc; rc.a = p[0]; rc.b = p[1]; return rc; };
@@ -1620,9 +1616,6 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     }
     __syncthreads();
     SG_T(12);
-#ifdef SG_KO_SWEEPS
-    if (it >= SG_KO_SWEEPS) running = false;
-#endif
     for (int pass = 0; pass < 2; pass++) {
       const bool mine = running && g < 8 && ((c == 0 || !shared) ? pass == 0 : pass == 1);
       if (!__ballot(mine)) continue;
@@ -1647,26 +1640,12 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
       struct Row { double2 j01, j23, jsb, fw, a01, a2s, p12, p3i; };
       auto load_row = [&](Row& w, const double2* p) {
         w.j01 = p[-4 * 64]; w.j23 = p[-3 * 64]; w.jsb = p[-2 * 64]; w.fw = p[-1 * 64];
-#ifdef SG_X_A13  // experiment: 13 fields -- A[r][0..2] are not read but recomputed from J_F, W and J_s
-        w.a01 = make_double2(0.0, 0.0); w.a2s = p[1 * 64]; w.p12 = p[2 * 64]; w.p3i = p[3 * 64];
-#else
         w.a01 = p[0]; w.a2s = p[1 * 64]; w.p12 = p[2 * 64]; w.p3i = p[3 * 64];
-#endif
       };
       auto update_row = [&](Row& w, int i, const double2* pl) {
         if (i < nsl) {
           const double J0 = w.j01.x, J1 = w.j01.y, J2 = w.j23.x, J3 = w.j23.y, Js = w.jsb.x, bb = w.jsb.y, fo = w.fw.x, wv = w.fw.y;
-#ifdef SG_X_A13
-          const double JsI = w.a2s.y, W0 = w.p12.x, W1 = w.p12.y, W2 = w.p3i.x;
-          // A[r][s] = sum_q J_F[r][q] W_s[q] + (invm Js[r]) Js[s]: lane q holds W_s[q], so every lane's three W values are broadcast
-          double A0 = JsI * sg_qb<0>(Js), A1 = JsI * sg_qb<1>(Js), A2 = JsI * sg_qb<2>(Js);
-          A0 += J0 * sg_qb<0>(W0) + J1 * sg_qb<1>(W0) + J2 * sg_qb<2>(W0) + J3 * sg_qb<3>(W0);
-          A1 += J0 * sg_qb<0>(W1) + J1 * sg_qb<1>(W1) + J2 * sg_qb<2>(W1) + J3 * sg_qb<3>(W1);
-          A2 += J0 * sg_qb<0>(W2) + J1 * sg_qb<1>(W2) + J2 * sg_qb<2>(W2) + J3 * sg_qb<3>(W2);
-          A0 += rsel0 * w.p3i.y; A1 += rsel1 * w.p3i.y; A2 += rsel2 * w.p3i.y;  // the stored A carries R on its diagonal
-#else
           const double A0 = w.a01.x, A1 = w.a01.y, A2 = w.a2s.x, JsI = w.a2s.y, W0 = w.p12.x, W1 = w.p12.y, W2 = w.p3i.x;
-#endif
           // what the rows share sits on lane 3 (fields 0 .. 4); its own "row" is inert: f = A f = A = invm Js = 0 and no rsel
           const double Rr = w.p3i.y;  // R: replicated on the row lanes (field 15), 0 on lane 3
           const double P11 = sg_qb<3>(J0), P12 = sg_qb<3>(J1), P22 = sg_qb<3>(J2);  // early: off the update's dependency chain

@@ -62,6 +62,7 @@ class ManEnv(Env):
         self.device_index = device
         self.contact_flag_mode = contact_flag_mode
         self.rng = np.random  # the reference draws from the global NumPy RNG (manenv.py:104)
+        self.n_resets = 0     # envs reset after a simulation warning (what `except MujocoException: self.reset()` did, manenv.py:50-51)
         self._load(env_paths[0])
         self.is_closing = True
 
@@ -90,7 +91,9 @@ class ManEnv(Env):
         for name in type(self).finger_names if self.contact_flag_mode == "reference" else self.finger_names:
             self._finger_bits.append(sum(1 << b for b, gname in bits.items() if name in gname))
         self._finger_bits_names = list(self.finger_names)
-        self._fingers_left = [list(self.finger_names) for _ in range(self.n_envs)]  # "reference" mode state
+        # "reference" mode state: which names are still in the list the reference aliases and never refills (manenv.py:70,80), one
+        # list per env, kept on the device as a bit mask (bit i = finger_names[i] not yet removed)
+        self._fingers_left = torch.full((self.n_envs,), (1 << len(self._finger_bits_names)) - 1, dtype=torch.int32, device=dev)
         if self.check_scene:
             try:
                 self._check_scene(path)
@@ -177,6 +180,7 @@ class ManEnv(Env):
             idx = torch.nonzero(bad_mask).flatten().cpu().numpy()
             if idx.size == 0:
                 return
+            self.n_resets += int(idx.size)
             self.stiffness[idx] = self.rng.uniform(lo, hi, size=idx.size) if idx.size > 1 else self.rng.uniform(lo, hi)
             self.env.set_stiffness(self.stiffness, self.joint_ids, self.tendon_ids)
             mask = bad_mask.to(torch.uint8).contiguous()
@@ -195,17 +199,13 @@ class ManEnv(Env):
             for bits in self._finger_bits:
                 ok &= (touch & bits) != 0
             return ok
-        # "reference": reproduce the aliased, never-refilled list of manenv.py:70-83 per env
-        t = touch.cpu().numpy()
-        ncon = self.env.solver_stats()["ncon"].cpu().numpy()
-        out = np.zeros(self.n_envs, dtype=bool)
-        for e in range(self.n_envs):
-            left = self._fingers_left[e]
-            for name, bits in zip(self._finger_bits_names, self._finger_bits):
-                if name in left and (t[e] & bits):
-                    left.remove(name)
-            out[e] = len(left) == 0 and ncon[e] > 0
-        return torch.from_numpy(out).to(touch.device)
+        # "reference": reproduce the aliased, never-refilled list of manenv.py:70-83 per env -- on the device, no host round trip:
+        # a name leaves an env's list the first time one of its boxes touches an object geom; once the list is empty the flag is up
+        # whenever there is any contact at all
+        ncon = self.env.solver_stats()["ncon"]
+        for i, bits in enumerate(self._finger_bits):
+            self._fingers_left &= ~(((touch & bits) != 0).to(torch.int32) << i)
+        return (self._fingers_left == 0) & (ncon > 0)
 
     def _result(self):
         flag = self._contact_flags()

@@ -18,7 +18,7 @@ SYMBOLS = [
     "sg_model_nsensordata", "sg_model_ntendon", "sg_model_nelem", "sg_batch_create", "sg_batch_destroy",
     "sg_batch_nenvs", "sg_batch_device", "sg_set_stiffness", "sg_set_ctrl", "sg_reset", "sg_step", "sg_get_state",
     "sg_set_state", "sg_get_solver_stats", "sg_set_pipeline", "sg_profile_enable", "sg_profile_read", "sg_profile_read_solver",
-    "sg_model_compile", "sg_mjcf_compile", "sg_blob_free",
+    "sg_model_compile", "sg_mjcf_compile", "sg_blob_free", "sg_set_solver_envs_per_wavefront", "sg_solver_envs_per_wavefront",
 ]
 SG_COMPILE_NO_NEIGHBORS, SG_COMPILE_IMPLICIT_TENDON_DAMPER = 1, 2
 
@@ -65,6 +65,8 @@ def lib():
     L.sg_set_state.argtypes = [vp, dp, dp, dp, dp, dp, vp]
     L.sg_get_solver_stats.argtypes = [vp, ip, ip, ip, vp]
     L.sg_set_pipeline.argtypes = [vp, C.c_int]
+    L.sg_set_solver_envs_per_wavefront.argtypes = [vp, C.c_int]
+    L.sg_solver_envs_per_wavefront.argtypes = [vp]
     L.sg_profile_enable.argtypes = [vp, C.c_int]
     L.sg_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.sg_profile_read_solver.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
@@ -177,6 +179,12 @@ class NativeBatch:
 
     def set_pipeline(self, name):
         check(lib().sg_set_pipeline(self.ptr, {"fused": 0, "split": 1, "rows": 2}[name]))
+
+    def set_solver_envs_per_wavefront(self, epw):
+        check(lib().sg_set_solver_envs_per_wavefront(self.ptr, int(epw)))
+
+    def solver_envs_per_wavefront(self):
+        return lib().sg_solver_envs_per_wavefront(self.ptr)
 
     def profile_enable(self, on=True):
         check(lib().sg_profile_enable(self.ptr, int(on)))

@@ -108,8 +108,29 @@ def test_create_dataset_main_two_ranks(tmp_path):
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     files = sorted(os.listdir(tmp_path / "ds"))
-    assert files == ["sweep.rank0.part00000.pickle", "sweep.rank0.part00001.pickle", "sweep.rank0.pickle",
-                     "sweep.rank1.part00000.pickle", "sweep.rank1.part00001.pickle", "sweep.rank1.pickle"]
+    assert files == ["sweep.rank0.part00000.pickle", "sweep.rank0.part00001.pickle", "sweep.rank0.pickle", "sweep.rank0.summary.json",
+                     "sweep.rank1.part00000.pickle", "sweep.rank1.part00001.pickle", "sweep.rank1.pickle", "sweep.rank1.summary.json"]
     k0 = pickle.load(open(tmp_path / "ds" / "sweep.rank0.pickle", "rb"))["stiffness"]
     k1 = pickle.load(open(tmp_path / "ds" / "sweep.rank1.pickle", "rb"))["stiffness"]
     assert len(k0) == 12 and len(k1) == 12 and all(300 <= k < 850 for k in k0) and all(850 <= k < 1400 for k in k1)
+
+
+def test_create_dataset_launches_its_own_ranks(tmp_path):
+    """`python -m softgrip_amd.create_dataset --gpus 2` with no launcher starts its own two ranks (a child
+    torch.distributed.run, before anything touches a GPU), each with its own stiffness bin and shard; the parent adds the ranks'
+    summary files up into one JSON line.  --total-episodes fixes the dataset size (BASELINE configs[3]: 8 x 4096 x 4)."""
+    import json
+    import pickle
+    from helpers import model_path
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    out = subprocess.run([sys.executable, "-m", "softgrip_amd.create_dataset", "--gpus", "2", "--mujoco-model-paths", model_path("softbox"),
+                          "--n-envs", "5", "--total-episodes", "30", "--seed", "3", "--data-folder", str(tmp_path / "ds"), "--data-name", "cfg4",
+                          "--fake-native-for-tests"], capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["episodes"] == 30 and res["env_steps"] == 30 * 200 and len(res["per_rank_env_steps_per_s"]) == 2
+    assert res["envs_reset_after_a_warning"] == 0 and len(res["shard_bytes"]) == 2 and res["env_steps_per_s"] > 0
+    k0 = pickle.load(open(tmp_path / "ds" / "cfg4.rank0.pickle", "rb"))["stiffness"]
+    k1 = pickle.load(open(tmp_path / "ds" / "cfg4.rank1.pickle", "rb"))["stiffness"]
+    assert len(k0) == 15 and len(k1) == 15 and all(300 <= k < 850 for k in k0) and all(850 <= k < 1400 for k in k1)

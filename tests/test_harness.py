@@ -148,7 +148,7 @@ def test_incremental_shards_and_resume(fake_native, tmp_path):
     full = tmp_path / "full"; part = tmp_path / "part"
     np.random.seed(5)
     ref = pickle.load(open(cd.log_into_file(args(full)), "rb"))
-    assert len(ref["data"]) == 12 and sorted(os.listdir(full)) == ["fx.part00000.pickle", "fx.part00001.pickle", "fx.part00002.pickle", "fx.pickle"]
+    assert len(ref["data"]) == 12 and sorted(os.listdir(full)) == ["fx.part00000.pickle", "fx.part00001.pickle", "fx.part00002.pickle", "fx.pickle", "fx.summary.json"]
     # interrupted run: only the first part exists (as after a crash during batch 1)
     os.makedirs(part)
     import shutil
@@ -159,6 +159,57 @@ def test_incremental_shards_and_resume(fake_native, tmp_path):
     assert got["stiffness"] == ref["stiffness"]
     assert all(np.array_equal(a, b) for a, b in zip(got["data"], ref["data"]))
     assert sum(1 for e in fake_native.log if e[0] == "reset") == 2        # only the two missing batches were simulated
+
+
+def test_resume_refuses_foreign_parts_and_restores_the_rng(fake_native, tmp_path, monkeypatch):
+    """(a) a part left by a run with another seed / batch size / scene list is refused, not merged; (b) a batch in which an
+    env failed and had its label re-drawn consumed MORE than n draws -- the resumed run continues from the RNG state stored with the
+    part, so its labels equal the uninterrupted run's (counting n draws per skipped batch did not)"""
+    import shutil
+
+    def args(folder, **kw):
+        a = _args(folder, n_envs=4)
+        a.num_batches, a.incremental, a.seed = 3, True, 5
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+    calls = {"n": 0, "on": True}
+    orig = fake_native._advance
+
+    def failing(self, n, sens, flags, touch):          # env 2 fails once, in the first batch
+        orig(self, n, sens, flags, touch)
+        calls["n"] += 1
+        if calls["on"] and calls["n"] == 30 and flags is not None:
+            flags[2] = 4
+    monkeypatch.setattr(fake_native, "_advance", failing)
+    full = tmp_path / "full"
+    np.random.seed(5)
+    ref = pickle.load(open(cd.log_into_file(args(full)), "rb"))
+    d0 = pickle.load(open(full / "fx.part00000.pickle", "rb"))
+    assert set(d0) == {"data", "stiffness", "config", "rng_state"} and d0["config"]["seed"] == 5 and d0["config"]["n_envs"] == 4
+    assert set(ref) == {"data", "stiffness"}                       # the final pickle keeps the reference's schema
+    # (b) resume after the batch with the re-draw
+    calls["on"] = False
+    part = tmp_path / "part"
+    os.makedirs(part)
+    shutil.copy(full / "fx.part00000.pickle", part / "fx.part00000.pickle")
+    np.random.seed(5)
+    got = pickle.load(open(cd.log_into_file(args(part)), "rb"))
+    assert got["stiffness"] == ref["stiffness"]
+    # (a) foreign parts
+    for kw, what in ((dict(seed=6), "seed"), (dict(n_envs=3), "n_envs"), (dict(mask_contact=True), "mask_contact")):
+        other = tmp_path / ("other_" + what)
+        os.makedirs(other)
+        shutil.copy(full / "fx.part00000.pickle", other / "fx.part00000.pickle")
+        with pytest.raises(cd.PartMismatch, match=what):
+            cd.log_into_file(args(other, **kw))
+    legacy = tmp_path / "legacy"
+    os.makedirs(legacy)
+    pickle.dump({"data": d0["data"], "stiffness": d0["stiffness"]}, open(legacy / "fx.part00000.pickle", "wb"))
+    with pytest.raises(cd.PartMismatch, match="no configuration stored"):
+        cd.log_into_file(args(legacy))
+    summary = __import__("json").load(open(full / "fx.summary.json"))
+    assert summary["episodes"] == 12 and summary["envs_reset_after_a_warning"] == 1 and summary["env_steps"] == 12 * 200
 
 
 def test_labels_are_the_pre_episode_draw_after_a_mid_episode_failure(fake_native, tmp_path, monkeypatch):
