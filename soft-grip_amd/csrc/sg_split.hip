@@ -77,7 +77,8 @@ struct SgPhaseArgs {
 // Field k of lane (8 * env_in_wave + 4 * chain + r), r < 3:
 //   0..3 Jf[r][0..3] | 4 Js[r] | 5 b[r] | 6 f[r] | 7 (A f)[r] | 8..10 A[r][0..2] | 11 invm * Js[r] | 12..14 W_0[r] W_1[r] W_2[r] | 15 R
 // of lane r = 3:
-//   0..2 inverse friction block P11 P12 P22 | 3 zero | 4 slider index | 5..11 zero | 12..14 W_0[3] W_1[3] W_2[3] | 15 zero
+//   0..2 inverse friction block P11 P12 P22 | 3 zero | 4 slider index | 5..7 zero | 8..11 eigen-decomposition of the friction-scaled
+//   block S = Q diag(e1, e2) Q': e1 e2 cos sin (for the QCQP Newton iteration) | 12..14 W_0[3] W_1[3] W_2[3] | 15 zero
 // W_k = M^-1 J_F[k]' (4 values per row k; lane q keeps the q-th of each): the finger update aF[q] += sum_k W_k[q] df_k is three
 // multiply-adds on lane q after broadcasting the three force changes, instead of four more quad sums and a 4 x 4 product on
 // every lane.  f and A f (fields 6, 7: one pair) are the only fields the solver writes.  Blocks nwb and nwb + 1 of every slot
@@ -538,6 +539,14 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             const double S11 = c.A[3] * H.con_mu[0] * H.con_mu[0], S22 = c.A[5] * H.con_mu[1] * H.con_mu[1], S12 = c.A[4] * H.con_mu[0] * H.con_mu[1];
             const double det = S11 * S22 - S12 * S12, di = det < 1e-10 ? 0.0 : sg_div(1.0, det);
             const double P11 = S22 * di, P22 = S11 * di, P12 = -S12 * di;
+            // eigen-decomposition of the (friction-scaled) block S = Q diag(e1, e2) Q', Q = [[cs, sn], [-sn, cs]] (one Jacobi rotation):
+            // constant over the solve, so mju_QCQP2's Newton iteration in the solver runs in these coordinates (sg_pgs_rows_kernel)
+            double ecs = 1.0, esn = 0.0, ee1 = S11, ee2 = S22;
+            if (fabs(S12) > 1e-300) {
+              const double tau = (S22 - S11) / (2.0 * S12), tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+              ecs = 1.0 / sqrt(1.0 + tt * tt); esn = tt * ecs;
+              ee1 = S11 - tt * S12; ee2 = S22 + tt * S12;
+            }
             const double Afull[3][3] = {{c.A[0], c.A[1], c.A[2]}, {c.A[1], c.A[3], c.A[4]}, {c.A[2], c.A[4], c.A[5]}};
             double Wm[3][SG_CD];  // W_r = M^-1 J_F[r]': lane q of the quad keeps (W_0[q], W_1[q], W_2[q]), its column of the finger update
 #pragma unroll
@@ -564,6 +573,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
                 fld[15] = c.R;
               } else {  // the fourth lane carries what the three rows share (R is replicated on the row lanes: no broadcast)
                 fld[0] = P11; fld[1] = P12; fld[2] = P22; fld[4] = __hiloint2double(0, sl);
+                fld[8] = ee1; fld[9] = ee2; fld[10] = ecs; fld[11] = esn;
               }
               fld[12] = Wm[0][r]; fld[13] = Wm[1][r]; fld[14] = Wm[2][r];
 #pragma unroll
@@ -1319,8 +1329,16 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   const double mur = r == 1 ? mu0 : mu1;
   const double rsel0 = r == 0 ? 1.0 : 0.0, rsel1 = r == 1 ? 1.0 : 0.0, rsel2 = r == 2 ? 1.0 : 0.0;
   const int max_iter = H.iterations;
-  const bool valid = in_wave && env < a.nenv && W.pending[env < a.nenv ? env : 0] != 0;
-  if (!__ballot(valid)) return;
+  // which of the wavefront's envs have a substep pending: read ONCE, all EPW words together (uniform addresses: scalar loads).  The staging
+  // loops and the epilogue used to re-read the word per env behind a branch -- EPW dependent memory round trips in a row, twice per launch
+  unsigned pendmask = 0;
+#pragma unroll
+  for (int e2 = 0; e2 < EPW; e2++) {
+    const int env2 = blockIdx.x * EPW + e2;
+    pendmask |= (env2 < a.nenv && W.pending[env2 < a.nenv ? env2 : 0] != 0) ? 1u << e2 : 0u;
+  }
+  const bool valid = in_wave && ((pendmask >> lec) & 1u) != 0;
+  if (pendmask == 0) return;
   // LDS: joint-fix rows padded to NR = 8 * NSL per env (padding rows are neutral: b = 0, R = 1, 1/(A+R) = 0, so their update
   // is a no-op and the row loop needs no bound test).  Per env: AF[j] = (a_s, f) [the only pair written], BR[j] = (b, R),
   // RI[j] = 1 / (A_jj + R_j); shared by the wavefront's envs: IC[j] = (1/m, tendon coefficient).  A row is three 16-byte reads + one 8-byte.
@@ -1356,7 +1374,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
 #pragma unroll 1
   for (int e2 = 0; e2 < EPW; e2++) {
     const int env2 = blockIdx.x * EPW + e2;
-    const bool v2 = env2 < a.nenv && W.pending[env2 < a.nenv ? env2 : 0] != 0;  // uniform
+    const bool v2 = ((pendmask >> e2) & 1u) != 0;  // uniform
     if constexpr (!NB) {
       double2* const AF2 = (double2*)lds + (size_t)e2 * NR;
       double2* const BR2 = (double2*)lds + (size_t)EPW * NR + (size_t)e2 * NR;
@@ -1409,7 +1427,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
 #pragma unroll
       for (int e2 = 0; e2 < EPW; e2++) {
         const int env2 = blockIdx.x * EPW + e2;
-        const bool v2 = env2 < a.nenv && W.pending[env2 < a.nenv ? env2 : 0] != 0;  // uniform
+        const bool v2 = ((pendmask >> e2) & 1u) != 0;  // uniform
         double2* const REC2 = (double2*)(lds + (size_t)EPW * NA + (size_t)e2 * RECW);
         double gg = 0.0, cc = 0.0;
         if (v2 && have) { gg = bb[e2] + Rr[e2] * ff[e2]; cc = sg_div(im0s, (fix ? im0s : 2.0 * im0s) + Rr[e2]); }
@@ -1515,15 +1533,17 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
           double* const px = (double*)(Ab + (tt.x & 0xffffu));   // lane 0: slider e itself; lane 1: partner of row 2
           double* const py = (double*)(Ab + (tt.x >> 16));       // partner of row 1 / row 3
           const double X = *px, Y = *py;
-          const double cA = rc.a.y, cB = rc.b.y, mA = 1.0 - cA, mB = 1.0 - cB;
+          const double cA = rc.a.y, cB = rc.b.y;
           const double PA = fma(X, hm, Pfix), dA = rc.a.x - PA, dB = rc.b.x - Y;
-          // nu = -c d, written so that it is ONE operation behind the slider reads: (c hm) X + c (Pfix - g) and c Y - c g
-          const double nuA = fma(cA * hm, X, cA * (Pfix - rc.a.x)), nuB = fma(cB, Y, -(cB * rc.b.x));
-          const double e2 = fma(fma(X, mA, nuA), mB, nuB);       // lane 0: e after rows 0, 1
-          const double T = sg_dpp<0xB1>(e2);                     // quad_perm [1,0,3,2]: the pair's other lane
+          // a row's step on slider e: s = d + e (its residual), w = c s (its push on the partner), e' = e - w.  Lane 0 runs its two rows
+          // from e = a_e, hands the result over, lane 1 runs its two rows from there (both lanes execute both passes: in the second one
+          // lane 0 repeats its own numbers).  r02 wrote e' = e (1 - c) - c d with precomputed products to shorten the dependent chain;
+          // a wavefront alone on its SIMD issues one instruction per ~7 cycles dependent or not, so what counts is their number: 30
+          // arithmetic instructions per round instead of 38
+          const double sA0 = dA + X, O10 = X - cA * sA0, O20 = O10 - cB * (dB + O10);   // lane 0: e after rows 0, 1
+          const double T = sg_dpp<0xB1>(O20);                    // quad_perm [1,0,3,2]: the pair's other lane
           const double I = hh ? T : X;                           // my first row's e_k
-          const double O1 = fma(I, mA, nuA), O2 = fma(O1, mB, nuB);
-          const double sA = dA + I, sB = dB + O1, wA = cA * sA, wB = cB * sB;
+          const double sA = dA + I, wA = cA * sA, O1 = I - wA, sB = dB + O1, wB = cB * sB, O2 = O1 - wB;
           const double PAn = fma(wA, hm, PA), Yn = Y + wB;
           const double e4 = sg_dpp<0xB1>(O2);                    // lane 0 receives the block's result from lane 1
           *px = hh ? PAn : e4;
@@ -1692,7 +1712,14 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
             // val = (|w|^2 - g0^2 det^2) / det^2 and the Newton step -val / (d val / d la) = (|w|^2 - g0^2 det^2) det / (2 w' adj w);
             // v itself is only needed after the last evaluation.  (Two divisions and three nested exec-mask branches per
             // evaluation before: 460 cycles each, profiles/r01_v11_nb_kernel_sections.txt.)
-            const double S11 = sg_qb<1>(A1) * mu0 * mu0, S22 = sg_qb<2>(A2) * mu1 * mu1, S12 = sg_qb<1>(A2) * mu0 * mu1, r2 = g0 * g0;
+            // In the eigen-coordinates of S (exported by the phase kernel on the quad's fourth lane: S = Q diag(e1, e2) Q', constant over
+            // the solve) with c = Q' b, x_k = e_k + la:  |v|^2 = c1^2 / x1^2 + c2^2 / x2^2, so with y_k = x_k^2
+            //   val det^2 = N = c1^2 y2 + c2^2 y1 - g0^2 y1 y2,   w' adj w = D = c1^2 y2 x2 + c2^2 y1 x1,   det = x1 x2,
+            // and the Newton step is N x1 x2 / (2 D): 18 flops per evaluation instead of 27, and the loop is a plain divergent one (lanes
+            // that have stopped are masked off and keep their last x1, x2; no selects, no wave-wide flags).
+            const double e1 = sg_qb<3>(A0), e2 = sg_qb<3>(A1), qcs = sg_qb<3>(A2), qsn = sg_qb<3>(JsI);
+            const double c1 = qcs * b1 - qsn * b2, c2 = qsn * b1 + qcs * b2;
+            const double C1h = 0.5 * c1 * c1, C2h = 0.5 * c2 * c2, R2h = 0.5 * g0 * g0;
             double la = 0.0;
             bool run = true;
             {
@@ -1700,26 +1727,80 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
               run = !(delta < 1e-10);
               la = run ? delta : 0.0;
             }
-            // A stream that has stopped keeps evaluating with its la frozen while the wavefront's slowest stream finishes: the
-            // same inputs give the same t, det every time, so nothing but la needs a guarded update inside the loop, and a
-            // stream's result does not depend on its wavefront mates (streams that never started take the fast path's values)
             const bool ever = run;
-            double t1 = u1, t2 = u2, det = 1.0;
-            for (int it = 1; it < 20; it++) {
-              if (!__ballot(run)) break;
+            double x1 = e1, x2 = e2;
+            if (run) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SG_SECTION_COUNT)
+              // the loop by hand (the compiler's lowering of the divergent loop spends 14 of its 41 instructions per evaluation on exec-mask
+              // bookkeeping; a lone wavefront pays ~7 cycles for each, scalar or vector): 30 instructions per evaluation.  Lanes leave by
+              // having their exec bit cleared; exec is restored at the end.  v_rcp_f64 (a transcendental-unit op) has two independent
+              // instructions between it and its first consumer.
+              double y1, y2, xx, ah, bh, yy, nh, dh, rc, nx, er, dl, ox1, ox2;  // ox1, ox2: early-clobber outputs (as read-write
+              unsigned long long sv, m0, m1;                                    // operands initialised with e1, e2 they were given e1's, e2's registers)
+              unsigned cnt;
+              asm volatile(
+                  "s_mov_b64 %[sv], exec\n\t"
+                  "s_mov_b32 %[cnt], 19\n"
+                  "1:\n\t"
+                  "v_add_f64 %[x1], %[e1], %[la]\n\t"
+                  "v_add_f64 %[x2], %[e2], %[la]\n\t"
+                  "v_mul_f64 %[y1], %[x1], %[x1]\n\t"
+                  "v_mul_f64 %[y2], %[x2], %[x2]\n\t"
+                  "v_mul_f64 %[xx], %[x1], %[x2]\n\t"
+                  "v_mul_f64 %[ah], %[C1h], %[y2]\n\t"
+                  "v_mul_f64 %[bh], %[C2h], %[y1]\n\t"
+                  "v_mul_f64 %[yy], %[y1], %[y2]\n\t"
+                  "v_add_f64 %[nh], %[ah], %[bh]\n\t"
+                  "v_mul_f64 %[dh], %[bh], %[x1]\n\t"
+                  "v_fma_f64 %[nh], %[nR2h], %[yy], %[nh]\n\t"
+                  "v_fma_f64 %[dh], %[ah], %[x2], %[dh]\n\t"
+                  "v_cmp_gt_f64_e64 %[m0], %[tol], %[xx]\n\t"
+                  "v_add_f64 %[dh], %[dh], %[dh]\n\t"
+                  "v_mul_f64 %[yy], %[yy], %[tolh]\n\t"
+                  "v_rcp_f64_e32 %[rc], %[dh]\n\t"
+                  "v_mul_f64 %[nx], %[nh], %[xx]\n\t"
+                  "v_cmp_lt_f64_e64 %[m1], %[nh], %[yy]\n\t"
+                  "v_fma_f64 %[er], -%[dh], %[rc], 1.0\n\t"
+                  "s_or_b64 %[m0], %[m0], %[m1]\n\t"
+                  "v_fma_f64 %[rc], %[er], %[rc], %[rc]\n\t"
+                  "v_mul_f64 %[dl], %[nx], %[rc]\n\t"
+                  "v_cmp_gt_f64_e64 %[m1], %[tol], %[dl]\n\t"
+                  "s_or_b64 %[m0], %[m0], %[m1]\n\t"
+                  "s_andn2_b64 exec, exec, %[m0]\n\t"
+                  "s_cbranch_execz 2f\n\t"
+                  "v_add_f64 %[la], %[la], %[dl]\n\t"
+                  "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+                  "s_cmp_lg_u32 %[cnt], 0\n\t"
+                  "s_cbranch_scc1 1b\n"
+                  "2:\n\t"
+                  "s_mov_b64 exec, %[sv]"
+                  : [x1] "=&v"(ox1), [x2] "=&v"(ox2), [la] "+v"(la), [y1] "=&v"(y1), [y2] "=&v"(y2), [xx] "=&v"(xx), [ah] "=&v"(ah), [bh] "=&v"(bh),
+                    [yy] "=&v"(yy), [nh] "=&v"(nh), [dh] "=&v"(dh), [rc] "=&v"(rc), [nx] "=&v"(nx), [er] "=&v"(er), [dl] "=&v"(dl),
+                    [sv] "=&s"(sv), [m0] "=&s"(m0), [m1] "=&s"(m1), [cnt] "=&s"(cnt)
+                  : [e1] "v"(e1), [e2] "v"(e2), [C1h] "v"(C1h), [C2h] "v"(C2h), [nR2h] "v"(-R2h), [tol] "s"(1e-10), [tolh] "s"(0.5e-10)
+                  : "vcc", "scc");
+              x1 = ox1; x2 = ox2;
+#else
+#pragma unroll 1
+              for (int it = 1; it < 20; it++) {
 #ifdef SG_SECTION_COUNT
-              if (lane == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&a.w.secprof[33], 1ull);  // Newton iterations per wavefront
+                if (lane == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&a.w.secprof[33], 1ull);  // Newton iterations per wavefront
 #endif
-              const double ca = S11 + la, cc = S22 + la;
-              det = ca * cc - S12 * S12;
-              t1 = S12 * b2 - cc * b1; t2 = S12 * b1 - ca * b2;                    // -adj(S + la) b
-              const double d2 = det * det, num = (t1 * t1 + t2 * t2) - r2 * d2;    // val det^2
-              const double qf = (cc * t1 * t1 + ca * t2 * t2) - 2.0 * S12 * t1 * t2;  // w' adj w
-              const double delta = sg_div_fast(num * det, 2.0 * qf);  // a Newton step: its last bits are absorbed by the next evaluation
-              const bool go = run && !(det < 1e-10 || num < 1e-10 * d2 || delta < 1e-10);
-              la = go ? la + delta : la;
-              run = go;
+                x1 = e1 + la; x2 = e2 + la;
+                const double y1 = x1 * x1, y2 = x2 * x2, ah = C1h * y2, bh = C2h * y1, yy = y1 * y2;
+                const double Nh = fma(-R2h, yy, ah + bh);            // val det^2 / 2
+                const double Dh = fma(ah, x2, bh * x1);              // w' adj w / 2
+                const double xx = x1 * x2;                           // det
+                const double delta = sg_div_fast(Nh * xx, Dh + Dh);  // a Newton step: its last bits are absorbed by the next evaluation
+                if (xx < 1e-10 || Nh < 0.5e-10 * yy || delta < 1e-10) break;
+                la += delta;
+              }
+#endif
             }
+            const double det = x1 * x2;
+            // last evaluation, back in the contact's coordinates: v = Q (-c1 / x1, -c2 / x2) = (t1, t2) / det
+            const double t1e = -c1 * x2, t2e = -c2 * x1;
+            const double t1 = qcs * t1e + qsn * t2e, t2 = qcs * t2e - qsn * t1e;
             const bool sing = ever && det < 1e-10;
             const double w1 = ever ? t1 : u1, w2 = ever ? t2 : u2, wdet = ever ? det : 1.0;  // last evaluation: v = (w1, w2) / wdet
             const bool active = la != 0.0 && !sing;
@@ -1791,7 +1872,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
 #pragma unroll 1
   for (int e2 = 0; e2 < EPW; e2++) {  // slider accelerations back to the workspace, lane = element
     const int env2 = blockIdx.x * EPW + e2;
-    if (env2 < a.nenv && W.pending[env2] != 0) {
+    if ((pendmask >> e2) & 1u) {
       const double* const AS2 = NB ? lds + (size_t)e2 * NA : lds + (size_t)2 * e2 * NR;
       const double off2 = NB ? Lenv[EPW + e2] : 0.0;
       for (int j = lane; j < N; j += 64) W.as[(size_t)env2 * N + j] = AS2[ASS * j] + off2;
