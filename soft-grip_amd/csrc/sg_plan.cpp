@@ -529,8 +529,9 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
     }
   }
   // Safe slider range per element: while q stays inside (QLO, QHI) the capsule cannot touch the plane (exact: the lower of its two
-  // end spheres) and its bounding sphere cannot touch a static box, so those pairs (legal in the model, never active in the reference scenes) need no narrowphase; outside it the kernels
-  // raise the "unsupported pair" flag.  The distance to a convex static geom is convex in q, so the unsafe set is one interval.
+  // end spheres) and its bounding sphere cannot touch a static box, so those pairs (legal in the model, never active in the reference
+  // scenes) need no narrowphase on the fast path; outside it the env's substep runs on the general contact path (sg_general.h).
+  // The distance to a convex static geom is convex in q, so the unsafe set is one interval.
   for (int e = 0; e < nelem; e++) {
     double ax[3] = {E(SGE_AX, e), E(SGE_AY, e), E(SGE_AZ, e)}, g0[3] = {E(SGE_GX, e), E(SGE_GY, e), E(SGE_GZ, e)}, q0 = E(SGE_QPOS0, e);
     double qlo = -1e30, qhi = 1e30;
@@ -552,7 +553,10 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
     };
     for (int kind = 0; kind < 2; kind++)
       for (int k = 0; k < (kind == 0 ? H.has_plane : H.nstatic); k++) {
-        if (clearance(kind, k, q0) <= 0) FAIL("an element capsule touches a static geom in the reference pose");
+        if (clearance(kind, k, q0) <= 0) {   // within reach of a static geom already in the reference pose (an object resting on the
+          qlo = qhi = q0;                     // ground): no safe range, the env always runs on the general contact path
+          continue;
+        }
         for (int dir = -1; dir <= 1; dir += 2) {  // march outwards from q0 to bracket the first unsafe q, then bisect
           double lo = q0, hi = q0, step = 0.01;
           bool found = false;
@@ -571,6 +575,58 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
       }
     E(SGE_QLO, e) = qlo; E(SGE_QHI, e) = qhi;
     if (getenv("SG_PLAN_DEBUG")) fprintf(stderr, "elem %d safe slider range (%g, %g)\n", e, qlo - q0, qhi - q0);
+  }
+  // ---- the general contact path's candidate pairs (sg_general.h): mj_collision's pair list for this model, as the oracle builds it --
+  //      body pairs (b1 < b2) ascending, geoms of b1 outer, geoms of b2 inner; filtered by contype / conaffinity, weld group and the
+  //      parent-child rule; geoms of a pair ordered by type.  A pair whose mixed parameters differ from the finger / object pairs'
+  //      keeps its place in the list as SGP_UNSUPPORTED: within reach it raises the unsupported-pair flag instead of a contact.
+  {
+    std::vector<int> ref_of(ngeom, 0);
+    int nst = 0;
+    for (int g = 0; g < ngeom; g++) {
+      const int b = geom_bodyid[g];
+      if (body_weldid[b] != 0) continue;
+      bool hits_chain = false, hits_elem = allowed(g, P.elem_geom[0]);
+      for (int cg : chain_geoms) hits_chain |= allowed(g, cg);
+      if (!hits_chain && !hits_elem) continue;
+      if (geom_type[g] == 0 /* plane */) ref_of[g] = 1 << 16;
+      else if (geom_type[g] == SG_GEOM_SPHERE) ref_of[g] = 3 << 16;
+      else if (geom_type[g] == SG_GEOM_BOX) ref_of[g] = (2 << 16) | nst++;   // same order as H.st_* above
+    }
+    for (int c = 0; c < nchain; c++)
+      for (int k = 0; k < H.chain[c].ngeom; k++) ref_of[H.chain[c].g_id[k]] = (4 << 16) | (c * SG_CG + k);
+    for (int e = 0; e < nelem; e++) ref_of[P.elem_geom[e]] = (5 << 16) | e;
+    auto pair_allowed = [&](int g1, int g2) {
+      const int b1 = geom_bodyid[g1], b2 = geom_bodyid[g2];
+      if (!allowed(g1, g2)) return false;
+      const int w1 = body_weldid[b1], w2 = body_weldid[b2];
+      if (w1 == w2) return false;
+      const int wp1 = body_weldid[body_parentid[w1]], wp2 = body_weldid[body_parentid[w2]];
+      if (w1 != 0 && w2 != 0 && (w1 == wp2 || w2 == wp1)) return false;
+      return true;
+    };
+    for (int b1 = 0; b1 < nbody; b1++)
+      for (int b2 = b1 + 1; b2 < nbody; b2++)
+        for (int i = 0; i < body_geomnum[b1]; i++)
+          for (int j = 0; j < body_geomnum[b2]; j++) {
+            int g1 = body_geomadr[b1] + i, g2 = body_geomadr[b2] + j;
+            if (!pair_allowed(g1, g2)) continue;
+            if (geom_type[g1] > geom_type[g2]) std::swap(g1, g2);
+            const int t1 = geom_type[g1], t2 = geom_type[g2];
+            SgGenPair gp;
+            gp.g1 = ref_of[g1]; gp.g2 = ref_of[g2]; gp.pad = 0;
+            if (t1 == 0 && t2 == SG_GEOM_CAPSULE) gp.kind = 0;
+            else if (t1 == 0 && t2 == SG_GEOM_BOX) gp.kind = 1;
+            else if (t1 == SG_GEOM_SPHERE && t2 == SG_GEOM_BOX) gp.kind = 2;
+            else if (t1 == SG_GEOM_CAPSULE && t2 == SG_GEOM_BOX) gp.kind = 3;
+            else if (t1 == SG_GEOM_BOX && t2 == SG_GEOM_BOX) gp.kind = 4;
+            else FAIL("unsupported collision pair types");
+            if (gp.g1 == 0 || gp.g2 == 0) FAIL("a collision pair involves a geom outside the plan class");
+            if (!check_pair(g1, g2)) gp.kind = 5;   // SGP_UNSUPPORTED
+            P.gpairs.push_back(gp);
+          }
+    if (P.gpairs.size() > 60000) FAIL("too many candidate collision pairs");
+    H.ngpair = (int)P.gpairs.size();
   }
   // mixed contact parameters of the reference pair
   {

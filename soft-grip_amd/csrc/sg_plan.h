@@ -63,9 +63,9 @@ enum {
 
 struct SgPlanHeader {
   int nv, nu, nsensordata, ntendon, nchain, nelem, elem_dof0, iterations, nstatic, has_center, has_plane, center_geom, plane_geom;
+  int ngpair;     // entries of SgPlan::gpairs (the general contact path's candidate pairs)
   int nnb;        // neighbour equality rows (0: the model has none)
   int eq_rounds;  // rounds of the equality-row schedule (SgPlan::sched), 0 when nnb == 0
-  int pad;
   double timestep, gravity[3], tolerance, impratio, meaninertia, pgs_scale;
   // element-uniform parameters
   double cap_radius, cap_hl, cap_rbound;
@@ -94,8 +94,17 @@ struct SgEqSlot {
   int p[3];  // partner slider of the block's d-th neighbour row (workspace slot d * nelem + e); nelem = no such row
 };
 
+// one candidate pair of the general contact path (sg_general.h): narrowphase routine, geometry references (kind << 16 | index) of
+// geom1 / geom2 in mj_collideGeoms' order, the pair's bounding radii summed (for the sphere filter)
+struct SgGenPair {
+  int kind, g1, g2, pad;
+};
+
 struct SgPlan {
   SgPlanHeader h;
+  // every geom pair mj_collision would look at, in its order (body pairs ascending, geoms of the first body outer): what an env on
+  // the general contact path walks (sg_general.h).  The fast path's pairs (finger box x capsule / centre sphere) are part of it.
+  std::vector<SgGenPair> gpairs;
   // neighbour rows: ints [9 * nelem + 3 * nnb] = out_e2[3][nelem] | out_slot[3][nelem] | in_slot[3][nelem] | row_e1[nnb] | row_e2[nnb] | row_slot[nnb]
   //   a row's workspace SLOT is d * nelem + e1 (d = its rank among the rows registered for element e1, MuJoCo's order): per env the
   //   workspace arrays nbf / nbb / nbR have 3 * nelem slots, so the phase kernel's lanes (= elements) store them coalesced

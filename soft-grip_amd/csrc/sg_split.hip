@@ -1732,15 +1732,15 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
             if (run) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SG_SECTION_COUNT)
               // the loop by hand (the compiler's lowering of the divergent loop spends 14 of its 41 instructions per evaluation on exec-mask
-              // bookkeeping; a lone wavefront pays ~7 cycles for each, scalar or vector): 30 instructions per evaluation.  Lanes leave by
-              // having their exec bit cleared; exec is restored at the end.  v_rcp_f64 (a transcendental-unit op) has two independent
+              // bookkeeping; a lone wavefront pays ~7 cycles for each, scalar or vector): 28 instructions per evaluation, two evaluations
+              // per trip.  Lanes leave by having their exec bit cleared; exec is restored at the end.  v_rcp_f64 (a transcendental-unit op) has two independent
               // instructions between it and its first consumer.
               double y1, y2, xx, ah, bh, yy, nh, dh, rc, nx, er, dl, ox1, ox2;  // ox1, ox2: early-clobber outputs (as read-write
               unsigned long long sv, m0, m1;                                    // operands initialised with e1, e2 they were given e1's, e2's registers)
               unsigned cnt;
               asm volatile(
                   "s_mov_b64 %[sv], exec\n\t"
-                  "s_mov_b32 %[cnt], 19\n"
+                  "s_mov_b32 %[cnt], 19\n"      // evaluations 1 .. 19 (the fast path did evaluation 0): nine trips of two and one more
                   "1:\n\t"
                   "v_add_f64 %[x1], %[e1], %[la]\n\t"
                   "v_add_f64 %[x2], %[e2], %[la]\n\t"
@@ -1769,9 +1769,36 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
                   "s_andn2_b64 exec, exec, %[m0]\n\t"
                   "s_cbranch_execz 2f\n\t"
                   "v_add_f64 %[la], %[la], %[dl]\n\t"
-                  "s_sub_u32 %[cnt], %[cnt], 1\n\t"
-                  "s_cmp_lg_u32 %[cnt], 0\n\t"
-                  "s_cbranch_scc1 1b\n"
+                  "s_cmp_eq_u32 %[cnt], 1\n\t"
+                  "s_cbranch_scc1 2f\n\t"
+                  "v_add_f64 %[x1], %[e1], %[la]\n\t"
+                  "v_add_f64 %[x2], %[e2], %[la]\n\t"
+                  "v_mul_f64 %[y1], %[x1], %[x1]\n\t"
+                  "v_mul_f64 %[y2], %[x2], %[x2]\n\t"
+                  "v_mul_f64 %[xx], %[x1], %[x2]\n\t"
+                  "v_mul_f64 %[ah], %[C1h], %[y2]\n\t"
+                  "v_mul_f64 %[bh], %[C2h], %[y1]\n\t"
+                  "v_mul_f64 %[yy], %[y1], %[y2]\n\t"
+                  "v_add_f64 %[nh], %[ah], %[bh]\n\t"
+                  "v_mul_f64 %[dh], %[bh], %[x1]\n\t"
+                  "v_fma_f64 %[nh], %[nR2h], %[yy], %[nh]\n\t"
+                  "v_fma_f64 %[dh], %[ah], %[x2], %[dh]\n\t"
+                  "v_cmp_gt_f64_e64 %[m0], %[tol], %[xx]\n\t"
+                  "v_add_f64 %[dh], %[dh], %[dh]\n\t"
+                  "v_mul_f64 %[yy], %[yy], %[tolh]\n\t"
+                  "v_rcp_f64_e32 %[rc], %[dh]\n\t"
+                  "v_mul_f64 %[nx], %[nh], %[xx]\n\t"
+                  "v_cmp_lt_f64_e64 %[m1], %[nh], %[yy]\n\t"
+                  "v_fma_f64 %[er], -%[dh], %[rc], 1.0\n\t"
+                  "s_or_b64 %[m0], %[m0], %[m1]\n\t"
+                  "v_fma_f64 %[rc], %[er], %[rc], %[rc]\n\t"
+                  "v_mul_f64 %[dl], %[nx], %[rc]\n\t"
+                  "v_cmp_gt_f64_e64 %[m1], %[tol], %[dl]\n\t"
+                  "s_or_b64 %[m0], %[m0], %[m1]\n\t"
+                  "s_andn2_b64 exec, exec, %[m0]\n\t"
+                  "v_add_f64 %[la], %[la], %[dl]\n\t"   // (with every lane masked off this adds nothing)
+                  "s_sub_u32 %[cnt], %[cnt], 2\n\t"
+                  "s_cbranch_execnz 1b\n"
                   "2:\n\t"
                   "s_mov_b64 exec, %[sv]"
                   : [x1] "=&v"(ox1), [x2] "=&v"(ox2), [la] "+v"(la), [y1] "=&v"(y1), [y2] "=&v"(y2), [xx] "=&v"(xx), [ah] "=&v"(ah), [bh] "=&v"(bh),

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../soft-grip_amd/csrc/sg_math.h"
+#include "../../soft-grip_amd/csrc/sg_general.h"
 
 using namespace sgm;
 
@@ -27,6 +28,8 @@ struct Emu {
   std::vector<double> sens;
   int ncon, nefc, iters, flags;
   std::vector<Contact> dbg_con[SG_MAXCH];
+  int general;  // the last substep ran on the general contact path (sg_general.h)
+  std::vector<GenContact> dbg_gcon;
 };
 
 extern "C" {
@@ -139,6 +142,12 @@ int emu_contact(Emu* E, int i, int* chain, int* sl, double* R, double* b3) {
   return 0;
 }
 int emu_nefc(Emu* E) { return E->nefc; }
+int emu_general(Emu* E) { return E->general; }
+int emu_gcontact(Emu* E, int i, double* out) {  // the i-th general contact as built (before the solve), SG_GEN_W doubles
+  if (i < 0 || i >= (int)E->dbg_gcon.size()) return 0;
+  gen_contact_store(out, E->dbg_gcon[i]);
+  return 1;
+}
 int emu_iters(Emu* E) { return E->iters; }
 
 // one mj_forward (+ Euler when integrate != 0)
@@ -220,27 +229,101 @@ int emu_substep(Emu* E, int integrate) {
       }
     }
   }
-  // envelope checks (detection only)
+  // envelope checks: a pair outside the fast path's two kinds within reach -> this substep runs on the general contact path
+  bool special = false;
   for (int c = 0; c < H.nchain; c++)
     for (int g = 0; g < H.chain[c].ngeom; g++) {
       const SgChain& C = H.chain[c];
       for (int s = 0; s < H.nstatic; s++) {
         double dif[3] = {boxp[c][g][0] - H.st_pos[s][0], boxp[c][g][1] - H.st_pos[s][1], boxp[c][g][2] - H.st_pos[s][2]}, bd = C.g_rbound[g] + H.st_rbound[s];
-        if (dot3(dif, dif) <= bd * bd && box_box_overlap(boxp[c][g], boxm[c][g], C.g_size[g], H.st_pos[s], H.st_mat[s], H.st_size[s], 0)) flags |= 32;
+        if (dot3(dif, dif) <= bd * bd && box_box_overlap(boxp[c][g], boxm[c][g], C.g_size[g], H.st_pos[s], H.st_mat[s], H.st_size[s], 0)) special = true;
       }
       for (int c2 = c + 1; c2 < H.nchain; c2++)
         for (int g2 = 0; g2 < H.chain[c2].ngeom; g2++) {
           double dif[3] = {boxp[c][g][0] - boxp[c2][g2][0], boxp[c][g][1] - boxp[c2][g2][1], boxp[c][g][2] - boxp[c2][g2][2]}, bd = C.g_rbound[g] + H.chain[c2].g_rbound[g2];
-          if (dot3(dif, dif) <= bd * bd && box_box_overlap(boxp[c][g], boxm[c][g], C.g_size[g], boxp[c2][g2], boxm[c2][g2], H.chain[c2].g_size[g2], 0)) flags |= 32;
+          if (dot3(dif, dif) <= bd * bd && box_box_overlap(boxp[c][g], boxm[c][g], C.g_size[g], boxp[c2][g2], boxm[c2][g2], H.chain[c2].g_size[g2], 0)) special = true;
         }
       if (H.has_plane) {
         double dif[3] = {boxp[c][g][0] - H.plane_pos[0], boxp[c][g][1] - H.plane_pos[1], boxp[c][g][2] - H.plane_pos[2]}, ext = 0;
         for (int k = 0; k < 3; k++) ext += C.g_size[g][k] * fabs(H.plane_normal[0] * boxm[c][g][k] + H.plane_normal[1] * boxm[c][g][3 + k] + H.plane_normal[2] * boxm[c][g][6 + k]);
-        if (dot3(dif, H.plane_normal) - ext <= 0) flags |= 32;
+        if (dot3(dif, H.plane_normal) - ext <= 0) special = true;
       }
     }
   for (int e = 0; e < N; e++)
-    if (!(E->qe[e] > EL(SGE_QLO, e) && E->qe[e] < EL(SGE_QHI, e))) flags |= 32;
+    if (!(E->qe[e] > EL(SGE_QLO, e) && E->qe[e] < EL(SGE_QHI, e))) special = true;
+  // ---- general contact path (sg_general.h): ONE ordered list over the plan's candidate pairs, generic rows ----
+  std::vector<GenContact> gcon;
+  E->general = special;
+  if (special) {
+    for (int c = 0; c < H.nchain; c++) con[c].clear();
+    double bxp[SG_MAXCH * SG_CG][3], bxm[SG_MAXCH * SG_CG][9];
+    for (int c = 0; c < SG_MAXCH; c++)
+      for (int g = 0; g < SG_CG; g++) { memcpy(bxp[c * SG_CG + g], boxp[c][g], 24); memcpy(bxm[c * SG_CG + g], boxm[c][g], 72); }
+    std::vector<double> ebinvw(N);
+    for (int e = 0; e < N; e++) ebinvw[e] = EL(SGE_BINVW, e);
+    double Minv2[SG_MAXCH][16], vc2[SG_MAXCH][SG_CD], asm2[SG_MAXCH][SG_CD], warm2[SG_MAXCH][SG_CD];
+    for (int c = 0; c < SG_MAXCH; c++) {
+      for (int i = 0; i < 16; i++) Minv2[c][i] = c < H.nchain ? D[c].Minv[i] : 0.0;
+      for (int d = 0; d < SG_CD; d++) { vc2[c][d] = c < H.nchain ? E->vc[c][d] : 0.0; asm2[c][d] = c < H.nchain ? D[c].qacc_smooth[d] : 0.0; warm2[c][d] = c < H.nchain ? E->wc[c][d] : 0.0; }
+    }
+    for (const SgGenPair& gp : P.gpairs) {
+      ConRec rec[8];
+      int n = 0;
+      const double* hint = nullptr;
+      double cax[3], cp[3];
+      auto capsule_of = [&](int ref) {
+        const int e = sgg_index(ref);
+        cp[0] = cpos[3 * e]; cp[1] = cpos[3 * e + 1]; cp[2] = cpos[3 * e + 2];
+        cax[0] = EL(SGE_CX, e); cax[1] = EL(SGE_CY, e); cax[2] = EL(SGE_CZ, e);
+      };
+      const double *p2 = nullptr, *R2 = nullptr, *s2 = nullptr, *p1 = nullptr, *R1 = nullptr, *s1 = nullptr;
+      double rb1 = 0, rb2 = 0;
+      if (gp.kind == SGP_PLANE_CAP) {
+        capsule_of(gp.g2);
+        double dif[3] = {cp[0] - H.plane_pos[0], cp[1] - H.plane_pos[1], cp[2] - H.plane_pos[2]};
+        if (dot3(dif, H.plane_normal) > H.con_margin + H.cap_rbound) continue;
+        n = gen_plane_capsule(H.plane_pos, H.plane_normal, cp, cax, H.cap_radius, H.cap_hl, H.con_margin, rec);
+        hint = cax;
+      } else if (gp.kind == SGP_PLANE_BOX) {
+        gen_box_of(gp.g2, H, bxp, bxm, p2, R2, s2, rb2);
+        double dif[3] = {p2[0] - H.plane_pos[0], p2[1] - H.plane_pos[1], p2[2] - H.plane_pos[2]};
+        if (dot3(dif, H.plane_normal) > H.con_margin + rb2) continue;
+        n = gen_plane_box(H.plane_pos, H.plane_normal, p2, R2, s2, H.con_margin, rec);
+      } else {
+        if (gp.kind == SGP_SPH_BOX) { cp[0] = H.center_pos[0]; cp[1] = H.center_pos[1]; cp[2] = H.center_pos[2]; rb1 = H.center_radius; }
+        else if (gp.kind == SGP_CAP_BOX) { capsule_of(gp.g1); rb1 = H.cap_rbound; }
+        else if (gp.kind == SGP_BOX_BOX || gp.kind == SGP_UNSUPPORTED) {
+          if (sgg_kind(gp.g1) != SGG_BOX && sgg_kind(gp.g1) != SGG_STATIC) { flags |= 32; continue; }  // an unsupported pair that is not box - box: flag whenever checked
+          gen_box_of(gp.g1, H, bxp, bxm, p1, R1, s1, rb1);
+          cp[0] = p1[0]; cp[1] = p1[1]; cp[2] = p1[2];
+        }
+        gen_box_of(gp.g2, H, bxp, bxm, p2, R2, s2, rb2);
+        double dif[3] = {p2[0] - cp[0], p2[1] - cp[1], p2[2] - cp[2]}, bound = rb1 + rb2 + H.con_margin;
+        if (dot3(dif, dif) > bound * bound) continue;
+        if (gp.kind == SGP_SPH_BOX) n = sphere_box(cp, H.center_radius, p2, R2, s2, H.con_margin, rec[0]);
+        else if (gp.kind == SGP_CAP_BOX) {
+          int mk = capsule_box(cp, cax, H.cap_radius, H.cap_hl, p2, R2, s2, H.con_margin, rec[0], rec[1]);
+          if ((mk & 2) && !(mk & 1)) rec[0] = rec[1];
+          n = (mk & 1) + ((mk >> 1) & 1);
+        } else {
+          n = gen_box_box(p1, R1, s1, p2, R2, s2, H.con_margin, rec);
+          if (gp.kind == SGP_UNSUPPORTED) { if (n > 0) flags |= 32; continue; }
+        }
+      }
+      const GenSide S1 = gen_side_of(gp.g1, H, ebinvw.data()), S2 = gen_side_of(gp.g2, H, ebinvw.data());
+      const int sl = S1.sl >= 0 ? S1.sl : S2.sl;
+      for (int q = 0; q < n; q++) {
+        if (!(rec[q].dist < H.con_margin)) continue;
+        if ((int)gcon.size() == SG_GEN_MAXCON) { flags |= 8; break; }
+        GenContact gc;
+        double ax[3] = {0, 0, 0};
+        if (sl >= 0) { ax[0] = EL(SGE_AX, sl); ax[1] = EL(SGE_AY, sl); ax[2] = EL(SGE_AZ, sl); }
+        gen_contact_build(gc, rec[q], hint, S1, S2, K, Minv2, vc2, asm2, warm2, ax, sl >= 0 ? E->ve[sl] : 0.0, sl >= 0 ? asm_e[sl] : 0.0,
+                          sl >= 0 ? E->we[sl] : 0.0, sl >= 0 ? invm[sl] : 0.0, H);
+        gcon.push_back(gc);
+      }
+    }
+  }
   // ---- equality rows ----
   std::vector<double> eqR(N), eqb(N), eqf(N);
   for (int e = 0; e < N; e++) {
@@ -261,8 +344,10 @@ int emu_substep(Emu* E, int integrate) {
   for (int c = 0; c < H.nchain; c++) limits_build(H.chain[c], E->qc[c], E->vc[c], D[c].qacc_smooth, E->wc[c], Lm[c]);
   E->ncon = 0; E->nefc = N + 1;
   for (int c = 0; c < H.nchain; c++) { E->ncon += (int)con[c].size(); E->nefc += __builtin_popcount(Lm[c].active) + 3 * (int)con[c].size(); }
+  E->ncon += (int)gcon.size(); E->nefc += 3 * (int)gcon.size();
 
   for (int c = 0; c < H.nchain; c++) E->dbg_con[c] = con[c];
+  E->dbg_gcon = gcon;
   // ---- M^-1 J' f from scratch ----
   std::vector<double> ae(N);
   double aF[SG_MAXCH][SG_CD];
@@ -276,12 +361,16 @@ int emu_substep(Emu* E, int integrate) {
         for (int d = 0; d < SG_CD; d++) g[d] += ct.Jf[0][d] * ct.f[0] + ct.Jf[1][d] * ct.f[1] + ct.Jf[2][d] * ct.f[2];
         if (ct.sl >= 0) ae[ct.sl] += ct.invm * (ct.Js[0] * ct.f[0] + ct.Js[1] * ct.f[1] + ct.Js[2] * ct.f[2]);
       }
+      for (auto& gc : gcon)
+        for (int d = 0; d < SG_CD; d++) g[d] += gc.Jf[c][0][d] * gc.f[0] + gc.Jf[c][1][d] * gc.f[1] + gc.Jf[c][2][d] * gc.f[2];
       for (int a = 0; a < SG_CD; a++) {
         double s = 0;
         for (int b = 0; b < SG_CD; b++) s += D[c].Minv[4 * a + b] * g[b];
         aF[c][a] = s;
       }
     }
+    for (auto& gc : gcon)
+      if (gc.sl >= 0) ae[gc.sl] += gc.invm * (gc.Js[0] * gc.f[0] + gc.Js[1] * gc.f[1] + gc.Js[2] * gc.f[2]);
   };
   recompute_a();
   // ---- warmstart cost 0.5 f'(A+R)f + f'b ----
@@ -298,7 +387,15 @@ int emu_substep(Emu* E, int integrate) {
         cost += ct.f[r] * (0.5 * (Ja + ct.R * ct.f[r]) + ct.b[r]);
       }
   }
+  for (auto& gc : gcon)
+    for (int r = 0; r < 3; r++) {
+      double Ja = gc.sl >= 0 ? gc.Js[r] * ae[gc.sl] : 0.0;
+      for (int c = 0; c < SG_MAXCH; c++)
+        for (int d = 0; d < SG_CD; d++) Ja += gc.Jf[c][r][d] * aF[c][d];
+      cost += gc.f[r] * (0.5 * (Ja + gc.R * gc.f[r]) + gc.b[r]);
+    }
   if (cost > 0) {
+    for (auto& gc : gcon) gc.f[0] = gc.f[1] = gc.f[2] = 0;
     std::fill(eqf.begin(), eqf.end(), 0.0);
     tf = 0;
     for (int c = 0; c < H.nchain; c++) {
@@ -342,6 +439,17 @@ int emu_substep(Emu* E, int integrate) {
           for (int b = 0; b < SG_CD; b++) aF[c][a] += D[c].Minv[4 * a + b] * g[b];
         if (ct.sl >= 0) ae[ct.sl] += ct.invm * (ct.Js[0] * df[0] + ct.Js[1] * df[1] + ct.Js[2] * df[2]);
       }
+    for (auto& gc : gcon) {   // the general path's single stream, in mj_collision's order (after both chains' limit rows)
+      double df[3], as_ = gc.sl >= 0 ? ae[gc.sl] : 0.0;
+      improvement -= gen_contact_update(gc, aF, as_, H.con_mu, df);
+      for (int c = 0; c < H.nchain; c++) {
+        double g[SG_CD];
+        for (int d = 0; d < SG_CD; d++) g[d] = gc.Jf[c][0][d] * df[0] + gc.Jf[c][1][d] * df[1] + gc.Jf[c][2][d] * df[2];
+        for (int a = 0; a < SG_CD; a++)
+          for (int b = 0; b < SG_CD; b++) aF[c][a] += D[c].Minv[4 * a + b] * g[b];
+      }
+      if (gc.sl >= 0) ae[gc.sl] += gc.invm * (gc.Js[0] * df[0] + gc.Js[1] * df[1] + gc.Js[2] * df[2]);
+    }
     E->iters = it + 1;
     if (improvement * H.pgs_scale < H.tolerance) break;
   }

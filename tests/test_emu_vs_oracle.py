@@ -206,3 +206,76 @@ def test_one_slider_under_both_fingers(tmp_path):
         worst = max(worst, np.abs(e.sensordata - s.sensordata).max())
         assert e.ncon == s.ncon
     assert shared > 300 and worst < 1e-8        # free-running: this scene does not amplify round-off
+
+
+# ---- the general contact path (csrc/sg_general.h): every pair kind mj_collision has for this model class ----
+def general_path_scene(kind, path):
+    """variants of the own scene in which a collision pair outside the fast path's two kinds becomes active:
+    fingers -- the object out of reach, wider hinge ranges: the finger tips close on EACH OTHER (box - box, both chains in one row);
+    stop    -- a static block in the way of the left finger tip (finger box - static box, up to 8 contacts per pair);
+    plate   -- a thin static plate in the object's mid-plane: squeezed capsules reach it from both sides (static box - capsule);
+    rest    -- the object resting on the ground plane (plane - capsule, from the first step on);
+    sledge  -- the finger tips resting on the ground plane (plane - box)."""
+    import os
+    from helpers import ROOT
+    x = open(os.path.join(ROOT, "tests", "data", "mini_gripper.xml")).read()
+    ground = '<geom name="ground" type="plane" size="0 0 1" condim="1"/>'
+    if kind == "fingers":
+        x = x.replace('<body pos="1.15 0 1.0">', '<body pos="2.6 0 1.0">').replace('range="-0.5 0.1"', 'range="-0.9 0.1"').replace('range="-0.1 0.5"', 'range="-0.1 0.9"')
+    elif kind == "stop":
+        x = x.replace(ground, ground + '\n    <geom name="stop" class="link" pos="1.5 0.38 1.0" size="0.04 0.04 0.1"/>')
+    elif kind == "plate":
+        x = x.replace(ground, ground + '\n    <geom name="plate" class="link" pos="1.15 0 1.0" size="0.12 0.004 0.12"/>')
+    elif kind == "rest":
+        x = x.replace('<body pos="0 0 1.0">', '<body pos="0 0 0.3">').replace('<body pos="1.15 0 1.0">', '<body pos="1.15 0 0.236">')
+    elif kind == "sledge":
+        x = (x.replace('<body pos="0 0 1.0">', '<body pos="0 0 0.1995">').replace('<body pos="1.15 0 1.0">', '<body pos="1.15 0 0.5">')
+             .replace('size="0.3 0.08 0.2"', 'size="0.3 0.08 0.15"').replace('size="0.15 0.1 0.2"', 'size="0.15 0.1 0.15"'))
+    else:
+        raise ValueError(kind)
+    with open(path, "w") as f:
+        f.write(x)
+    return str(path)
+
+
+GENERAL_PAIRS = {"fingers": ("fL2", "fR2"), "stop": ("stop", "fL2"), "plate": ("OBJG", "plat"), "rest": ("grou", "OBJG"), "sledge": ("grou", "fL2")}
+
+
+def special_contacts(m, contacts, kind):
+    """contacts of the scene's special pair in an oracle contact list"""
+    want = GENERAL_PAIRS[kind]
+    return sum(1 for c in contacts if (m.geom_names[c["geom1"]][:4], m.geom_names[c["geom2"]][:4]) == want)
+
+
+@pytest.mark.parametrize("kind", ["fingers", "stop", "plate", "rest", "sledge"])
+def test_general_contact_path_against_the_oracle(tmp_path, kind):
+    """the general path's math (narrowphase for box - box / plane - box / plane - capsule / static box - capsule, rows with both chains'
+    Jacobian blocks, one ordered stream) run lane-serially against the oracle over the squeeze schedule, free-running: sensors,
+    contact counts and sweep counts at every substep; the oracle's contact list confirms the special pair is active"""
+    import ctypes
+    from oracle import oracle as O
+    m = sg.compile_mjcf(general_path_scene(kind, tmp_path / (kind + ".xml")), composite_neighbors=False)
+    e = Emu(m.to_blob(), m.nv)
+    e.L.emu_general.argtypes = [ctypes.c_void_p]
+    s = O.OracleSim(O.OracleModel(m.to_blob()))
+    s._om = s.model
+    k = 640.0
+    s.jnt_stiffness[8:] = k
+    s.tendon_stiffness[0] = k
+    e.set_stiffness(k, list(range(8, m.nv)), [0])
+    e.reset(); s.reset()
+    e.substep(False); s.forward()
+    e.substep(True); s.step()
+    worst, general, special = 0.0, 0, 0
+    for t, c in enumerate(episode_schedule()[:150]):
+        if c is not None:
+            e.set_ctrl(c)
+            s.ctrl[:] = c
+        for _ in range(7):
+            assert e.substep(True) == 0 and s.step() == 0, t
+            assert e.ncon == s.ncon and e.L.emu_iters(e.p) == s.solver_iter, t
+            general += e.L.emu_general(e.p)
+        special += special_contacts(m, s.contacts(), kind)
+        worst = max(worst, np.abs(e.sensordata - s.sensordata).max())
+    assert special > 100 and general > 300, (special, general)
+    assert worst < 1e-7, worst
