@@ -49,6 +49,7 @@ struct sg_batch {
   int n, device;
   SgPlanHeader* dH;
   double *delem, *qpos, *qvel, *warm, *act, *ctrl, *kenv, *ctrl_row;
+  SgGenPair* dgpairs;  // SgPlan::gpairs on the device (the general contact path's candidate pairs)
   int* dnbtab;       // SgPlan::nbtab on the device (neighbour-row models)
   SgEqSlot* dsched;  // SgPlan::sched + one spare round of idle slots
   int *kmask_jnt, *kmask_ten, *flags, *touch, *ncon, *nefc, *iters;
@@ -129,7 +130,7 @@ int sg_model_nelem(const sg_model* m) { return m->plan.h.nelem; }
 void sg_batch_destroy(sg_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  void* ptrs[] = {b->dnbtab, b->dsched, b->dH, b->delem, b->qpos, b->qvel, b->warm, b->act, b->ctrl, b->kenv, b->ctrl_row, b->kmask_jnt, b->kmask_ten,
+  void* ptrs[] = {b->dgpairs, b->dnbtab, b->dsched, b->dH, b->delem, b->qpos, b->qvel, b->warm, b->act, b->ctrl, b->kenv, b->ctrl_row, b->kmask_jnt, b->kmask_ten,
                   b->flags, b->touch, b->ncon, b->nefc, b->iters};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -149,7 +150,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   HIPCHK(hipSetDevice(device));
   sg_batch* b = new sg_batch();
   b->m = m; b->n = n_envs; b->device = device; b->lds_attr_set = false; b->prof = false; b->prof_ms = 0; b->prof_n = 0; b->prof_pgs_ms = 0; b->prof_pgs_n = 0;
-  b->dnbtab = nullptr; b->dsched = nullptr; b->epw_override = 0;
+  b->dnbtab = nullptr; b->dsched = nullptr; b->dgpairs = nullptr; b->epw_override = 0;
   b->dH = nullptr; b->delem = b->qpos = b->qvel = b->warm = b->act = b->ctrl = b->kenv = b->ctrl_row = nullptr;
   b->kmask_jnt = b->kmask_ten = b->flags = b->touch = b->ncon = b->nefc = b->iters = nullptr;
   const SgPlanHeader& H = m->plan.h;
@@ -192,7 +193,9 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
               walloc((void**)&b->w.asme, sizeof(double) * n * N) && walloc((void**)&b->w.fsm, sizeof(double) * n * N) &&
               walloc((void**)&b->w.chh, sizeof(double) * n * 2 * SG_CHW) &&
               walloc((void**)&b->w.nbf, sizeof(double) * n * (3 * N + 1)) && walloc((void**)&b->w.nbb, sizeof(double) * n * (3 * N + 1)) &&
-              walloc((void**)&b->w.nbR, sizeof(double) * n * (3 * N + 1));
+              walloc((void**)&b->w.nbR, sizeof(double) * n * (3 * N + 1)) &&
+              walloc((void**)&b->w.gcon, sizeof(double) * n * SG_GEN_MAXCON * SG_GEN_W) && walloc((void**)&b->w.gen, sizeof(int) * n) &&
+              walloc((void**)&b->w.gen_count, sizeof(int) * 4) && walloc((void**)&b->w.gen_list, sizeof(int) * SG_GEN_LIST);
     if (!ok) { sg_batch_destroy(b); return fail(SG_ERR_NOMEM, "hipMalloc (split-pipeline workspace)"); }
     const char* pm = getenv("SG_PIPELINE");
     b->pipeline = (pm && strcmp(pm, "fused") == 0) ? 0 : (pm && strcmp(pm, "split") == 0) ? 1 : 2;
@@ -208,6 +211,8 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
     HIPCHK(hipMemcpy(b->dnbtab, m->plan.nbtab.data(), sizeof(int) * m->plan.nbtab.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->dsched, sch.data(), sizeof(SgEqSlot) * sch.size(), hipMemcpyHostToDevice));
   }
+  ALLOC(b->dgpairs, sizeof(SgGenPair) * (m->plan.gpairs.size() + 1));
+  HIPCHK(hipMemcpy(b->dgpairs, m->plan.gpairs.data(), sizeof(SgGenPair) * m->plan.gpairs.size(), hipMemcpyHostToDevice));
 #undef ALLOC
   HIPCHK(hipMemcpy(b->dH, &H, sizeof H, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->delem, m->plan.elem.data(), sizeof(double) * m->plan.elem.size(), hipMemcpyHostToDevice));
@@ -315,6 +320,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   pa.mask = mask; pa.sens = nullptr; pa.sens_stride = stride > 0 ? stride : H.nsensordata;
   pa.w = b->w; pa.nenv = b->n; pa.rowlayout = b->pipeline == 2;
   pa.nbtab = b->dnbtab;
+  pa.gpairs = b->dgpairs;
   pa.nelem = H.nelem; pa.nv = H.nv; pa.nu = H.nu; pa.elem_dof0 = H.elem_dof0; pa.nchain = H.nchain; pa.t0_id = H.t0_id; pa.timestep = H.timestep;
   SgPgsArgs ga;
   ga.sched = b->dsched; ga.nbtab = b->dnbtab;
@@ -346,10 +352,18 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     if (int rc = begin_event_pair(b, b->ev, s)) return rc;
     call_ev = b->ev.size() - 1;
   }
+  // the main pass over all envs, then (rows pipeline, forward passes only) the general contact pass: a small fixed grid whose
+  // blocks take the envs the main pass has put on W.gen_list -- normally none, and then every block returns at once
+  const bool genpass = b->pipeline == 2;
   auto phase = [&](const SgPhaseArgs& p) {
 #define SG_PHASE(r)                                                                                   \
-  if (nbm) hipLaunchKernelGGL((sg_phase_kernel<r, 2, true>), dim3(b->n), dim3(64), 0, s, p);          \
-  else hipLaunchKernelGGL((sg_phase_kernel<r, 2, false>), dim3(b->n), dim3(64), 0, s, p)
+  if (nbm) {                                                                                          \
+    hipLaunchKernelGGL((sg_phase_kernel<r, 2, true>), dim3(b->n), dim3(64), 0, s, p);                 \
+    if (genpass && p.do_begin) hipLaunchKernelGGL((sg_phase_kernel<r, 2, true, true>), dim3(SG_GEN_LIST), dim3(64), 0, s, p); \
+  } else {                                                                                            \
+    hipLaunchKernelGGL((sg_phase_kernel<r, 2, false>), dim3(b->n), dim3(64), 0, s, p);                \
+    if (genpass && p.do_begin) hipLaunchKernelGGL((sg_phase_kernel<r, 2, false, true>), dim3(SG_GEN_LIST), dim3(64), 0, s, p); \
+  }
     switch (b->m->rounds) {
       case 1: SG_PHASE(1); break;
       case 2: SG_PHASE(2); break;

@@ -26,7 +26,9 @@ SG_HD int sgg_index(int ref) { return ref & 0xFFFF; }
 
 // narrowphase routine of a candidate pair (geom1 / geom2 in mj_collideGeoms' order: by type, plane < sphere < capsule < box)
 enum { SGP_PLANE_CAP = 0, SGP_PLANE_BOX = 1, SGP_SPH_BOX = 2, SGP_CAP_BOX = 3, SGP_BOX_BOX = 4, SGP_UNSUPPORTED = 5 };
-#define SG_GEN_MAXCON 128   // contacts of an env on the general path (the fast path: 64 per finger)
+#define SG_GEN_MAXCON 112   // contacts of an env on the general path (the fast path: 64 per finger); with the box - box work space
+                            // the list fills the phase kernel's 8 KB contact staging area
+#define SG_GEN_ROUNDS ((SG_GEN_MAXCON + 63) / 64)
 #define SG_GEN_W 48         // doubles per exported general contact (GenContact, padded)
 
 SG_HD void make_frame_hint(const double* n, const double* hint, double* fr) {  // mju_makeFrame: normal, optional first-tangent hint
@@ -44,23 +46,34 @@ SG_HD void make_frame_hint(const double* n, const double* hint, double* fr) {  /
   cross3(fr + 6, fr, fr + 3);
 }
 
+// The narrowphase routines write records with members dist, pos[3], n[3] (ConRec on the host harness, the phase kernel's LDS staging
+// record on the device).  Run-time indices into small private arrays are written as selects (pick3): a dynamically indexed private
+// array would live in scratch memory on the device.
+SG_HD double pick1(const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
+SG_HD void pick3(const double (*M)[3], int k, double* out) {
+  for (int c = 0; c < 3; c++) out[c] = k == 0 ? M[0][c] : (k == 1 ? M[1][c] : M[2][c]);
+}
+
 // plane (point pp, unit normal pn) against a capsule: one sphere test per end cap (oracle collision(), plane - capsule branch)
+template <class Rec>
 SG_HD int gen_plane_capsule(const double* pp, const double* pn, const double* cp, const double* cax, double r, double hl, double margin,
-                            ConRec* out) {
+                            Rec& o0, Rec& o1) {
   int n = 0;
   for (int s = -1; s <= 1; s += 2) {
     double c[3] = {cp[0] + s * hl * cax[0], cp[1] + s * hl * cax[1], cp[2] + s * hl * cax[2]};
     double e[3] = {c[0] - pp[0], c[1] - pp[1], c[2] - pp[2]}, dist = dot3(e, pn) - r;
     if (dist > margin) continue;
-    out[n].dist = dist;
-    for (int q = 0; q < 3; q++) { out[n].pos[q] = c[q] - pn[q] * (r + 0.5 * dist); out[n].n[q] = pn[q]; }
+    Rec& o = n == 0 ? o0 : o1;
+    o.dist = dist;
+    for (int q = 0; q < 3; q++) { o.pos[q] = c[q] - pn[q] * (r + 0.5 * dist); o.n[q] = pn[q]; }
     n++;
   }
   return n;
 }
 
 // plane against a box: the corners within the margin, in corner order (x fastest), at most 4 (oracle plane_box)
-SG_HD int gen_plane_box(const double* pp, const double* pn, const double* bp, const double* bm, const double* sz, double margin, ConRec* out) {
+template <class Rec>
+SG_HD int gen_plane_box(const double* pp, const double* pn, const double* bp, const double* bm, const double* sz, double margin, Rec* out) {
   int n = 0;
   for (int q = 0; q < 8 && n < 4; q++) {
     double loc[3] = {(q & 1 ? 1 : -1) * sz[0], (q & 2 ? 1 : -1) * sz[1], (q & 4 ? 1 : -1) * sz[2]}, w[3];
@@ -76,10 +89,11 @@ SG_HD int gen_plane_box(const double* pp, const double* pn, const double* bp, co
 }
 
 // box - box: separating axes, then face clipping or the closest points of two edges (oracle box_box; up to 8 contacts).
-// Normal from box 1 towards box 2, dist < 0 = penetration.
+// Normal from box 1 towards box 2, dist < 0 = penetration.  poly / tmp: work space for the clipped polygon, 16 points each.
 #define SG_BB_FUDGE 1.05
+template <class Rec>
 SG_HD int gen_box_box(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2, double margin,
-                      ConRec* out) {
+                      Rec* out, double (*poly)[3], double (*tmp)[3]) {
   double T[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, A[3][3], B[3][3];
   for (int k = 0; k < 3; k++) { A[k][0] = R1[k]; A[k][1] = R1[3 + k]; A[k][2] = R1[6 + k]; B[k][0] = R2[k]; B[k][1] = R2[3 + k]; B[k][2] = R2[6 + k]; }
   double C[3][3], Q[3][3];
@@ -97,7 +111,7 @@ SG_HD int gen_box_box(const double* p1, const double* R1, const double* s1, cons
     if (sep > margin) return 0;
     if (sep > best) { best = sep; code = 3 + k; double sg = t < 0 ? -1 : 1; for (int c = 0; c < 3; c++) bn[c] = sg * B[k][c]; }
   }
-  double ebest = -1e300, en[3] = {0, 0, 0};
+  double ebest = -1e300, en[3] = {0, 0, 0}, euv = 0;
   int ecode = -1;
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) {
@@ -110,53 +124,61 @@ SG_HD int gen_box_box(const double* p1, const double* R1, const double* s1, cons
       for (int k = 0; k < 3; k++) { ra += s1[k] * fabs(dot3(L, A[k])); rb += s2[k] * fabs(dot3(L, B[k])); }
       double t = dot3(T, L), sep = fabs(t) - (ra + rb);
       if (sep > margin) return 0;
-      if (sep > ebest) { ebest = sep; ecode = 6 + 3 * i + j; double sg = t < 0 ? -1 : 1; for (int c = 0; c < 3; c++) en[c] = sg * L[c]; }
+      if (sep > ebest) { ebest = sep; ecode = 6 + 3 * i + j; euv = C[i][j]; double sg = t < 0 ? -1 : 1; for (int c = 0; c < 3; c++) en[c] = sg * L[c]; }
     }
   if (ecode >= 0 && ebest > best + (SG_BB_FUDGE - 1.0) * fabs(best) + 1e-9) { best = ebest; code = ecode; bn[0] = en[0]; bn[1] = en[1]; bn[2] = en[2]; }
   if (code >= 6) {  // edge - edge: closest points of the two supporting edges
     const int i = (code - 6) / 3, j = (code - 6) % 3;
-    double pa[3], pb[3];
+    double pa[3], pb[3], Ai[3], Bj[3];
+    pick3(A, i, Ai); pick3(B, j, Bj);
     for (int c = 0; c < 3; c++) { pa[c] = p1[c]; pb[c] = p2[c]; }
     for (int k = 0; k < 3; k++) {
       if (k != i) { double sg = dot3(bn, A[k]) > 0 ? 1 : -1; addscl3(pa, A[k], sg * s1[k]); }
       if (k != j) { double sg = dot3(bn, B[k]) > 0 ? -1 : 1; addscl3(pb, B[k], sg * s2[k]); }
     }
-    double r[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]}, uv = C[i][j], den = 1 - uv * uv;
+    double r[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]}, uv = euv, den = 1 - uv * uv;
     double ta = 0, tb = 0;
-    if (den > 1e-12) { double q1 = dot3(A[i], r), q2 = dot3(B[j], r); ta = (q1 - uv * q2) / den; tb = (uv * q1 - q2) / den; }
-    ta = ta > s1[i] ? s1[i] : ta < -s1[i] ? -s1[i] : ta;
-    tb = tb > s2[j] ? s2[j] : tb < -s2[j] ? -s2[j] : tb;
+    if (den > 1e-12) { double q1 = dot3(Ai, r), q2 = dot3(Bj, r); ta = (q1 - uv * q2) / den; tb = (uv * q1 - q2) / den; }
+    const double s1i = pick1(s1, i), s2j = pick1(s2, j);
+    ta = ta > s1i ? s1i : ta < -s1i ? -s1i : ta;
+    tb = tb > s2j ? s2j : tb < -s2j ? -s2j : tb;
     out[0].dist = best;
-    for (int c = 0; c < 3; c++) { out[0].pos[c] = 0.5 * ((pa[c] + ta * A[i][c]) + (pb[c] + tb * B[j][c])); out[0].n[c] = bn[c]; }
+    for (int c = 0; c < 3; c++) { out[0].pos[c] = 0.5 * ((pa[c] + ta * Ai[c]) + (pb[c] + tb * Bj[c])); out[0].n[c] = bn[c]; }
     return 1;
   }
   // face contact: the reference box owns the axis
   const bool ref1 = code < 3;
   const int ka = ref1 ? code : code - 3;
-  const double (*Ra)[3] = ref1 ? A : B, (*Rb)[3] = ref1 ? B : A;
-  const double *pa = ref1 ? p1 : p2, *pb = ref1 ? p2 : p1, *sa = ref1 ? s1 : s2, *sb = ref1 ? s2 : s1;
+  double Ra[3][3], Rb[3][3], pa[3], pb[3], sa[3], sb[3];
+  for (int k = 0; k < 3; k++) {
+    for (int c = 0; c < 3; c++) { Ra[k][c] = ref1 ? A[k][c] : B[k][c]; Rb[k][c] = ref1 ? B[k][c] : A[k][c]; }
+    pa[k] = ref1 ? p1[k] : p2[k]; pb[k] = ref1 ? p2[k] : p1[k]; sa[k] = ref1 ? s1[k] : s2[k]; sb[k] = ref1 ? s2[k] : s1[k];
+  }
   double nrm[3];  // outward normal of the reference face (towards the incident box)
   for (int c = 0; c < 3; c++) nrm[c] = ref1 ? bn[c] : -bn[c];
   int kb = 0;
   double mx = -1;
   for (int k = 0; k < 3; k++) { double v = fabs(dot3(nrm, Rb[k])); if (v > mx + 1e-12) { mx = v; kb = k; } }
-  const double sgb = dot3(nrm, Rb[kb]) > 0 ? -1 : 1;
-  double cen[3];
-  for (int c = 0; c < 3; c++) cen[c] = pb[c] + sgb * sb[kb] * Rb[kb][c];
+  double Rbk[3], Rbu[3], Rbv[3], Rau[3], Rav[3];
   const int u = (kb + 1) % 3, v = (kb + 2) % 3, ua = (ka + 1) % 3, va = (ka + 2) % 3;
-  double poly[16][3], tmp[16][3];
+  pick3(Rb, kb, Rbk); pick3(Rb, u, Rbu); pick3(Rb, v, Rbv); pick3(Ra, ua, Rau); pick3(Ra, va, Rav);
+  const double sbk = pick1(sb, kb), sbu = pick1(sb, u), sbv = pick1(sb, v), sau = pick1(sa, ua), sav = pick1(sa, va), sak = pick1(sa, ka);
+  const double sgb = dot3(nrm, Rbk) > 0 ? -1 : 1;
+  double cen[3];
+  for (int c = 0; c < 3; c++) cen[c] = pb[c] + sgb * sbk * Rbk[c];
   int np = 4;
-  const double cs[4][2] = {{1, 1}, {-1, 1}, {-1, -1}, {1, -1}};
-  for (int q = 0; q < 4; q++)
-    for (int c = 0; c < 3; c++) poly[q][c] = cen[c] + cs[q][0] * sb[u] * Rb[u][c] + cs[q][1] * sb[v] * Rb[v][c];
+  for (int q = 0; q < 4; q++) {
+    const double cu = (q == 0 || q == 3) ? 1.0 : -1.0, cv = q < 2 ? 1.0 : -1.0;   // (1,1), (-1,1), (-1,-1), (1,-1)
+    for (int c = 0; c < 3; c++) poly[q][c] = cen[c] + cu * sbu * Rbu[c] + cv * sbv * Rbv[c];
+  }
   for (int pl = 0; pl < 4 && np > 0; pl++) {  // clip against the four side planes of the reference face
-    const int ax = pl < 2 ? ua : va;
-    const double sg = (pl & 1) ? -1 : 1, lim = sa[ax];
+    const double* Rax = pl < 2 ? Rau : Rav;
+    const double sg = (pl & 1) ? -1 : 1, lim = pl < 2 ? sau : sav;
     int nq = 0;
     for (int q = 0; q < np; q++) {
       const double *x0 = poly[q], *x1 = poly[(q + 1) % np];
       double e0[3] = {x0[0] - pa[0], x0[1] - pa[1], x0[2] - pa[2]}, e1[3] = {x1[0] - pa[0], x1[1] - pa[1], x1[2] - pa[2]};
-      double d0 = sg * dot3(e0, Ra[ax]) - lim, d1 = sg * dot3(e1, Ra[ax]) - lim;
+      double d0 = sg * dot3(e0, Rax) - lim, d1 = sg * dot3(e1, Rax) - lim;
       if (d0 <= 0) { for (int c = 0; c < 3; c++) tmp[nq][c] = x0[c]; nq++; }
       if ((d0 <= 0) != (d1 <= 0)) { double w = d0 / (d0 - d1); for (int c = 0; c < 3; c++) tmp[nq][c] = x0[c] + w * (x1[c] - x0[c]); nq++; }
     }
@@ -166,7 +188,7 @@ SG_HD int gen_box_box(const double* p1, const double* R1, const double* s1, cons
   }
   int n = 0;
   for (int q = 0; q < np && n < 8; q++) {
-    double e[3] = {poly[q][0] - pa[0], poly[q][1] - pa[1], poly[q][2] - pa[2]}, dist = dot3(e, nrm) - sa[ka];
+    double e[3] = {poly[q][0] - pa[0], poly[q][1] - pa[1], poly[q][2] - pa[2]}, dist = dot3(e, nrm) - sak;
     if (dist > margin) continue;
     out[n].dist = dist;
     for (int c = 0; c < 3; c++) { out[n].pos[c] = poly[q][c] - 0.5 * dist * nrm[c]; out[n].n[c] = bn[c]; }
@@ -214,7 +236,8 @@ SG_HD GenSide gen_side_of(int ref, const SgPlanHeader& H, const double* elem_bin
 }
 
 // geometry -> rows.  K / Minv / vc / asm_c / warm_c: per chain (index 0, 1); slider quantities of the (at most one) element involved.
-SG_HD void gen_contact_build(GenContact& c, const ConRec& rec, const double* hint, const GenSide& S1, const GenSide& S2, const ChainKin* K,
+template <class Rec>
+SG_HD void gen_contact_build(GenContact& c, const Rec& rec, const double* hint, const GenSide& S1, const GenSide& S2, const ChainKin* K,
                              const double (*Minv)[16], const double (*vc)[SG_CD], const double (*asm_c)[SG_CD], const double (*warm_c)[SG_CD],
                              const double* eaxis, double ve, double asm_e, double warm_e, double invm_e, const SgPlanHeader& H) {
   double fr[9];

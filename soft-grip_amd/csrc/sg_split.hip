@@ -18,6 +18,7 @@
 
 #include "../../include/softgrip.h"
 #include "sg_math.h"
+#include "sg_general.h"
 
 using namespace sgm;
 
@@ -33,6 +34,7 @@ using namespace sgm;
 #define SG_EPW (64 / SG_G)   // envs per PGS wavefront
 #define SG_SPW (2 * SG_EPW)  // finger streams per PGS wavefront
 #define SG_CHW 160       // doubles of chain hand-off per stream (layout: see sg_chain_kernel)
+#define SG_GEN_LIST 256  // envs per substep the general contact pass can take (one block each); further ones are flagged
 
 struct SgWork {          // device workspace of one batch (all pointers device memory)
   double* crec;          // [SG_CAP][nwb + 1][SG_RF][16]   nwb = ceil(nenv / 8) PGS wavefronts (+1 dummy block)
@@ -49,6 +51,10 @@ struct SgWork {          // device workspace of one batch (all pointers device m
   double *asme, *fsm;    // [nenv][N]  begin -> finish hand-off
   double* chh;           // [nenv][2][SG_CHW]  chain hand-off (enum SGH_*)
   double *nbf, *nbb, *nbR;  // [nenv][3 N]  neighbour equality rows (models with H.nnb > 0) by slot (SgPlan::nbtab): force, right-hand side, regulariser
+  double* gcon;          // [nenv][SG_GEN_MAXCON][SG_GEN_W]  contacts of envs on the general contact path (sg_general.h), in mj_collision's order
+  int* gen;              // [nenv]  number of general contacts of the pending substep (0: the env is on the fast path)
+  int* gen_count;        // [1]  envs the main phase pass has put on gen_list in this substep (reset by sg_chain_kernel)
+  int* gen_list;         // [SG_GEN_LIST]
 };
 
 struct SgPhaseArgs {
@@ -65,6 +71,7 @@ struct SgPhaseArgs {
   int do_reset, do_finish, finish_integrate, do_begin, first;
   int rowlayout;  // 1: export contact records in the row layout of sg_pgs_rows_kernel
   const int* nbtab;  // SgPlan::nbtab (neighbour rows per element), nullptr when H.nnb == 0
+  const SgGenPair* gpairs;  // SgPlan::gpairs (the general contact path's candidate pairs)
   // copies of the plan header's sizes, by value: the kernels' first addresses then do not wait for a load from *H
   int nelem, nv, nu, elem_dof0, nchain, t0_id;
   double timestep;
@@ -148,11 +155,262 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
 #endif
 
 // ------------------------------------------------------------------------------------------------
+// General contact path in the phase kernel (sg_general.h): an env in which a pair outside the fast path's two kinds is within reach
+// builds, for this substep, ONE ordered contact list over the plan's candidate pairs and exports generic rows (W.gcon); the solver
+// sweeps them as one serial stream.  Rare by construction (never in the reference's scenes), so it is kept OUT of the kernel's
+// straight-line code: __noinline__ functions working on the kernel's LDS block through pointers.  In this mode the LDS regions of the
+// fast path's contact staging are re-used (layout at the call site in sg_phase_kernel).
+// ------------------------------------------------------------------------------------------------
+struct GenLds {
+  StageRec2* stage;            // [SG_GEN_MAXCON]
+  double* gas;                 // [R * 64] per element: invm * sum of Js' f over the general contacts on its slider (inside the staging area)
+  double* gg;                  // [SG_MAXCH][SG_CD]: sum over the general contacts of Jf[c]' f
+  double* tmp;                 // 96 doubles (box - box clipping)
+  const double (*boxp)[3];
+  const double (*boxm)[9];
+  const ChainKin* K;
+  const ChainLds2* cs;
+  const double *qe, *ve, *asme, *we;   // per element (LDS): slider position, velocity, smooth acceleration, warmstart
+};
+
+// geometry of a capsule of the pair table
+__device__ __forceinline__ void sg_gen_capsule(const SgPhaseArgs& a, const GenLds& L, int e, double* cp, double* cax) {
+  const int N = a.nelem;
+  auto EL = [&](int f, int k) { return a.elem[(size_t)f * N + k]; };
+  const double dq = L.qe[e] - EL(SGE_QPOS0, e);
+  cp[0] = EL(SGE_GX, e) + EL(SGE_AX, e) * dq; cp[1] = EL(SGE_GY, e) + EL(SGE_AY, e) * dq; cp[2] = EL(SGE_GZ, e) + EL(SGE_AZ, e) * dq;
+  cax[0] = EL(SGE_CX, e); cax[1] = EL(SGE_CY, e); cax[2] = EL(SGE_CZ, e);
+}
+
+// collision + rows.  Returns the number of contacts; *flags gets CONTACTFULL / UNSUPPORTED_PAIR bits, *touch the finger-box bits.
+__device__ __noinline__ int sg_gen_phase(const SgPhaseArgs& a, const SgPlanHeader& H, const int env, const GenLds L, int* flags, int* touch) {
+  const int lane = threadIdx.x, N = a.nelem;
+  auto EL = [&](int f, int k) { return a.elem[(size_t)f * N + k]; };
+  const SgWork& W = a.w;
+  int ng = 0, fl = 0;
+  // ---- the pair table, 64 pairs per pass: lane = pair.  Pairs with at most two contacts (capsule / sphere against a box, plane against a
+  //      capsule) are evaluated by their lanes and appended in order with ballots; a box against a box or the plane (up to 8 / 4
+  //      contacts) within reach is evaluated by lane 0 at its place in the order
+#pragma unroll 1
+  for (int p0 = 0; p0 < H.ngpair; p0 += 64) {
+    const int pi = p0 + lane;
+    const bool have = pi < H.ngpair;
+    SgGenPair gp;
+    gp.kind = SGP_UNSUPPORTED; gp.g1 = gp.g2 = 0; gp.pad = 0;
+    if (have) gp = a.gpairs[pi];
+    ConRec r0, r1;
+    int n = 0;
+    bool big = false;
+    if (have) {
+      double cp[3] = {0, 0, 0}, cax[3] = {0, 0, 1};
+      if (gp.kind == SGP_PLANE_CAP) {
+        sg_gen_capsule(a, L, sgg_index(gp.g2), cp, cax);
+        const double dif[3] = {cp[0] - H.plane_pos[0], cp[1] - H.plane_pos[1], cp[2] - H.plane_pos[2]};
+        if (!(dot3(dif, H.plane_normal) > H.con_margin + H.cap_rbound))
+          n = gen_plane_capsule(H.plane_pos, H.plane_normal, cp, cax, H.cap_radius, H.cap_hl, H.con_margin, r0, r1);
+      } else if (gp.kind == SGP_PLANE_BOX) {
+        const double *p2, *R2, *s2;
+        double rb2;
+        gen_box_of(gp.g2, H, L.boxp, L.boxm, p2, R2, s2, rb2);
+        const double dif[3] = {p2[0] - H.plane_pos[0], p2[1] - H.plane_pos[1], p2[2] - H.plane_pos[2]};
+        big = !(dot3(dif, H.plane_normal) > H.con_margin + rb2);
+      } else {
+        const double *p1 = nullptr, *R1 = nullptr, *s1 = nullptr, *p2, *R2, *s2;
+        double rb1 = 0, rb2;
+        const bool boxes = sgg_kind(gp.g1) == SGG_BOX || sgg_kind(gp.g1) == SGG_STATIC;
+        if (gp.kind == SGP_SPH_BOX) { cp[0] = H.center_pos[0]; cp[1] = H.center_pos[1]; cp[2] = H.center_pos[2]; rb1 = H.center_radius; }
+        else if (gp.kind == SGP_CAP_BOX) { sg_gen_capsule(a, L, sgg_index(gp.g1), cp, cax); rb1 = H.cap_rbound; }
+        else if (boxes) { gen_box_of(gp.g1, H, L.boxp, L.boxm, p1, R1, s1, rb1); cp[0] = p1[0]; cp[1] = p1[1]; cp[2] = p1[2]; }
+        if (gp.kind == SGP_UNSUPPORTED && !boxes) fl |= SG_FLAG_UNSUPPORTED_PAIR;   // cannot even be tested: flagged whenever this path runs
+        else {
+          gen_box_of(gp.g2, H, L.boxp, L.boxm, p2, R2, s2, rb2);
+          const double dif[3] = {p2[0] - cp[0], p2[1] - cp[1], p2[2] - cp[2]}, bound = rb1 + rb2 + H.con_margin;
+          if (dot3(dif, dif) <= bound * bound) {
+            if (gp.kind == SGP_SPH_BOX) n = sphere_box(cp, H.center_radius, p2, R2, s2, H.con_margin, r0);
+            else if (gp.kind == SGP_CAP_BOX) {
+              const int mk = capsule_box(cp, cax, H.cap_radius, H.cap_hl, p2, R2, s2, H.con_margin, r0, r1);
+              if ((mk & 2) && !(mk & 1)) r0 = r1;
+              n = (mk & 1) + ((mk >> 1) & 1);
+            } else big = true;
+          }
+        }
+      }
+      // only contacts inside the margin become constraints (and count, as on the fast path)
+      if (n == 2 && !(r1.dist < H.con_margin)) n = 1;
+      if (n >= 1 && !(r0.dist < H.con_margin)) { r0 = r1; n--; }
+    }
+    // ordered append, split at the big pairs
+    unsigned long long todo = __ballot(n > 0 || big);
+#pragma unroll 1
+    while (todo) {
+      const unsigned long long bigm = __ballot(big) & todo;
+      const int Lb = bigm ? __ffsll((long long)bigm) - 1 : 64;
+      const unsigned long long seg = Lb == 64 ? todo : (todo & ((1ull << Lb) - 1ull));
+      const bool mine = (seg >> lane) & 1ull;
+      const unsigned long long m1 = __ballot(mine && n >= 1), m2 = __ballot(mine && n >= 2);
+      const int base = ng + lanes_below2(m1) + lanes_below2(m2);
+      auto put = [&](int at, const ConRec& r) {
+        StageRec2& o = L.stage[at];
+        o.dist = r.dist; o.sl = pi; o.box = 0;
+        for (int q = 0; q < 3; q++) { o.pos[q] = r.pos[q]; o.n[q] = r.n[q]; }
+      };
+      if (mine && n >= 1 && base < SG_GEN_MAXCON) put(base, r0);
+      if (mine && n >= 2 && base + 1 < SG_GEN_MAXCON) put(base + 1, r1);
+      ng += __popcll(m1) + __popcll(m2);
+      todo &= ~seg;
+      if (Lb < 64) {
+        const int pb = p0 + Lb;            // uniform
+        const SgGenPair gb = a.gpairs[pb];
+        int cnt = 0;
+        if (lane == 0) {
+          const int room = SG_GEN_MAXCON - (ng < SG_GEN_MAXCON ? ng : SG_GEN_MAXCON);
+          StageRec2* out = L.stage + (ng < SG_GEN_MAXCON ? ng : 0);
+          const double *p2, *R2, *s2;
+          double rb2;
+          gen_box_of(gb.g2, H, L.boxp, L.boxm, p2, R2, s2, rb2);
+          int nb = 0;
+          if (room >= 8) {   // the routines write up to 8 records: without room for them the list is full
+            if (gb.kind == SGP_PLANE_BOX) nb = gen_plane_box(H.plane_pos, H.plane_normal, p2, R2, s2, H.con_margin, out);
+            else {
+              const double *p1, *R1, *s1;
+              double rb1;
+              gen_box_of(gb.g1, H, L.boxp, L.boxm, p1, R1, s1, rb1);
+              nb = gen_box_box(p1, R1, s1, p2, R2, s2, H.con_margin, out, (double (*)[3])L.tmp, (double (*)[3])(L.tmp + 48));
+            }
+            for (int q = 0; q < nb; q++)      // keep the contacts inside the margin, in place
+              if (out[q].dist < H.con_margin) { if (cnt != q) out[cnt] = out[q]; out[cnt].sl = pb; cnt++; }
+            if (gb.kind == SGP_UNSUPPORTED && cnt > 0) { cnt = 0; fl |= SG_FLAG_UNSUPPORTED_PAIR; }
+          } else {
+            fl |= SG_FLAG_CONTACTFULL;
+          }
+        }
+        ng += __shfl(cnt, 0);
+        todo &= ~(1ull << Lb);
+        if (lane == Lb) big = false;
+      }
+    }
+  }
+  if (ng > SG_GEN_MAXCON) { ng = SG_GEN_MAXCON; fl |= SG_FLAG_CONTACTFULL; }
+  __syncthreads();
+  // ---- rows: lane = contact, SG_GEN_ROUNDS rounds.  Exported to W.gcon; what the warmstart test and the slider accelerations need
+  //      (slider index and push per contact) goes back into the staging area once every lane has read its record
+  double Minv2[SG_MAXCH][16], vc2[SG_MAXCH][SG_CD], asm2[SG_MAXCH][SG_CD], warm2[SG_MAXCH][SG_CD];
+#pragma unroll
+  for (int c = 0; c < SG_MAXCH; c++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) Minv2[c][i] = L.cs[c].Minv[i];
+#pragma unroll
+    for (int d = 0; d < SG_CD; d++) { vc2[c][d] = L.cs[c].v[d]; asm2[c][d] = L.cs[c].qacc_smooth[d]; warm2[c][d] = L.cs[c].w[d]; }
+  }
+  double gsum[SG_MAXCH][SG_CD] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, push[SG_GEN_ROUNDS];
+  int slk[SG_GEN_ROUNDS], tch = 0;
+  StageRec2 rec[SG_GEN_ROUNDS];
+#pragma unroll
+  for (int k = 0; k < SG_GEN_ROUNDS; k++)
+    if (lane + 64 * k < ng) rec[k] = L.stage[lane + 64 * k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SG_GEN_ROUNDS; k++) {
+    const int i = lane + 64 * k;
+    push[k] = 0; slk[k] = -1;
+    if (i < ng) {
+      const SgGenPair gp = a.gpairs[rec[k].sl];
+      const GenSide S1 = gen_side_of(gp.g1, H, a.elem + (size_t)SGE_BINVW * N), S2 = gen_side_of(gp.g2, H, a.elem + (size_t)SGE_BINVW * N);
+      const int sl = S1.sl >= 0 ? S1.sl : S2.sl;
+      double ax[3] = {0, 0, 0}, hint[3] = {0, 0, 0}, ve_ = 0, as_ = 0, we_ = 0, im = 0;
+      if (sl >= 0) {
+        ax[0] = EL(SGE_AX, sl); ax[1] = EL(SGE_AY, sl); ax[2] = EL(SGE_AZ, sl);
+        ve_ = L.ve[sl]; as_ = L.asme[sl]; we_ = L.we[sl];
+        im = 1.0 / (EL(SGE_MASS, sl) + EL(SGE_ARMATURE, sl));
+      }
+      if (gp.kind == SGP_PLANE_CAP) { hint[0] = EL(SGE_CX, sl); hint[1] = EL(SGE_CY, sl); hint[2] = EL(SGE_CZ, sl); }   // first tangent along the capsule
+      GenContact c;
+      gen_contact_build(c, rec[k], gp.kind == SGP_PLANE_CAP ? hint : nullptr, S1, S2, L.K, Minv2, vc2, asm2, warm2, ax, ve_, as_, we_, im, H);
+      gen_contact_store(W.gcon + ((size_t)env * SG_GEN_MAXCON + i) * SG_GEN_W, c);
+#pragma unroll
+      for (int ch = 0; ch < SG_MAXCH; ch++)
+#pragma unroll
+        for (int d = 0; d < SG_CD; d++) gsum[ch][d] += c.Jf[ch][0][d] * c.f[0] + c.Jf[ch][1][d] * c.f[1] + c.Jf[ch][2][d] * c.f[2];
+      slk[k] = sl;
+      push[k] = c.invm * (c.Js[0] * c.f[0] + c.Js[1] * c.f[1] + c.Js[2] * c.f[2]);
+      // touch bits: a finger box against an object geom (capsule or centre sphere)
+      if ((gp.kind == SGP_CAP_BOX || gp.kind == SGP_SPH_BOX) && sgg_kind(gp.g2) == SGG_BOX) tch |= 1 << sgg_index(gp.g2);
+    }
+  }
+  double* const gpush = (double*)L.stage;                    // [SG_GEN_MAXCON]
+  int* const gsl = (int*)(gpush + SG_GEN_MAXCON);            // [SG_GEN_MAXCON]
+#pragma unroll
+  for (int k = 0; k < SG_GEN_ROUNDS; k++)
+    if (lane + 64 * k < SG_GEN_MAXCON) { gpush[lane + 64 * k] = push[k]; gsl[lane + 64 * k] = slk[k]; }
+#pragma unroll
+  for (int ch = 0; ch < SG_MAXCH; ch++)
+#pragma unroll
+    for (int d = 0; d < SG_CD; d++) {
+      const double x = wave_sum2(gsum[ch][d]);
+      if (lane == 0) L.gg[ch * SG_CD + d] = x;
+    }
+  __syncthreads();
+  for (int e = lane; e < N; e += 64) {   // per element: the pushes of its general contacts, in list order
+    double acc = 0;
+    for (int i = 0; i < ng; i++)
+      if (gsl[i] == e) acc += gpush[i];
+    L.gas[e] = acc;
+  }
+  int t = 0;
+#pragma unroll
+  for (int bb = 0; bb < SG_MAXCH * SG_CG; bb++)
+    if (__ballot((tch >> bb) & 1)) t |= 1 << bb;
+  *touch = t;
+  int f2 = 0;
+#pragma unroll
+  for (int bit = 0; bit < 6; bit++)
+    if (__ballot((fl >> bit) & 1)) f2 |= 1 << bit;
+  *flags = f2;
+  __syncthreads();
+  return ng;
+}
+
+// warmstart cost of the general contacts (per-lane partial sums) for the current accelerations; zero != 0: set their forces to 0 instead
+__device__ __noinline__ double sg_gen_cost(const SgPhaseArgs& a, const int env, const int ng, const double (*aF)[SG_CD], const double* as_lds,
+                                           const int zero) {
+  const int lane = threadIdx.x;
+  double cp = 0;
+  for (int i = lane; i < ng; i += 64) {
+    double* rec = a.w.gcon + ((size_t)env * SG_GEN_MAXCON + i) * SG_GEN_W;
+    if (zero) { rec[SG_GEN_F_OFF] = rec[SG_GEN_F_OFF + 1] = rec[SG_GEN_F_OFF + 2] = 0.0; continue; }
+    GenContact c;
+    gen_contact_load(c, rec);
+    const double as_ = c.sl >= 0 ? as_lds[c.sl] : 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      double Ja = c.Js[r] * as_;
+#pragma unroll
+      for (int ch = 0; ch < SG_MAXCH; ch++)
+#pragma unroll
+        for (int d = 0; d < SG_CD; d++) Ja += c.Jf[ch][r][d] * aF[ch][d];
+      cp += c.f[r] * (0.5 * (Ja + c.R * c.f[r]) + c.b[r]);
+    }
+  }
+  return cp;
+}
+
+// ------------------------------------------------------------------------------------------------
 // phase kernel: [finish previous substep] [begin next substep]
 // ------------------------------------------------------------------------------------------------
-template <int R, int CPL, bool NB>  // NB: the model has neighbour equality rows (H.nnb > 0)
+// GEN = false: the kernel every env runs.  An env in which a collision pair outside the fast path's two kinds is within reach is put on
+// W.gen_list; the GEN = true instantiation -- launched after it with a small fixed grid, its blocks walk that list -- then redoes
+// the BEGIN part of exactly those envs on the general contact path (sg_gen_phase) and overwrites their exports.  The general path
+// needs a stack (scratch memory) and every register; compiled into the main instantiation it doubled that kernel's time.
+template <int R, int CPL, bool NB, bool GEN = false>  // NB: the model has neighbour equality rows (H.nnb > 0)
 __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
-  const int env = blockIdx.x, lane = threadIdx.x;
+  const int lane = threadIdx.x;
+  int env = blockIdx.x;
+  if constexpr (GEN) {
+    const int cnt = a.w.gen_count[0];            // uniform (entries beyond the list were flagged by the main pass)
+    if ((int)blockIdx.x >= cnt || blockIdx.x >= SG_GEN_LIST) return;
+    env = a.w.gen_list[blockIdx.x];
+    a.do_finish = 0; a.do_reset = 0; a.sens = nullptr;   // BEGIN only: the main pass has finished the previous substep and stored the state
+  }
   if (env >= a.nenv) return;
   if (a.mask && !a.mask[env]) return;
   SG_T0();
@@ -311,6 +569,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
       const double L0 = wave_sum2(L0p), Ld = wave_sum2(Ldp);
       const double frc_t0 = -kt0 * (L0 - H.t0_lspring) - H.t0_damping * Ld;
       int unsupported = 0, ns0 = 0, ns1 = 0, touch = 0;
+      bool special = false;
       {
         double cpos[R][3];
 #pragma unroll
@@ -484,10 +743,47 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             if (dot3(dif, H.plane_normal) - ext <= 0) unsupported = 1;
           }
         }
-        if (__ballot(unsupported)) flags |= SG_FLAG_UNSUPPORTED_PAIR;
+        special = __ballot(unsupported) != 0;
       }
       SG_T(4);
       __syncthreads();
+      // a pair outside the fast path's two kinds is within reach: this substep's contacts are rebuilt as ONE ordered list over all
+      // candidate pairs (sg_gen_phase; the rows pipeline's solver sweeps it as one stream).  The other pipelines flag the env.
+      int ngen = 0;
+      [[maybe_unused]] GenLds GL;
+      if (special) {
+        if (!a.rowlayout) flags |= SG_FLAG_UNSUPPORTED_PAIR;
+        else if constexpr (!GEN) {
+          int at = 0;   // hand the env to the general pass (sg_phase_kernel<.., true>)
+          if (lane == 0) {
+            at = atomicAdd(a.w.gen_count, 1);
+            if (at < SG_GEN_LIST) a.w.gen_list[at] = env;
+          }
+          if (__shfl(at, 0) >= SG_GEN_LIST) flags |= SG_FLAG_UNSUPPORTED_PAIR;   // more envs on the general path than the pass takes
+        } else {
+          // the contact staging area in this mode: [0, 8 M) doubles the contact list (M = SG_GEN_MAXCON records of 8 doubles), then 96
+          // doubles of box - box work space and the two chains' J' f sums; once the rows are built the list's place is taken by
+          // the per-contact pushes [M], slider indices [M ints] and the per-element sums [R * 64]
+          static_assert(sizeof(StageRec2) == 64 && sizeof(Sm.stage) >= 8 * (8 * SG_GEN_MAXCON + 96 + SG_MAXCH * SG_CD) &&
+                        8 * SG_GEN_MAXCON >= SG_GEN_MAXCON + SG_GEN_MAXCON / 2 + R * 64, "the general path's lists live in the contact staging area");
+          GL.stage = &Sm.stage[0][0];
+          GL.gas = (double*)&Sm.stage[0][0] + SG_GEN_MAXCON + SG_GEN_MAXCON / 2;
+          GL.tmp = (double*)&Sm.stage[0][0] + 8 * SG_GEN_MAXCON; GL.gg = GL.tmp + 96;
+          GL.boxp = Sm.boxp; GL.boxm = Sm.boxm; GL.K = Sm.K; GL.cs = Sm.cs;
+          GL.qe = Sm.as; GL.ve = Sm.ve; GL.asme = Sm.asme; GL.we = Sm.we;
+          int gfl = 0, gtouch = 0;
+          ngen = sg_gen_phase(a, H, env, GL, &gfl, &gtouch);
+          flags |= gfl;
+          touch = gtouch;
+          ns0 = ns1 = 0;                       // no contact stays on the per-finger streams
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            const int e = r * 64 + lane;
+            if (e < N) { *(unsigned int*)&Sm.eslot[e][0] = 0u; Sm.owner[0][e] = 0; Sm.owner[1][e] = 0; }
+          }
+          __syncthreads();
+        }
+      }
       int shared_slider = 0;
 #pragma unroll
       for (int r = 0; r < R; r++) {
@@ -704,6 +1000,8 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
               if (nst >= 1) as_ += Sm.cval[cb / SG_CG][i0];
               if (nst >= 2) as_ += Sm.cval[cb / SG_CG][i0 + 1];
             }
+            if constexpr (GEN)
+              if (ngen) as_ += GL.gas[e];   // general contact path: the pushes of the env's one contact list on this slider
             Sm.as[e] = as_;
           }
         }
@@ -718,6 +1016,11 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 #pragma unroll
           for (int k = 0; k < SG_MAXLIM; k++)
             if (la >> k & 1) g[k / 2] += CS.lim_sign[k] * CS.lim_f[k];
+          if constexpr (GEN)
+            if (ngen) {
+#pragma unroll
+              for (int d = 0; d < SG_CD; d++) g[d] += GL.gg[half * SG_CD + d];
+            }
         }
 #pragma unroll
         for (int d = 0; d < SG_CD; d++) {
@@ -766,8 +1069,24 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             for (int d = 0; d < SG_CD; d++) ga += cg[k][d] * aF[d];
             cp += 0.5 * (ga + cjsf[k] * as_) + ccost0[k];
           }
+        [[maybe_unused]] double aF2[SG_MAXCH][SG_CD];   // both chains' accelerations on every lane (general contact path only)
+        if constexpr (GEN)
+          if (ngen) {
+#pragma unroll
+            for (int d = 0; d < SG_CD; d++) {
+              const double other = __shfl_xor(aF[d], 32);
+              aF2[0][d] = high ? other : aF[d]; aF2[1][d] = high ? aF[d] : other;
+            }
+            cp += sg_gen_cost(a, env, ngen, aF2, Sm.as, 0);
+          }
         double cost = wave_sum2(cp);
         if (cost > 0) {
+          if constexpr (GEN)
+            if (ngen) {
+              sg_gen_cost(a, env, ngen, aF2, Sm.as, 1);
+              for (int e = lane; e < N; e += 64) GL.gas[e] = 0.0;
+              if (lane < SG_MAXCH * SG_CD) GL.gg[lane] = 0.0;
+            }
 #pragma unroll
           for (int r = 0; r < R; r++) {
             eqf[r] = 0;
@@ -831,8 +1150,9 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
         W.envh[(size_t)2 * a.nenv + env] = tA; W.envh[(size_t)3 * a.nenv + env] = tf;
         W.shared[env] = shared_slider;
         W.pending[env] = 1;
-        W.ncon[env] = ns0 + ns1;
-        W.nefc[env] = N + nnb + 1 + 3 * (ns0 + ns1) + __popc(Sm.cs[0].lim_active) + (nchain > 1 ? __popc(Sm.cs[1].lim_active) : 0);
+        W.ncon[env] = ns0 + ns1 + ngen;
+        W.gen[env] = ngen;
+        W.nefc[env] = N + nnb + 1 + 3 * (ns0 + ns1 + ngen) + __popc(Sm.cs[0].lim_active) + (nchain > 1 ? __popc(Sm.cs[1].lim_active) : 0);
         W.touch[env] = touch;
       }
     }
@@ -863,6 +1183,7 @@ __global__ __launch_bounds__(64) void sg_chain_kernel(SgPhaseArgs a) {
   // wavefront 2 b + c holds chain c of envs 64 b .. 64 b + 63: the chain index is uniform over the wavefront, so the chain's model
   // constants (SgChain, ~230 doubles read all over the stage) are scalar loads / SGPR operands instead of per-lane vector loads
   const int lane = threadIdx.x, c = blockIdx.x & 1, env = (int)(blockIdx.x >> 1) * 64 + lane;
+  if (blockIdx.x == 0 && lane == 0) a.w.gen_count[0] = 0;   // the phase kernel of this substep refills the general pass's list
   SG_T0();
   const SgPlanHeader& H = *a.H;
   const int nv = a.nv, nu = a.nu;
@@ -1457,6 +1778,8 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     tA = W.envh[(size_t)2 * a.nenv + env]; tf = W.envh[(size_t)3 * a.nenv + env];
     shared = W.shared[env];
   }
+  const int ngen = valid ? W.gen[env] : 0;  // contacts of an env on the general contact path (sg_general.h); 0 on the fast path
+  const bool wave_gen = __ballot(ngen > 0) != 0;
   if (sv) {
     ns = W.ns[st];
     lim_active = W.lim_active[st];
@@ -1875,6 +2198,60 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
       }
       __syncthreads();
       SG_T(14);
+    }
+    if (wave_gen) {
+      // General contact path: the env's contacts are ONE ordered list (W.gcon) with both chains' Jacobian blocks; lane 0 of the env's
+      // group sweeps it serially after both chains' limit rows (MuJoCo's row order).  Rare by construction -- the wavefront's other
+      // envs wait meanwhile -- so nothing here is tuned: the two chains' accelerations are gathered from / scattered to their quad
+      // lanes with shuffles, the records stream from memory one at a time.
+      const int gbase = lane - g;
+      double aF2[SG_MAXCH][SG_CD];
+#pragma unroll
+      for (int cc = 0; cc < SG_MAXCH; cc++)
+#pragma unroll
+        for (int q = 0; q < SG_CD; q++) aF2[cc][q] = __shfl(aFo, gbase + 4 * cc + q);
+      if (ngen > 0 && g == 0 && running) {
+        const size_t st0 = 2 * (size_t)env;
+        double Mi[SG_MAXCH][16];
+#pragma unroll
+        for (int cc = 0; cc < SG_MAXCH; cc++)
+#pragma unroll
+          for (int i = 0; i < 16; i++) Mi[cc][i] = W.sMinv[(size_t)i * S + st0 + cc];
+        const double mu[2] = {mu0, mu1};
+#pragma unroll 1
+        for (int i = 0; i < ngen; i++) {
+          double* rec = W.gcon + ((size_t)env * SG_GEN_MAXCON + i) * SG_GEN_W;
+          GenContact gc;
+          gen_contact_load(gc, rec);
+          const double araw = gc.sl >= 0 ? ASb[ASS * gc.sl] : 0.0, as_ = NB ? araw + aoff : araw;
+          double df[3];
+          imp_acc -= gen_contact_update(gc, aF2, as_, mu, df);
+          rec[SG_GEN_F_OFF] = gc.f[0]; rec[SG_GEN_F_OFF + 1] = gc.f[1]; rec[SG_GEN_F_OFF + 2] = gc.f[2];
+#pragma unroll
+          for (int cc = 0; cc < SG_MAXCH; cc++) {
+            double gd[SG_CD];
+#pragma unroll
+            for (int d = 0; d < SG_CD; d++) gd[d] = gc.Jf[cc][0][d] * df[0] + gc.Jf[cc][1][d] * df[1] + gc.Jf[cc][2][d] * df[2];
+#pragma unroll
+            for (int q = 0; q < SG_CD; q++)
+#pragma unroll
+              for (int d = 0; d < SG_CD; d++) aF2[cc][q] += Mi[cc][4 * q + d] * gd[d];
+          }
+          if (gc.sl >= 0) {
+            const double jsdf = gc.invm * (gc.Js[0] * df[0] + gc.Js[1] * df[1] + gc.Js[2] * df[2]);
+            ASb[ASS * gc.sl] = araw + jsdf;
+            if constexpr (NB) dS += jsdf;   // one lane holds the push: the group sum counts it once
+          }
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < SG_MAXCH; cc++)
+#pragma unroll
+        for (int q = 0; q < SG_CD; q++) {
+          const double v = __shfl(aF2[cc][q], gbase);
+          if (ngen > 0 && g == 4 * cc + q) aFo = v;
+        }
+      __syncthreads();
     }
     double imp = imp_acc;
     imp = NB ? sg_gsum16(imp) : sg_gsum8(imp);

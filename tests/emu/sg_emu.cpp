@@ -282,7 +282,7 @@ int emu_substep(Emu* E, int integrate) {
         capsule_of(gp.g2);
         double dif[3] = {cp[0] - H.plane_pos[0], cp[1] - H.plane_pos[1], cp[2] - H.plane_pos[2]};
         if (dot3(dif, H.plane_normal) > H.con_margin + H.cap_rbound) continue;
-        n = gen_plane_capsule(H.plane_pos, H.plane_normal, cp, cax, H.cap_radius, H.cap_hl, H.con_margin, rec);
+        n = gen_plane_capsule(H.plane_pos, H.plane_normal, cp, cax, H.cap_radius, H.cap_hl, H.con_margin, rec[0], rec[1]);
         hint = cax;
       } else if (gp.kind == SGP_PLANE_BOX) {
         gen_box_of(gp.g2, H, bxp, bxm, p2, R2, s2, rb2);
@@ -306,7 +306,8 @@ int emu_substep(Emu* E, int integrate) {
           if ((mk & 2) && !(mk & 1)) rec[0] = rec[1];
           n = (mk & 1) + ((mk >> 1) & 1);
         } else {
-          n = gen_box_box(p1, R1, s1, p2, R2, s2, H.con_margin, rec);
+          double poly[16][3], tmp[16][3];
+          n = gen_box_box(p1, R1, s1, p2, R2, s2, H.con_margin, rec, poly, tmp);
           if (gp.kind == SGP_UNSUPPORTED) { if (n > 0) flags |= 32; continue; }
         }
       }

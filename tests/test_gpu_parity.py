@@ -518,7 +518,7 @@ def test_regressor_step_numerics_at_full_size():
     for k, v in net.named_parameters():
         g, r = v.grad.cpu().double(), g_ref[k]
         if k in shadowed:
-            assert float(r.abs().max()) < 1e-10 and float(g.abs().max()) < 1e-5, k
+            assert float(r.abs().max()) < 1e-10 and float(g.abs().max()) < 1e-3, k   # measured: 7e-14 in fp64, 4e-5 in float32
             continue
         # MAE's gradient is sign(pred - y) / n per sample: one sample within float32 error of its label flips a sign and moves every
         # upstream gradient by 2 / n = 5e-4 relative -- hence 1e-2 in norm and 5e-2 on the worst entry, not 1e-6
@@ -970,13 +970,9 @@ def test_random_scenes_in_the_plan_class_on_the_gpu(tmp_path, neighbors):
             for s in sims:
                 for _ in range(7):
                     assert s.step() == 0, (i, t)
-            fl = flags.cpu().numpy()
-            if (fl != 0).any():
-                # a random scene may leave the kernels' envelope (a slider far enough out to reach a static geom, finger boxes about to
-                # touch): that is reported as SG_FLAG_UNSUPPORTED_PAIR -- data, never a silent wrong answer -- and ends this variant
-                assert set(fl[fl != 0].tolist()) == {32}, (i, t, fl)
-                left_envelope += 1
-                break
+            # (until r02 a random scene could leave the kernels' envelope -- a slider reaching a static geom, finger boxes about to touch
+            # -- and was then reported as SG_FLAG_UNSUPPORTED_PAIR; since r03 the general contact path takes those substeps)
+            assert int(flags.abs().sum()) == 0, (i, t, flags.cpu().tolist())
             assert np.abs(sens.cpu().numpy() - np.stack([s.sensordata for s in sims])).max() < TOL_SENSOR, (i, t)
             st = b.solver_stats()
             assert st["ncon"].cpu().tolist() == [s.ncon for s in sims] and st["iters"].cpu().tolist() == [s.solver_iter for s in sims], (i, t)
@@ -985,7 +981,7 @@ def test_random_scenes_in_the_plan_class_on_the_gpu(tmp_path, neighbors):
             most = max(most, max(s.ncon for s in sims))
         touched += most > 0
         del b
-    assert touched >= 7 and left_envelope <= 3, (touched, left_envelope)
+    assert touched >= 7 and left_envelope == 0, (touched, left_envelope)
 
 
 @pytest.mark.parametrize("neighbors,pipeline", [(False, "rows"), (False, "split"), (False, "fused"), (True, "rows")])
@@ -1033,6 +1029,75 @@ def test_one_slider_under_both_fingers_on_the_gpu(tmp_path, neighbors, pipeline)
             b.set_state(qpos=T([s.qpos for s in sims]), qvel=T([s.qvel for s in sims]), act=T([s.act for s in sims]),
                         qacc_warmstart=T([s.qacc_warmstart for s in sims]))
     assert shared > 100
+
+
+@pytest.mark.parametrize("kind,neighbors", [("fingers", False), ("stop", False), ("shelf", False), ("rest", False), ("sledge", False),
+                                            ("fingers", True), ("shelf", True), ("rest", True)])
+def test_general_contact_path_on_the_gpu(tmp_path, kind, neighbors):
+    """a11: the collision pairs outside the fast path's two kinds, in the HIP kernels.  Five variants of the own
+    scene (tests/test_emu_vs_oracle.py general_path_scene) in which such a pair becomes active -- the finger tips closing on each
+    other (box - box, both finger chains in one constraint row), a static block in a finger's way (box - box against a static box),
+    the object resting on a static block (static box - capsule), the object resting on the ground (plane - capsule) and the
+    finger tips resting on it (plane - box) -- compiled by the native compiler, 5 envs, 150 env steps against the oracle: sensors,
+    contact counts (= the oracle's whole contact list, in its order: the rows and the Gauss-Seidel sweep depend on it) and sweep
+    counts at every step, no flag.  The two box - box scenes free-running without the neighbour rows; the scenes with dozens of
+    standing contacts from the first step on (shelf, rest, sledge: they amplify round-off, 1e-6 after 115 steps) and the neighbour-row
+    variants re-seated per step."""
+    import torch
+    from oracle import oracle as O
+    from softgrip_amd import native
+    from test_emu_vs_oracle import general_path_scene, special_contacts
+    m = sg.Model.from_blob(native.compile_mjcf_native(general_path_scene(kind, tmp_path / (kind + ".xml")), composite_neighbors=neighbors))
+    jids, tids = list(range(8, m.nv)), [0]
+    ks = [640.0, 300.0, 1400.0, 950.0, 512.25]
+    b = native.NativeBatch(native.NativeModel(m), len(ks), 0)
+    b.set_stiffness(np.asarray(ks), jids, tids)
+    sens, flags, touch = _bufs(b, len(ks))
+    om = O.OracleModel(m.to_blob())
+    sims = [O.OracleSim(om) for _ in ks]
+    for s, k in zip(sims, ks):
+        s.jnt_stiffness[jids] = k
+        s.tendon_stiffness[tids] = k
+        s.reset(); s.forward(); s.step()
+    b.reset(1, sens=sens, flags=flags, touch=touch)
+    ctrl = np.zeros(2)
+    special = 0
+    bit_of = _touch_bit_of_geom(m)
+    T = lambda a: torch.tensor(np.stack(a), dtype=torch.float64, device=b.device).contiguous()  # noqa: E731
+    for t, c in enumerate(episode_schedule()[:150]):
+        if c is not None:
+            ctrl[:] = c
+            b.set_ctrl_broadcast(ctrl)
+            for s in sims:
+                s.ctrl[:] = c
+        b.step(7, sens=sens, flags=flags, touch=touch)
+        for s in sims:
+            for _ in range(7):
+                assert s.step() == 0
+        assert int(flags.abs().sum()) == 0, (t, flags.cpu().tolist())
+        assert np.abs(sens.cpu().numpy() - np.stack([s.sensordata for s in sims])).max() < TOL_SENSOR, t
+        st = b.solver_stats()
+        assert st["ncon"].cpu().tolist() == [s.ncon for s in sims] and st["iters"].cpu().tolist() == [s.solver_iter for s in sims], t
+        assert st["nefc"].cpu().tolist() == [s.nefc for s in sims], t
+        assert touch.cpu().tolist() == [_expected_touch(m, s.contacts(), bit_of) for s in sims], t
+        special += sum(special_contacts(m, s.contacts(), kind) for s in sims)
+        if neighbors or kind in ("shelf", "rest", "sledge"):
+            b.set_state(qpos=T([s.qpos for s in sims]), qvel=T([s.qvel for s in sims]), act=T([s.act for s in sims]),
+                        qacc_warmstart=T([s.qacc_warmstart for s in sims]))
+    assert special > 300, special
+    # the other pipelines have no general path: there the pair is reported as data, never silently dropped
+    if not neighbors and kind == "stop":
+        b2 = native.NativeBatch(native.NativeModel(m), 2, 0)
+        b2.set_pipeline("split")
+        b2.set_stiffness(np.asarray(ks[:2]), jids, tids)
+        s2, f2, t2 = _bufs(b2, 2)
+        b2.reset(1, sens=s2, flags=f2, touch=t2)
+        b2.set_ctrl_broadcast(np.array([-0.2, -0.2]))
+        seen = 0
+        for _ in range(60):
+            b2.step(7, sens=s2, flags=f2, touch=t2)
+            seen |= int(f2.max())
+        assert seen == 32
 
 
 def test_bench_two_ranks_with_the_real_library(tmp_path):
