@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 device_sync = None   # torch.cuda.synchronize (set in main)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-PROFILE_TAG = "r02"    # profiles/<tag>_<scene>_{hbm_traffic,sq_totals}.json: the committed rocprofv3 PMC passes of this workload
+PROFILE_TAG = "r03"    # profiles/<tag>_<scene>_{hbm_traffic,sq_totals}.json: the committed rocprofv3 PMC passes of this workload
 
 
 def algorithmic_bytes_per_env_step(nq, nv, na, nu, nsens):
@@ -193,9 +193,12 @@ class Runner:
         b.profile_enable(False)
         return dt, kernel_ms, launches, desc, steps
 
-    def measure(self, steps, barrier, after_episode=None):
+    def measure(self, steps, barrier, after_episode=None, event_pass=True):
         """headline pass (uninstrumented), then the same timed region once more with the HIP events on for the kernel durations"""
         dt, _, _, desc, nsteps = self.timed(steps, barrier, after_episode, profile=False)
+        if not event_pass:
+            self.solver_ms, self.solver_launches = 0.0, 0
+            return dt, 0.0, 0, desc, nsteps, dt
         dtp, kernel_ms, launches, _, _ = self.timed(steps, barrier, None, profile=True)
         return dt, kernel_ms, launches, desc, nsteps, dtp
 
@@ -212,6 +215,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fix-variant", action="store_true", help="skip the labelled secondary measurement on the fix-rows-only model")
     ap.add_argument("--with-regressor", action="store_true", help="BASELINE configs[4]: ConvNet forward + one Adam step on every finished [n,200,12] block, inside the timed region (needs --steps a multiple of 200)")
+    ap.add_argument("--no-event-pass", action="store_true",
+                    help="profiler runs (scripts/profile_round.sh): skip the second, HIP-event-instrumented pass over the timed region, so that the "
+                         "trace holds exactly one reset + the timed steps; the line then carries no kernel durations")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL over xGMI) or gloo (for testing the multi-process path)")
     ap.add_argument("--force-device", type=int, default=-1, help="testing only: put every rank on this GPU")
     ap.add_argument("--fake-native-for-tests", action="store_true",
@@ -293,7 +299,7 @@ def main():
         del wnet, wx
     barrier()
     R.flags_or.zero_()
-    dt, kernel_ms, launches, desc, nsteps, dt_prof = R.measure(args.steps, barrier, after_episode)
+    dt, kernel_ms, launches, desc, nsteps, dt_prof = R.measure(args.steps, barrier, after_episode, not args.no_event_pass)
     if dist is not None:  # the only collectives of the run: barriers and this MAX (timing, not data path)
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         per_rank = [torch.zeros_like(tt) for _ in range(world)]
@@ -375,7 +381,7 @@ def main():
             for t in range(args.warmup):
                 R2.step(t)
             barrier()
-            dt2, km2, _, desc2, ns2, _ = R2.measure(args.steps, barrier)
+            dt2, km2, _, desc2, ns2, _ = R2.measure(args.steps, barrier, None, not args.no_event_pass)
             res["config"]["fix_only_variant"] = {"value": n * ns2 / dt2, "unit": "env-steps/s", "avg_kernel_ms": km2, "equality_rows": R2.model.neq,
                                                  "note": "same workload on models/%s_fix.sgmodel (composite without its neighbour equalities) -- NOT the headline" % args.scene}
             del R2

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Profile passes of one round (run on the GPU box through gpurun): kernel trace + stats, HBM traffic (FETCH_SIZE / WRITE_SIZE in
-# separate passes), SQ instruction totals -- all over `python3 bench.py --steps 200 --warmup 0 --no-cpu-baseline --no-fix-variant`.
+# separate passes), SQ instruction totals -- all over `python3 bench.py --steps 200 --warmup 0 --no-cpu-baseline --no-fix-variant
+# --no-event-pass` (one reset + 200 sg_step calls: the line bench.py prints by default also runs the region a second time with HIP events).
 # usage: scripts/profile_round.sh <tag> <scene>      -> gpurun_out/<tag>_<scene>_*  (copy the summaries into profiles/)
 set -e
 TAG=$1; SCENE=$2
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
-CMD="python3 $ROOT/bench.py --steps 200 --warmup 0 --no-cpu-baseline --no-fix-variant --scene $SCENE"
+CMD="python3 $ROOT/bench.py --steps 200 --warmup 0 --no-cpu-baseline --no-fix-variant --no-event-pass --scene $SCENE"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_* 
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $CMD > $OUT/${TAG}_${SCENE}_bench_line.json 2>/dev/null

@@ -52,6 +52,7 @@ struct sg_batch {
   SgGenPair* dgpairs;  // SgPlan::gpairs on the device (the general contact path's candidate pairs)
   int* dnbtab;       // SgPlan::nbtab on the device (neighbour-row models)
   SgEqSlot* dsched;  // SgPlan::sched + one spare round of idle slots
+  uint2* dtab;       // the same schedule as the solver's LDS table words
   int *kmask_jnt, *kmask_ten, *flags, *touch, *ncon, *nefc, *iters;
   int epw_override;  // sg_set_solver_envs_per_wavefront: 0 = automatic
   int pipeline;  // 0 fused (one kernel per call), 1 split (chain / phase / pgs kernel chain), 2 split with the row-parallel PGS kernel
@@ -130,7 +131,7 @@ int sg_model_nelem(const sg_model* m) { return m->plan.h.nelem; }
 void sg_batch_destroy(sg_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  void* ptrs[] = {b->dgpairs, b->dnbtab, b->dsched, b->dH, b->delem, b->qpos, b->qvel, b->warm, b->act, b->ctrl, b->kenv, b->ctrl_row, b->kmask_jnt, b->kmask_ten,
+  void* ptrs[] = {b->dtab, b->dgpairs, b->dnbtab, b->dsched, b->dH, b->delem, b->qpos, b->qvel, b->warm, b->act, b->ctrl, b->kenv, b->ctrl_row, b->kmask_jnt, b->kmask_ten,
                   b->flags, b->touch, b->ncon, b->nefc, b->iters};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -150,7 +151,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   HIPCHK(hipSetDevice(device));
   sg_batch* b = new sg_batch();
   b->m = m; b->n = n_envs; b->device = device; b->lds_attr_set = false; b->prof = false; b->prof_ms = 0; b->prof_n = 0; b->prof_pgs_ms = 0; b->prof_pgs_n = 0;
-  b->dnbtab = nullptr; b->dsched = nullptr; b->dgpairs = nullptr; b->epw_override = 0;
+  b->dnbtab = nullptr; b->dsched = nullptr; b->dgpairs = nullptr; b->dtab = nullptr; b->epw_override = 0;
   b->dH = nullptr; b->delem = b->qpos = b->qvel = b->warm = b->act = b->ctrl = b->kenv = b->ctrl_row = nullptr;
   b->kmask_jnt = b->kmask_ten = b->flags = b->touch = b->ncon = b->nefc = b->iters = nullptr;
   const SgPlanHeader& H = m->plan.h;
@@ -210,6 +211,17 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
     ALLOC(b->dsched, sizeof(SgEqSlot) * sch.size());
     HIPCHK(hipMemcpy(b->dnbtab, m->plan.nbtab.data(), sizeof(int) * m->plan.nbtab.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->dsched, sch.data(), sizeof(SgEqSlot) * sch.size(), hipMemcpyHostToDevice));
+    // the solver's table words (sg_pgs_rows_kernel): lane 2 b + h of a 16-lane group holds, for the block e in slot b of the round,
+    // (x | y << 16, record offset) in LDS bytes, (x, y) = (e, p0) for h = 0 and (p1, p2) for h = 1
+    std::vector<uint2> tab(2 * sch.size());
+    for (size_t i = 0; i < tab.size(); i++) {
+      const SgEqSlot& sl = sch[i >> 1];
+      const int h = (int)(i & 1);
+      const unsigned x = h ? sl.p[1] : sl.e, y = h ? sl.p[2] : sl.p[0];
+      tab[i] = make_uint2((8u * x) | ((8u * y) << 16), 64u * (unsigned)sl.e + 32u * (unsigned)h);
+    }
+    ALLOC(b->dtab, sizeof(uint2) * tab.size());
+    HIPCHK(hipMemcpy(b->dtab, tab.data(), sizeof(uint2) * tab.size(), hipMemcpyHostToDevice));
   }
   ALLOC(b->dgpairs, sizeof(SgGenPair) * (m->plan.gpairs.size() + 1));
   HIPCHK(hipMemcpy(b->dgpairs, m->plan.gpairs.data(), sizeof(SgGenPair) * m->plan.gpairs.size(), hipMemcpyHostToDevice));
@@ -323,7 +335,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   pa.gpairs = b->dgpairs;
   pa.nelem = H.nelem; pa.nv = H.nv; pa.nu = H.nu; pa.elem_dof0 = H.elem_dof0; pa.nchain = H.nchain; pa.t0_id = H.t0_id; pa.timestep = H.timestep;
   SgPgsArgs ga;
-  ga.sched = b->dsched; ga.nbtab = b->dnbtab;
+  ga.sched = b->dsched; ga.nbtab = b->dnbtab; ga.tab = b->dtab;
   ga.H = b->dH; ga.elem = b->delem; ga.w = b->w; ga.nenv = b->n;
   const size_t lds = sizeof(double) * ((size_t)(5 * 8 + 2) * H.nelem + 16 * 4 * SG_MAXLIM + 72);
   // rows kernel: joint-fix rows per lane (template parameter, the smallest instantiated value >= ceil(nelem / 8)); its LDS

@@ -1369,6 +1369,7 @@ __global__ __launch_bounds__(64) void sg_chain_kernel(SgPhaseArgs a) {
 // PGS kernel: 8 lanes per env, 8 envs per wavefront
 // ------------------------------------------------------------------------------------------------
 struct SgPgsArgs {
+  const uint2* tab;       // the schedule as the solver's LDS table words (lane 2 b + h of a 16-lane group, block slot b; sg_api.hip)
   const SgEqSlot* sched;  // SgPlan::sched (equality-row schedule of neighbour-row models), nullptr when H.nnb == 0
   const int* nbtab;       // SgPlan::nbtab
   const SgPlanHeader* H;
@@ -1692,7 +1693,9 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   // contiguous bytes and the loads of an env are independent of each other (until r02 every lane strode through its own env 8
   // rows apart, 41 trips with two dependent loads each: ~100 us per launch for the neighbour-row models, more than the 30 sweeps
   // of a contact-free substep).
-#pragma unroll 1
+  // (unrolled over the envs: their loads are independent and go out together -- the prologue is a chain of memory round trips, ~1.5 us
+  // each, and used to take ~35 us of a 160 us contact-free launch)
+#pragma unroll
   for (int e2 = 0; e2 < EPW; e2++) {
     const int env2 = blockIdx.x * EPW + e2;
     const bool v2 = ((pendmask >> e2) & 1u) != 0;  // uniform
@@ -1733,11 +1736,15 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     // equality records of all the wavefront's envs, lane = row: the loads of a row (one table word, three values per env) are
     // independent of each other and of the other rows' -- they are issued together, not one memory round trip after the other
     const double im0s = 1.0 / (a.elem[(size_t)SGE_MASS * N] + a.elem[(size_t)SGE_ARMATURE * N]);
-#pragma unroll 2
-    for (int u = lane; u < 4 * (N + 1); u += 64) {  // row u = 4 e + d: d = 0 the fix row of e, d = 1 .. 3 its neighbour row in workspace slot (d - 1) N + e
+    constexpr int REC_TRIPS = (4 * (NR + 1) + 63) / 64;   // NR >= N
+#pragma unroll 4
+    for (int t = 0; t < REC_TRIPS; t++) {  // row u = 4 e + d: d = 0 the fix row of e, d = 1 .. 3 its neighbour row in workspace slot (d - 1) N + e
+      const int u = lane + 64 * t;
+      if (u >= 4 * (N + 1)) continue;
       const int e = u >> 2, d = u & 3, ec = e < N ? e : 0;
       const bool fix = d == 0;
-      const bool have = e < N && (fix || a.nbtab[(fix ? 0 : d - 1) * N + ec] >= 0);
+      const int tabw = a.nbtab[(fix ? 0 : d - 1) * N + ec];   // loaded beside the rows, not in front of them
+      const bool have = e < N && (fix || tabw >= 0);
       double bb[EPW], Rr[EPW], ff[EPW];
 #pragma unroll
       for (int e2 = 0; e2 < EPW; e2++) {
@@ -1757,12 +1764,9 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     }
   }
   if constexpr (NB) {  // the schedule (plus four idle rounds for the look-ahead) as LDS byte offsets: lane 2 b + h of a group, block slot b
-    for (int i = lane; i < 16 * (H.eq_rounds + 4); i += 64) {
-      const SgEqSlot sl = a.sched[i >> 1];  // slot (round, pair)
-      const int h = i & 1;
-      const unsigned x = h ? sl.p[1] : sl.e, y = h ? sl.p[2] : sl.p[0];
-      ((uint2*)TAB)[i] = make_uint2((8u * x) | ((8u * y) << 16), 64u * (unsigned)sl.e + 32u * (unsigned)h);
-    }
+    const int ntab = 16 * (H.eq_rounds + 4);   // a.tab: the same words, laid out by the host once per batch (sg_api.hip)
+#pragma unroll 4
+    for (int i = lane; i < ntab; i += 64) ((uint2*)TAB)[i] = a.tab[i];
   }
   const bool sv = valid && g < 8;  // lanes of the env's two finger quads
   const size_t st = 2 * (size_t)(sv ? env : 0) + (sv ? c : 0);

@@ -547,7 +547,10 @@ def test_regressor_step_numerics_at_full_size():
     with torch.no_grad():
         e_gpu = convnet.normalize_predictions(net((x - mean) / std)).cpu().double().numpy()
         e_ref = convnet.normalize_predictions(ref((xc - mc) / sc)).numpy()
-    assert np.abs(e_gpu - e_ref).max() < 2e-4 * 1400
+    # looser than before the step: Adam's first step moves EVERY weight by ~lr, also the six bias vectors whose gradient is zero in
+    # exact arithmetic (float32 noise decides their sign), and in inference mode the moving statistics no longer cancel a bias shift:
+    # measured 0.94 on predictions of ~700
+    assert np.abs(e_gpu - e_ref).max() < 3e-3 * 1400
     print("regressor step on the GPU vs fp64: worst relative gradient error (L2, per tensor) %.2e" % worst)
 
 
