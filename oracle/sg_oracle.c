@@ -37,6 +37,17 @@
 #define MAXCHAIN 16
 #define MAXCON 512
 
+/* Sensitivity switches (scripts/d5_sensitivity.py; 0 in every test and everywhere else): each bit flips ONE of the places where this
+ * restatement had to resolve something the documentation leaves open, to see whether a different
+ * resolution changes a qualitative result (does the explicit volume-tendon damper survive the ball scene's start?).
+ *   1  the warmstart saved for the next step is the implicit-damping acceleration the Euler step integrates, not the solver's qacc
+ *   2  direct-format solref (-stiffness, -damping) taken literally: K = -solref[0], B = -solref[1], no division by dmax^2 / dmax
+ *   4  equality rows use the impedance at zero violation (d0) instead of d(|pos|)
+ *   8  the tendon equality's diagApprox is the sum of its dofs' invweights instead of tendon_invweight0
+ *  16  no warmstart at all (every solve starts from f = 0) */
+static int g_variant = 0;
+void sgo_set_variant(int bits) { g_variant = bits; }
+
 enum { EFC_EQUALITY = 0, EFC_LIMIT = 3, EFC_CONTACT_FRICTIONLESS = 5, EFC_CONTACT_ELLIPTIC = 7 };
 
 typedef struct {
@@ -942,8 +953,13 @@ static void make_constraint(const sgo_model* m, sgo_data* d) {
       solref = m->eq_solref + 2 * id; solimp = m->eq_solimp + 5 * id;
       if (m->eq_type[id] == SG_EQ_JOINT) /* joint equality: the invweights of its one or two dofs */
         dA = m->dof_invweight0[m->eq_obj1id[id]] + (m->eq_obj2id[id] >= 0 ? m->dof_invweight0[m->eq_obj2id[id]] : 0.0);
-      else
+      else {
         dA = m->tendon_invweight0[m->eq_obj1id[id]];
+        if (g_variant & 8) {
+          dA = 0;
+          for (int k = d->J_rowadr[i]; k < d->J_rowadr[i + 1]; k++) dA += d->J_val[k] * d->J_val[k] * m->dof_invweight0[d->J_col[k]];
+        }
+      }
     } else if (d->efc_type[i] == EFC_LIMIT) {
       solref = m->jnt_solref + 2 * id; solimp = m->jnt_solimp + 5 * id; dA = m->dof_invweight0[id];
     } else {
@@ -953,7 +969,7 @@ static void make_constraint(const sgo_model* m, sgo_data* d) {
     }
     d->efc_diagApprox[i] = dA;
     double imp, dmax = fmin(MAXIMP, fmax(MINIMP, solimp[1])), K, B;
-    impedance(solimp, d->efc_pos[i], d->efc_margin[i], &imp);
+    impedance(solimp, ((g_variant & 4) && d->efc_type[i] == EFC_EQUALITY) ? 0.0 : d->efc_pos[i], d->efc_margin[i], &imp);
     d->efc_R[i] = fmax(MINVAL, (1 - imp) / imp * dA);
     if (solref[0] > 0 && solref[1] > 0) { /* (timeconst, dampratio); timeconst >= 2h (refsafe) */
       double tc = fmax(solref[0], 2 * m->timestep);
@@ -962,6 +978,7 @@ static void make_constraint(const sgo_model* m, sgo_data* d) {
     } else { /* direct (-stiffness, -damping) */
       K = -solref[0] / fmax(MINVAL, dmax * dmax);
       B = -solref[1] / fmax(MINVAL, dmax);
+      if (g_variant & 2) { K = -solref[0]; B = -solref[1]; }
     }
     d->efc_KBIP[4 * i] = K; d->efc_KBIP[4 * i + 1] = B; d->efc_KBIP[4 * i + 2] = imp; d->efc_KBIP[4 * i + 3] = 0;
   }
@@ -1097,6 +1114,7 @@ static void rne_bias(const sgo_model* m, sgo_data* d) {
     for (int k = 0; k < cj.n; k++) d->qfrc_bias[cj.dof[k]] += dot3(cj.jp[k], f) + dot3(cj.jr[k], n);
   }
 }
+
 
 /* ------------------------------------------------------------------ PGS (mj_solPGS) */
 long long sgo_dbg_counters[8];
@@ -1293,6 +1311,7 @@ int sgo_forward(const sgo_model* m, sgo_data* d) {
     /* warmstart: forces implied by last step's qacc, kept only if they beat f = 0 */
     for (int i = 0; i < ne; i++) d->efc_jar[i] = jdot(d, i, d->qacc_warmstart) - d->efc_aref[i];
     constraint_update(d, d->efc_jar, d->efc_force);
+    if (g_variant & 16) memset(d->efc_force, 0, sizeof(double) * ne);
     double cost = 0;
     for (int i = 0; i < ne; i++) {
       double s = 0;
@@ -1367,6 +1386,7 @@ int sgo_step(const sgo_model* m, sgo_data* d) {
       }
     }
   }
+  if (g_variant & 1) memcpy(d->qacc_warmstart, qacc, sizeof(double) * nv);
   for (int u = 0; u < m->nu; u++) d->act[u] += h * d->act_dot[u];
   for (int i = 0; i < nv; i++) d->qvel[i] += h * qacc[i];
   for (int i = 0; i < nv; i++) d->qpos[i] += h * d->qvel[i];

@@ -67,6 +67,9 @@ int sgo_solver_iter(const sgo_data*);
 /* contact i: geom ids, dist, pos[3], frame[9] (normal first) */
 void sgo_contact(const sgo_data*, int i, int* geom1, int* geom2, double* dist, double* pos3, double* frame9);
 
+/* sensitivity switches for scripts/d5_sensitivity.py (bit mask, 0 = the restatement as tested); see sg_oracle.c */
+void sgo_set_variant(int bits);
+
 /* batched helper for the CPU baseline: run `nsteps` mj_step on each of n independent envs */
 int sgo_step_many(const sgo_model*, sgo_data** envs, int n, int nsteps, int nthreads);
 

@@ -9,6 +9,8 @@ sample, plus the compiled-model counts the MJCF compiler must reproduce).
 
 usage: capture_mujoco_golden.py --xml <reference>/data/gripper/soft_experiments_softbox_adjusted_for_2_fingers.xml \
            --stiffness 700 903.6948543200572 300 1400 --out tests/golden/mujoco_softbox.npz
+       (once per scene: softbox, softball, softcylinder -- the ball / cylinder captures answer DESIGN.md D5: meta["d5"] holds neq,
+       the contacts at reset, the env step of the first simulation warning and the volume tendon's equality force in the idle phase)
 
 It drives MuJoCo exactly as reference environment/manenv.py:44-109 and create_dataset.py:33-72 do: stiffness on joints 11..63 and
 tendon 0, reset + forward + sim_start(1) steps, then 200 env steps of sim_step(7) substeps under the 40 idle / close at 40 /
@@ -34,8 +36,9 @@ class PyBackend:  # mujoco_py 2.0.x
 
     def reset(self): self.sim.reset()
     def forward(self): self.sim.forward()
-    def step(self): self.sim.step()
+    def step(self): self.sim.step()     # mujoco_py raises MujocoException on a simulation warning (what reference manenv.py:50 catches)
     def iters(self): return int(self.data.solver_iter)
+    def warnings(self): return [int(w.number) for w in self.data.warning]
 
 
 class NewBackend:  # `mujoco` bindings
@@ -50,6 +53,7 @@ class NewBackend:  # `mujoco` bindings
     def forward(self): self.mj.mj_forward(self.model, self.data)
     def step(self): self.mj.mj_step(self.model, self.data)
     def iters(self): return int(np.sum(np.atleast_1d(self.data.solver_niter)))
+    def warnings(self): return [int(w.number) for w in self.data.warning]
 
 
 def backend(xml):
@@ -87,6 +91,10 @@ def main():
             "dof_invweight0": [float(x) for x in m.dof_invweight0], "tendon_invweight0": [float(x) for x in m.tendon_invweight0],
             "body_invweight0": np.asarray(m.body_invweight0).tolist(), "opt": {"timestep": float(m.opt.timestep), "iterations": int(m.opt.iterations),
                                                                             "tolerance": float(m.opt.tolerance), "impratio": float(m.opt.impratio)}}
+    # what settles SURVEY U2 and DESIGN D5 at once: the number of equality rows the composite compiles to, the
+    # contacts the scene starts with, whether a warning fires in the idle phase (ctrl = 0) and the force on the volume tendon's
+    # equality row (the last equality) during it
+    d5 = {"neq": int(m.neq), "ncon_at_reset": [], "first_warning_env_step": [], "warning_counts": [], "tendon_row_force_idle": []}
     sens = np.zeros((len(args.stiffness), N_STEPS + 1, m.nsensordata))
     ncon = np.zeros((len(args.stiffness), N_STEPS + 1), dtype=np.int32)
     nefc = np.zeros_like(ncon)
@@ -98,15 +106,30 @@ def main():
         for t in TENDON_IDS:
             m.tendon_stiffness[t] = k
         B.reset(); B.forward()
+        d5["ncon_at_reset"].append(int(B.data.ncon))
+        first_warning, tforce = None, []
         for _ in range(SIM_START):
             B.step()
         sens[i, 0], ncon[i, 0], nefc[i, 0], iters[i, 0], qpos[i, 0] = B.data.sensordata, B.data.ncon, B.data.nefc, B.iters(), B.data.qpos
         for t, c in enumerate(schedule()):
             if c is not None:
                 B.data.ctrl[:] = c
-            for _ in range(SIM_STEP):
-                B.step()
+            try:
+                for _ in range(SIM_STEP):
+                    B.step()
+            except Exception as err:  # noqa: BLE001 -- mujoco_py.builder.MujocoException: the reference would reset() here
+                first_warning = first_warning if first_warning is not None else t
+                print("k = %g: %s at env step %d" % (k, type(err).__name__, t))
+                break
+            if first_warning is None and any(B.warnings()):
+                first_warning = t
+            if t < START_STEP and m.neq > 0 and B.data.nefc >= m.neq:
+                tforce.append(float(B.data.efc_force[m.neq - 1]))
             sens[i, t + 1], ncon[i, t + 1], nefc[i, t + 1], iters[i, t + 1], qpos[i, t + 1] = B.data.sensordata, B.data.ncon, B.data.nefc, B.iters(), B.data.qpos
+        d5["first_warning_env_step"].append(first_warning)
+        d5["warning_counts"].append(B.warnings())
+        d5["tendon_row_force_idle"].append(tforce)
+    meta["d5"] = d5
     np.savez_compressed(args.out, stiffness=np.array(args.stiffness), sensordata=sens, ncon=ncon, nefc=nefc, iters=iters, qpos=qpos,
                         meta=json.dumps(meta))
     print("wrote", args.out, meta["mujoco"], meta["counts"])
