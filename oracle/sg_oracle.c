@@ -34,7 +34,7 @@
 #define MAXVAL 1e10
 #define MINIMP 1e-4
 #define MAXIMP 0.9999
-#define MAXCHAIN 16
+#define MAXCHAIN 24
 #define MAXCON 512
 
 /* Sensitivity switches (scripts/d5_sensitivity.py; 0 in every test and everywhere else): each bit flips ONE of the places where this

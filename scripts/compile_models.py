@@ -18,8 +18,32 @@ SCENES = {
     "softball": "soft_experiments_softball_adjusted_for_2_fingers.xml",
 }
 
+def fourfinger_scene(tmpdir):
+    """the reference's FOUR-finger gripper (data/gripper/soft_grip_four_fingers.xml; its ids survive only as comments
+    in environment/manenv.py:11,16) squeezing the soft ball.  The reference has no experiment file for the pair that is not also a
+    free-joint scene, so this one is the two-finger ball experiment with its <include> switched to the four-finger gripper --
+    generated here from the reference's files (copied to a scratch directory; nothing is written into the reference)."""
+    import shutil
+    for f in os.listdir(REF):
+        if f.endswith(".xml"):
+            shutil.copy(os.path.join(REF, f), tmpdir)
+    x = open(os.path.join(tmpdir, "soft_experiments_softball_adjusted_for_2_fingers.xml")).read()
+    assert "soft_grip_two_fingers.xml" in x
+    path = os.path.join(tmpdir, "soft_experiments_softball_four_fingers.xml")
+    with open(path, "w") as f:
+        f.write(x.replace("soft_grip_two_fingers.xml", "soft_grip_four_fingers.xml"))
+    return path
+
+
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "models"), exist_ok=True)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:   # oracle / compiler scope only: the kernels' plan class is two 4-dof fingers (DESIGN.md 7)
+        m = sg.compile_mjcf(fourfinger_scene(tmp), composite_neighbors=False)
+        out = os.path.join(ROOT, "models", "fourfinger_softball_fix.sgmodel")
+        with open(out, "wb") as f:
+            f.write(m.to_blob())
+        print("fourfinger_softball_fix nv", m.nv, "neq", m.neq, "->", out, os.path.getsize(out), "bytes")
     # <scene>.sgmodel: the composite as MuJoCo's documentation describes it -- fix rows, neighbour equalities, tendon row (the
     # default, DESIGN.md 2, U2; rows pipeline only); <scene>_fix.sgmodel: the same scene without the neighbour equalities (opt-in)
     for suffix, nb in (("", True), ("_fix", False)):
