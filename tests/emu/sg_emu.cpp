@@ -61,11 +61,6 @@ Emu* emu_new(const void* blob, size_t n, char* err, size_t errlen) {
     return nullptr;
   }
   const SgPlanHeader& H = E->P.h;
-  if (H.nnb > 0) {  // the harness emulates the fused kernel, which has no neighbour rows (models/*_nb.sgmodel)
-    snprintf(err, errlen, "the lane-serial harness does not support neighbour equality rows");
-    delete E;
-    return nullptr;
-  }
   E->N = H.nelem;
   E->qe.resize(E->N); E->ve.resize(E->N); E->we.resize(E->N); E->ke.resize(E->N);
   E->sens.assign(H.nsensordata, 0.0);
@@ -341,9 +336,27 @@ int emu_substep(Emu* E, int integrate) {
     tb += cf * asm_e[e]; tjar += cf * E->we[e]; tA += cf * cf * invm[e];
   }
   double tf = -tjar / tR;
+  // ---- neighbour equality rows (models with the composite's neighbour equalities: slider e = slider e2, J = +1 / -1), as the phase
+  //      kernel builds them: by workspace slot d * N + e (the d-th row registered for element e, MuJoCo's order)
+  const int nnb = H.nnb;
+  const int* nbt = P.nbtab.data();
+  std::vector<double> nbf(3 * N + 1, 0.0), nbb(3 * N + 1, 0.0), nbR(3 * N + 1, 1.0);
+  std::vector<int> nb_e2(3 * N + 1, -1), nb_e1(3 * N + 1, -1);
+  if (nnb > 0)
+    for (int e = 0; e < N; e++)
+      for (int d = 0; d < 3; d++) {
+        const int e2 = nbt[d * N + e];
+        if (e2 < 0) continue;
+        const int id = nbt[(3 + d) * N + e];
+        const double pos = (E->qe[e] - EL(SGE_QPOS0, e)) - (E->qe[e2] - EL(SGE_QPOS0, e2)), imp = impedance(H.eqj_solimp, pos, 0);
+        const double Rr = fmax(SG_MINVAL, (1 - imp) / imp * (EL(SGE_INVW, e) + EL(SGE_INVW, e2)));
+        const double aref = -H.eqj_B * (E->ve[e] - E->ve[e2]) - H.eqj_K * imp * pos;
+        nbb[id] = (asm_e[e] - asm_e[e2]) - aref; nbR[id] = Rr; nbf[id] = -((E->we[e] - E->we[e2]) - aref) / Rr;
+        nb_e1[id] = e; nb_e2[id] = e2;
+      }
   LimitRows Lm[SG_MAXCH];
   for (int c = 0; c < H.nchain; c++) limits_build(H.chain[c], E->qc[c], E->vc[c], D[c].qacc_smooth, E->wc[c], Lm[c]);
-  E->ncon = 0; E->nefc = N + 1;
+  E->ncon = 0; E->nefc = N + 1 + nnb;
   for (int c = 0; c < H.nchain; c++) { E->ncon += (int)con[c].size(); E->nefc += __builtin_popcount(Lm[c].active) + 3 * (int)con[c].size(); }
   E->ncon += (int)gcon.size(); E->nefc += 3 * (int)gcon.size();
 
@@ -353,7 +366,14 @@ int emu_substep(Emu* E, int integrate) {
   std::vector<double> ae(N);
   double aF[SG_MAXCH][SG_CD];
   auto recompute_a = [&]() {
-    for (int e = 0; e < N; e++) ae[e] = invm[e] * (eqf[e] + EL(SGE_COEF, e) * tf);
+    for (int e = 0; e < N; e++) {
+      double fe = eqf[e] + EL(SGE_COEF, e) * tf;
+      if (nnb > 0) {   // + its own neighbour rows (J = +1), - the rows that have it as second joint (J = -1), in the kernel's order
+        for (int d = 0; d < 3; d++) if (nbt[d * N + e] >= 0) fe += nbf[nbt[(3 + d) * N + e]];
+        for (int d = 0; d < 3; d++) { const int ii = nbt[(6 + d) * N + e]; if (ii >= 0) fe -= nbf[ii]; }
+      }
+      ae[e] = invm[e] * fe;
+    }
     for (int c = 0; c < H.nchain; c++) {
       double g[SG_CD] = {0, 0, 0, 0};
       for (int k = 0; k < SG_MAXLIM; k++)
@@ -378,6 +398,8 @@ int emu_substep(Emu* E, int integrate) {
   double cost = 0, tJa = 0;
   for (int e = 0; e < N; e++) { cost += eqf[e] * (0.5 * (ae[e] + eqR[e] * eqf[e]) + eqb[e]); tJa += EL(SGE_COEF, e) * ae[e]; }
   cost += tf * (0.5 * (tJa + tR * tf) + tb);
+  for (int id = 0; id < 3 * N && nnb > 0; id++)
+    if (nb_e1[id] >= 0) cost += nbf[id] * (0.5 * ((ae[nb_e1[id]] - ae[nb_e2[id]]) + nbR[id] * nbf[id]) + nbb[id]);
   for (int c = 0; c < H.nchain; c++) {
     for (int k = 0; k < SG_MAXLIM; k++)
       if (Lm[c].active >> k & 1) cost += Lm[c].f[k] * (0.5 * (Lm[c].sign[k] * aF[c][k / 2] + Lm[c].R[k] * Lm[c].f[k]) + Lm[c].b[k]);
@@ -397,6 +419,7 @@ int emu_substep(Emu* E, int integrate) {
     }
   if (cost > 0) {
     for (auto& gc : gcon) gc.f[0] = gc.f[1] = gc.f[2] = 0;
+    std::fill(nbf.begin(), nbf.end(), 0.0);
     std::fill(eqf.begin(), eqf.end(), 0.0);
     tf = 0;
     for (int c = 0; c < H.nchain; c++) {
@@ -407,8 +430,56 @@ int emu_substep(Emu* E, int integrate) {
   }
   // ---- PGS ----
   E->iters = 0;
+  // Neighbour-row models: the solver kernel's formulation of the equality block (sg_pgs_rows_kernel<.., NB = true>), lane-serially --
+  // the plan's block schedule (one block = element e's fix row and its up to three neighbour rows, all on slider e), per row the state
+  // g = b + R f and the step factor c = (1/m) / (A + R), slider accelerations kept MINUS the env's offset aoff (the tendon row's
+  // push, the same for every slider), the tendon row's J a tracked instead of summed
+  const double im0 = nnb > 0 ? invm[0] : 0.0;
+  std::vector<double> Ae(N + 1, 0.0), recg(4 * (N + 1), 0.0), recc(4 * (N + 1), 0.0);
+  double aoff = 0.0, Ssum = 0.0, dS = 0.0;
+  if (nnb > 0) {
+    for (int e = 0; e < N; e++) {
+      Ae[e] = ae[e]; Ssum += ae[e];
+      recg[4 * e] = eqb[e] + eqR[e] * eqf[e]; recc[4 * e] = sg_div(im0, im0 + eqR[e]);
+      for (int d = 0; d < 3; d++)
+        if (nbt[d * N + e] >= 0) {
+          const int id = nbt[(3 + d) * N + e];
+          recg[4 * e + 1 + d] = nbb[id] + nbR[id] * nbf[id]; recc[4 * e + 1 + d] = sg_div(im0, 2.0 * im0 + nbR[id]);
+        }
+    }
+  }
   for (int it = 0; it < H.iterations; it++) {
     double improvement = 0;
+    if (nnb > 0) {
+      double qc = 0, sc = 0;
+      for (size_t si = 0; si < P.sched.size(); si++) {
+        const SgEqSlot& sl = P.sched[si];
+        const int e = sl.e;
+        if (e >= N) continue;   // idle slot
+        double ek = Ae[e];
+        for (int k = 0; k < 4; k++) {
+          const int pk = k == 0 ? -1 : sl.p[k - 1];
+          if (k > 0 && pk >= N) continue;                      // no such row (its record is (0, 0): w = 0)
+          const double Pk = k == 0 ? -aoff : Ae[pk], g = recg[4 * e + k], c = recc[4 * e + k];
+          const double dk = g - Pk, sk = dk + ek, wk = c * sk, en = ek - wk, Pn = k == 0 ? Pk : Pk + wk;
+          if (k > 0) Ae[pk] = Pn;
+          recg[4 * e + k] = Pn - en;
+          qc += sk * wk;
+          if (k == 0) sc += wk;
+          ek = en;
+        }
+        Ae[e] = ek;
+      }
+      improvement += 0.5 * qc * (1.0 / im0);
+      dS -= sc;
+      const double Ja = Ssum + dS, old = tf;
+      improvement -= scalar_update(tf, tb, Ja, tR, tA, false);
+      const double dft = tf - old;
+      aoff += im0 * dft;
+      Ssum = Ja + (tA - tR) * dft;
+      dS = 0.0;
+      for (int e = 0; e < N; e++) ae[e] = Ae[e] + aoff;       // the contact rows below read and push the true accelerations
+    } else {
     for (int e = 0; e < N; e++) {
       double old = eqf[e];
       improvement -= scalar_update(eqf[e], eqb[e], ae[e], eqR[e], invm[e] + eqR[e], false);
@@ -420,6 +491,8 @@ int emu_substep(Emu* E, int integrate) {
       improvement -= scalar_update(tf, tb, Ja, tR, tA, false);
       for (int e = 0; e < N; e++) ae[e] += invm[e] * EL(SGE_COEF, e) * (tf - old);
     }
+    }
+    const std::vector<double> ae_before = ae;   // (NB) what the contact rows add to the sliders goes into the tracked sum
     for (int c = 0; c < H.nchain; c++) {
       for (int k = 0; k < SG_MAXLIM; k++) {
         if (!(Lm[c].active >> k & 1)) continue;
@@ -451,10 +524,12 @@ int emu_substep(Emu* E, int integrate) {
       }
       if (gc.sl >= 0) ae[gc.sl] += gc.invm * (gc.Js[0] * df[0] + gc.Js[1] * df[1] + gc.Js[2] * df[2]);
     }
+    if (nnb > 0)
+      for (int e = 0; e < N; e++) { dS += ae[e] - ae_before[e]; Ae[e] = ae[e] - aoff; }
     E->iters = it + 1;
     if (improvement * H.pgs_scale < H.tolerance) break;
   }
-  recompute_a();
+  if (nnb == 0) recompute_a();   // (NB: the block formulation keeps states g, not forces -- the accelerations it maintains ARE the result, as in the kernel)
   // ---- qacc, sensors, warmstart ----
   double qaccc[SG_MAXCH][SG_CD];
   for (int c = 0; c < H.nchain; c++) {

@@ -282,3 +282,48 @@ def test_general_contact_path_against_the_oracle(tmp_path, kind):
             e.set_state(s.qpos, s.qvel, s.qacc_warmstart, s.act)
     assert special > 100 and general > 300, (special, general)
     assert worst < 1e-7, worst
+
+
+@pytest.mark.parametrize("scene,damper,n_steps", [("softbox", None, 110), ("softball", "implicit", 30), ("mini", None, 120)])
+def test_neighbour_row_models_step_by_step(scene, damper, n_steps):
+    """the solver's formulation of the equality block for the DEFAULT models (composite neighbour equalities) -- the
+    plan's block schedule, per row the state g = b + R f and step factor c, slider accelerations kept minus the env's offset, the
+    tendon row's J a tracked instead of summed (sg_pgs_rows_kernel<.., NB = true>) -- run lane-serially on the CPU against the oracle,
+    which sweeps an explicit A = J M^-1 J' + R row by row.  These models amplify round-off once the fingers touch, so the
+    comparison is step by step along the oracle's trajectory (re-seated after every env step), contact and sweep counts exactly.
+    (scripts/sanitize/run_emu_oracle.sh runs this file under ASan + UBSan.)"""
+    import os
+    from helpers import ROOT
+    from oracle import oracle as O
+    if scene == "mini":
+        m = sg.compile_mjcf(os.path.join(ROOT, "tests", "data", "mini_gripper.xml"))
+        jids = list(range(8, m.nv))
+    else:
+        m = sg.load_model(model_path(scene), damper)
+        jids = list(range(11, 64))
+    assert (m.eq_obj2id >= 0).any()
+    e = Emu(m.to_blob(), m.nv)
+    s = O.OracleSim(O.OracleModel(m.to_blob()))
+    s._om = s.model
+    k = 903.6948543200572
+    s.jnt_stiffness[jids] = k
+    s.tendon_stiffness[0] = k
+    e.set_stiffness(k, jids, [0])
+    e.reset(); s.reset()
+    e.substep(False); s.forward()
+    np.testing.assert_allclose(e.sensordata, s.sensordata, atol=1e-12)
+    e.substep(True); s.step()
+    most, worst = 0, 0.0
+    for t, c in enumerate(episode_schedule()[:n_steps]):
+        if c is not None:
+            e.set_ctrl(c)
+            s.ctrl[:] = c
+        for _ in range(7):
+            assert e.substep(True) == 0 and s.step() == 0, t
+            assert e.ncon == s.ncon and e.L.emu_iters(e.p) == s.solver_iter and e.L.emu_nefc(e.p) == s.nefc, (t, e.ncon, s.ncon, e.L.emu_iters(e.p), s.solver_iter)
+        q, v, w, a = e.state()
+        worst = max(worst, np.abs(e.sensordata - s.sensordata).max())
+        assert np.abs(e.sensordata - s.sensordata).max() < 1e-7 and np.abs(q - s.qpos).max() < 1e-9, (t, worst)
+        e.set_state(s.qpos, s.qvel, s.qacc_warmstart, s.act)
+        most = max(most, s.ncon)
+    assert most >= 6, most
