@@ -1853,53 +1853,63 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         const double Pfix = h0 * -aoff;  // row 0's "partner" -aoff on lane 0 (added to hm * X)
         double qc = 0.0, sc = 0.0;
         const int nrounds = H.eq_rounds;
-        struct Pend { double2* p; double ga, gb; };
         struct Rec { double2 a, b; };  // (g, c) of my two rows
-        auto ld_rec = [&](const uint2 tt) { const double2* p = (const double2*)(Rb + (tt.y & 0xffffu)); Rec rc; rc.a = p[0]; rc.b = p[1]; return rc; };
-        auto round = [&](const uint2 tt, const Rec rc, Pend& out) {
-          double* const px = (double*)(Ab + (tt.x & 0xffffu));   // lane 0: slider e itself; lane 1: partner of row 2
-          double* const py = (double*)(Ab + (tt.x >> 16));       // partner of row 1 / row 3
-          const double X = *px, Y = *py;
+        struct Adr { double *px, *py; double2* rec; };   // lane 0: slider e itself / partner of row 1; lane 1: partners of rows 2, 3; my rows' records
+        struct Off { double sA, wA, sB, wB, ga, gb; };   // what a round leaves for its off-chain part
+        auto adr_of = [&](const uint2 tt) {
+          Adr q;
+          q.px = (double*)(Ab + (tt.x & 0xffffu)); q.py = (double*)(Ab + (tt.x >> 16)); q.rec = (double2*)(Rb + (tt.y & 0xffffu));
+          return q;
+        };
+        auto ld_rec = [&](const Adr q) { Rec rc; rc.a = q.rec[0]; rc.b = q.rec[1]; return rc; };
+        // The CHAIN of a round -- slider reads -> two rows on lane 0 -> hand-over -> two rows on lane 1 -> hand-over -> slider writes, which
+        // the next round's reads wait for -- is ~250 cycles of latency; the round's other ~24 instructions (cost sums, new row states and
+        // their stores, the next records / table words / addresses) are OFF the chain.  r03 measured 459 cycles per round against
+        // 44 x 7 = 308 of issue: so the loop is written as chain(r) | reads(r + 1) | off-chain(r), with scheduling barriers between the
+        // groups, and the off-chain work of a round runs in the shadow of the next round's LDS reads.
+        auto chain = [&](const Adr q, const Rec rc, const double X, const double Y, Off& o) {
           const double cA = rc.a.y, cB = rc.b.y;
           const double PA = fma(X, hm, Pfix), dA = rc.a.x - PA, dB = rc.b.x - Y;
           // a row's step on slider e: s = d + e (its residual), w = c s (its push on the partner), e' = e - w.  Lane 0 runs its two rows
           // from e = a_e, hands the result over, lane 1 runs its two rows from there (both lanes execute both passes: in the second one
-          // lane 0 repeats its own numbers).  r02 wrote e' = e (1 - c) - c d with precomputed products to shorten the dependent chain;
-          // a wavefront alone on its SIMD issues one instruction per ~7 cycles dependent or not, so what counts is their number: 30
-          // arithmetic instructions per round instead of 38
+          // lane 0 repeats its own numbers)
           const double sA0 = dA + X, O10 = X - cA * sA0, O20 = O10 - cB * (dB + O10);   // lane 0: e after rows 0, 1
           const double T = sg_dpp<0xB1>(O20);                    // quad_perm [1,0,3,2]: the pair's other lane
           const double I = hh ? T : X;                           // my first row's e_k
           const double sA = dA + I, wA = cA * sA, O1 = I - wA, sB = dB + O1, wB = cB * sB, O2 = O1 - wB;
           const double PAn = fma(wA, hm, PA), Yn = Y + wB;
           const double e4 = sg_dpp<0xB1>(O2);                    // lane 0 receives the block's result from lane 1
-          *px = hh ? PAn : e4;
-          *py = Yn;
-          qc += sA * wA + sB * wB;
-          sc += wA * h0;
-          out.p = (double2*)(Rb + (tt.y & 0xffffu));
-          out.ga = PAn - O1; out.gb = Yn - O2;
+          *q.px = hh ? PAn : e4;
+          *q.py = Yn;
+          o.sA = sA; o.wA = wA; o.sB = sB; o.wB = wB; o.ga = PAn - O1; o.gb = Yn - O2;
         };
-        // two rounds per trip; table words are fetched two rounds ahead, records one round ahead (no row of a round writes the
-        // records of another block), and a round's new states are written after the NEXT round has issued its slider reads
-        uint2 tA = tp[0], tB = tp[16];
-        Rec rA = ld_rec(tA), rB;
-        Pend pend;
-        pend.p = (double2*)(Rb + 64 * N); pend.ga = pend.gb = 0.0;  // first "pending" store: zeros into the idle group
+        auto offchain = [&](const Adr q, const Off& o) {
+          qc += o.sA * o.wA + o.sB * o.wB;
+          sc += o.wA * h0;
+          q.rec[0].x = o.ga; q.rec[1].x = o.gb;                  // the rows' new states g' = P' - e' (their residual is zero after the update)
+        };
+        // two rounds per trip (register sets A, B); table words are fetched two rounds ahead, records and addresses one round ahead
+        uint2 tC = tp[0], tD = tp[16];
+        Adr qA = adr_of(tC), qB = adr_of(tD);
+        Rec rA = ld_rec(qA), rB = ld_rec(qB);
+        double XA = *qA.px, YA = *qA.py, XB, YB;
+        Off oA, oB;
         for (int k = 0; k < nrounds; k += 2) {  // an odd count runs one idle round (the table ends with four)
           tp += 32;
-          const uint2 tC = tp[0], tD = tp[16];
-          Pend pa, pb;
-          rB = ld_rec(tB);
-          round(tA, rA, pa);
-          pend.p[0].x = pend.ga; pend.p[1].x = pend.gb;
-          rA = ld_rec(tC);
-          round(tB, rB, pb);
-          pa.p[0].x = pa.ga; pa.p[1].x = pa.gb;
-          pend = pb;
-          tA = tC; tB = tD;
+          tC = tp[0]; tD = tp[16];
+          chain(qA, rA, XA, YA, oA);
+          XB = *qB.px; YB = *qB.py;
+          __builtin_amdgcn_sched_barrier(0);
+          offchain(qA, oA);
+          qA = adr_of(tC); rA = ld_rec(qA);
+          __builtin_amdgcn_sched_barrier(0);
+          chain(qB, rB, XB, YB, oB);
+          XA = *qA.px; YA = *qA.py;
+          __builtin_amdgcn_sched_barrier(0);
+          offchain(qB, oB);
+          qB = adr_of(tD); rB = ld_rec(qB);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        pend.p[0].x = pend.ga; pend.p[1].x = pend.gb;
         imp_acc += 0.5 * qc * (1.0 / im0);
         dS -= sc;
       }
