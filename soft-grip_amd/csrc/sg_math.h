@@ -622,13 +622,11 @@ SG_HD int qcqp2(double* res, const double* Ain, const double* bin, const double*
 // Same operations as the textbook sequence (normal-or-ray update, friction QCQP with the normal fixed, cost check); the
 // common case -- active normal force, friction inside the cone after one Newton evaluation -- runs without a data-dependent
 // branch (selects), because on the GPU every branch drains the wave's pipeline; the uncommon cases share one fallback.
-SG_HD double contact_update(Contact& c, const double* aF, double as_, const double* mu, double* df) {
-  const double o0 = c.f[0], o1 = c.f[1], o2 = c.f[2];
-  const double A00 = c.A[0], A01 = c.A[1], A02 = c.A[2], A11 = c.A[3], A12 = c.A[4], A22 = c.A[5];
-  double res[3];
-#pragma unroll
-  for (int r = 0; r < 3; r++)  // two independent partial sums: half the dependency depth of a serial accumulation
-    res[r] = ((c.b[r] + c.Js[r] * as_) + (c.Jf[r][0] * aF[0] + c.Jf[r][1] * aF[1])) + ((c.R * c.f[r] + c.Jf[r][2] * aF[2]) + c.Jf[r][3] * aF[3]);
+// the block update proper: A = the contact's 3 x 3 block [00,01,02,11,12,22], res = its residual (A + R) f + b at the current forces
+// f (in / out); writes the force change df and returns the cost change (<= 0)
+SG_HD double contact_block_update(const double* A, const double* res, double* f, const double* mu, double* df) {
+  const double o0 = f[0], o1 = f[1], o2 = f[2];
+  const double A00 = A[0], A01 = A[1], A02 = A[2], A11 = A[3], A12 = A[4], A22 = A[5];
   // ---- normal (f0 ~ 0) or ray update ----
   double g0, g1, g2;
   {
@@ -692,9 +690,16 @@ SG_HD double contact_update(Contact& c, const double* aF, double as_, const doub
   double change = 0.5 * (d0 * (A00 * d0 + A01 * d1 + A02 * d2) + d1 * (A01 * d0 + A11 * d1 + A12 * d2) + d2 * (A02 * d0 + A12 * d1 + A22 * d2)) +
                   d0 * res[0] + d1 * res[1] + d2 * res[2];
   const bool reject = change > 1e-10;  // the update must not increase the cost
-  c.f[0] = reject ? o0 : g0; c.f[1] = reject ? o1 : g1; c.f[2] = reject ? o2 : g2;
+  f[0] = reject ? o0 : g0; f[1] = reject ? o1 : g1; f[2] = reject ? o2 : g2;
   df[0] = reject ? 0.0 : d0; df[1] = reject ? 0.0 : d1; df[2] = reject ? 0.0 : d2;
   return reject ? 0.0 : change;
+}
+SG_HD double contact_update(Contact& c, const double* aF, double as_, const double* mu, double* df) {
+  double res[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)  // two independent partial sums: half the dependency depth of a serial accumulation
+    res[r] = ((c.b[r] + c.Js[r] * as_) + (c.Jf[r][0] * aF[0] + c.Jf[r][1] * aF[1])) + ((c.R * c.f[r] + c.Jf[r][2] * aF[2]) + c.Jf[r][3] * aF[3]);
+  return contact_block_update(c.A, res, c.f, mu, df);
 }
 
 // scalar row update (equality: free, limit: f >= 0); returns cost change, writes new force

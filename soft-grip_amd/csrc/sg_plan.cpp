@@ -66,7 +66,18 @@ void mulmat3(double* r, const double* M, const double* v) {
   const int* var = (const int*)B.find(name, SG_DT_I32, &cnt);                    \
   if (!var) FAIL(std::string("model blob lacks ") + name)
 
-bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* err) {
+static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* tree, std::string* err);
+bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* err) { return plan_build(blob, nbytes, out, nullptr, err); }
+bool sg_tree_plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* tree, std::string* err) {
+  if (!tree) {
+    if (err) *err = "sg_tree_plan_build: no tree table";
+    return false;
+  }
+  return plan_build(blob, nbytes, out, tree, err);
+}
+
+// tree == nullptr: the two-finger class of sg_plan.h (SgPlanHeader::chain); else the chains go into *tree (sg_tree_plan.h)
+static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* tree, std::string* err) {
   const sg_blob_header* hd = (const sg_blob_header*)blob;
   if (nbytes < sizeof *hd || hd->magic != SG_BLOB_MAGIC || hd->version != SG_BLOB_VERSION || (size_t)hd->total_bytes != nbytes)
     FAIL("not a softgrip model blob");
@@ -111,7 +122,8 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
   NEEDI(sensor_type, "sensor_type");
   const int nsensor = (int)cnt;
   NEEDI(sensor_objid, "sensor_objid"); NEEDI(sensor_adr, "sensor_adr");
-  (void)nsite; (void)geom_quat; (void)geom_priority;
+  (void)geom_quat; (void)geom_priority;
+  if (tree) memset(tree, 0, sizeof *tree);
 
   SgPlan& P = *out;
   P = SgPlan();
@@ -165,7 +177,82 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
   if (H.elem_dof0 + nelem != nv) FAIL("element dofs must be the last dofs of the model");
 
   int nchain = 0;
-  for (int b = 1; b < nbody; b++) {
+  auto lim_kb = [&](int j, double* K, double* Bd) {
+    const double *sr = jnt_solref + 2 * j, *si = jnt_solimp + 5 * j;
+    double dmax = fmin(0.9999, fmax(1e-4, si[1]));
+    if (sr[0] > 0 && sr[1] > 0) {
+      double tc = fmax(sr[0], 2 * H.timestep);
+      *K = 1 / fmax(1e-15, dmax * dmax * tc * tc * sr[1] * sr[1]);
+      *Bd = 2 / fmax(1e-15, dmax * tc);
+    } else {
+      *K = -sr[0] / fmax(1e-15, dmax * dmax);
+      *Bd = -sr[1] / fmax(1e-15, dmax);
+    }
+  };
+  std::vector<int> tb_of(nbody, -1);   // tree mode: flat chain-body index of a model body
+  if (tree) {
+    SgTreeDev& T = *tree;
+    for (int b = 1; b < nbody; b++) {
+      if (body_weldid[b] == 0 || is_elem[b]) continue;
+      if (b >= first_elem) FAIL("chain bodies must precede the composite elements");
+      if (body_jntnum[b] < 1) FAIL("a moving chain body without a joint");
+      for (int k = 0; k < body_jntnum[b]; k++)
+        if (jnt_type[body_jntadr[b] + k] != SG_JNT_HINGE) FAIL("chain bodies may only have hinge joints");
+      const int p = body_parentid[b];
+      int c;
+      if (body_weldid[p] == 0) {  // new chain
+        if (T.K == SGT_MAXCH) FAIL("more finger chains than the tree pipeline holds");
+        c = T.K++;
+        T.c_body0[c] = T.NB; T.c_nbody[c] = 0; T.c_dof0[c] = T.ND; T.c_ndof[c] = 0;
+        memcpy(T.c_root_pos[c], &wpos[3 * p], 24); memcpy(T.c_root_quat[c], &wquat[4 * p], 32);
+      } else {
+        c = chain_of[p];
+        if (c < 0 || c != T.K - 1 || tb_of[p] != T.NB - 1) FAIL("finger chains must be serial (no branching) and listed one after the other");
+      }
+      if (T.NB == SGT_MAXB) FAIL("more chain bodies than the tree pipeline holds");
+      const int tb = T.NB++;
+      chain_of[b] = c; cbidx[b] = T.c_nbody[c]++; tb_of[b] = tb;
+      T.b_chain[tb] = c; T.b_njnt[tb] = body_jntnum[b]; T.b_dof0[tb] = T.ND;
+      memcpy(T.b_pos[tb], body_pos + 3 * b, 24); memcpy(T.b_quat[tb], body_quat + 4 * b, 32);
+      memcpy(T.b_ipos[tb], body_ipos + 3 * b, 24); memcpy(T.b_imat[tb], body_imat + 9 * b, 72);
+      T.b_mass[tb] = body_mass[b]; T.b_invw[tb] = body_invweight0[2 * b];
+      for (int k = 0; k < body_jntnum[b]; k++) {
+        const int j = body_jntadr[b] + k;
+        if (T.ND == SGT_MAXD) FAIL("more chain dofs than the tree pipeline holds");
+        if (T.c_ndof[c] == SGT_CHD) FAIL("a finger chain has more dofs than the tree pipeline holds");
+        const int d = T.ND++;
+        T.c_ndof[c]++;
+        if (d > 0 && T.d_chain[d - 1] == c && j != T.d_gid[d - 1] + 1) FAIL("chain dofs must be contiguous");
+        T.d_body[d] = tb; T.d_chain[d] = c; T.d_limited[d] = jnt_limited[j]; T.d_gid[d] = j;
+        memcpy(T.d_axis[d], jnt_axis + 3 * j, 24); memcpy(T.d_pos[d], jnt_pos + 3 * j, 24);
+        T.d_qpos0[d] = qpos0[j]; T.d_range[d][0] = jnt_range[2 * j]; T.d_range[d][1] = jnt_range[2 * j + 1]; T.d_margin[d] = jnt_margin[j];
+        T.d_damping[d] = dof_damping[j]; T.d_armature[d] = dof_armature[j]; T.d_stiffness[d] = jnt_stiffness[j]; T.d_springref[d] = qpos_spring[j];
+        T.d_invw[d] = dof_invweight0[j];
+        lim_kb(j, &T.d_limK[d], &T.d_limB[d]);
+        memcpy(T.d_solimp[d], jnt_solimp + 5 * j, 40);
+      }
+      T.b_nabove[tb] = T.c_ndof[c];
+      for (int k = 0; k < body_geomnum[b]; k++) {
+        const int g = body_geomadr[b] + k;
+        if (geom_type[g] != SG_GEOM_BOX) FAIL("chain bodies may only carry box geoms");
+        if (T.NG == SGT_MAXG) FAIL("more finger boxes than the tree pipeline holds");
+        const int gi = T.NG++;
+        T.g_body[gi] = tb; T.g_id[gi] = g;
+        memcpy(T.g_pos[gi], geom_pos + 3 * g, 24);
+        quat2mat(T.g_mat[gi], geom_quat + 4 * g);
+        memcpy(T.g_size[gi], geom_size + 3 * g, 24);
+        T.g_rbound[gi] = geom_rbound[g];
+      }
+    }
+    if (T.K == 0) FAIL("model has no finger chain");
+    T.NMAT = 0; T.CS = 0;
+    for (int c = 0; c < T.K; c++) {
+      T.c_mat0[c] = T.NMAT; T.NMAT += T.c_ndof[c] * T.c_ndof[c];
+      T.CS = std::max(T.CS, T.c_ndof[c]);
+    }
+    if (T.ND + nelem != nv) FAIL("the model has dofs that belong neither to a finger chain nor to a composite element");
+  }
+  for (int b = 1; b < nbody && !tree; b++) {
     if (body_weldid[b] == 0 || is_elem[b]) continue;
     if (b >= first_elem) FAIL("chain bodies must precede the composite elements");
     for (int k = 0; k < body_jntnum[b]; k++)
@@ -225,7 +312,7 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
     }
   }
   H.nchain = nchain;
-  if (nchain == 0) FAIL("model has no finger chain");
+  if (nchain == 0 && !tree) FAIL("model has no finger chain");
   // the kernels are compiled for one chain topology: SG_CB bodies with SG_CJ hinges each
   for (int c = 0; c < nchain; c++) {
     if (H.chain[c].nbody != SG_CB) FAIL("finger chains must have exactly 2 moving bodies");
@@ -259,7 +346,16 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
     E(SGE_MASS, e) = body_mass[b]; E(SGE_ARMATURE, e) = dof_armature[j]; E(SGE_DAMPING, e) = dof_damping[j];
     E(SGE_K0, e) = jnt_stiffness[j]; E(SGE_SPRINGREF, e) = qpos_spring[j]; E(SGE_QPOS0, e) = qpos0[j];
     E(SGE_INVW, e) = dof_invweight0[j]; E(SGE_BINVW, e) = body_invweight0[2 * b];
-    if (jnt_limited[j]) FAIL("limited element sliders are not supported");
+    if (jnt_limited[j]) {
+      if (!tree) FAIL("limited element sliders are not supported");
+      double K, Bd;
+      lim_kb(j, &K, &Bd);
+      if (H.nlimited_elem == 0) { H.lime_K = K; H.lime_B = Bd; memcpy(H.lime_solimp, jnt_solimp + 5 * j, 40); H.lime_margin = jnt_margin[j]; }
+      else if (K != H.lime_K || Bd != H.lime_B || memcmp(H.lime_solimp, jnt_solimp + 5 * j, 40) || H.lime_margin != jnt_margin[j])
+        FAIL("limited element sliders must share solref / solimp / margin");
+      H.nlimited_elem++;
+      E(SGE_LIMITED, e) = 1; E(SGE_RLO, e) = jnt_range[2 * j]; E(SGE_RHI, e) = jnt_range[2 * j + 1];
+    }
     if (e == 0) { H.cap_radius = geom_size[3 * g]; H.cap_hl = geom_size[3 * g + 1]; H.cap_rbound = geom_rbound[g]; }
     else if (geom_size[3 * g] != H.cap_radius || geom_size[3 * g + 1] != H.cap_hl) FAIL("element capsules must share one size");
     if (body_mass[b] <= 0) FAIL("element without mass");
@@ -267,7 +363,7 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
 
   // ---- tendons ----
   H.t0_id = -1;
-  std::vector<int> site_used_by_chain(ntendon, -1);
+  std::vector<int> tree_site_id;   // tree mode: model site id of tree site q
   for (int t = 0; t < ntendon; t++) {
     int a = tendon_adr[t], n = tendon_num[t];
     if (wrap_type[a] == SG_WRAP_JOINT) {
@@ -279,6 +375,44 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
       }
       H.t0_id = t; H.t0_k0 = tendon_stiffness[t]; H.t0_damping = tendon_damping[t]; H.t0_lspring = tendon_lengthspring[t];
       H.t0_L0 = tendon_length0[t]; H.eqt_invw = tendon_invweight0[t];
+    } else if (tree) {
+      SgTreeDev& T = *tree;
+      if (n < 2 || n > SGT_MAXTS) FAIL("a spatial tendon needs 2 .. 16 sites");
+      int c = -1;
+      for (int w = 0; w < n; w++) {
+        if (wrap_type[a + w] != SG_WRAP_SITE) FAIL("spatial tendons may only wrap sites");
+        const int bs = site_bodyid[wrap_objid[a + w]];
+        if (body_weldid[bs] == 0) continue;
+        if (chain_of[bs] < 0) FAIL("a tendon site sits on a body that is no finger body");
+        if (c >= 0 && chain_of[bs] != c) FAIL("a spatial tendon runs over more than one finger chain");
+        c = chain_of[bs];
+      }
+      if (c < 0) FAIL("a spatial tendon without a moving site");
+      if (T.t_has[c]) FAIL("more than one spatial tendon on a finger chain");
+      T.t_has[c] = 1; T.t_id[c] = t; T.t_nsite[c] = n;
+      T.t_k0[c] = tendon_stiffness[t]; T.t_damping[c] = tendon_damping[t]; T.t_lspring[c] = tendon_lengthspring[t];
+      for (int w = 0; w < n; w++) {
+        const int sid = wrap_objid[a + w], bs = site_bodyid[sid];
+        if (body_weldid[bs] == 0) {
+          T.t_site[c][w] = -1;
+          double tt[3];
+          mulmat3(tt, &wmat[9 * bs], site_pos + 3 * sid);
+          for (int q = 0; q < 3; q++) T.t_fixed[c][w][q] = wpos[3 * bs + q] + tt[q];
+        } else {
+          int found = -1;
+          for (int q = 0; q < T.NS; q++)
+            if (tree_site_id[q] == sid) found = q;
+          if (found < 0) {
+            if (T.NS == SGT_MAXS) FAIL("more chain sites than the tree pipeline holds");
+            found = T.NS++;
+            tree_site_id.push_back(sid);
+            T.s_body[found] = tb_of[bs];
+            memcpy(T.s_pos[found], site_pos + 3 * sid, 24);
+            quat2mat(T.s_mat[found], site_quat + 4 * sid);
+          }
+          T.t_site[c][w] = found;
+        }
+      }
     } else {
       if (n != 2) FAIL("spatial tendons must have exactly two sites");
       int s0 = wrap_objid[a], s1 = wrap_objid[a + 1], b0 = site_bodyid[s0], b1 = site_bodyid[s1];
@@ -303,6 +437,8 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
   if (H.t0_implicit) {
     for (int c = 0; c < H.nchain; c++)
       if (H.chain[c].has_ten && H.chain[c].ten_damping != 0) FAIL("implicit tendon damping covers the elements' fixed tendon only: a finger tendon has a damper");
+    for (int c = 0; tree && c < tree->K; c++)
+      if (tree->t_has[c] && tree->t_damping[c] != 0) FAIL("implicit tendon damping covers the elements' fixed tendon only: a finger tendon has a damper");
     double T = 0;
     for (int e = 0; e < nelem; e++) T += E(SGE_COEF, e) * E(SGE_COEF, e) / (E(SGE_MASS, e) + E(SGE_ARMATURE, e) + H.timestep * E(SGE_DAMPING, e));
     H.t0_hcT = H.timestep * H.t0_damping * T;
@@ -345,6 +481,7 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
   }
   H.nnb = neq - 1 - nelem;
   H.eq_rounds = 0;
+  if (tree && H.nnb > 0) FAIL("the tree pipeline runs fix-rows-only models (compile the scene without the composite's neighbour equalities)");
   if (H.nnb > 0) {
     const int N = nelem, nnb = H.nnb;
     P.nbtab.assign((size_t)9 * N + 3 * nnb, -1);
@@ -432,7 +569,37 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
   }
 
   // ---- actuators and sensors ----
-  for (int u = 0; u < nu; u++) {
+  for (int u = 0; tree && u < nu; u++) {
+    SgTreeDev& T = *tree;
+    int t = actuator_trnid[u], found = -1;
+    for (int c = 0; c < T.K; c++)
+      if (T.t_has[c] && T.t_id[c] == t) found = c;
+    if (found < 0) FAIL("actuators must act on a finger tendon");
+    if (T.a_has[found]) FAIL("more than one actuator on a finger tendon");
+    T.a_has[found] = 1; T.a_id[found] = u; T.a_gain[found] = actuator_gain[u]; T.a_tc[found] = actuator_timeconst[u]; T.a_gear[found] = actuator_gear[u];
+    memcpy(T.a_bias[found], actuator_bias + 3 * u, 24);
+  }
+  for (int s = 0; tree && s < nsensor; s++) {
+    SgTreeDev& T = *tree;
+    const int sid = sensor_objid[s], bs = site_bodyid[sid];
+    if (sid < 0 || sid >= nsite || chain_of[bs] < 0) FAIL("sensors must sit on finger bodies");
+    if (sensor_type[s] != SG_SENS_ACCELEROMETER && sensor_type[s] != SG_SENS_GYRO) FAIL("unsupported sensor type");
+    if (T.NSENS == SGT_MAXSENS) FAIL("more sensors than the tree pipeline holds");
+    int found = -1;
+    for (int q = 0; q < T.NS; q++)
+      if (tree_site_id[q] == sid) found = q;
+    if (found < 0) {
+      if (T.NS == SGT_MAXS) FAIL("more chain sites than the tree pipeline holds");
+      found = T.NS++;
+      tree_site_id.push_back(sid);
+      T.s_body[found] = tb_of[bs];
+      memcpy(T.s_pos[found], site_pos + 3 * sid, 24);
+      quat2mat(T.s_mat[found], site_quat + 4 * sid);
+    }
+    const int k = T.NSENS++;
+    T.sn_type[k] = sensor_type[s]; T.sn_site[k] = found; T.sn_adr[k] = sensor_adr[s];
+  }
+  for (int u = 0; !tree && u < nu; u++) {
     int t = actuator_trnid[u], found = -1;
     for (int c = 0; c < nchain; c++)
       if (H.chain[c].has_ten && H.chain[c].ten_id == t) found = c;
@@ -443,7 +610,7 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
     memcpy(C.act_bias, actuator_bias + 3 * u, 24);
   }
   std::map<int, std::pair<int, int>> site_slot;  // site id -> (chain, slot)
-  for (int s = 0; s < nsensor; s++) {
+  for (int s = 0; !tree && s < nsensor; s++) {
     int site = sensor_objid[s], b = site_bodyid[site];
     if (chain_of[b] < 0) FAIL("sensors must sit on finger bodies");
     auto it = site_slot.find(site);
@@ -483,6 +650,7 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
   std::vector<int> chain_geoms;
   for (int c = 0; c < nchain; c++)
     for (int k = 0; k < H.chain[c].ngeom; k++) chain_geoms.push_back(H.chain[c].g_id[k]);
+  for (int g = 0; tree && g < tree->NG; g++) chain_geoms.push_back(tree->g_id[g]);
   if (chain_geoms.empty()) FAIL("finger chains carry no geoms");
   for (int g : chain_geoms) {
     if (!allowed(g, P.elem_geom[0])) FAIL("finger boxes must be able to collide with the element capsules");
@@ -595,6 +763,7 @@ bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* er
     }
     for (int c = 0; c < nchain; c++)
       for (int k = 0; k < H.chain[c].ngeom; k++) ref_of[H.chain[c].g_id[k]] = (4 << 16) | (c * SG_CG + k);
+    for (int g = 0; tree && g < tree->NG; g++) ref_of[tree->g_id[g]] = (4 << 16) | g;
     for (int e = 0; e < nelem; e++) ref_of[P.elem_geom[e]] = (5 << 16) | e;
     auto pair_allowed = [&](int g1, int g2) {
       const int b1 = geom_bodyid[g1], b2 = geom_bodyid[g2];

@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 
+#include "sg_tree_plan.h"
+
 #define SG_MAXCH 2  // chains
 #define SG_CB 2     // bodies per chain (exactly)
 #define SG_CJ 2     // hinge joints per chain body (exactly)
@@ -58,6 +60,7 @@ enum {
   SGE_BINVW,                         // body_invweight0 (translational)
   SGE_COEF,                          // coefficient in the fixed tendon
   SGE_QLO, SGE_QHI,                  // slider range inside which the capsule cannot reach any static geom
+  SGE_LIMITED, SGE_RLO, SGE_RHI,     // limited slider (tree plans only: sg_tree_plan.h) and its range
   SGE_NFIELD
 };
 
@@ -72,6 +75,9 @@ struct SgPlanHeader {
   double eqj_K, eqj_B, eqj_solimp[5];            // joint-fix equality rows
   double eqt_K, eqt_B, eqt_solimp[5], eqt_invw;  // tendon-fix equality row
   double t0_k0, t0_damping, t0_lspring, t0_L0;   // the fixed tendon's own spring/damper
+  // limit rows of the element sliders (tree plans only; uniform over the limited sliders, checked at build)
+  double lime_K, lime_B, lime_solimp[5], lime_margin;
+  int nlimited_elem;
   int t0_id;
   int t0_implicit;   // model flag opt_i[3]: FINISH integrates the fixed tendon's damper implicitly (Sherman-Morrison)
   double t0_hcT;     // h c sum_e coef_e^2 / (m_e + armature_e + h d_e), the rank-one term's denominator is 1 + t0_hcT
@@ -119,3 +125,6 @@ struct SgPlan {
 // Parses a model blob and fills the plan.  Returns false and sets err if the model is
 // outside the supported class.
 bool sg_plan_build(const void* blob, size_t nbytes, SgPlan* out, std::string* err);
+// The same with the finger chains described by a tree table (sg_tree_plan.h) instead of SgPlanHeader::chain (h.nchain stays 0):
+// any number of serial hinge chains within the SGT_* capacities.  The box references of `gpairs` are flat box indices then.
+bool sg_tree_plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* tree, std::string* err);

@@ -1,0 +1,1039 @@
+// sg_tree.h -- the TREE pipeline: mj_step for grippers outside the two-finger class (sg_tree_plan.h), one env per wavefront.
+//
+// What it replaces: the same calls as the fast kernels -- sim.step() / sim.reset() / sim.forward() of reference
+// environment/manenv.py:48-61 -- for the reference's four-finger gripper (data/gripper/soft_grip_four_fingers.xml; SURVEY.md 8(f)
+// rank 4).  The stages follow the oracle's restatement of mj_forward / mj_step (oracle/sg_oracle.c: kinematics, tendons,
+// mass_matrix + factor, collision, make_constraint, rne_bias, the actuation and smooth-acceleration stages, sol_pgs, the sensor
+// stage, Euler with implicit joint damping), restructured for the model class:
+//   * a dense mass-matrix block per finger chain (<= 24 x 24) with MuJoCo's L'DL, its inverse by columns; the composite's sliders
+//     are 1 x 1 blocks;
+//   * A = J M^-1 J' is never formed: a constraint row keeps J and W = M^-1 J', the sweep keeps the accelerations a = M^-1 J' f;
+//   * the equality / limit rows of the sliders commute among themselves (each touches its own slider): one row per lane;
+//     a chain's limit rows run serially on one lane per chain; contacts run serially in mj_collision's order, the lanes of the
+//     wavefront spread over the dofs of the contact's chain block(s);
+//   * collision walks the plan's candidate-pair table (SgPlan::gpairs = mj_collision's pair order) 64 pairs at a time:
+//     bounding tests per lane, hits ranked by pair index, one lane per hit in the narrowphase (sg_math.h / sg_general.h).
+//
+// The code is BULK-SYNCHRONOUS: parallel loops over work items (SGT_PAR), single-lane sections (SGT_ONE) and barriers (SGT_SYNC)
+// between them; lanes talk through the env's LDS block and its global work space only.  That is what lets tests/emu run the very
+// same source on the host (a parallel loop becomes a serial loop, a wavefront sum the identity) against the oracle -- and the
+// sanitizers over it.  On the device the env's state lives in LDS for the whole call (all substeps in one launch).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/softgrip.h"
+#include "../../include/softgrip_model.h"
+#include "sg_general.h"
+#include "sg_plan.h"
+
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define SGT_DEVICE 1
+#else
+#define SGT_DEVICE 0
+#endif
+
+namespace sgt {
+using namespace sgm;
+
+#define SGT_MAXCON 128   // contacts of an env
+#define SGT_MAXHIT 256   // candidate pairs that pass the bounding tests
+#define SGT_HITREC 8     // contacts one pair can produce (box - box)
+#define SGT_RECW 10      // doubles of a staged narrowphase record: dist, pos[3], n[3], tangent hint[3]
+#define SGT_CSC 32       // scalar doubles of a contact record in the work space
+
+struct TreeArgs {
+  const SgPlanHeader* H;
+  const SgTreeDev* T;
+  const double* elem;        // SgPlan::elem (SoA over elements)
+  const SgGenPair* gpairs;
+  double *qpos, *qvel, *warm, *act, *ctrl;   // [n][nv], [n][nu]
+  const double* kenv;
+  const int *kmask_jnt, *kmask_ten;
+  const unsigned char* mask;  // mode 1: envs to reset (nullptr = all)
+  double* sens;
+  long long sens_stride;
+  int *flags, *touch, *touch_words, *ncon, *nefc, *iters;   // touch_words: [n][2], bit g = finger box g touches an object geom
+  double* cws;               // per-env work space, cws_stride doubles each
+  long long cws_stride;
+  int nenv, nsub, mode;      // mode 1: reset + one forward without integration, then nsub steps
+};
+
+// work-space layout (doubles): staged narrowphase records | contact rows
+SG_HD long long cws_row_doubles(int CS) { return 12LL * CS + SGT_CSC; }   // 2 blocks x (J, W) x 3 rows x CS + scalars
+SG_HD long long cws_doubles(int CS) { return (long long)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (long long)SGT_MAXCON * cws_row_doubles(CS); }
+
+// scalar part of a contact record
+enum { CS_A = 0, CS_B = 6, CS_F0 = 9, CS_R = 12, CS_INVM = 13, CS_JS = 14, CS_SL = 17, CS_C1 = 18, CS_N1 = 19, CS_C2 = 20, CS_N2 = 21,
+       CS_ROWS = 22, CS_TOUCH = 23 };
+
+struct Lds {
+  double *q, *v, *warm, *asm_, *aF, *fs, *fc, *bias, *tenJ, *kd, *qacc;
+  double *xpos, *xmat, *xipos, *ximat, *bw, *bal, *ba, *bf, *bn;
+  double *anchor, *axis, *gpos, *gmat, *spos;
+  double *M, *L, *Minv;
+  double *qe, *ve, *we, *asme, *ae, *fse, *ffix, *bfix, *Rfix, *flim, *blim, *Rlim, *ke;
+  double *lrow, *seg, *chs, *cf, *red;
+  int *hit_pair, *hit_sorted, *hit_cnt, *hit_off, *con_src, *icnt;
+};
+enum { IC_NHIT = 0, IC_NCON, IC_FLAGS, IC_NLIM0 /* + chain */, IC_N = IC_NLIM0 + SGT_MAXCH };
+// per-chain scalars in LDS (chs[c * CHS_N + ..])
+enum { CHS_TLEN = 0, CHS_TVEL, CHS_TFRC, CHS_AFRC, CHS_ACTDOT, CHS_ACT, CHS_CTRL, CHS_KT, CHS_N };
+
+SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N) {
+  double* p = base;
+  auto take = [&](size_t n) { double* r = p; p += (n + 1) & ~(size_t)1; return r; };
+  const int ND = T.ND, NB = T.NB;
+  L.q = take(ND); L.v = take(ND); L.warm = take(ND); L.asm_ = take(ND); L.aF = take(ND); L.fs = take(ND); L.fc = take(ND);
+  L.bias = take(ND); L.tenJ = take(ND); L.kd = take(ND); L.qacc = take(ND);
+  L.xpos = take(3 * NB); L.xmat = take(9 * NB); L.xipos = take(3 * NB); L.ximat = take(9 * NB); L.bw = take(3 * NB);
+  L.bal = take(3 * NB); L.ba = take(3 * NB); L.bf = take(3 * NB); L.bn = take(3 * NB);
+  L.anchor = take(3 * ND); L.axis = take(3 * ND); L.gpos = take(3 * T.NG); L.gmat = take(9 * T.NG); L.spos = take(3 * T.NS);
+  L.M = take(T.NMAT); L.L = take(T.NMAT); L.Minv = take(T.NMAT);
+  L.qe = take(N); L.ve = take(N); L.we = take(N); L.asme = take(N); L.ae = take(N); L.fse = take(N); L.ffix = take(N);
+  L.bfix = take(N); L.Rfix = take(N); L.flim = take(2 * N); L.blim = take(2 * N); L.Rlim = take(2 * N); L.ke = take(N);
+  L.lrow = take(5 * 2 * ND); L.seg = take(4 * SGT_MAXCH * SGT_MAXTS); L.chs = take(CHS_N * SGT_MAXCH); L.cf = take(3 * SGT_MAXCON);
+  L.red = take(16);
+  int* ip = (int*)p;
+  L.hit_pair = ip; ip += SGT_MAXHIT;
+  L.hit_sorted = ip; ip += SGT_MAXHIT;
+  L.hit_cnt = ip; ip += SGT_MAXHIT;
+  L.hit_off = ip; ip += SGT_MAXHIT;
+  L.con_src = ip; ip += SGT_MAXCON;
+  L.icnt = ip; ip += 32;
+  return (size_t)((char*)ip - (char*)base);
+}
+SG_HD size_t lds_bytes(const SgTreeDev& T, int N) {
+  Lds L;
+  return lds_carve(L, reinterpret_cast<double*>((uintptr_t)4096), T, N);
+}
+
+#if SGT_DEVICE
+#define SGT_PAR(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
+#define SGT_ONE if (threadIdx.x == 0)
+#define SGT_SYNC() __syncthreads()
+__device__ __forceinline__ double wsum(double x) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+  return x;
+}
+__device__ __forceinline__ int lds_inc(int* p) { return atomicAdd(p, 1); }
+#else
+#define SGT_PAR(i, n) for (int i = 0; i < (n); i++)
+#define SGT_ONE if (true)
+#define SGT_SYNC() ((void)0)
+inline double wsum(double x) { return x; }
+inline int lds_inc(int* p) { return (*p)++; }
+#endif
+
+// solve (L'DL) x = x for one chain block (MuJoCo's mj_solveLD on a serial chain: dof_parentid[k] = k - 1); Lc: nd x nd, row-major,
+// L[k][i] (i < k) below the diagonal, D on it
+SG_HD void chain_solve(const double* Lc, int nd, double* x) {
+  for (int k = nd - 1; k >= 1; k--) {
+    const double xk = x[k];
+    for (int i = k - 1; i >= 0; i--) x[i] -= Lc[k * nd + i] * xk;
+  }
+  for (int k = 0; k < nd; k++) x[k] /= Lc[k * nd + k];
+  for (int k = 1; k < nd; k++) {
+    double s = x[k];
+    for (int i = k - 1; i >= 0; i--) s -= Lc[k * nd + i] * x[i];
+    x[k] = s;
+  }
+}
+// in-place L'DL of a chain block (mj_factorM restricted to a serial chain)
+SG_HD void chain_factor(double* Lc, int nd) {
+  for (int k = nd - 1; k >= 1; k--) {
+    const double dk = Lc[k * nd + k];
+    for (int i = k - 1; i >= 0; i--) {
+      const double a = Lc[k * nd + i] / dk;
+      for (int j = i; j >= 0; j--) Lc[i * nd + j] -= a * Lc[k * nd + j];
+      Lc[k * nd + i] = a;
+    }
+  }
+}
+
+// the whole call for one env.  lane: threadIdx.x on the device, 0 on the host
+SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
+  const SgPlanHeader& H = *A.H;
+  const SgTreeDev& T = *A.T;
+  const int N = H.nelem, ND = T.ND, NB = T.NB, K = T.K, nv = H.nv, nu = H.nu, CS = T.CS;
+  const double h = H.timestep;
+  Lds S;
+  lds_carve(S, lds_base, T, N);
+  auto E = [&](int f, int e) { return A.elem[(size_t)f * N + e]; };
+  double* const cw = A.cws + (size_t)env * A.cws_stride;
+  double* const stage = cw;
+  double* const crow0 = cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW;
+  const long long CW = cws_row_doubles(CS);
+  auto crow = [&](int c) { return crow0 + (size_t)c * CW; };                 // J1[3][CS] | W1[3][CS] | J2[3][CS] | W2[3][CS] | scalars
+  auto cscal = [&](int c) { return crow0 + (size_t)c * CW + 12 * CS; };
+
+  if (A.mode == 1 && A.mask && !A.mask[env]) return;   // masked reset: the other envs keep everything
+  double* const gq = A.qpos + (size_t)env * nv;
+  double* const gv = A.qvel + (size_t)env * nv;
+  double* const gw = A.warm + (size_t)env * nv;
+  double* const gact = A.act + (size_t)env * (nu > 0 ? nu : 1);
+  double* const gctrl = A.ctrl + (size_t)env * (nu > 0 ? nu : 1);
+
+  // ---------------------------------------------------------------- state in
+  const double kenv = A.kenv[env];
+  SGT_PAR(d, ND) {
+    const int j = T.d_gid[d];
+    const bool rs = A.mode == 1;
+    S.q[d] = rs ? T.d_qpos0[d] : gq[j];
+    S.v[d] = rs ? 0.0 : gv[j];
+    S.warm[d] = rs ? 0.0 : gw[j];
+    S.kd[d] = A.kmask_jnt[j] ? kenv : T.d_stiffness[d];
+    S.qacc[d] = 0;
+  }
+  SGT_PAR(e, N) {
+    const int j = H.elem_dof0 + e;
+    const bool rs = A.mode == 1;
+    S.qe[e] = rs ? E(SGE_QPOS0, e) : gq[j];
+    S.ve[e] = rs ? 0.0 : gv[j];
+    S.we[e] = rs ? 0.0 : gw[j];
+    S.ke[e] = A.kmask_jnt[j] ? kenv : E(SGE_K0, e);
+  }
+  SGT_PAR(c, K) {
+    double* cs = S.chs + c * CHS_N;
+    const bool rs = A.mode == 1;
+    cs[CHS_ACT] = (T.a_has[c] && !rs) ? gact[T.a_id[c]] : 0.0;
+    cs[CHS_CTRL] = (T.a_has[c] && !rs) ? gctrl[T.a_id[c]] : 0.0;
+    cs[CHS_KT] = T.t_has[c] ? (A.kmask_ten[T.t_id[c]] ? kenv : T.t_k0[c]) : 0.0;
+  }
+  SGT_ONE {
+    for (int i = 0; i < 32; i++) S.icnt[i] = 0;
+    if (A.mode == 1)
+      for (int u = 0; u < nu; u++) gctrl[u] = 0.0;   // mj_resetData clears ctrl
+  }
+  const double kt0 = A.kmask_ten[H.t0_id] ? kenv : H.t0_k0;
+  SGT_SYNC();
+
+  int ncon = 0, nefc = 0, iters = 0, flags = 0;
+  unsigned touch_lo = 0, touch_hi = 0;
+  const int nfwd = A.nsub + (A.mode == 1 ? 1 : 0);
+  for (int sub = 0; sub < nfwd; sub++) {
+    const bool integrate = !(A.mode == 1 && sub == 0);
+    const bool last = sub == nfwd - 1;
+    // ---------------------------------------------------------------- mj_checkPos / mj_checkVel
+    {
+      double bad = 0;
+      SGT_PAR(d, ND) bad += (isbad(S.q[d]) ? 1.0 : 0.0) + (isbad(S.v[d]) ? 1024.0 : 0.0);
+      SGT_PAR(e, N) bad += (isbad(S.qe[e]) ? 1.0 : 0.0) + (isbad(S.ve[e]) ? 1024.0 : 0.0);
+      bad = wsum(bad);
+      if (bad > 0) {
+        const int nb = (int)bad;
+        if (nb % 1024) flags |= SG_FLAG_BADQPOS;
+        if (nb / 1024) flags |= SG_FLAG_BADQVEL;
+        break;   // uniform: the env stops integrating for the rest of the call
+      }
+    }
+    // ---------------------------------------------------------------- stage 1: kinematics, one lane per chain
+    SGT_PAR(c, K) {
+      double pos[3], quat[4], mat[9], ppos[3], pquat[4], pmat[9], t[3];
+      for (int k = 0; k < 3; k++) ppos[k] = T.c_root_pos[c][k];
+      for (int k = 0; k < 4; k++) pquat[k] = T.c_root_quat[c][k];
+      quat2mat(pmat, pquat);
+      for (int bi = 0; bi < T.c_nbody[c]; bi++) {
+        const int tb = T.c_body0[c] + bi;
+        mulmat3(t, pmat, T.b_pos[tb]);
+        for (int k = 0; k < 3; k++) pos[k] = ppos[k] + t[k];
+        quatmul(quat, pquat, T.b_quat[tb]);
+        for (int kj = 0; kj < T.b_njnt[tb]; kj++) {
+          const int d = T.b_dof0[tb] + kj;
+          quat2mat(mat, quat);
+          mulmat3(t, mat, T.d_pos[d]);
+          for (int k = 0; k < 3; k++) S.anchor[3 * d + k] = pos[k] + t[k];
+          mulmat3(S.axis + 3 * d, mat, T.d_axis[d]);
+          const double dq = S.q[d] - T.d_qpos0[d], sn = sin(0.5 * dq);
+          const double ql[4] = {cos(0.5 * dq), T.d_axis[d][0] * sn, T.d_axis[d][1] * sn, T.d_axis[d][2] * sn};
+          quatmul(quat, quat, ql);
+          quat2mat(mat, quat);
+          mulmat3(t, mat, T.d_pos[d]);
+          for (int k = 0; k < 3; k++) pos[k] = S.anchor[3 * d + k] - t[k];
+        }
+        const double nq = sqrt(quat[0] * quat[0] + quat[1] * quat[1] + quat[2] * quat[2] + quat[3] * quat[3]);
+        for (int k = 0; k < 4; k++) quat[k] /= nq;
+        quat2mat(mat, quat);
+        for (int k = 0; k < 3; k++) S.xpos[3 * tb + k] = pos[k];
+        for (int k = 0; k < 9; k++) S.xmat[9 * tb + k] = mat[k];
+        mulmat3(t, mat, T.b_ipos[tb]);
+        for (int k = 0; k < 3; k++) S.xipos[3 * tb + k] = pos[k] + t[k];
+        double RI[9], Rt[9];
+        mulmat33(RI, mat, T.b_imat[tb]);
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++) Rt[3 * a + b] = mat[3 * b + a];
+        mulmat33(S.ximat + 9 * tb, RI, Rt);
+        for (int k = 0; k < 3; k++) ppos[k] = pos[k];
+        for (int k = 0; k < 4; k++) pquat[k] = quat[k];
+        for (int k = 0; k < 9; k++) pmat[k] = mat[k];
+      }
+    }
+    SGT_SYNC();
+    SGT_PAR(g, T.NG) {
+      const int tb = T.g_body[g];
+      double t[3];
+      mulmat3(t, S.xmat + 9 * tb, T.g_pos[g]);
+      for (int k = 0; k < 3; k++) S.gpos[3 * g + k] = S.xpos[3 * tb + k] + t[k];
+      mulmat33(S.gmat + 9 * g, S.xmat + 9 * tb, T.g_mat[g]);
+    }
+    SGT_PAR(s, T.NS) {
+      const int tb = T.s_body[s];
+      double t[3];
+      mulmat3(t, S.xmat + 9 * tb, T.s_pos[s]);
+      for (int k = 0; k < 3; k++) S.spos[3 * s + k] = S.xpos[3 * tb + k] + t[k];
+    }
+    SGT_SYNC();
+    // ---------------------------------------------------------------- stage 3: tendons.  segments, then one lane per dof
+    SGT_PAR(i, K * SGT_MAXTS) {
+      const int c = i / SGT_MAXTS, w = i % SGT_MAXTS;
+      if (T.t_has[c] && w + 1 < T.t_nsite[c]) {
+        const int s0 = T.t_site[c][w], s1 = T.t_site[c][w + 1];
+        const double* p0 = s0 >= 0 ? S.spos + 3 * s0 : T.t_fixed[c][w];
+        const double* p1 = s1 >= 0 ? S.spos + 3 * s1 : T.t_fixed[c][w + 1];
+        double dif[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+        const double len = sqrt(dot3(dif, dif));
+        double* sg = S.seg + 4 * i;
+        sg[3] = len;
+        for (int k = 0; k < 3; k++) sg[k] = len < SG_MINVAL ? 0.0 : dif[k] / len;
+      }
+    }
+    SGT_SYNC();
+    SGT_PAR(d, ND) {
+      const int c = T.d_chain[d], dl = d - T.c_dof0[c];
+      double J = 0;
+      if (T.t_has[c])
+        for (int w = 0; w + 1 < T.t_nsite[c]; w++) {
+          const double* sg = S.seg + 4 * (c * SGT_MAXTS + w);
+          if (sg[3] < SG_MINVAL) continue;
+          const int s0 = T.t_site[c][w], s1 = T.t_site[c][w + 1];
+          double r[3], jp[3];
+          if (s1 >= 0 && T.b_nabove[T.s_body[s1]] > dl) {
+            for (int k = 0; k < 3; k++) r[k] = S.spos[3 * s1 + k] - S.anchor[3 * d + k];
+            cross3(jp, S.axis + 3 * d, r);
+            J += dot3(sg, jp);
+          }
+          if (s0 >= 0 && T.b_nabove[T.s_body[s0]] > dl) {
+            for (int k = 0; k < 3; k++) r[k] = S.spos[3 * s0 + k] - S.anchor[3 * d + k];
+            cross3(jp, S.axis + 3 * d, r);
+            J -= dot3(sg, jp);
+          }
+        }
+      S.tenJ[d] = J;
+    }
+    SGT_SYNC();
+    // tendon length / velocity, spring-damper and actuator force (stages 3, 7, 8), one lane per chain
+    SGT_PAR(c, K) {
+      double* cs = S.chs + c * CHS_N;
+      double Lt = 0, vel = 0;
+      if (T.t_has[c]) {
+        for (int w = 0; w + 1 < T.t_nsite[c]; w++) Lt += S.seg[4 * (c * SGT_MAXTS + w) + 3];
+        for (int dl = 0; dl < T.c_ndof[c]; dl++) vel += S.tenJ[T.c_dof0[c] + dl] * S.v[T.c_dof0[c] + dl];
+      }
+      cs[CHS_TLEN] = Lt; cs[CHS_TVEL] = vel;
+      cs[CHS_TFRC] = T.t_has[c] ? -cs[CHS_KT] * (Lt - T.t_lspring[c]) - T.t_damping[c] * vel : 0.0;
+      double afrc = 0, adot = 0;
+      if (T.a_has[c]) {
+        const double g = T.a_gear[c];
+        adot = (cs[CHS_CTRL] - cs[CHS_ACT]) / fmax(SG_MINVAL, T.a_tc[c]);
+        afrc = T.a_gain[c] * cs[CHS_ACT] + T.a_bias[c][0] + T.a_bias[c][1] * (g * Lt) + T.a_bias[c][2] * (g * vel);
+        afrc *= g;   // qfrc_actuator = gear * J * force
+      }
+      cs[CHS_AFRC] = afrc; cs[CHS_ACTDOT] = adot;
+    }
+    // ---------------------------------------------------------------- stage 4: mass matrix, one lane per entry of the lower triangles
+    SGT_PAR(i, T.NMAT) {
+      int c = 0;
+      while (c + 1 < K && i >= T.c_mat0[c + 1]) c++;
+      const int nd = T.c_ndof[c], a = (i - T.c_mat0[c]) / nd, b = (i - T.c_mat0[c]) % nd;
+      if (b <= a) {
+        const int da = T.c_dof0[c] + a, db = T.c_dof0[c] + b;
+        double s = a == b ? T.d_armature[da] : 0.0;
+        for (int tb = T.d_body[da]; tb < T.c_body0[c] + T.c_nbody[c]; tb++) {
+          const double mass = T.b_mass[tb];
+          if (mass <= 0) continue;
+          double ra[3], rb[3], ja[3], jb[3], Ir[3];
+          for (int k = 0; k < 3; k++) { ra[k] = S.xipos[3 * tb + k] - S.anchor[3 * da + k]; rb[k] = S.xipos[3 * tb + k] - S.anchor[3 * db + k]; }
+          cross3(ja, S.axis + 3 * da, ra);
+          cross3(jb, S.axis + 3 * db, rb);
+          mulmat3(Ir, S.ximat + 9 * tb, S.axis + 3 * da);
+          s += mass * dot3(ja, jb) + dot3(Ir, S.axis + 3 * db);
+        }
+        S.M[T.c_mat0[c] + a * nd + b] = s;
+        S.M[T.c_mat0[c] + b * nd + a] = s;
+      }
+    }
+    SGT_SYNC();
+    SGT_PAR(i, T.NMAT) S.L[i] = S.M[i];
+    SGT_SYNC();
+    SGT_PAR(c, K) chain_factor(S.L + T.c_mat0[c], T.c_ndof[c]);
+    SGT_SYNC();
+    SGT_PAR(d, ND) {   // M^-1 by columns (= rows): solve for the unit vector of dof d
+      const int c = T.d_chain[d], nd = T.c_ndof[c], dl = d - T.c_dof0[c];
+      double* x = S.Minv + T.c_mat0[c] + dl * nd;
+      for (int k = 0; k < nd; k++) x[k] = k == dl ? 1.0 : 0.0;
+      chain_solve(S.L + T.c_mat0[c], nd, x);
+    }
+    // ---------------------------------------------------------------- stage 7: bias forces (RNE with qacc = 0), body velocities
+    auto tree_motion = [&](const double* qacc) {
+      SGT_PAR(c, K) {
+        double w[3] = {0, 0, 0}, al[3] = {0, 0, 0}, a[3] = {-H.gravity[0], -H.gravity[1], -H.gravity[2]}, P[3], r[3], t[3], t2[3];
+        for (int k = 0; k < 3; k++) P[k] = T.c_root_pos[c][k];
+        for (int bi = 0; bi < T.c_nbody[c]; bi++) {
+          const int tb = T.c_body0[c] + bi;
+          for (int kj = 0; kj <= T.b_njnt[tb]; kj++) {
+            const bool lastj = kj == T.b_njnt[tb];
+            const int d = T.b_dof0[tb] + kj;
+            const double* Q = lastj ? S.xpos + 3 * tb : S.anchor + 3 * d;
+            for (int k = 0; k < 3; k++) r[k] = Q[k] - P[k];
+            cross3(t, w, r);
+            cross3(t2, al, r); addscl3(a, t2, 1);
+            cross3(t2, w, t); addscl3(a, t2, 1);
+            for (int k = 0; k < 3; k++) P[k] = Q[k];
+            if (lastj) break;
+            const double* u = S.axis + 3 * d;
+            const double qd = S.v[d], qdd = qacc ? qacc[d] : 0.0;
+            cross3(t, w, u);
+            addscl3(al, u, qdd); addscl3(al, t, qd);
+            addscl3(w, u, qd);
+          }
+          for (int k = 0; k < 3; k++) { S.bw[3 * tb + k] = w[k]; S.bal[3 * tb + k] = al[k]; S.ba[3 * tb + k] = a[k]; }
+        }
+      }
+    };
+    tree_motion(nullptr);
+    SGT_SYNC();
+    SGT_PAR(tb, NB) {
+      const double *w = S.bw + 3 * tb, *al = S.bal + 3 * tb;
+      double c[3], t[3], t2[3], f[3], n[3], Iw[3];
+      for (int k = 0; k < 3; k++) { c[k] = S.xipos[3 * tb + k] - S.xpos[3 * tb + k]; f[k] = S.ba[3 * tb + k]; }
+      cross3(t, al, c); addscl3(f, t, 1);
+      cross3(t, w, c); cross3(t2, w, t); addscl3(f, t2, 1);
+      for (int k = 0; k < 3; k++) f[k] *= T.b_mass[tb];
+      mulmat3(n, S.ximat + 9 * tb, al);
+      mulmat3(Iw, S.ximat + 9 * tb, w);
+      cross3(t, w, Iw); addscl3(n, t, 1);
+      for (int k = 0; k < 3; k++) { S.bf[3 * tb + k] = f[k]; S.bn[3 * tb + k] = n[k]; }
+    }
+    SGT_SYNC();
+    SGT_PAR(d, ND) {
+      const int c = T.d_chain[d];
+      double s = 0;
+      for (int tb = T.d_body[d]; tb < T.c_body0[c] + T.c_nbody[c]; tb++) {
+        if (T.b_mass[tb] <= 0) continue;
+        double r[3], jp[3];
+        for (int k = 0; k < 3; k++) r[k] = S.xipos[3 * tb + k] - S.anchor[3 * d + k];
+        cross3(jp, S.axis + 3 * d, r);
+        s += dot3(jp, S.bf + 3 * tb) + dot3(S.axis + 3 * d, S.bn + 3 * tb);
+      }
+      S.bias[d] = s;
+      // passive (joint spring / damper, tendon spring / damper) - bias + actuator
+      const double* cs = S.chs + c * CHS_N;
+      const double pas = -S.kd[d] * (S.q[d] - T.d_springref[d]) - T.d_damping[d] * S.v[d] + S.tenJ[d] * cs[CHS_TFRC];
+      S.fs[d] = pas - s + S.tenJ[d] * cs[CHS_AFRC];
+      S.asm_[d] = S.fs[d];
+    }
+    SGT_SYNC();
+    SGT_PAR(c, K) chain_solve(S.L + T.c_mat0[c], T.c_ndof[c], S.asm_ + T.c_dof0[c]);
+    // ---------------------------------------------------------------- the composite's sliders: smooth forces (stages 7 - 9)
+    double t0_len = 0, t0_vel = 0;
+    SGT_PAR(e, N) { t0_len += E(SGE_COEF, e) * S.qe[e]; t0_vel += E(SGE_COEF, e) * S.ve[e]; }
+    t0_len = wsum(t0_len); t0_vel = wsum(t0_vel);
+    const double t0_frc = -kt0 * (t0_len - H.t0_lspring) - H.t0_damping * t0_vel;
+    SGT_PAR(e, N) {
+      const double m = E(SGE_MASS, e), ga = H.gravity[0] * E(SGE_AX, e) + H.gravity[1] * E(SGE_AY, e) + H.gravity[2] * E(SGE_AZ, e);
+      const double pas = -S.ke[e] * (S.qe[e] - E(SGE_SPRINGREF, e)) - E(SGE_DAMPING, e) * S.ve[e] + E(SGE_COEF, e) * t0_frc;
+      S.fse[e] = pas + m * ga;   // - bias, bias = -m g . axis
+      S.asme[e] = S.fse[e] / (m + E(SGE_ARMATURE, e));
+    }
+    SGT_SYNC();
+
+    // ---------------------------------------------------------------- stage 5: collision over the candidate-pair table
+    SGT_ONE { S.icnt[IC_NHIT] = 0; }
+    SGT_SYNC();
+    auto elem_center = [&](int e, double* c) {
+      const double dq = S.qe[e] - E(SGE_QPOS0, e);
+      c[0] = E(SGE_GX, e) + E(SGE_AX, e) * dq; c[1] = E(SGE_GY, e) + E(SGE_AY, e) * dq; c[2] = E(SGE_GZ, e) + E(SGE_AZ, e) * dq;
+    };
+    SGT_PAR(p, H.ngpair) {
+      const SgGenPair gp = A.gpairs[p];
+      const int i1 = sgg_index(gp.g1), i2 = sgg_index(gp.g2), k2 = sgg_kind(gp.g2);
+      bool hit = false;
+      if (gp.kind == SGP_PLANE_CAP || gp.kind == SGP_PLANE_BOX) {
+        double c[3], rb;
+        if (gp.kind == SGP_PLANE_CAP) { elem_center(i2, c); rb = H.cap_rbound; }
+        else if (k2 == SGG_BOX) { for (int k = 0; k < 3; k++) c[k] = S.gpos[3 * i2 + k]; rb = T.g_rbound[i2]; }
+        else { for (int k = 0; k < 3; k++) c[k] = H.st_pos[i2][k]; rb = H.st_rbound[i2]; }
+        const double dif[3] = {c[0] - H.plane_pos[0], c[1] - H.plane_pos[1], c[2] - H.plane_pos[2]};
+        hit = !(dot3(dif, H.plane_normal) > H.con_margin + rb);
+      } else if (gp.kind != SGP_UNSUPPORTED) {
+        // geom2 is a box (finger or static); geom1 the centre sphere, an element capsule or a box
+        const double* bp = k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[i2];
+        const double rb2 = k2 == SGG_BOX ? T.g_rbound[i2] : H.st_rbound[i2];
+        double c[3], rb1;
+        const int k1 = sgg_kind(gp.g1);
+        if (k1 == SGG_CENTER) { for (int k = 0; k < 3; k++) c[k] = H.center_pos[k]; rb1 = H.center_radius; }
+        else if (k1 == SGG_ELEM) { elem_center(i1, c); rb1 = H.cap_rbound; }
+        else if (k1 == SGG_BOX) { for (int k = 0; k < 3; k++) c[k] = S.gpos[3 * i1 + k]; rb1 = T.g_rbound[i1]; }
+        else { for (int k = 0; k < 3; k++) c[k] = H.st_pos[i1][k]; rb1 = H.st_rbound[i1]; }
+        const double dif[3] = {bp[0] - c[0], bp[1] - c[1], bp[2] - c[2]}, bound = rb1 + rb2 + H.con_margin;
+        hit = !(dot3(dif, dif) > bound * bound);
+        if (hit && k1 == SGG_ELEM) {   // tighter: the capsule's bounding sphere against the box itself
+          const double* bm = k2 == SGG_BOX ? S.gmat + 9 * i2 : H.st_mat[i2];
+          const double* sz = k2 == SGG_BOX ? T.g_size[i2] : H.st_size[i2];
+          const double t[3] = {-dif[0], -dif[1], -dif[2]};
+          double loc[3];
+          mulmatT3(loc, bm, t);
+          hit = !(box_sdist(loc, sz) - H.cap_rbound > H.con_margin);
+        }
+      } else {
+        hit = false;   // a pair with other contact parameters: never generated (plan: SGP_UNSUPPORTED keeps its place only)
+      }
+      if (hit) {
+        const int idx = lds_inc(&S.icnt[IC_NHIT]);
+        if (idx < SGT_MAXHIT) S.hit_pair[idx] = p;
+      }
+    }
+    SGT_SYNC();
+    int nhit = S.icnt[IC_NHIT];
+    if (nhit > SGT_MAXHIT) { nhit = SGT_MAXHIT; flags |= SG_FLAG_CONTACTFULL; }
+    SGT_PAR(i, nhit) {   // rank by pair index = mj_collision's order
+      const int p = S.hit_pair[i];
+      int r = 0;
+      for (int j = 0; j < nhit; j++) r += S.hit_pair[j] < p ? 1 : 0;
+      S.hit_sorted[r] = p;
+    }
+    SGT_SYNC();
+    SGT_PAR(i, nhit) {   // narrowphase, one lane per hit
+      const SgGenPair gp = A.gpairs[S.hit_sorted[i]];
+      const int i1 = sgg_index(gp.g1), i2 = sgg_index(gp.g2), k1 = sgg_kind(gp.g1), k2 = sgg_kind(gp.g2);
+      double* out = stage + (size_t)i * SGT_HITREC * SGT_RECW;
+      int n = 0;
+      auto put = [&](const ConRec& r, const double* hint) {
+        double* o = out + n * SGT_RECW;
+        o[0] = r.dist;
+        for (int k = 0; k < 3; k++) { o[1 + k] = r.pos[k]; o[4 + k] = r.n[k]; o[7 + k] = hint ? hint[k] : 0.0; }
+        n++;
+      };
+      const double* bp = k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[i2];
+      const double* bm = k2 == SGG_BOX ? S.gmat + 9 * i2 : H.st_mat[i2];
+      const double* sz = k2 == SGG_BOX ? T.g_size[i2] : H.st_size[i2];
+      if (gp.kind == SGP_PLANE_CAP) {
+        double c[3];
+        elem_center(i2, c);
+        const double cax[3] = {E(SGE_CX, i2), E(SGE_CY, i2), E(SGE_CZ, i2)};
+        ConRec r0, r1;
+        const int m = gen_plane_capsule(H.plane_pos, H.plane_normal, c, cax, H.cap_radius, H.cap_hl, H.con_margin, r0, r1);
+        if (m > 0) put(r0, cax);
+        if (m > 1) put(r1, cax);
+      } else if (gp.kind == SGP_PLANE_BOX) {
+        ConRec r[4];
+        const int m = gen_plane_box(H.plane_pos, H.plane_normal, bp, bm, sz, H.con_margin, r);
+        for (int k = 0; k < m; k++) put(r[k], nullptr);
+      } else if (gp.kind == SGP_SPH_BOX) {
+        ConRec r0;
+        if (sphere_box(H.center_pos, H.center_radius, bp, bm, sz, H.con_margin, r0)) put(r0, nullptr);
+      } else if (gp.kind == SGP_CAP_BOX) {
+        double c[3];
+        elem_center(i1, c);
+        const double cax[3] = {E(SGE_CX, i1), E(SGE_CY, i1), E(SGE_CZ, i1)};
+        ConRec r0, r1;
+        const int m = capsule_box(c, cax, H.cap_radius, H.cap_hl, bp, bm, sz, H.con_margin, r0, r1);
+        if (m & 1) put(r0, nullptr);
+        if (m & 2) put(r1, nullptr);
+      } else if (gp.kind == SGP_BOX_BOX) {
+        const double* p1 = k1 == SGG_BOX ? S.gpos + 3 * i1 : H.st_pos[i1];
+        const double* R1 = k1 == SGG_BOX ? S.gmat + 9 * i1 : H.st_mat[i1];
+        const double* s1 = k1 == SGG_BOX ? T.g_size[i1] : H.st_size[i1];
+        ConRec r[8];
+        double poly[16][3], tmp[16][3];
+        const int m = gen_box_box(p1, R1, s1, bp, bm, sz, H.con_margin, r, poly, tmp);
+        for (int k = 0; k < m; k++) put(r[k], nullptr);
+      }
+      S.hit_cnt[i] = n;
+    }
+    SGT_SYNC();
+    SGT_ONE {
+      int off = 0;
+      for (int i = 0; i < nhit; i++) { S.hit_off[i] = off; off += S.hit_cnt[i]; }
+      S.icnt[IC_NCON] = off;
+    }
+    SGT_SYNC();
+    ncon = S.icnt[IC_NCON];
+    if (ncon > SGT_MAXCON) { ncon = SGT_MAXCON; flags |= SG_FLAG_CONTACTFULL; }
+    SGT_PAR(i, nhit)
+      for (int k = 0; k < S.hit_cnt[i]; k++)
+        if (S.hit_off[i] + k < SGT_MAXCON) S.con_src[S.hit_off[i] + k] = i * SGT_HITREC + k;
+    SGT_SYNC();
+
+    // ---------------------------------------------------------------- stage 6: constraint rows
+    // (a) equality rows: one joint-fix row per element, the tendon-fix row over all sliders
+    double tj_pos = 0, tj_vel = 0, tj_asm = 0, tj_warm = 0, tj_A = 0;
+    SGT_PAR(e, N) {
+      const double pos = S.qe[e] - E(SGE_QPOS0, e), imp = impedance(H.eqj_solimp, pos, 0.0);
+      const double R = fmax(SG_MINVAL, (1 - imp) / imp * E(SGE_INVW, e));
+      const double aref = -H.eqj_B * S.ve[e] - H.eqj_K * imp * pos;
+      S.Rfix[e] = R; S.bfix[e] = S.asme[e] - aref;
+      S.ffix[e] = -(S.we[e] - aref) / R;
+      const double co = E(SGE_COEF, e), invm = 1.0 / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
+      tj_pos += co * S.qe[e]; tj_vel += co * S.ve[e]; tj_asm += co * S.asme[e]; tj_warm += co * S.we[e]; tj_A += co * co * invm;
+      // (d) limit rows of the slider: slot 0 lower side, slot 1 upper side (MuJoCo's order)
+      for (int sd = 0; sd < 2; sd++) {
+        const int side = 2 * sd - 1;
+        double Rl = 0, bl = 0, fl = 0;   // R = 0 marks an inactive slot
+        if (E(SGE_LIMITED, e) != 0.0) {
+          const double dist = side * ((sd ? E(SGE_RHI, e) : E(SGE_RLO, e)) - S.qe[e]);
+          if (dist < H.lime_margin) {
+            const double sg = -side, impl = impedance(H.lime_solimp, dist, H.lime_margin);
+            Rl = fmax(SG_MINVAL, (1 - impl) / impl * E(SGE_INVW, e));
+            const double arefl = -H.lime_B * sg * S.ve[e] - H.lime_K * impl * (dist - H.lime_margin);
+            const double jar = sg * S.we[e] - arefl;
+            bl = sg * S.asme[e] - arefl;
+            fl = jar < 0 ? -jar / Rl : 0.0;
+          }
+        }
+        S.Rlim[2 * e + sd] = Rl; S.blim[2 * e + sd] = bl; S.flim[2 * e + sd] = fl;
+      }
+    }
+    tj_pos = wsum(tj_pos); tj_vel = wsum(tj_vel); tj_asm = wsum(tj_asm); tj_warm = wsum(tj_warm); tj_A = wsum(tj_A);
+    double ten_R, ten_b, ten_f;
+    {
+      const double pos = tj_pos - H.t0_L0, imp = impedance(H.eqt_solimp, pos, 0.0);
+      ten_R = fmax(SG_MINVAL, (1 - imp) / imp * H.eqt_invw);
+      const double aref = -H.eqt_B * tj_vel - H.eqt_K * imp * pos;
+      ten_b = tj_asm - aref;
+      ten_f = -(tj_warm - aref) / ten_R;
+    }
+    // (c) limit rows of the chain dofs, one lane per chain: compact list in dof order, lower side first
+    SGT_PAR(c, K) {
+      int n = 0;
+      double* rows = S.lrow + 5 * 2 * T.c_dof0[c];
+      for (int dl = 0; dl < T.c_ndof[c]; dl++) {
+        const int d = T.c_dof0[c] + dl;
+        if (!T.d_limited[d]) continue;
+        for (int sd = 0; sd < 2; sd++) {
+          const int side = 2 * sd - 1;
+          const double dist = side * (T.d_range[d][sd] - S.q[d]);
+          if (!(dist < T.d_margin[d])) continue;
+          const double sg = -side, imp = impedance(T.d_solimp[d], dist, T.d_margin[d]);
+          const double R = fmax(SG_MINVAL, (1 - imp) / imp * T.d_invw[d]);
+          const double aref = -T.d_limB[d] * sg * S.v[d] - T.d_limK[d] * imp * (dist - T.d_margin[d]);
+          const double jar = sg * S.warm[d] - aref;
+          double* r = rows + 5 * n++;
+          r[0] = dl; r[1] = sg; r[2] = R; r[3] = sg * S.asm_[d] - aref; r[4] = jar < 0 ? -jar / R : 0.0;
+        }
+      }
+      S.icnt[IC_NLIM0 + c] = n;
+    }
+    // (e) contact rows, one lane per contact
+    SGT_PAR(ci, ncon) {
+      const int src = S.con_src[ci], hi = src / SGT_HITREC;
+      const double* rec = stage + (size_t)src * SGT_RECW;
+      const SgGenPair gp = A.gpairs[S.hit_sorted[hi]];
+      double* J1 = crow(ci);
+      double *W1 = J1 + 3 * CS, *J2 = J1 + 6 * CS, *W2 = J1 + 9 * CS, *sc = cscal(ci);
+      double fr[9];
+      const double hint[3] = {rec[7], rec[8], rec[9]};
+      make_frame_hint(rec + 4, (hint[0] != 0 || hint[1] != 0 || hint[2] != 0) ? hint : nullptr, fr);
+      // the two sides: geom1's body enters the row with -, geom2's with +
+      int ch[2] = {-1, -1}, nd[2] = {0, 0}, sl = -1, touchbit = -1;
+      double binvw = 0, Js[3] = {0, 0, 0}, invm = 0;
+      bool obj = false;
+      int nblk = 0;
+      for (int side = 0; side < 2; side++) {
+        const int ref = side ? gp.g2 : gp.g1, kind = sgg_kind(ref), idx = sgg_index(ref);
+        const double sg = side ? 1.0 : -1.0;
+        if (kind == SGG_BOX) {
+          const int tb = T.g_body[idx], c = T.b_chain[tb], n = T.b_nabove[tb], d0 = T.c_dof0[c];
+          binvw += T.b_invw[tb];
+          touchbit = idx;
+          int blk = -1;
+          for (int b = 0; b < nblk; b++)
+            if (ch[b] == c) blk = b;
+          const bool fresh = blk < 0;
+          if (fresh) { blk = nblk++; ch[blk] = c; nd[blk] = 0; }
+          double* J = blk ? J2 : J1;
+          const int nold = nd[blk];
+          for (int dl = 0; dl < (n > nold ? n : nold); dl++) {
+            double jp[3] = {0, 0, 0};
+            if (dl < n) {
+              double r[3];
+              for (int k = 0; k < 3; k++) r[k] = rec[1 + k] - S.anchor[3 * (d0 + dl) + k];
+              cross3(jp, S.axis + 3 * (d0 + dl), r);
+            }
+            for (int rr = 0; rr < 3; rr++) {
+              const double add = sg * dot3(fr + 3 * rr, jp);
+              J[rr * CS + dl] = (dl < nold ? J[rr * CS + dl] : 0.0) + add;
+            }
+          }
+          if (n > nold) nd[blk] = n;
+        } else if (kind == SGG_ELEM) {
+          sl = idx; obj = true;
+          binvw += E(SGE_BINVW, idx);
+          invm = 1.0 / (E(SGE_MASS, idx) + E(SGE_ARMATURE, idx));
+          const double ax[3] = {E(SGE_AX, idx), E(SGE_AY, idx), E(SGE_AZ, idx)};
+          for (int rr = 0; rr < 3; rr++) Js[rr] += sg * dot3(fr + 3 * rr, ax);
+        } else if (kind == SGG_CENTER) {
+          obj = true;
+        }
+      }
+      // W = J M^-1 over the whole chain, A = J M^-1 J' + R
+      double Am[6] = {0, 0, 0, 0, 0, 0}, vel[3], js[3], jw[3];
+      for (int rr = 0; rr < 3; rr++) {
+        vel[rr] = sl >= 0 ? Js[rr] * S.ve[sl] : 0.0;
+        js[rr] = sl >= 0 ? Js[rr] * S.asme[sl] : 0.0;
+        jw[rr] = sl >= 0 ? Js[rr] * S.we[sl] : 0.0;
+      }
+      for (int b = 0; b < nblk; b++) {
+        const int c = ch[b], ndc = T.c_ndof[c], d0 = T.c_dof0[c], n = nd[b];
+        const double* Mi = S.Minv + T.c_mat0[c];
+        double* J = b ? J2 : J1;
+        double* W = b ? W2 : W1;
+        for (int rr = 0; rr < 3; rr++) {
+          for (int dl = 0; dl < ndc; dl++) {
+            double s = 0;
+            for (int e2 = 0; e2 < n; e2++) s += J[rr * CS + e2] * Mi[e2 * ndc + dl];
+            W[rr * CS + dl] = s;
+          }
+          for (int dl = 0; dl < n; dl++) {
+            vel[rr] += J[rr * CS + dl] * S.v[d0 + dl];
+            js[rr] += J[rr * CS + dl] * S.asm_[d0 + dl];
+            jw[rr] += J[rr * CS + dl] * S.warm[d0 + dl];
+          }
+        }
+        int k = 0;
+        for (int rr = 0; rr < 3; rr++)
+          for (int s2 = rr; s2 < 3; s2++) {
+            double s = 0;
+            for (int dl = 0; dl < n; dl++) s += W[rr * CS + dl] * J[s2 * CS + dl];
+            Am[k++] += s;
+          }
+      }
+      const double dist = rec[0], imp = impedance(H.con_solimp, dist, H.con_margin);
+      const double R = fmax(SG_MINVAL, (1 - imp) / imp * binvw), D = 1 / R;
+      {
+        int k = 0;
+        for (int rr = 0; rr < 3; rr++)
+          for (int s2 = rr; s2 < 3; s2++) { Am[k] += Js[rr] * Js[s2] * invm + (rr == s2 ? R : 0.0); k++; }
+      }
+      double bb[3], jar[3];
+      for (int rr = 0; rr < 3; rr++) {
+        const double aref = -H.con_B * vel[rr] - (rr == 0 ? H.con_K * imp * (dist - H.con_margin) : 0.0);
+        bb[rr] = js[rr] - aref;
+        jar[rr] = jw[rr] - aref;
+      }
+      double f[3];
+      {  // warmstart force: primal -> dual map of the elliptic cone (mj_constraintUpdate)
+        const double mu = H.con_mu[0], U0 = jar[0] * mu, U1 = jar[1] * H.con_mu[0], U2 = jar[2] * H.con_mu[1];
+        const double Nn = U0, Tt = sqrt(U1 * U1 + U2 * U2);
+        if (Nn >= mu * Tt || (Tt <= 0 && Nn >= 0)) { f[0] = f[1] = f[2] = 0; }
+        else if (mu * Nn + Tt <= 0 || (Tt <= 0 && Nn < 0)) { for (int rr = 0; rr < 3; rr++) f[rr] = -D * jar[rr]; }
+        else {
+          const double Dm = D / (mu * mu * (1 + mu * mu)), NmT = Nn - mu * Tt;
+          f[0] = -Dm * NmT * mu;
+          f[1] = -f[0] / Tt * U1 * H.con_mu[0];
+          f[2] = -f[0] / Tt * U2 * H.con_mu[1];
+        }
+      }
+      const bool rows = dist < H.con_margin;   // mj_makeConstraint: a contact at dist >= margin - gap is listed but gets no rows
+      for (int k = 0; k < 6; k++) sc[CS_A + k] = Am[k];
+      for (int k = 0; k < 3; k++) { sc[CS_B + k] = bb[k]; sc[CS_F0 + k] = rows ? f[k] : 0.0; sc[CS_JS + k] = Js[k]; S.cf[3 * ci + k] = rows ? f[k] : 0.0; }
+      sc[CS_R] = R; sc[CS_INVM] = invm; sc[CS_SL] = sl;
+      sc[CS_C1] = ch[0]; sc[CS_N1] = nd[0]; sc[CS_C2] = ch[1]; sc[CS_N2] = nd[1];
+      sc[CS_ROWS] = rows ? 1.0 : 0.0;
+      sc[CS_TOUCH] = (obj && touchbit >= 0) ? touchbit : -1;
+    }
+    SGT_SYNC();
+    // row count (nefc) and the touch bits of this contact list
+    {
+      int nl = 0;
+      for (int c = 0; c < K; c++) nl += S.icnt[IC_NLIM0 + c];
+      double cnt = 0;
+      SGT_PAR(e, N) cnt += (S.Rlim[2 * e] != 0.0 ? 1.0 : 0.0) + (S.Rlim[2 * e + 1] != 0.0 ? 1.0 : 0.0);
+      SGT_PAR(ci, ncon) cnt += cscal(ci)[CS_ROWS] != 0.0 ? 3.0 : 0.0;
+      nefc = N + 1 + nl + (int)wsum(cnt);
+      touch_lo = touch_hi = 0;
+      for (int ci = 0; ci < ncon; ci++) {   // uniform loop: every lane ends up with the same words
+        const int tbit = (int)cscal(ci)[CS_TOUCH];
+        if (tbit >= 0 && tbit < 32) touch_lo |= 1u << tbit;
+        else if (tbit >= 32 && tbit < 64) touch_hi |= 1u << (tbit - 32);
+      }
+    }
+
+    // ---------------------------------------------------------------- stage 10: warmstart (kept only if it beats f = 0), PGS
+    // a = M^-1 J' f of the current forces: chains in aF, sliders in ae
+    auto apply_all = [&]() {
+      SGT_PAR(e, N) {
+        const double invm = 1.0 / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
+        S.ae[e] = invm * (S.ffix[e] + E(SGE_COEF, e) * ten_f + S.flim[2 * e] - S.flim[2 * e + 1]);
+      }
+      SGT_PAR(d, ND) {
+        const int c = T.d_chain[d], ndc = T.c_ndof[c], dl = d - T.c_dof0[c];
+        const double* rows = S.lrow + 5 * 2 * T.c_dof0[c];
+        double s = 0;
+        for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) s += S.Minv[T.c_mat0[c] + (int)rows[5 * i] * ndc + dl] * rows[5 * i + 1] * rows[5 * i + 4];
+        S.aF[d] = s;
+      }
+      SGT_SYNC();
+      for (int ci = 0; ci < ncon; ci++) {   // contacts add their pushes one after the other (a slider / chain may be shared)
+        const double* sc = cscal(ci);
+        if (sc[CS_ROWS] == 0.0) continue;
+        const double* f = S.cf + 3 * ci;
+        const int c1 = (int)sc[CS_C1], c2 = (int)sc[CS_C2], n1c = c1 >= 0 ? T.c_ndof[c1] : 0, n2c = c2 >= 0 ? T.c_ndof[c2] : 0;
+        SGT_PAR(i, n1c + n2c) {
+          const bool second = i >= n1c;
+          const int dl = second ? i - n1c : i;
+          const double* W = crow(ci) + (second ? 9 * CS : 3 * CS);
+          S.aF[T.c_dof0[second ? c2 : c1] + dl] += W[dl] * f[0] + W[CS + dl] * f[1] + W[2 * CS + dl] * f[2];
+        }
+        SGT_ONE {
+          const int sl = (int)sc[CS_SL];
+          if (sl >= 0) S.ae[sl] += sc[CS_INVM] * (sc[CS_JS] * f[0] + sc[CS_JS + 1] * f[1] + sc[CS_JS + 2] * f[2]);
+        }
+        SGT_SYNC();
+      }
+    };
+    apply_all();
+    {
+      double cost = 0, S_ae = 0;
+      SGT_PAR(e, N) {
+        S_ae += E(SGE_COEF, e) * S.ae[e];
+        cost += S.ffix[e] * (0.5 * (S.ae[e] + S.Rfix[e] * S.ffix[e]) + S.bfix[e]);
+        cost += S.flim[2 * e] * (0.5 * (S.ae[e] + S.Rlim[2 * e] * S.flim[2 * e]) + S.blim[2 * e]);
+        cost += S.flim[2 * e + 1] * (0.5 * (-S.ae[e] + S.Rlim[2 * e + 1] * S.flim[2 * e + 1]) + S.blim[2 * e + 1]);
+      }
+      SGT_PAR(c, K) {
+        const double* rows = S.lrow + 5 * 2 * T.c_dof0[c];
+        for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) {
+          const double* r = rows + 5 * i;
+          cost += r[4] * (0.5 * (r[1] * S.aF[T.c_dof0[c] + (int)r[0]] + r[2] * r[4]) + r[3]);
+        }
+      }
+      SGT_PAR(ci, ncon) {
+        const double* sc = cscal(ci);
+        if (sc[CS_ROWS] == 0.0) continue;
+        const double* f = S.cf + 3 * ci;
+        const int sl = (int)sc[CS_SL];
+        for (int rr = 0; rr < 3; rr++) {
+          double ja = sl >= 0 ? sc[CS_JS + rr] * S.ae[sl] : 0.0;
+          for (int b = 0; b < 2; b++) {
+            const int c = (int)sc[b ? CS_C2 : CS_C1], n = (int)sc[b ? CS_N2 : CS_N1];
+            if (c < 0) continue;
+            const double* J = crow(ci) + (b ? 6 * CS : 0) + rr * CS;
+            for (int dl = 0; dl < n; dl++) ja += J[dl] * S.aF[T.c_dof0[c] + dl];
+          }
+          cost += f[rr] * (0.5 * (ja + sc[CS_R] * f[rr]) + sc[CS_B + rr]);
+        }
+      }
+      S_ae = wsum(S_ae);
+      cost = wsum(cost) + ten_f * (0.5 * (S_ae + ten_R * ten_f) + ten_b);
+      if (cost > 0) {   // uniform
+        ten_f = 0;
+        SGT_PAR(e, N) { S.ffix[e] = 0; S.flim[2 * e] = 0; S.flim[2 * e + 1] = 0; S.ae[e] = 0; }
+        SGT_PAR(d, ND) S.aF[d] = 0;
+        SGT_PAR(c, K)
+          for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) S.lrow[5 * (2 * T.c_dof0[c] + i) + 4] = 0;
+        SGT_PAR(i, 3 * ncon) S.cf[i] = 0;
+      }
+      SGT_SYNC();
+    }
+    iters = 0;
+    for (int it = 0; it < H.iterations; it++) {
+      double imp_par = 0, imp_uni = 0;
+      // joint-fix rows: each on its own slider
+      double S_ae = 0;
+      SGT_PAR(e, N) {
+        const double invm = 1.0 / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
+        double f = S.ffix[e];
+        const double old = f;
+        imp_par -= scalar_update(f, S.bfix[e], S.ae[e], S.Rfix[e], invm + S.Rfix[e], false);
+        S.ffix[e] = f;
+        S.ae[e] += invm * (f - old);
+        S_ae += E(SGE_COEF, e) * S.ae[e];
+      }
+      S_ae = wsum(S_ae);
+      {  // the tendon-fix row over all sliders
+        const double old = ten_f;
+        imp_uni -= scalar_update(ten_f, ten_b, S_ae, ten_R, tj_A + ten_R, false);
+        const double dfl = ten_f - old;
+        SGT_PAR(e, N) S.ae[e] += E(SGE_COEF, e) * dfl / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
+      }
+      // chain limit rows: serial within a chain, the chains side by side
+      SGT_PAR(c, K) {
+        const int ndc = T.c_ndof[c], d0 = T.c_dof0[c];
+        double* rows = S.lrow + 5 * 2 * d0;
+        const double* Mi = S.Minv + T.c_mat0[c];
+        for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) {
+          double* r = rows + 5 * i;
+          const int dl = (int)r[0];
+          double f = r[4];
+          const double old = f;
+          imp_par -= scalar_update(f, r[3], r[1] * S.aF[d0 + dl], r[2], Mi[dl * ndc + dl] + r[2], true);
+          r[4] = f;
+          const double dfl = r[1] * (f - old);
+          if (dfl != 0.0)
+            for (int k = 0; k < ndc; k++) S.aF[d0 + k] += Mi[dl * ndc + k] * dfl;
+        }
+      }
+      // slider limit rows
+      SGT_PAR(e, N) {
+        const double invm = 1.0 / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
+        for (int sd = 0; sd < 2; sd++) {
+          const double R = S.Rlim[2 * e + sd];
+          if (R == 0.0) continue;
+          const double sg = sd ? -1.0 : 1.0;
+          double f = S.flim[2 * e + sd];
+          const double old = f;
+          imp_par -= scalar_update(f, S.blim[2 * e + sd], sg * S.ae[e], R, invm + R, true);
+          S.flim[2 * e + sd] = f;
+          S.ae[e] += invm * sg * (f - old);
+        }
+      }
+      SGT_SYNC();
+      // contacts, in order
+      for (int ci = 0; ci < ncon; ci++) {
+        const double* sc = cscal(ci);
+        if (sc[CS_ROWS] == 0.0) continue;
+        const int c1 = (int)sc[CS_C1], c2 = (int)sc[CS_C2], n1 = (int)sc[CS_N1], n2 = (int)sc[CS_N2], sl = (int)sc[CS_SL];
+        double p0 = 0, p1 = 0, p2 = 0;
+        SGT_PAR(i, n1 + n2) {
+          const bool second = i >= n1;
+          const int dl = second ? i - n1 : i;
+          const double* J = crow(ci) + (second ? 6 * CS : 0);
+          const double a = S.aF[T.c_dof0[second ? c2 : c1] + dl];
+          p0 += J[dl] * a; p1 += J[CS + dl] * a; p2 += J[2 * CS + dl] * a;
+        }
+        p0 = wsum(p0); p1 = wsum(p1); p2 = wsum(p2);
+        const double as_ = sl >= 0 ? S.ae[sl] : 0.0;
+        double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
+        const double res[3] = {sc[CS_B] + sc[CS_JS] * as_ + p0 + sc[CS_R] * f[0], sc[CS_B + 1] + sc[CS_JS + 1] * as_ + p1 + sc[CS_R] * f[1],
+                               sc[CS_B + 2] + sc[CS_JS + 2] * as_ + p2 + sc[CS_R] * f[2]};
+        imp_uni -= contact_block_update(sc + CS_A, res, f, H.con_mu, df);
+        SGT_SYNC();   // every lane has read the old forces and accelerations
+        const int n1c = c1 >= 0 ? T.c_ndof[c1] : 0, n2c = c2 >= 0 ? T.c_ndof[c2] : 0;
+        SGT_PAR(i, n1c + n2c) {
+          const bool second = i >= n1c;
+          const int dl = second ? i - n1c : i;
+          const double* W = crow(ci) + (second ? 9 * CS : 3 * CS);
+          S.aF[T.c_dof0[second ? c2 : c1] + dl] += W[dl] * df[0] + W[CS + dl] * df[1] + W[2 * CS + dl] * df[2];
+        }
+        SGT_ONE {
+          S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
+          if (sl >= 0) S.ae[sl] += sc[CS_INVM] * (sc[CS_JS] * df[0] + sc[CS_JS + 1] * df[1] + sc[CS_JS + 2] * df[2]);
+        }
+        SGT_SYNC();
+      }
+      const double improvement = (wsum(imp_par) + imp_uni) * H.pgs_scale;
+      iters = it + 1;
+      if (improvement < H.tolerance) break;
+    }
+
+    // ---------------------------------------------------------------- qacc, qfrc_constraint, warmstart, sensors
+    SGT_PAR(d, ND) {
+      const int c = T.d_chain[d], dl = d - T.c_dof0[c];
+      double s = 0;
+      const double* rows = S.lrow + 5 * 2 * T.c_dof0[c];
+      for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++)
+        if ((int)rows[5 * i] == dl) s += rows[5 * i + 1] * rows[5 * i + 4];
+      for (int ci = 0; ci < ncon; ci++) {
+        const double* sc = cscal(ci);
+        if (sc[CS_ROWS] == 0.0) continue;
+        for (int b = 0; b < 2; b++)
+          if ((int)sc[b ? CS_C2 : CS_C1] == c && dl < (int)sc[b ? CS_N2 : CS_N1]) {
+            const double* J = crow(ci) + (b ? 6 * CS : 0);
+            s += J[dl] * S.cf[3 * ci] + J[CS + dl] * S.cf[3 * ci + 1] + J[2 * CS + dl] * S.cf[3 * ci + 2];
+          }
+      }
+      S.fc[d] = s;
+      S.qacc[d] = S.asm_[d] + S.aF[d];
+      S.warm[d] = S.qacc[d];
+    }
+    double badacc = 0;
+    SGT_PAR(d, ND) badacc += isbad(S.qacc[d]) ? 1.0 : 0.0;
+    SGT_PAR(e, N) {
+      const double qa = S.asme[e] + S.ae[e];
+      S.we[e] = qa;
+      badacc += isbad(qa) ? 1.0 : 0.0;
+    }
+    badacc = wsum(badacc);
+    SGT_SYNC();
+    if (last && A.sens) {   // sensordata of the call = that of the last forward pass
+      tree_motion(S.qacc);
+      SGT_SYNC();
+      SGT_PAR(i, T.NSENS) {
+        const int s = T.sn_site[i], tb = T.s_body[s];
+        double sm[9], out[3];
+        mulmat33(sm, S.xmat + 9 * tb, T.s_mat[s]);
+        if (T.sn_type[i] == SG_SENS_GYRO) {
+          mulmatT3(out, sm, S.bw + 3 * tb);
+        } else {
+          const double *w = S.bw + 3 * tb, *al = S.bal + 3 * tb;
+          double r[3], a[3], t[3], t2[3];
+          for (int k = 0; k < 3; k++) { r[k] = S.spos[3 * s + k] - S.xpos[3 * tb + k]; a[k] = S.ba[3 * tb + k]; }
+          cross3(t, al, r); addscl3(a, t, 1);
+          cross3(t, w, r); cross3(t2, w, t); addscl3(a, t2, 1);
+          mulmatT3(out, sm, a);
+        }
+        double* so = A.sens + (size_t)env * A.sens_stride + T.sn_adr[i];
+        so[0] = out[0]; so[1] = out[1]; so[2] = out[2];
+      }
+    }
+    if (badacc > 0) { flags |= SG_FLAG_BADQACC; break; }
+    if (!integrate) continue;
+    // ---------------------------------------------------------------- stage 12: Euler with implicit joint damping
+    SGT_PAR(i, T.NMAT) {
+      int c = 0;
+      while (c + 1 < K && i >= T.c_mat0[c + 1]) c++;
+      const int nd = T.c_ndof[c], a = (i - T.c_mat0[c]) / nd, b = (i - T.c_mat0[c]) % nd;
+      S.L[i] = S.M[i] + (a == b ? h * T.d_damping[T.c_dof0[c] + a] : 0.0);
+    }
+    SGT_PAR(d, ND) S.bias[d] = S.fs[d] + S.fc[d];   // right-hand side (the bias array is free now)
+    SGT_SYNC();
+    SGT_PAR(c, K) {
+      chain_factor(S.L + T.c_mat0[c], T.c_ndof[c]);
+      chain_solve(S.L + T.c_mat0[c], T.c_ndof[c], S.bias + T.c_dof0[c]);
+      double* cs = S.chs + c * CHS_N;
+      cs[CHS_ACT] += h * cs[CHS_ACTDOT];
+    }
+    double Jx = 0, Jy = 0;
+    SGT_PAR(e, N) {
+      const double m = E(SGE_MASS, e) + E(SGE_ARMATURE, e), fce = m * S.ae[e], den = m + h * E(SGE_DAMPING, e), co = E(SGE_COEF, e);
+      const double x = (S.fse[e] + fce) / den;
+      S.asme[e] = x;   // (asme is rebuilt by the next forward pass)
+      Jx += co * x; Jy += co * co / den;
+    }
+    Jx = wsum(Jx); Jy = wsum(Jy);
+    const double kk = H.t0_implicit ? h * H.t0_damping * Jx / (1 + h * H.t0_damping * Jy) : 0.0;   // D5: Sherman-Morrison
+    SGT_SYNC();
+    SGT_PAR(e, N) {
+      const double den = E(SGE_MASS, e) + E(SGE_ARMATURE, e) + h * E(SGE_DAMPING, e);
+      const double x = S.asme[e] - kk * E(SGE_COEF, e) / den;
+      S.ve[e] += h * x;
+      S.qe[e] += h * S.ve[e];
+    }
+    SGT_PAR(d, ND) {
+      S.v[d] += h * S.bias[d];
+      S.q[d] += h * S.v[d];
+    }
+    SGT_SYNC();
+  }
+
+  // ---------------------------------------------------------------- state and outputs back
+  SGT_SYNC();
+  SGT_PAR(d, ND) {
+    const int j = T.d_gid[d];
+    gq[j] = S.q[d]; gv[j] = S.v[d]; gw[j] = S.warm[d];
+  }
+  SGT_PAR(e, N) {
+    const int j = H.elem_dof0 + e;
+    gq[j] = S.qe[e]; gv[j] = S.ve[e]; gw[j] = S.we[e];
+  }
+  SGT_PAR(c, K)
+    if (T.a_has[c]) gact[T.a_id[c]] = S.chs[c * CHS_N + CHS_ACT];
+  SGT_ONE {
+    A.flags[env] = flags; A.ncon[env] = ncon; A.nefc[env] = nefc; A.iters[env] = iters;
+    A.touch[env] = (int)touch_lo;
+    A.touch_words[2 * env] = (int)touch_lo; A.touch_words[2 * env + 1] = (int)touch_hi;
+  }
+}
+
+}  // namespace sgt

@@ -1,0 +1,85 @@
+// sg_tree_emu.cpp -- host-side driver of the TREE pipeline's source (csrc/sg_tree.h).
+//
+// TEST HARNESS ONLY (tests/test_tree_emu.py): sg_tree.h is bulk-synchronous code -- parallel loops, single-lane sections, barriers --
+// and compiles for the host with a parallel loop as a serial loop and a wavefront sum as the identity.  This file gives that build
+// the few entry points a test needs (state, stiffness, ctrl, reset, step), one env at a time, so that the restructured algorithm
+// (dense per-chain blocks, matrix-free rows, pair-table collision) is checked against the general-purpose oracle without a GPU, and
+// under ASan / UBSan.  It is not reachable from the product package.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../soft-grip_amd/csrc/sg_tree.h"
+
+struct TreeEmu {
+  SgPlan P;
+  SgTreeDev T;
+  std::vector<double> qpos, qvel, warm, act, ctrl, sens, cws, lds;
+  std::vector<int> kmask_jnt, kmask_ten;
+  double kenv;
+  int flags, touch, touchw[2], ncon, nefc, iters;
+};
+
+extern "C" {
+
+TreeEmu* temu_new(const void* blob, size_t n, char* err, size_t errlen) {
+  TreeEmu* E = new TreeEmu();
+  std::string e;
+  if (!sg_tree_plan_build(blob, n, &E->P, &E->T, &e)) {
+    snprintf(err, errlen, "%s", e.c_str());
+    delete E;
+    return nullptr;
+  }
+  const SgPlanHeader& H = E->P.h;
+  const int nu = H.nu > 0 ? H.nu : 1;
+  E->qpos.assign(H.nv, 0.0); E->qvel.assign(H.nv, 0.0); E->warm.assign(H.nv, 0.0); E->act.assign(nu, 0.0); E->ctrl.assign(nu, 0.0);
+  E->sens.assign(H.nsensordata, 0.0);
+  E->kmask_jnt.assign(H.nv, 0); E->kmask_ten.assign(H.ntendon, 0);
+  E->kenv = 0;
+  E->cws.assign((size_t)sgt::cws_doubles(E->T.CS), 0.0);
+  E->lds.assign(sgt::lds_bytes(E->T, H.nelem) / 8 + 8, 0.0);
+  for (int d = 0; d < E->T.ND; d++) E->qpos[E->T.d_gid[d]] = E->T.d_qpos0[d];
+  for (int e2 = 0; e2 < H.nelem; e2++) E->qpos[H.elem_dof0 + e2] = E->P.elem[(size_t)SGE_QPOS0 * H.nelem + e2];
+  E->flags = E->touch = E->ncon = E->nefc = E->iters = 0;
+  E->touchw[0] = E->touchw[1] = 0;
+  return E;
+}
+void temu_free(TreeEmu* E) { delete E; }
+int temu_nv(TreeEmu* E) { return E->P.h.nv; }
+int temu_nu(TreeEmu* E) { return E->P.h.nu; }
+int temu_nsens(TreeEmu* E) { return E->P.h.nsensordata; }
+size_t temu_lds_bytes(TreeEmu* E) { return sgt::lds_bytes(E->T, E->P.h.nelem); }
+double* temu_qpos(TreeEmu* E) { return E->qpos.data(); }
+double* temu_qvel(TreeEmu* E) { return E->qvel.data(); }
+double* temu_warm(TreeEmu* E) { return E->warm.data(); }
+double* temu_act(TreeEmu* E) { return E->act.data(); }
+double* temu_ctrl(TreeEmu* E) { return E->ctrl.data(); }
+double* temu_sens(TreeEmu* E) { return E->sens.data(); }
+int temu_flags(TreeEmu* E) { return E->flags; }
+int temu_ncon(TreeEmu* E) { return E->ncon; }
+int temu_nefc(TreeEmu* E) { return E->nefc; }
+int temu_iters(TreeEmu* E) { return E->iters; }
+int temu_touch_word(TreeEmu* E, int w) { return E->touchw[w & 1]; }
+// stiffness by joint / tendon id sets, as sg_set_stiffness
+void temu_set_stiffness(TreeEmu* E, double k, const int* jnt, int nj, const int* ten, int nt) {
+  std::fill(E->kmask_jnt.begin(), E->kmask_jnt.end(), 0);
+  std::fill(E->kmask_ten.begin(), E->kmask_ten.end(), 0);
+  for (int i = 0; i < nj; i++) E->kmask_jnt[jnt[i]] = 1;
+  for (int i = 0; i < nt; i++) E->kmask_ten[ten[i]] = 1;
+  E->kenv = k;
+}
+// mode 1: reset + forward + nsub steps; mode 0: nsub steps
+void temu_run(TreeEmu* E, int mode, int nsub) {
+  sgt::TreeArgs A;
+  A.H = &E->P.h; A.T = &E->T; A.elem = E->P.elem.data(); A.gpairs = E->P.gpairs.data();
+  A.qpos = E->qpos.data(); A.qvel = E->qvel.data(); A.warm = E->warm.data(); A.act = E->act.data(); A.ctrl = E->ctrl.data();
+  A.kenv = &E->kenv; A.kmask_jnt = E->kmask_jnt.data(); A.kmask_ten = E->kmask_ten.data();
+  A.mask = nullptr; A.sens = E->sens.data(); A.sens_stride = E->P.h.nsensordata;
+  A.flags = &E->flags; A.touch = &E->touch; A.touch_words = E->touchw; A.ncon = &E->ncon; A.nefc = &E->nefc; A.iters = &E->iters;
+  A.cws = E->cws.data(); A.cws_stride = (long long)E->cws.size();
+  A.nenv = 1; A.nsub = nsub; A.mode = mode;
+  sgt::tree_env(A, 0, E->lds.data());
+}
+
+}  // extern "C"

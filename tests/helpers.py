@@ -158,3 +158,59 @@ def assert_ensembles_match(a, b, ks, t0=47, tol=ENS_TOL):
     bad = {k: (rep[k], tol[k]) for k in tol if not rep[k] <= tol[k]}
     assert not bad, "ensembles differ beyond sampling error: %s (full report %s)" % (bad, rep)
     return rep
+
+
+class TreeEmu:
+    """ctypes wrapper of tests/emu/libsgtreeemu.so: the tree pipeline's source (csrc/sg_tree.h) compiled for the host, one env."""
+
+    def __init__(self, model):
+        so = os.path.join(ROOT, "tests", "emu", "libsgtreeemu.so")
+        subprocess.check_call(["make", "-C", os.path.dirname(so)], stdout=subprocess.DEVNULL)
+        L = C.CDLL(so)
+        L.temu_new.restype = C.c_void_p
+        L.temu_new.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.temu_free.argtypes = [C.c_void_p]
+        L.temu_lds_bytes.restype = C.c_size_t
+        for f in ("temu_nv", "temu_nu", "temu_nsens", "temu_flags", "temu_ncon", "temu_nefc", "temu_iters", "temu_lds_bytes"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        for f in ("temu_qpos", "temu_qvel", "temu_warm", "temu_act", "temu_ctrl", "temu_sens"):
+            getattr(L, f).restype = C.POINTER(C.c_double)
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.temu_touch_word.argtypes = [C.c_void_p, C.c_int]
+        L.temu_set_stiffness.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.temu_run.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        blob = model.to_blob()
+        err = C.create_string_buffer(256)
+        self.L = L
+        self.p = L.temu_new(blob, len(blob), err, 256)
+        if not self.p:
+            raise RuntimeError(err.value.decode())
+        nv, nu, ns = L.temu_nv(self.p), L.temu_nu(self.p), L.temu_nsens(self.p)
+        arr = lambda f, n: np.ctypeslib.as_array(getattr(L, f)(self.p), shape=(n,))  # noqa: E731
+        self.qpos, self.qvel, self.warm = arr("temu_qpos", nv), arr("temu_qvel", nv), arr("temu_warm", nv)
+        self.act, self.ctrl, self.sensordata = arr("temu_act", nu), arr("temu_ctrl", nu), arr("temu_sens", ns)
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.temu_free(self.p)
+
+    def set_stiffness(self, k, joint_ids, tendon_ids):
+        ja, ta = (C.c_int * len(joint_ids))(*joint_ids), (C.c_int * len(tendon_ids))(*tendon_ids)
+        self.L.temu_set_stiffness(self.p, k, ja, len(joint_ids), ta, len(tendon_ids))
+
+    def reset(self, sim_start=1):
+        self.L.temu_run(self.p, 1, sim_start)
+        return self.flags
+
+    def step(self, nsub=7):
+        self.L.temu_run(self.p, 0, nsub)
+        return self.flags
+
+    flags = property(lambda self: self.L.temu_flags(self.p))
+    ncon = property(lambda self: self.L.temu_ncon(self.p))
+    nefc = property(lambda self: self.L.temu_nefc(self.p))
+    iters = property(lambda self: self.L.temu_iters(self.p))
+    lds_bytes = property(lambda self: self.L.temu_lds_bytes(self.p))
+
+    def touch_bits(self):
+        return (self.L.temu_touch_word(self.p, 0) & 0xFFFFFFFF) | ((self.L.temu_touch_word(self.p, 1) & 0xFFFFFFFF) << 32)

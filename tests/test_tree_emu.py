@@ -1,0 +1,97 @@
+"""The TREE pipeline's source (csrc/sg_tree.h: grippers outside the two-finger class) compiled for the host
+(tests/emu/sg_tree_emu.cpp: a parallel loop becomes a serial loop) against the oracle: the reference's four-finger gripper
+(soft_grip_four_fingers.xml) and, as a cross-check of the general code on models the fast kernels also run, the two-finger scenes."""
+import numpy as np
+import pytest
+
+import softgrip_amd as sg
+from helpers import JOINT_IDS, TENDON_IDS, TreeEmu, model_path, oracle_sim
+from softgrip_amd.create_dataset import episode_schedule
+
+FF_JOINTS = list(range(65, 283))      # reference environment/manenv.py:11 (commented four-finger ids): the ball's sliders
+
+
+def _pair(scene, k, damper, jids, tids):
+    m = sg.load_model(model_path(scene), damper)
+    s = oracle_sim(m)
+    s.jnt_stiffness[jids] = k
+    s.tendon_stiffness[tids] = k
+    s.reset(); s.forward(); s.step()
+    e = TreeEmu(m)
+    e.set_stiffness(k, jids, tids)
+    assert e.reset(1) == 0
+    return m, e, s
+
+
+@pytest.mark.parametrize("scene,damper,tol", [("softbox_fix", None, 1e-9), ("softball_fix", "implicit", 1e-8)])
+def test_two_finger_scenes_free_running(scene, damper, tol):
+    """the general code on the two-finger class: a whole squeeze episode free-running, contacts, row and sweep counts exact"""
+    m, e, s = _pair(scene, 903.6948543200572, damper, JOINT_IDS, TENDON_IDS)
+    np.testing.assert_allclose(e.qpos, s.qpos, atol=1e-14)
+    worst = 0.0
+    for t, c in enumerate(episode_schedule()):
+        if c is not None:
+            e.ctrl[:] = c
+            s.ctrl[:] = c
+        for _ in range(7):
+            assert s.step() == 0
+        assert e.step(7) == 0
+        worst = max(worst, np.abs(e.sensordata - s.sensordata).max())
+        assert (e.ncon, e.nefc, e.iters) == (s.ncon, s.nefc, s.solver_iter), t
+    assert worst < tol
+    np.testing.assert_allclose(e.qpos, s.qpos, atol=tol)
+    np.testing.assert_allclose(e.act, s.act, atol=1e-14)
+
+
+def test_four_finger_episode_step_by_step():
+    """soft_grip_four_fingers.xml closing on the ball (4 chains of 16 / 17 dofs, 64 boxes, 8-site tendons, 218 limited sliders:
+    437 - 531 rows): along the oracle's trajectory -- the emulation re-seated on the oracle's state after every env step, which this
+    scene needs (218 active limit rows make it amplify round-off: free-running the two part by 1e-5 after 30 steps) -- sensors of all
+    24 channels, contact, row and sweep counts and the touch bits at every step"""
+    m, e, s = _pair("fourfinger_softball_fix", 700.0, "implicit", FF_JOINTS, [0])
+    boxes = [g for g in range(m.ngeom) if m.geom_type[g] == 6 and m.body_weldid[m.geom_bodyid[g]] != 0]
+    worst, touched = 0.0, 0
+    for t, c in enumerate(episode_schedule()):
+        if c is not None:
+            e.ctrl[:] = c
+            s.ctrl[:] = c
+        e.qpos[:] = s.qpos; e.qvel[:] = s.qvel; e.warm[:] = s.qacc_warmstart; e.act[:] = s.act
+        for _ in range(7):
+            assert s.step() == 0
+        assert e.step(7) == 0
+        worst = max(worst, np.abs(e.sensordata - s.sensordata).max())
+        assert (e.ncon, e.nefc, e.iters) == (s.ncon, s.nefc, s.solver_iter), t
+        np.testing.assert_allclose(e.qvel, s.qvel, atol=1e-10)
+        want = 0
+        for cc in s.contacts():
+            for g, o in ((cc["geom1"], cc["geom2"]), (cc["geom2"], cc["geom1"])):
+                if g in boxes and "OBJ" in (m.geom_names[o] or ""):
+                    want |= 1 << boxes.index(g)
+        assert e.touch_bits() == want, t
+        touched |= want
+    assert worst < 1e-9
+    assert bin(touched).count("1") >= 8          # boxes of all four fingers reach the ball
+    for f in range(4):
+        assert touched >> (16 * f) & 0xFFFF, f
+
+
+def test_four_finger_first_steps_free_running():
+    """free-running until the round-off amplification sets in: the first 15 env steps (105 substeps) at 1e-9"""
+    m, e, s = _pair("fourfinger_softball_fix", 1100.0, "implicit", FF_JOINTS, [0])
+    for t, c in enumerate(episode_schedule()[:15]):
+        if c is not None:
+            e.ctrl[:] = c
+            s.ctrl[:] = c
+        for _ in range(7):
+            assert s.step() == 0
+        assert e.step(7) == 0
+        assert np.abs(e.sensordata - s.sensordata).max() < 1e-9
+        assert (e.ncon, e.nefc, e.iters) == (s.ncon, s.nefc, s.solver_iter), t
+    np.testing.assert_allclose(e.qpos, s.qpos, atol=1e-11)
+
+
+def test_tree_plan_refuses_what_it_cannot_run():
+    m = sg.load_model(model_path("softbox"))       # neighbour equality rows
+    with pytest.raises(RuntimeError) as ei:
+        TreeEmu(m)
+    assert "fix-rows-only" in str(ei.value)
