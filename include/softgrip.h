@@ -115,13 +115,24 @@ int sg_set_state(sg_batch* b, const double* qpos, const double* qvel, const doub
  * number of contacts, constraint rows and PGS sweeps of the final substep */
 int sg_get_solver_stats(sg_batch* b, int32_t* ncon, int32_t* nefc, int32_t* iters, void* stream);
 
-/* kernel pipeline (same results to round-off, all parity-tested): 2 = rows (default: chain / phase / row-parallel PGS
+/* kernel pipeline (same results to round-off, all parity-tested): 3 = tree (csrc/sg_tree.h: one env per wavefront, state in LDS;
+ * the only pipeline for grippers outside the two-finger class -- any number of serial finger chains up to 24 dofs, multi-site
+ * tendons, limited sliders: the reference's soft_grip_four_fingers.xml -- and selectable for fix-rows-only two-finger models),
+ * 2 = rows (default for the two-finger class: chain / phase / row-parallel PGS
  * kernels, a lane quad per finger stream in the solver), 1 = split (same chain with one lane per finger stream),
  * 0 = fused (one kernel per call, everything on chip).  The env var SG_PIPELINE=fused|split|rows sets the default of
  * new batches.  A model compiled with the composite's neighbour equalities (two-joint equality rows, eq_obj2id >= 0;
  * softgrip_model.h, mjcf.py composite_neighbors=True) runs in the rows pipeline only: its batches start there and
  * sg_set_pipeline(b, 0 or 1) returns SG_ERR_MODEL. */
 int sg_set_pipeline(sg_batch* b, int pipeline);
+
+/* Contact read-out for grippers with more than 32 finger boxes (the four-finger gripper has 64; replaces the loop over
+ * data.contact of manenv.py:65-85): out [n_envs][nwords] int32, bit g of an env's words (word g / 32, bit g % 32) set when moving
+ * finger box g -- the model's box geoms on moving bodies in geom-id order -- touches an object geom in the contact list of the
+ * last sg_step / sg_reset.  Word 0 equals touch_out for models with up to 32 boxes.  (Fused pipeline: valid when the call passed
+ * touch_out = NULL.)  sg_model_nboxes: the number of such boxes. */
+int sg_get_touch_words(sg_batch* b, int32_t* out, int nwords, void* stream);
+int sg_model_nboxes(const sg_model* m);
 
 /* envs per wavefront of the rows pipeline's solver kernel: 8 fills the wavefront (fix-rows-only models, chosen automatically from
  * 8185 envs on, where 8 per wavefront still give every SIMD of the chip a wavefront), 4 spreads a smaller batch over twice as many

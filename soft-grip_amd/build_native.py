@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libsoftgrip.so")
 SOURCES = ["sg_api.hip", "sg_plan.cpp", "sg_mjcf.cpp"]
-DEPS = SOURCES + ["sg_kernels.hip", "sg_split.hip", "sg_math.h", "sg_plan.h", "sg_mjcf.h", "../../include/softgrip.h", "../../include/softgrip_model.h"]
+DEPS = SOURCES + ["sg_kernels.hip", "sg_split.hip", "sg_tree.hip", "sg_tree.h", "sg_tree_plan.h", "sg_general.h", "sg_math.h", "sg_plan.h", "sg_mjcf.h", "../../include/softgrip.h", "../../include/softgrip_model.h"]
 
 
 def needs_build():

@@ -9,6 +9,7 @@
 #include "sg_kernels.hip"
 #include "sg_mjcf.h"
 #include "sg_split.hip"
+#include "sg_tree.hip"
 
 namespace {
 thread_local std::string g_err;
@@ -40,8 +41,12 @@ __global__ void sg_masked_copy_kernel(const unsigned char* mask, int n, const in
 }  // namespace
 
 struct sg_model {
-  SgPlan plan;
-  int rounds;  // ceil(nelem / 64)
+  SgPlan plan;      // the fast kernels' plan (has_fast), else a copy of tplan: header, elements and sizes serve every entry point
+  int rounds;       // ceil(nelem / 64)
+  bool has_fast;    // the model is in the two-finger class of sg_plan.h
+  bool has_tree;    // the tree pipeline (sg_tree.h) runs it
+  SgPlan tplan;     // the tree pipeline's plan: same elements / equalities / statics, chains in `tree`, flat box references
+  SgTreeDev tree;
 };
 
 struct sg_batch {
@@ -55,7 +60,14 @@ struct sg_batch {
   uint2* dtab;       // the same schedule as the solver's LDS table words
   int *kmask_jnt, *kmask_ten, *flags, *touch, *ncon, *nefc, *iters;
   int epw_override;  // sg_set_solver_envs_per_wavefront: 0 = automatic
-  int pipeline;  // 0 fused (one kernel per call), 1 split (chain / phase / pgs kernel chain), 2 split with the row-parallel PGS kernel
+  int pipeline;  // 0 fused (one kernel per call), 1 split (chain / phase / pgs kernel chain), 2 split with the row-parallel PGS kernel, 3 tree
+  // tree pipeline (allocated when first selected)
+  SgPlanHeader* dTH;
+  SgTreeDev* dT;
+  double *dtelem, *tcws;
+  SgGenPair* dtpairs;
+  int* touch_words;   // [n][2]
+  bool tree_attr_set;
   SgWork w;
   std::vector<void*> wbufs;
   bool lds_attr_set;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this batch's device
@@ -70,6 +82,62 @@ struct sg_batch {
   long long prof_pgs_n;
 };
 
+static int begin_event_pair(sg_batch* b, std::vector<std::pair<hipEvent_t, hipEvent_t>>& list, hipStream_t s);
+
+// device tables and work space of the tree pipeline (sg_tree.h), allocated when the pipeline is first selected
+static int tree_alloc(sg_batch* b) {
+  if (b->dT) return SG_OK;
+  const sg_model* m = b->m;
+  if (!m->has_tree) return fail(SG_ERR_MODEL, "the tree pipeline does not run this model");
+  const size_t n = b->n;
+  const long long cwd = sgt::cws_doubles(m->tree.CS);
+#define TALLOC(p, bytes)                                                                  \
+  do {                                                                                    \
+    hipError_t e_ = hipMalloc((void**)&(p), (bytes));                                     \
+    if (e_ != hipSuccess) return fail(SG_ERR_NOMEM, std::string("hipMalloc (tree pipeline): ") + hipGetErrorString(e_)); \
+  } while (0)
+  TALLOC(b->dTH, sizeof(SgPlanHeader));
+  TALLOC(b->dT, sizeof(SgTreeDev));
+  TALLOC(b->dtelem, sizeof(double) * m->tplan.elem.size());
+  TALLOC(b->dtpairs, sizeof(SgGenPair) * (m->tplan.gpairs.size() + 1));
+  TALLOC(b->tcws, sizeof(double) * n * (size_t)cwd);
+  TALLOC(b->touch_words, sizeof(int) * 2 * n);
+#undef TALLOC
+  HIPCHK(hipMemcpy(b->dTH, &m->tplan.h, sizeof(SgPlanHeader), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->dT, &m->tree, sizeof(SgTreeDev), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->dtelem, m->tplan.elem.data(), sizeof(double) * m->tplan.elem.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->dtpairs, m->tplan.gpairs.data(), sizeof(SgGenPair) * m->tplan.gpairs.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(b->tcws, 0, sizeof(double) * n * (size_t)cwd));
+  HIPCHK(hipMemset(b->touch_words, 0, sizeof(int) * 2 * n));
+  return SG_OK;
+}
+
+// tree pipeline: one launch per call, one env per wavefront (sg_tree.hip)
+static int launch_tree(sg_batch* b, int mode, const uint8_t* mask, int nsub, double* sens, long long stride, int32_t* flags, int32_t* touch,
+                       hipStream_t s) {
+  const sg_model* m = b->m;
+  sgt::TreeArgs a;
+  a.H = b->dTH; a.T = b->dT; a.elem = b->dtelem; a.gpairs = b->dtpairs;
+  a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.act = b->act; a.ctrl = b->ctrl;
+  a.kenv = b->kenv; a.kmask_jnt = b->kmask_jnt; a.kmask_ten = b->kmask_ten;
+  a.mask = mask; a.sens = sens; a.sens_stride = stride > 0 ? stride : m->tplan.h.nsensordata;
+  a.flags = flags ? flags : b->flags; a.touch = touch ? touch : b->touch; a.touch_words = b->touch_words;
+  a.ncon = b->ncon; a.nefc = b->nefc; a.iters = b->iters;
+  a.cws = b->tcws; a.cws_stride = sgt::cws_doubles(m->tree.CS);
+  a.nenv = b->n; a.nsub = nsub; a.mode = mode;
+  const size_t lds = sgt::lds_bytes(m->tree, m->tplan.h.nelem);
+  if (!b->tree_attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)sg_tree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    b->tree_attr_set = true;
+  }
+  if (b->prof)
+    if (int rc = begin_event_pair(b, b->ev, s)) return rc;
+  hipLaunchKernelGGL(sg_tree_kernel, dim3(b->n), dim3(64), lds, s, a);
+  HIPCHK(hipGetLastError());
+  if (b->prof) HIPCHK(hipEventRecord(b->ev.back().second, s));
+  return SG_OK;
+}
+
 extern "C" {
 
 const char* sg_last_error(void) { return g_err.c_str(); }
@@ -78,17 +146,24 @@ const char* sg_version(void) { return "softgrip-mi355x 0.1 (gfx950)"; }
 int sg_model_create(const void* blob, size_t nbytes, sg_model** out) {
   if (!blob || !out) return fail(SG_ERR_INVALID, "sg_model_create: null argument");
   sg_model* m = new sg_model();
-  std::string err;
-  if (!sg_plan_build(blob, nbytes, &m->plan, &err)) {
-    delete m;
-    return fail(SG_ERR_MODEL, "sg_model_create: " + err);
+  std::string err, terr;
+  m->has_fast = sg_plan_build(blob, nbytes, &m->plan, &err);
+  m->has_tree = sg_tree_plan_build(blob, nbytes, &m->tplan, &m->tree, &terr);
+  if (m->has_tree && sgt::lds_bytes(m->tree, m->tplan.h.nelem) > 160 * 1024) {
+    m->has_tree = false;
+    terr = "the env's state does not fit the 160 KB of LDS";
   }
+  if (!m->has_fast && !m->has_tree) {
+    delete m;
+    return fail(SG_ERR_MODEL, "sg_model_create: " + err + " (two-finger kernels); " + terr + " (tree pipeline)");
+  }
+  if (!m->has_fast) m->plan = m->tplan;
   m->rounds = (m->plan.h.nelem + 63) / 64;
   if (m->rounds > 4) {
     delete m;
     return fail(SG_ERR_MODEL, "sg_model_create: more than 256 composite elements");
   }
-  if (m->plan.h.nnb > 0) {  // the rows PGS kernel keeps every equality row of 8 envs in LDS (launch_split)
+  if (m->has_fast && m->plan.h.nnb > 0) {  // the rows PGS kernel keeps every equality row of 8 envs in LDS (launch_split)
     const size_t na = 8 * (size_t)((m->plan.h.nelem + 7) / 8) + 8 + 48, neqp = 4 * (size_t)m->plan.h.nelem + 1;
     if (sizeof(double) * SG_ROWS_LDS_NB(4, na, m->plan.h.nelem, m->plan.h.eq_rounds) > 160 * 1024) {
       delete m;
@@ -131,6 +206,9 @@ int sg_model_nelem(const sg_model* m) { return m->plan.h.nelem; }
 void sg_batch_destroy(sg_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
+  void* tptrs[] = {b->dTH, b->dT, b->dtelem, b->tcws, b->dtpairs, b->touch_words};
+  for (void* p : tptrs)
+    if (p) (void)hipFree(p);
   void* ptrs[] = {b->dtab, b->dgpairs, b->dnbtab, b->dsched, b->dH, b->delem, b->qpos, b->qvel, b->warm, b->act, b->ctrl, b->kenv, b->ctrl_row, b->kmask_jnt, b->kmask_ten,
                   b->flags, b->touch, b->ncon, b->nefc, b->iters};
   for (void* p : ptrs)
@@ -152,6 +230,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   sg_batch* b = new sg_batch();
   b->m = m; b->n = n_envs; b->device = device; b->lds_attr_set = false; b->prof = false; b->prof_ms = 0; b->prof_n = 0; b->prof_pgs_ms = 0; b->prof_pgs_n = 0;
   b->dnbtab = nullptr; b->dsched = nullptr; b->dgpairs = nullptr; b->dtab = nullptr; b->epw_override = 0;
+  b->dTH = nullptr; b->dT = nullptr; b->dtelem = b->tcws = nullptr; b->dtpairs = nullptr; b->touch_words = nullptr; b->tree_attr_set = false;
   b->dH = nullptr; b->delem = b->qpos = b->qvel = b->warm = b->act = b->ctrl = b->kenv = b->ctrl_row = nullptr;
   b->kmask_jnt = b->kmask_ten = b->flags = b->touch = b->ncon = b->nefc = b->iters = nullptr;
   const SgPlanHeader& H = m->plan.h;
@@ -172,9 +251,10 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   ALLOC(b->kmask_jnt, sizeof(int) * nv); ALLOC(b->kmask_ten, sizeof(int) * nt);
   ALLOC(b->flags, sizeof(int) * n); ALLOC(b->touch, sizeof(int) * n); ALLOC(b->ncon, sizeof(int) * n); ALLOC(b->nefc, sizeof(int) * n);
   ALLOC(b->iters, sizeof(int) * n);
-  {  // workspace of the split pipeline
+  memset(&b->w, 0, sizeof b->w);
+  b->pipeline = 3;
+  if (m->has_fast) {  // workspace of the split pipeline
     const size_t S = 2 * n, N = H.nelem;
-    memset(&b->w, 0, sizeof b->w);
     auto walloc = [&](void** p, size_t bytes) -> bool {
       if (hipMalloc(p, bytes) != hipSuccess) return false;
       b->wbufs.push_back(*p);
@@ -199,10 +279,10 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
               walloc((void**)&b->w.gen_count, sizeof(int) * 4) && walloc((void**)&b->w.gen_list, sizeof(int) * SG_GEN_LIST);
     if (!ok) { sg_batch_destroy(b); return fail(SG_ERR_NOMEM, "hipMalloc (split-pipeline workspace)"); }
     const char* pm = getenv("SG_PIPELINE");
-    b->pipeline = (pm && strcmp(pm, "fused") == 0) ? 0 : (pm && strcmp(pm, "split") == 0) ? 1 : 2;
+    b->pipeline = (pm && strcmp(pm, "fused") == 0) ? 0 : (pm && strcmp(pm, "split") == 0) ? 1 : (pm && strcmp(pm, "tree") == 0 && m->has_tree) ? 3 : 2;
     if (H.nnb > 0) b->pipeline = 2;  // neighbour equality rows exist in the rows pipeline only
   }
-  if (H.nnb > 0) {
+  if (m->has_fast && H.nnb > 0) {
     std::vector<SgEqSlot> sch = m->plan.sched;
     SgEqSlot idle;
     idle.e = idle.p[0] = idle.p[1] = idle.p[2] = H.nelem;
@@ -232,6 +312,8 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   std::vector<double> q0(nv, 0.0);
   for (int c = 0; c < H.nchain; c++)
     for (int d = 0; d < H.chain[c].ndof; d++) q0[H.chain[c].dof0 + d] = H.chain[c].qpos0[d];
+  if (!m->has_fast)
+    for (int d = 0; d < m->tree.ND; d++) q0[m->tree.d_gid[d]] = m->tree.d_qpos0[d];
   for (int e = 0; e < H.nelem; e++) q0[H.elem_dof0 + e] = m->plan.elem[(size_t)SGE_QPOS0 * H.nelem + e];
   std::vector<double> qall(n * nv);
   for (size_t i = 0; i < n; i++) memcpy(&qall[i * nv], q0.data(), sizeof(double) * nv);
@@ -242,6 +324,8 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   HIPCHK(hipMemset(b->kmask_jnt, 0, sizeof(int) * nv)); HIPCHK(hipMemset(b->kmask_ten, 0, sizeof(int) * nt));
   HIPCHK(hipMemset(b->flags, 0, sizeof(int) * n)); HIPCHK(hipMemset(b->touch, 0, sizeof(int) * n));
   HIPCHK(hipMemset(b->ncon, 0, sizeof(int) * n)); HIPCHK(hipMemset(b->nefc, 0, sizeof(int) * n)); HIPCHK(hipMemset(b->iters, 0, sizeof(int) * n));
+  if (b->pipeline == 3)
+    if (int rc = tree_alloc(b)) { sg_batch_destroy(b); return rc; }
   *out = b;
   return SG_OK;
 }
@@ -433,6 +517,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
 
 static int launch(sg_batch* b, int mode, const uint8_t* mask, int nsub, double* sens, long long stride, int32_t* flags, int32_t* touch,
                   hipStream_t s) {
+  if (b->pipeline == 3) return launch_tree(b, mode, mask, nsub, sens, stride, flags, touch, s);
   if (b->pipeline >= 1) return launch_split(b, mode, mask, nsub, sens, stride, flags, touch, s);
   const SgPlanHeader& H = b->m->plan.h;
   SgKArgs a;
@@ -508,11 +593,40 @@ int sg_get_solver_stats(sg_batch* b, int32_t* ncon, int32_t* nefc, int32_t* iter
 }
 
 int sg_set_pipeline(sg_batch* b, int pipeline) {
-  if (!b || pipeline < 0 || pipeline > 2) return fail(SG_ERR_INVALID, "sg_set_pipeline: bad argument");
+  if (!b || pipeline < 0 || pipeline > 3) return fail(SG_ERR_INVALID, "sg_set_pipeline: bad argument");
+  if (pipeline == 3) {
+    if (!b->m->has_tree) return fail(SG_ERR_MODEL, "sg_set_pipeline: the tree pipeline does not run this model (fix-rows-only models within its capacities)");
+    HIPCHK(hipSetDevice(b->device));
+    if (int rc = tree_alloc(b)) return rc;
+    b->pipeline = 3;
+    return SG_OK;
+  }
+  if (!b->m->has_fast) return fail(SG_ERR_MODEL, "sg_set_pipeline: the model is outside the two-finger class, only the tree pipeline runs it");
   if (b->m->plan.h.nnb > 0 && pipeline != 2)
     return fail(SG_ERR_MODEL, "sg_set_pipeline: the model has neighbour equality rows, which only the rows pipeline supports");
   b->pipeline = pipeline;
   return SG_OK;
+}
+
+int sg_get_touch_words(sg_batch* b, int32_t* out, int nwords, void* stream) {
+  if (!b || !out || nwords < 1) return fail(SG_ERR_INVALID, "sg_get_touch_words: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(out, 0, sizeof(int32_t) * (size_t)b->n * nwords, s));
+  if (b->pipeline == 3)
+    HIPCHK(hipMemcpy2DAsync(out, sizeof(int32_t) * nwords, b->touch_words, sizeof(int32_t) * 2, sizeof(int32_t) * (nwords < 2 ? nwords : 2), b->n,
+                            hipMemcpyDeviceToDevice, s));
+  else
+    HIPCHK(hipMemcpy2DAsync(out, sizeof(int32_t) * nwords, b->pipeline == 0 ? b->touch : b->w.touch, sizeof(int32_t), sizeof(int32_t), b->n,
+                            hipMemcpyDeviceToDevice, s));
+  return SG_OK;
+}
+int sg_model_nboxes(const sg_model* m) {
+  if (!m) return 0;
+  if (!m->has_fast) return m->tree.NG;
+  int n = 0;
+  for (int c = 0; c < m->plan.h.nchain; c++) n += m->plan.h.chain[c].ngeom;
+  return n;
 }
 
 int sg_set_solver_envs_per_wavefront(sg_batch* b, int epw) {

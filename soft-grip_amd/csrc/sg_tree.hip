@@ -1,0 +1,19 @@
+// sg_tree.hip -- the TREE pipeline's kernel: one env per wavefront, the whole call (all substeps) in one launch, the env's state and
+// per-chain matrices in LDS for its duration (sg_tree.h is the code; tests/emu compiles the same source for the host).
+//
+// north_star's layout -- "one env per wavefront with per-env state staged in LDS" -- is exactly this kernel; the fast kernels
+// (sg_split.hip) left it for the two-finger class because 8 dofs per env leave a wavefront's lanes idle.  With 65 chain dofs, 64
+// boxes and 17 016 candidate pairs per env the lanes have work: the pair walk, the mass-matrix entries, the M^-1 columns, the slider
+// rows and a contact's chain block are all lane-parallel.  Bounds: fp64 VALU issue and LDS latency; HBM traffic is
+// the contact rows' J / W blocks (<= 128 x 1.9 KB per env, L2-resident) and the 272 KB pair table shared by all envs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sg_tree.h"
+
+__global__ __launch_bounds__(64) void sg_tree_kernel(sgt::TreeArgs a) {
+  extern __shared__ double sg_tree_lds[];
+  const int env = blockIdx.x;
+  if (env >= a.nenv) return;
+  sgt::tree_env(a, env, sg_tree_lds);
+}

@@ -37,9 +37,10 @@ class ManEnv(Env):
     tendon_ids = list(range(1))
     finger_names = ['g12', 'g2']
     obj_name = 'OBJ'
+    n_actuated = 2    # close_hand / loose_hand drive ctrl[0 .. n_actuated - 1] (`for i in range(2)`, reference manenv.py:93-101); 4 for the four-finger gripper
 
     def __init__(self, sim_start, sim_step, env_paths, is_vis=True, n_envs=1, device=0, contact_flag_mode="intent", check_scene=True,
-                 tendon_damper="auto", joint_ids=None, tendon_ids=None):
+                 tendon_damper="auto", joint_ids=None, tendon_ids=None, finger_names=None, n_actuated=None):
         """``joint_ids`` / ``tendon_ids``: which model entries ``set_new_stiffness`` writes; default = the reference's class attributes
         (joints 11..63 and tendon 0: manenv.py:12-13), to be overridden for a scene with another layout (e.g. a smaller shell).
         ``tendon_damper``: how the damper of the composite's volume tendon is integrated (mjcf.load_model).
@@ -55,6 +56,10 @@ class ManEnv(Env):
             self.joint_ids = [int(j) for j in joint_ids]      # instance attributes shadow the class lists (which stay the reference's)
         if tendon_ids is not None:
             self.tendon_ids = [int(t) for t in tendon_ids]
+        if finger_names is not None:      # e.g. ['g11', 'g12', 'g13', 'g2'] for the four-finger gripper (reference manenv.py:16)
+            self.finger_names = list(finger_names)
+        if n_actuated is not None:
+            self.n_actuated = int(n_actuated)
         self.check_scene = check_scene
         self.is_vis = is_vis  # no viewer exists; kept for signature parity (render() is a no-op)
         self.env_paths = env_paths
@@ -88,8 +93,9 @@ class ManEnv(Env):
         # which finger boxes (bit 2*chain+box of `touch`) match each name in finger_names
         self._finger_bits = []
         bits = self._chain_geom_bits()
-        for name in type(self).finger_names if self.contact_flag_mode == "reference" else self.finger_names:
-            self._finger_bits.append(sum(1 << b for b, gname in bits.items() if name in gname))
+        for name in self.finger_names:
+            v = sum(1 << b for b, gname in bits.items() if name in gname)
+            self._finger_bits.append(v - (1 << 64) if v >= (1 << 63) else v)      # as a signed 64-bit pattern (torch has no uint64 ops)
         self._finger_bits_names = list(self.finger_names)
         # "reference" mode state: which names are still in the list the reference aliases and never refills (manenv.py:70,80), one
         # list per env, kept on the device as a bit mask (bit i = finger_names[i] not yet removed)
@@ -127,20 +133,20 @@ class ManEnv(Env):
         self.env.reset(0, flags=flags)   # back to the state after mj_resetData
 
     def _chain_geom_bits(self):
-        """bit index -> geom name for the moving finger boxes, in the kernels' (chain, box) order"""
+        """bit index -> geom name for the moving finger boxes, in the kernels' order: (chain, body, geom) = geom id order (two boxes
+        per finger in the two-finger class: bit 2 * chain + box)"""
         m = self.model
         moving = [g for g in range(m.ngeom) if m.body_weldid[m.geom_bodyid[g]] != 0 and m.geom_type[g] == 6]
-        chains = {}
-        for g in moving:  # chain = root moving body of the finger
-            b = m.geom_bodyid[g]
-            while m.body_weldid[m.body_parentid[b]] != 0:
-                b = m.body_parentid[b]
-            chains.setdefault(b, []).append(g)
-        bits = {}
-        for c, root in enumerate(sorted(chains)):
-            for k, g in enumerate(chains[root]):
-                bits[2 * c + k] = m.geom_names[g]
-        return bits
+        return {i: m.geom_names[g] or "" for i, g in enumerate(moving)}
+
+    def _touch_bits(self):
+        """per env the contact read-out as one integer: int32 word of sg_step for up to 32 finger boxes, else the words of
+        sg_get_touch_words combined into an int64 (the four-finger gripper has 64 boxes)"""
+        import torch
+        if self.nmodel.nboxes <= 32:
+            return self._touch
+        w = self.env.touch_words(2).to(torch.int64) & 0xFFFFFFFF
+        return w[:, 0] | (w[:, 1] << 32)
 
     def load_env(self, num):
         if num < len(self.env_paths):
@@ -193,7 +199,7 @@ class ManEnv(Env):
 
     def _contact_flags(self):
         import torch
-        touch = self._touch
+        touch = self._touch_bits()
         if self.contact_flag_mode == "intent":
             ok = torch.ones(self.n_envs, dtype=torch.bool, device=touch.device)
             for bits in self._finger_bits:
@@ -204,7 +210,7 @@ class ManEnv(Env):
         # whenever there is any contact at all
         ncon = self.env.solver_stats()["ncon"]
         for i, bits in enumerate(self._finger_bits):
-            self._fingers_left &= ~(((touch & bits) != 0).to(torch.int32) << i)
+            self._fingers_left &= ~(((touch & bits) != 0).to(torch.int32) << i)   # (touch: int32, or int64 beyond 32 boxes)
         return (self._fingers_left == 0) & (ncon > 0)
 
     def _result(self):
@@ -224,12 +230,12 @@ class ManEnv(Env):
             self.close_hand()
 
     def close_hand(self):
-        self._ctrl[:2] = -0.2
+        self._ctrl[:self.n_actuated] = -0.2
         self.env.set_ctrl_broadcast(self._ctrl)
         self.is_closing = True
 
     def loose_hand(self):
-        self._ctrl[:2] = 0.2
+        self._ctrl[:self.n_actuated] = 0.2
         self.env.set_ctrl_broadcast(self._ctrl)
         self.is_closing = False
 
@@ -291,7 +297,7 @@ class ManEnv(Env):
             "env_paths": args.mujoco_model_paths,
             "is_vis": args.vis,
         }
-        for extra in ("n_envs", "device", "contact_flag_mode", "check_scene", "tendon_damper", "joint_ids", "tendon_ids"):
+        for extra in ("n_envs", "device", "contact_flag_mode", "check_scene", "tendon_damper", "joint_ids", "tendon_ids", "finger_names", "n_actuated"):
             if hasattr(args, extra):
                 spec[extra] = getattr(args, extra)
         return spec

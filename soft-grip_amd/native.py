@@ -19,6 +19,7 @@ SYMBOLS = [
     "sg_batch_nenvs", "sg_batch_device", "sg_set_stiffness", "sg_set_ctrl", "sg_reset", "sg_step", "sg_get_state",
     "sg_set_state", "sg_get_solver_stats", "sg_set_pipeline", "sg_profile_enable", "sg_profile_read", "sg_profile_read_solver",
     "sg_model_compile", "sg_mjcf_compile", "sg_blob_free", "sg_set_solver_envs_per_wavefront", "sg_solver_envs_per_wavefront",
+    "sg_get_touch_words", "sg_model_nboxes",
 ]
 SG_COMPILE_NO_NEIGHBORS, SG_COMPILE_IMPLICIT_TENDON_DAMPER = 1, 2
 
@@ -50,7 +51,8 @@ def lib():
     L.sg_mjcf_compile.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.sg_blob_free.argtypes = [vp]
     L.sg_blob_free.restype = None
-    for f in ("sg_model_nq", "sg_model_nu", "sg_model_nsensordata", "sg_model_ntendon", "sg_model_nelem"):
+    L.sg_get_touch_words.argtypes = [vp, ip, C.c_int, vp]
+    for f in ("sg_model_nq", "sg_model_nu", "sg_model_nsensordata", "sg_model_ntendon", "sg_model_nelem", "sg_model_nboxes"):
         getattr(L, f).argtypes = [vp]
     L.sg_batch_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.sg_batch_destroy.argtypes = [vp]
@@ -105,6 +107,7 @@ class NativeModel:
         self.nsensordata = L.sg_model_nsensordata(self.ptr)
         self.ntendon = L.sg_model_ntendon(self.ptr)
         self.nelem = L.sg_model_nelem(self.ptr)
+        self.nboxes = L.sg_model_nboxes(self.ptr)     # moving finger boxes = bits of the contact read-out
 
     def __del__(self):
         if getattr(self, "ptr", None) and _LIB is not None:
@@ -178,7 +181,14 @@ class NativeBatch:
         return dict(ncon=out[0], nefc=out[1], iters=out[2])
 
     def set_pipeline(self, name):
-        check(lib().sg_set_pipeline(self.ptr, {"fused": 0, "split": 1, "rows": 2}[name]))
+        check(lib().sg_set_pipeline(self.ptr, {"fused": 0, "split": 1, "rows": 2, "tree": 3}[name]))
+
+    def touch_words(self, nwords=2):
+        """[n, nwords] int32: bit g of an env's words = moving finger box g touches an object geom (sg_get_touch_words)"""
+        t = self.torch
+        out = t.empty(self.n, nwords, dtype=t.int32, device=self.device)
+        check(lib().sg_get_touch_words(self.ptr, _ptr(out), nwords, self._stream()))
+        return out
 
     def set_solver_envs_per_wavefront(self, epw):
         check(lib().sg_set_solver_envs_per_wavefront(self.ptr, int(epw)))

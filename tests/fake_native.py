@@ -7,6 +7,7 @@ import torch
 class FakeModel:
     def __init__(self, model):
         self.model, self.nq, self.nu, self.nsensordata, self.ntendon, self.nelem = model, model.nv, model.nu, 12, 3, 110
+        self.nboxes = 4
 
 
 class FakeBatch:

@@ -1,8 +1,8 @@
 """SURVEY 8(f) rank 4, first half: the reference's FOUR-finger gripper (data/gripper/soft_grip_four_fingers.xml: 4 fingers of 8 links /
 16 dofs, one spatial tendon through 8 sites per finger, 4 cylinder actuators, 8 sensors = 24 channels; its ids are comments in
-environment/manenv.py:11,16) on the model compilers and the oracle -- the way round 1 started the two-finger box.  The kernels' plan
-class is two fingers of two links: sg_model_create refuses this model with a reason; the free-floating ball of
-soft_experiments_softball.xml (<freejoint/>) is not built anywhere yet.
+environment/manenv.py:11,16) on the model compilers and the oracle -- the way round 1 started the two-finger box.  The fast kernels' plan
+class is two fingers of two links; this model runs in the tree pipeline (csrc/sg_tree.h; tests/test_tree_emu.py, tests/test_gpu_tree.py);
+the free-floating ball of soft_experiments_softball.xml (<freejoint/>) is not built anywhere yet.
 
 models/fourfinger_softball_fix.sgmodel is compiled by scripts/compile_models.py from the reference's files (the two-finger ball experiment
 with its <include> switched to the four-finger gripper)."""
@@ -108,11 +108,18 @@ def test_four_finger_squeeze_episode_on_the_oracle(model):
     assert touched == set(FINGERS), touched
 
 
-def test_kernels_refuse_the_four_finger_model_with_a_reason(model):
+def test_kernels_take_the_four_finger_model(model):
+    """the two-finger kernels refuse it, the tree pipeline (csrc/sg_tree.h) runs it: sg_model_create accepts the blob (no GPU needed for
+    that) and reports the 64 finger boxes; tests/test_tree_emu.py and tests/test_gpu_tree.py hold the pipeline against the oracle"""
     from softgrip_amd import native
+    nm = native.NativeModel(model)
+    assert nm.nboxes == 64 and nm.nsensordata == 24 and nm.nq == 283 and nm.nelem == 218
+    bad = sg.load_model(model_path("fourfinger_softball_fix"), "implicit")
+    bad.jnt_type = bad.jnt_type.copy()
+    bad.jnt_type[3] = 2                    # a slide joint in a finger chain: outside both classes
     with pytest.raises(native.SoftgripError) as ei:
-        native.NativeModel(model)
-    assert ei.value.code == native.SG_ERR_MODEL and ("finger" in str(ei.value) or "chain" in str(ei.value))
+        native.NativeModel(bad)
+    assert ei.value.code == native.SG_ERR_MODEL and "two-finger kernels" in str(ei.value) and "tree pipeline" in str(ei.value)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference's MJCF files (build container only)")

@@ -1,0 +1,169 @@
+"""GPU parity of the TREE pipeline (csrc/sg_tree.h / sg_tree.hip) through the C ABI: the reference's four-finger
+gripper (soft_grip_four_fingers.xml on the ball: 283 dofs, 64 finger boxes, 24 sensor channels) against the oracle, and the same
+kernel on the two-finger scenes against the oracle and against the fast kernels."""
+import numpy as np
+import pytest
+
+import softgrip_amd as sg
+from helpers import JOINT_IDS, TENDON_IDS, model_path, oracle_sim
+from softgrip_amd.create_dataset import episode_schedule
+
+pytestmark = pytest.mark.gpu
+FF_JOINTS = list(range(65, 283))
+FINGERS = ['g11', 'g12', 'g13', 'g2']           # reference environment/manenv.py:16
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _batch(model, ks, jids, tids, pipeline=None):
+    from softgrip_amd import native
+    torch = _torch()
+    nm = native.NativeModel(model)
+    b = native.NativeBatch(nm, len(ks), 0)
+    if pipeline:
+        b.set_pipeline(pipeline)
+    b.set_stiffness(np.asarray(ks, dtype=np.float64), jids, tids)
+    sens = torch.zeros(len(ks), nm.nsensordata, dtype=torch.float64, device=b.device)
+    flags = torch.zeros(len(ks), dtype=torch.int32, device=b.device)
+    return nm, b, sens, flags
+
+
+def _oracles(model, ks, jids, tids):
+    sims = []
+    for k in ks:
+        s = oracle_sim(model)
+        s.jnt_stiffness[jids] = k
+        s.tendon_stiffness[tids] = k
+        s.reset(); s.forward(); s.step()
+        sims.append(s)
+    return sims
+
+
+def test_four_finger_episode_matches_oracle():
+    """the whole squeeze schedule, 5 envs over the stiffness range, along the oracle's trajectories (the batch re-seated on the oracles'
+    states after every env step: 218 active limit rows make this scene amplify round-off, tests/test_tree_emu.py): every sensor
+    sample of the 24 channels at 1e-7, contact / row / sweep counts and the 64 touch bits exact at every step"""
+    torch = _torch()
+    m = sg.load_model(model_path("fourfinger_softball_fix"), "implicit")
+    ks = [300.0, 575.0, 850.0, 1125.0, 1400.0]
+    nm, b, sens, flags = _batch(m, ks, FF_JOINTS, [0])
+    assert nm.nboxes == 64 and nm.nsensordata == 24
+    sims = _oracles(m, ks, FF_JOINTS, [0])
+    b.reset(1, sens=sens, flags=flags)
+    assert int(flags.abs().sum()) == 0
+    st = b.get_state()
+    np.testing.assert_allclose(st["qpos"].cpu().numpy(), np.stack([s.qpos for s in sims]), atol=1e-12)
+    boxes = [g for g in range(m.ngeom) if m.geom_type[g] == 6 and m.body_weldid[m.geom_bodyid[g]] != 0]
+    worst, touched = 0.0, 0
+    for t, c in enumerate(episode_schedule()):
+        if c is not None:
+            b.set_ctrl_broadcast(np.full(4, c))
+            for s in sims:
+                s.ctrl[:] = c
+        dev = dict(device=b.device, dtype=torch.float64)
+        b.set_state(qpos=torch.tensor(np.stack([s.qpos for s in sims]), **dev), qvel=torch.tensor(np.stack([s.qvel for s in sims]), **dev),
+                    act=torch.tensor(np.stack([s.act for s in sims]), **dev),
+                    qacc_warmstart=torch.tensor(np.stack([s.qacc_warmstart for s in sims]), **dev))
+        for s in sims:
+            for _ in range(7):
+                assert s.step() == 0
+        b.step(7, sens=sens, flags=flags)
+        assert int(flags.abs().sum()) == 0, t
+        got = sens.cpu().numpy()
+        worst = max(worst, np.abs(got - np.stack([s.sensordata for s in sims])).max())
+        stats = {k: v.cpu().numpy() for k, v in b.solver_stats().items()}
+        words = b.touch_words(2).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        for i, s in enumerate(sims):
+            assert (stats["ncon"][i], stats["nefc"][i], stats["iters"][i]) == (s.ncon, s.nefc, s.solver_iter), (t, i)
+            want = 0
+            for cc in s.contacts():
+                for g, o in ((cc["geom1"], cc["geom2"]), (cc["geom2"], cc["geom1"])):
+                    if g in boxes and "OBJ" in (m.geom_names[o] or ""):
+                        want |= 1 << boxes.index(g)
+            assert int(words[i, 0]) | (int(words[i, 1]) << 32) == want, (t, i)
+            touched |= want
+    assert worst < 1e-7, worst
+    for f in range(4):
+        assert touched >> (16 * f) & 0xFFFF, f
+    print("four-finger episode: max |sensor - oracle| = %.2e" % worst)
+
+
+@pytest.mark.parametrize("scene,damper", [("softbox_fix", None), ("softball_fix", "implicit")])
+def test_tree_pipeline_on_two_finger_scenes(scene, damper):
+    """the tree kernel on models the fast kernels run too: a whole free-running episode against the oracle (sensors 1e-7, counts
+    exact) and against the rows pipeline"""
+    torch = _torch()
+    m = sg.load_model(model_path(scene), damper)
+    ks = [320.0, 903.6948543200572, 1390.0]
+    nm, b, sens, flags = _batch(m, ks, JOINT_IDS, TENDON_IDS, "tree")
+    nm2, b2, sens2, flags2 = _batch(m, ks, JOINT_IDS, TENDON_IDS, "rows")
+    sims = _oracles(m, ks, JOINT_IDS, TENDON_IDS)
+    touch, touch2 = torch.zeros(3, dtype=torch.int32, device=b.device), torch.zeros(3, dtype=torch.int32, device=b.device)
+    b.reset(1, sens=sens, flags=flags)
+    b2.reset(1, sens=sens2, flags=flags2)
+    worst = worst2 = 0.0
+    for t, c in enumerate(episode_schedule()):
+        if c is not None:
+            for x in (b, b2):
+                x.set_ctrl_broadcast(np.full(2, c))
+            for s in sims:
+                s.ctrl[:] = c
+        for s in sims:
+            for _ in range(7):
+                assert s.step() == 0
+        b.step(7, sens=sens, flags=flags, touch=touch)
+        b2.step(7, sens=sens2, flags=flags2, touch=touch2)
+        assert int(flags.abs().sum()) == 0 and int(flags2.abs().sum()) == 0
+        got = sens.cpu().numpy()
+        worst = max(worst, np.abs(got - np.stack([s.sensordata for s in sims])).max())
+        worst2 = max(worst2, np.abs(got - sens2.cpu().numpy()).max())
+        st, st2 = b.solver_stats(), b2.solver_stats()
+        for i, s in enumerate(sims):
+            assert (int(st["ncon"][i]), int(st["nefc"][i]), int(st["iters"][i])) == (s.ncon, s.nefc, s.solver_iter), (t, i)
+        assert torch.equal(st["ncon"], st2["ncon"]) and torch.equal(touch, touch2), t
+    assert worst < 1e-7 and worst2 < 1e-7, (worst, worst2)
+
+
+def test_four_finger_manenv_contact_flag_and_masked_reset():
+    """ManEnv on the four-finger scene with the reference's commented ids (finger_names g11 / g12 / g13 / g2, four actuators): the
+    squeeze brings the contact flag up for every env, an env given a NaN state is flagged, reset alone (masked) with a re-drawn
+    stiffness, and the others are untouched"""
+    torch = _torch()
+    from softgrip_amd.manenv import ManEnv
+    np.random.seed(3)
+    env = ManEnv(1, 7, [model_path("fourfinger_softball_fix")], is_vis=False, n_envs=6, tendon_damper="implicit",
+                 joint_ids=FF_JOINTS, tendon_ids=[0], finger_names=FINGERS, n_actuated=4)
+    assert env.nmodel.nboxes == 64 and all(bits != 0 for bits in env._finger_bits)
+    env.reset()
+    flag_seen = torch.zeros(6, dtype=torch.bool, device=env.env.device)
+    for t, c in enumerate(episode_schedule()[:100]):
+        if c is not None:
+            env.close_hand() if c < 0 else env.loose_hand()
+        sens, flag = env.step()
+        assert sens.shape == (6, 24) and bool(torch.isfinite(sens).all())
+        flag_seen |= flag
+    assert bool(flag_seen.all())          # all four fingers on the ball at some step, in every env
+    # one env breaks
+    st = env.env.get_state()
+    before = st["qpos"].clone()
+    k_before = env.stiffness.copy()
+    st["qpos"][2, 70] = float("nan")
+    env.env.set_state(qpos=st["qpos"])
+    sens, flag = env.step()
+    assert env.n_resets == 1 and env.stiffness[2] != k_before[2] and np.array_equal(np.delete(env.stiffness, 2), np.delete(k_before, 2))
+    after = env.env.get_state()["qpos"]
+    assert bool(torch.isfinite(after).all())
+    assert float((after[[0, 1, 3, 4, 5]] - before[[0, 1, 3, 4, 5]]).abs().max()) < 0.05     # they went on with their episode
+
+
+def test_model_outside_both_classes_is_refused_with_both_reasons():
+    from softgrip_amd import native
+    m = sg.load_model(model_path("fourfinger_softball_fix"), "implicit")
+    m.jnt_type = m.jnt_type.copy()
+    m.jnt_type[3] = 2                      # a slide joint in a finger chain
+    with pytest.raises(native.SoftgripError) as ei:
+        native.NativeModel(m)
+    assert ei.value.code == native.SG_ERR_MODEL and "two-finger kernels" in str(ei.value) and "tree pipeline" in str(ei.value)
