@@ -62,13 +62,20 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(model, ks, sim_step, sched, budget_envs, threads):
+def stiffness_ids(scene):
+    """(joint ids, tendon ids) that carry the per-env stiffness: the reference's class attributes (environment/manenv.py:12-13) for the
+    two-finger scenes; the ball's 218 sliders behind the 65 gripper joints for the four-finger scene (manenv.py:11's commented ids
+    belong to an older gripper file)"""
+    return (list(range(65, 283)) if scene.startswith("fourfinger") else list(range(11, 64))), [0]
+
+
+def cpu_baseline(model, ks, sim_step, sched, budget_envs, threads, scene="softbox"):
     """The CPU oracle (oracle/sg_oracle.c, a port -- not MuJoCo) on the host cores: `budget_envs`
     envs x one full 200-step episode, OpenMP over envs."""
     from oracle import oracle as O
     om = O.OracleModel(model.to_blob())
     sims = [O.OracleSim(om) for _ in range(budget_envs)]
-    jids, tids = list(range(11, 64)), [0]
+    jids, tids = stiffness_ids(scene)
     for s, k in zip(sims, ks):
         s.jnt_stiffness[jids] = k
         s.tendon_stiffness[tids] = k
@@ -126,7 +133,7 @@ class Runner:
         else:
             lo, hi = stiffness_bin(rank, world)
             self.ks = np.random.RandomState(1000 + rank).uniform(lo, hi, n)
-        self.batch.set_stiffness(self.ks, list(range(11, 64)), [0])
+        self.batch.set_stiffness(self.ks, *stiffness_ids(scene))
         self.sched = episode_schedule()
         self.T = len(self.sched)
         self.sim_step, self.sim_start = 7, 1
@@ -316,6 +323,8 @@ def main():
         abytes = algorithmic_bytes_per_env_step(nm.nq, nm.nq, nm.nu, nm.nu, R.nsd)
         ach = abytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         pipe = os.environ.get("SG_PIPELINE", "rows")
+        if args.scene.startswith("fourfinger"):
+            pipe = "tree"   # outside the two-finger class: the tree pipeline is the only one that runs it
         nb_on = bool((model.eq_obj2id >= 0).any())
         res = {
             "metric": "env steps/sec (whole node) at batch=4096",
@@ -332,7 +341,8 @@ def main():
                        "envs_flagged_bad": nbad, "launches_timed": launches, "steps_timed": nsteps, "timed_region": desc},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": None, "traffic_source": None,
-                         "kernel": {"rows": "sg_chain_kernel + sg_phase_kernel + sg_pgs_rows_kernel chain of one sg_step call (rows pipeline; dominant: sg_pgs_rows_kernel)", "split": "sg_chain_kernel + sg_phase_kernel + sg_pgs_kernel chain of one sg_step call (split pipeline)"}.get(pipe, "sg_step_kernel"),
+                         "kernel": {"rows": "sg_chain_kernel + sg_phase_kernel + sg_pgs_rows_kernel chain of one sg_step call (rows pipeline; dominant: sg_pgs_rows_kernel)", "split": "sg_chain_kernel + sg_phase_kernel + sg_pgs_kernel chain of one sg_step call (split pipeline)",
+                                    "tree": "sg_tree_kernel: one launch per sg_step call, one env per wavefront (tree pipeline)"}.get(pipe, "sg_step_kernel"),
                          "avg_kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": abytes,
                          "note": "one 'launch' = the kernel chain of one sg_step call (7 substeps), HIP events on the launch stream over the timed steps only "
@@ -391,8 +401,8 @@ def main():
             ks = np.random.RandomState(0).uniform(300, 1400, n)
             from softgrip_amd.create_dataset import episode_schedule
             sched = episode_schedule()
-            v, cdt = cpu_baseline(model, ks, 7, sched, envs, cores)
-            v1, cdt1 = cpu_baseline(model, ks, 7, sched, 2, 1)   # a 1-thread figure beside the all-cores one
+            v, cdt = cpu_baseline(model, ks, 7, sched, envs, cores, args.scene)
+            v1, cdt1 = cpu_baseline(model, ks, 7, sched, 2, 1, args.scene)   # a 1-thread figure beside the all-cores one
             probe = []
             for mod in ("mujoco", "mujoco_py"):                          # time MuJoCo itself iff it exists on the box -- probe, never assume
                 try:

@@ -109,6 +109,13 @@ static int tree_alloc(sg_batch* b) {
   HIPCHK(hipMemcpy(b->dtpairs, m->tplan.gpairs.data(), sizeof(SgGenPair) * m->tplan.gpairs.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(b->tcws, 0, sizeof(double) * n * (size_t)cwd));
   HIPCHK(hipMemset(b->touch_words, 0, sizeof(int) * 2 * n));
+  if (!b->w.secprof) {   // (a model outside the two-finger class has no split-pipeline work space)
+    void* p = nullptr;
+    if (hipMalloc(&p, sizeof(unsigned long long) * 48) != hipSuccess) return fail(SG_ERR_NOMEM, "hipMalloc (tree pipeline)");
+    b->wbufs.push_back(p);
+    b->w.secprof = (unsigned long long*)p;
+    HIPCHK(hipMemset(p, 0, sizeof(unsigned long long) * 48));
+  }
   return SG_OK;
 }
 
@@ -124,7 +131,7 @@ static int launch_tree(sg_batch* b, int mode, const uint8_t* mask, int nsub, dou
   a.flags = flags ? flags : b->flags; a.touch = touch ? touch : b->touch; a.touch_words = b->touch_words;
   a.ncon = b->ncon; a.nefc = b->nefc; a.iters = b->iters;
   a.cws = b->tcws; a.cws_stride = sgt::cws_doubles(m->tree.CS);
-  a.nenv = b->n; a.nsub = nsub; a.mode = mode;
+  a.nenv = b->n; a.nsub = nsub; a.mode = mode; a.secprof = b->w.secprof;
   const size_t lds = sgt::lds_bytes(m->tree, m->tplan.h.nelem);
   if (!b->tree_attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)sg_tree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -792,6 +792,14 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
             else FAIL("unsupported collision pair types");
             if (gp.g1 == 0 || gp.g2 == 0) FAIL("a collision pair involves a geom outside the plan class");
             if (!check_pair(g1, g2)) gp.kind = 5;   // SGP_UNSUPPORTED
+            {  // the pair's bounding distance as a float rounded UP (in `pad`): plane pairs margin + rbound(geom2), else the sum of the
+               // bounding radii + margin.  A filter on it passes every pair the exact test passes (the tree pipeline's pair walk)
+              const double mg = fmax(geom_margin[g1], geom_margin[g2]);
+              const double bd = (t1 == 0 ? 0.0 : geom_rbound[g1]) + geom_rbound[g2] + mg;
+              float bf = (float)bd;
+              if ((double)bf < bd) bf = nextafterf(bf, INFINITY);
+              memcpy(&gp.pad, &bf, 4);
+            }
             P.gpairs.push_back(gp);
           }
     if (P.gpairs.size() > 60000) FAIL("too many candidate collision pairs");

@@ -103,7 +103,8 @@ struct SgEqSlot {
 // one candidate pair of the general contact path (sg_general.h): narrowphase routine, geometry references (kind << 16 | index) of
 // geom1 / geom2 in mj_collideGeoms' order, the pair's bounding radii summed (for the sphere filter)
 struct SgGenPair {
-  int kind, g1, g2, pad;
+  int kind, g1, g2;
+  int pad;   // the bits of a float: the pair's bounding distance rounded up (sg_plan.cpp)
 };
 
 struct SgPlan {

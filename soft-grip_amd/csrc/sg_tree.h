@@ -20,6 +20,7 @@
 // sanitizers over it.  On the device the env's state lives in LDS for the whole call (all substeps in one launch).
 #pragma once
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/softgrip.h"
 #include "../../include/softgrip_model.h"
@@ -40,6 +41,7 @@ using namespace sgm;
 #define SGT_HITREC 8     // contacts one pair can produce (box - box)
 #define SGT_RECW 10      // doubles of a staged narrowphase record: dist, pos[3], n[3], tangent hint[3]
 #define SGT_CSC 32       // scalar doubles of a contact record in the work space
+#define SGT_LROW 6       // doubles of a chain limit row: dof, sign, R, b, f, 1 / (A + R)
 
 struct TreeArgs {
   const SgPlanHeader* H;
@@ -56,6 +58,7 @@ struct TreeArgs {
   double* cws;               // per-env work space, cws_stride doubles each
   long long cws_stride;
   int nenv, nsub, mode;      // mode 1: reset + one forward without integration, then nsub steps
+  unsigned long long* secprof;   // profiling build (-DSG_SECTION_PROF) only: cycle sums per section, else unused
 };
 
 // work-space layout (doubles): staged narrowphase records | contact rows
@@ -72,10 +75,11 @@ struct Lds {
   double *anchor, *axis, *gpos, *gmat, *spos;
   double *M, *L, *Minv;
   double *qe, *ve, *we, *asme, *ae, *fse, *ffix, *bfix, *Rfix, *flim, *blim, *Rlim, *ke;
+  double *einvm, *ecoef, *ecen, *Ifix, *Ilim;   // 1 / (m + armature), tendon coefficient, capsule centres [3][N], 1 / (A + R) of the fix / limit rows
   double *lrow, *seg, *chs, *cf, *red;
-  int *hit_pair, *hit_sorted, *hit_cnt, *hit_off, *con_src, *icnt;
+  int *hit_pair, *hit_sorted, *hit_cnt, *hit_off, *con_src, *con_chain, *icnt;
 };
-enum { IC_NHIT = 0, IC_NCON, IC_FLAGS, IC_NLIM0 /* + chain */, IC_N = IC_NLIM0 + SGT_MAXCH };
+enum { IC_NHIT = 0, IC_NCON, IC_SERIAL, IC_NLIM0 /* + chain */, IC_N = IC_NLIM0 + SGT_MAXCH };
 // per-chain scalars in LDS (chs[c * CHS_N + ..])
 enum { CHS_TLEN = 0, CHS_TVEL, CHS_TFRC, CHS_AFRC, CHS_ACTDOT, CHS_ACT, CHS_CTRL, CHS_KT, CHS_N };
 
@@ -91,7 +95,8 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N) {
   L.M = take(T.NMAT); L.L = take(T.NMAT); L.Minv = take(T.NMAT);
   L.qe = take(N); L.ve = take(N); L.we = take(N); L.asme = take(N); L.ae = take(N); L.fse = take(N); L.ffix = take(N);
   L.bfix = take(N); L.Rfix = take(N); L.flim = take(2 * N); L.blim = take(2 * N); L.Rlim = take(2 * N); L.ke = take(N);
-  L.lrow = take(5 * 2 * ND); L.seg = take(4 * SGT_MAXCH * SGT_MAXTS); L.chs = take(CHS_N * SGT_MAXCH); L.cf = take(3 * SGT_MAXCON);
+  L.einvm = take(N); L.ecoef = take(N); L.ecen = take(3 * N); L.Ifix = take(N); L.Ilim = take(2 * N);
+  L.lrow = take(SGT_LROW * 2 * ND); L.seg = take(4 * SGT_MAXCH * SGT_MAXTS); L.chs = take(CHS_N * SGT_MAXCH); L.cf = take(3 * SGT_MAXCON);
   L.red = take(16);
   int* ip = (int*)p;
   L.hit_pair = ip; ip += SGT_MAXHIT;
@@ -99,6 +104,7 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N) {
   L.hit_cnt = ip; ip += SGT_MAXHIT;
   L.hit_off = ip; ip += SGT_MAXHIT;
   L.con_src = ip; ip += SGT_MAXCON;
+  L.con_chain = ip; ip += SGT_MAXCON;
   L.icnt = ip; ip += 32;
   return (size_t)((char*)ip - (char*)base);
 }
@@ -107,7 +113,26 @@ SG_HD size_t lds_bytes(const SgTreeDev& T, int N) {
   return lds_carve(L, reinterpret_cast<double*>((uintptr_t)4096), T, N);
 }
 
+// section stamps (profiling build only: build_native.py --prof, scripts/tree_section_profile.py): lane 0 adds the cycles since the
+// previous stamp to secprof[k]
+#if defined(SG_SECTION_PROF) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define SGT_STAMP(k)                                                                  \
+  do {                                                                                \
+    if (threadIdx.x == 0) {                                                           \
+      const long long t_ = clock64();                                                 \
+      atomicAdd(&A.secprof[k], (unsigned long long)(t_ - sgt_t_last));                \
+      sgt_t_last = t_;                                                                \
+    }                                                                                 \
+  } while (0)
+#define SGT_STAMP_INIT() long long sgt_t_last = clock64()
+#else
+#define SGT_STAMP(k) ((void)0)
+#define SGT_STAMP_INIT() ((void)0)
+#endif
+
 #if SGT_DEVICE
+#define SGT_FIRST ((int)threadIdx.x)
+#define SGT_STRIDE 64
 #define SGT_PAR(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
 #define SGT_ONE if (threadIdx.x == 0)
 #define SGT_SYNC() __syncthreads()
@@ -118,6 +143,8 @@ __device__ __forceinline__ double wsum(double x) {
 }
 __device__ __forceinline__ int lds_inc(int* p) { return atomicAdd(p, 1); }
 #else
+#define SGT_FIRST 0
+#define SGT_STRIDE 1
 #define SGT_PAR(i, n) for (int i = 0; i < (n); i++)
 #define SGT_ONE if (true)
 #define SGT_SYNC() ((void)0)
@@ -138,6 +165,45 @@ SG_HD void chain_solve(const double* Lc, int nd, double* x) {
     for (int i = k - 1; i >= 0; i--) s -= Lc[k * nd + i] * x[i];
     x[k] = s;
   }
+}
+// the same solve with x in registers: fully unrolled over the SGT_CHD capacity, guarded by nd (LDS reads of L only, no dependent
+// read-modify-write chain through LDS: 9 k instead of 100 k cycles for the M^-1 columns).  Same operations in the same order.
+SG_HD void chain_solve_reg(const double* Lc, int nd, double* xmem) {
+  double x[SGT_CHD];
+#pragma unroll
+  for (int k = 0; k < SGT_CHD; k++) x[k] = k < nd ? xmem[k] : 0.0;
+#pragma unroll
+  for (int k = SGT_CHD - 1; k >= 1; k--)
+    if (k < nd) {
+      const double xk = x[k];
+#pragma unroll
+      for (int i = k - 1; i >= 0; i--) x[i] -= Lc[k * nd + i] * xk;
+    }
+#pragma unroll
+  for (int k = 0; k < SGT_CHD; k++)
+    if (k < nd) x[k] /= Lc[k * nd + k];
+#pragma unroll
+  for (int k = 1; k < SGT_CHD; k++)
+    if (k < nd) {
+      double s = x[k];
+#pragma unroll
+      for (int i = k - 1; i >= 0; i--) s -= Lc[k * nd + i] * x[i];
+      x[k] = s;
+    }
+#pragma unroll
+  for (int k = 0; k < SGT_CHD; k++)
+    if (k < nd) xmem[k] = x[k];
+}
+// scalar row update with the reciprocal of the row's diagonal A + R precomputed (as the fast kernels' equality rows)
+SG_HD double scalar_update_rcp(double& f, double b, double Ja, double R, double Adiag, double Ainv, bool inequality) {
+  const double res = b + Ja + R * f, old = f;
+  double fn = f - res * Ainv;
+  if (inequality && fn < 0) fn = 0;
+  const double d = fn - old;
+  double change = 0.5 * d * d * Adiag + d * res;
+  if (change > 1e-10) { fn = old; change = 0; }
+  f = fn;
+  return change;
 }
 // in-place L'DL of a chain block (mj_factorM restricted to a serial chain)
 SG_HD void chain_factor(double* Lc, int nd) {
@@ -192,6 +258,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     S.ve[e] = rs ? 0.0 : gv[j];
     S.we[e] = rs ? 0.0 : gw[j];
     S.ke[e] = A.kmask_jnt[j] ? kenv : E(SGE_K0, e);
+    S.einvm[e] = 1.0 / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
+    S.ecoef[e] = E(SGE_COEF, e);
   }
   SGT_PAR(c, K) {
     double* cs = S.chs + c * CHS_N;
@@ -208,6 +276,30 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   const double kt0 = A.kmask_ten[H.t0_id] ? kenv : H.t0_k0;
   SGT_SYNC();
 
+  SGT_STAMP_INIT();
+  // L'DL of every chain block in S.L at once (mj_factorM on serial chains): step s eliminates dof k = nd - 1 - s of each chain, one lane
+  // per row i < k: L[i][j] -= (L[k][i] / L[k][k]) L[k][j] for j <= i, then row k is scaled.  Same operations as chain_factor.
+  auto factor_all = [&]() {
+    for (int st = 0; st + 1 < CS; st++) {
+      SGT_PAR(d, ND) {
+        const int c = T.d_chain[d], nd = T.c_ndof[c], i = d - T.c_dof0[c], k = nd - 1 - st;
+        if (k >= 1 && i < k) {
+          double* Lc = S.L + T.c_mat0[c];
+          const double a = Lc[k * nd + i] / Lc[k * nd + k];
+          for (int j = i; j >= 0; j--) Lc[i * nd + j] -= a * Lc[k * nd + j];
+        }
+      }
+      SGT_SYNC();
+      SGT_PAR(d, ND) {
+        const int c = T.d_chain[d], nd = T.c_ndof[c], i = d - T.c_dof0[c], k = nd - 1 - st;
+        if (k >= 1 && i < k) {
+          double* Lc = S.L + T.c_mat0[c];
+          Lc[k * nd + i] = Lc[k * nd + i] / Lc[k * nd + k];
+        }
+      }
+      SGT_SYNC();
+    }
+  };
   int ncon = 0, nefc = 0, iters = 0, flags = 0;
   unsigned touch_lo = 0, touch_hi = 0;
   const int nfwd = A.nsub + (A.mode == 1 ? 1 : 0);
@@ -227,6 +319,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         break;   // uniform: the env stops integrating for the rest of the call
       }
     }
+    SGT_STAMP(0);
     // ---------------------------------------------------------------- stage 1: kinematics, one lane per chain
     SGT_PAR(c, K) {
       double pos[3], quat[4], mat[9], ppos[3], pquat[4], pmat[9], t[3];
@@ -283,6 +376,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       for (int k = 0; k < 3; k++) S.spos[3 * s + k] = S.xpos[3 * tb + k] + t[k];
     }
     SGT_SYNC();
+    SGT_STAMP(1);
     // ---------------------------------------------------------------- stage 3: tendons.  segments, then one lane per dof
     SGT_PAR(i, K * SGT_MAXTS) {
       const int c = i / SGT_MAXTS, w = i % SGT_MAXTS;
@@ -340,6 +434,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       }
       cs[CHS_AFRC] = afrc; cs[CHS_ACTDOT] = adot;
     }
+    SGT_STAMP(2);
     // ---------------------------------------------------------------- stage 4: mass matrix, one lane per entry of the lower triangles
     SGT_PAR(i, T.NMAT) {
       int c = 0;
@@ -363,16 +458,17 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       }
     }
     SGT_SYNC();
+    SGT_STAMP(3);
     SGT_PAR(i, T.NMAT) S.L[i] = S.M[i];
     SGT_SYNC();
-    SGT_PAR(c, K) chain_factor(S.L + T.c_mat0[c], T.c_ndof[c]);
-    SGT_SYNC();
+    factor_all();
     SGT_PAR(d, ND) {   // M^-1 by columns (= rows): solve for the unit vector of dof d
       const int c = T.d_chain[d], nd = T.c_ndof[c], dl = d - T.c_dof0[c];
       double* x = S.Minv + T.c_mat0[c] + dl * nd;
       for (int k = 0; k < nd; k++) x[k] = k == dl ? 1.0 : 0.0;
-      chain_solve(S.L + T.c_mat0[c], nd, x);
+      chain_solve_reg(S.L + T.c_mat0[c], nd, x);
     }
+    SGT_STAMP(4);
     // ---------------------------------------------------------------- stage 7: bias forces (RNE with qacc = 0), body velocities
     auto tree_motion = [&](const double* qacc) {
       SGT_PAR(c, K) {
@@ -433,7 +529,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       S.asm_[d] = S.fs[d];
     }
     SGT_SYNC();
-    SGT_PAR(c, K) chain_solve(S.L + T.c_mat0[c], T.c_ndof[c], S.asm_ + T.c_dof0[c]);
+    SGT_PAR(c, K) chain_solve_reg(S.L + T.c_mat0[c], T.c_ndof[c], S.asm_ + T.c_dof0[c]);
+    SGT_STAMP(5);
     // ---------------------------------------------------------------- the composite's sliders: smooth forces (stages 7 - 9)
     double t0_len = 0, t0_vel = 0;
     SGT_PAR(e, N) { t0_len += E(SGE_COEF, e) * S.qe[e]; t0_vel += E(SGE_COEF, e) * S.ve[e]; }
@@ -444,56 +541,59 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       const double pas = -S.ke[e] * (S.qe[e] - E(SGE_SPRINGREF, e)) - E(SGE_DAMPING, e) * S.ve[e] + E(SGE_COEF, e) * t0_frc;
       S.fse[e] = pas + m * ga;   // - bias, bias = -m g . axis
       S.asme[e] = S.fse[e] / (m + E(SGE_ARMATURE, e));
+      const double dq = S.qe[e] - E(SGE_QPOS0, e);   // the capsule's centre (the pair walk reads it from LDS)
+      S.ecen[3 * e] = E(SGE_GX, e) + E(SGE_AX, e) * dq; S.ecen[3 * e + 1] = E(SGE_GY, e) + E(SGE_AY, e) * dq; S.ecen[3 * e + 2] = E(SGE_GZ, e) + E(SGE_AZ, e) * dq;
     }
     SGT_SYNC();
 
+    SGT_STAMP(6);
     // ---------------------------------------------------------------- stage 5: collision over the candidate-pair table
     SGT_ONE { S.icnt[IC_NHIT] = 0; }
     SGT_SYNC();
-    auto elem_center = [&](int e, double* c) {
-      const double dq = S.qe[e] - E(SGE_QPOS0, e);
-      c[0] = E(SGE_GX, e) + E(SGE_AX, e) * dq; c[1] = E(SGE_GY, e) + E(SGE_AY, e) * dq; c[2] = E(SGE_GZ, e) + E(SGE_AZ, e) * dq;
-    };
-    SGT_PAR(p, H.ngpair) {
-      const SgGenPair gp = A.gpairs[p];
-      const int i1 = sgg_index(gp.g1), i2 = sgg_index(gp.g2), k2 = sgg_kind(gp.g2);
-      bool hit = false;
-      if (gp.kind == SGP_PLANE_CAP || gp.kind == SGP_PLANE_BOX) {
-        double c[3], rb;
-        if (gp.kind == SGP_PLANE_CAP) { elem_center(i2, c); rb = H.cap_rbound; }
-        else if (k2 == SGG_BOX) { for (int k = 0; k < 3; k++) c[k] = S.gpos[3 * i2 + k]; rb = T.g_rbound[i2]; }
-        else { for (int k = 0; k < 3; k++) c[k] = H.st_pos[i2][k]; rb = H.st_rbound[i2]; }
-        const double dif[3] = {c[0] - H.plane_pos[0], c[1] - H.plane_pos[1], c[2] - H.plane_pos[2]};
-        hit = !(dot3(dif, H.plane_normal) > H.con_margin + rb);
-      } else if (gp.kind != SGP_UNSUPPORTED) {
-        // geom2 is a box (finger or static); geom1 the centre sphere, an element capsule or a box
-        const double* bp = k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[i2];
-        const double rb2 = k2 == SGG_BOX ? T.g_rbound[i2] : H.st_rbound[i2];
-        double c[3], rb1;
-        const int k1 = sgg_kind(gp.g1);
-        if (k1 == SGG_CENTER) { for (int k = 0; k < 3; k++) c[k] = H.center_pos[k]; rb1 = H.center_radius; }
-        else if (k1 == SGG_ELEM) { elem_center(i1, c); rb1 = H.cap_rbound; }
-        else if (k1 == SGG_BOX) { for (int k = 0; k < 3; k++) c[k] = S.gpos[3 * i1 + k]; rb1 = T.g_rbound[i1]; }
-        else { for (int k = 0; k < 3; k++) c[k] = H.st_pos[i1][k]; rb1 = H.st_rbound[i1]; }
-        const double dif[3] = {bp[0] - c[0], bp[1] - c[1], bp[2] - c[2]}, bound = rb1 + rb2 + H.con_margin;
-        hit = !(dot3(dif, dif) > bound * bound);
-        if (hit && k1 == SGG_ELEM) {   // tighter: the capsule's bounding sphere against the box itself
-          const double* bm = k2 == SGG_BOX ? S.gmat + 9 * i2 : H.st_mat[i2];
-          const double* sz = k2 == SGG_BOX ? T.g_size[i2] : H.st_size[i2];
-          const double t[3] = {-dif[0], -dif[1], -dif[2]};
-          double loc[3];
-          mulmatT3(loc, bm, t);
-          hit = !(box_sdist(loc, sz) - H.cap_rbound > H.con_margin);
+    auto elem_center = [&](int e, double* c) { c[0] = S.ecen[3 * e]; c[1] = S.ecen[3 * e + 1]; c[2] = S.ecen[3 * e + 2]; };
+    {  // 64 pairs at a time; the next trip's table words are fetched before this trip's tests.  The bounding distance of a pair
+       // (sum of the bounding radii + margin; plane pairs: rbound + margin) travels in the table as a float rounded up: a filter
+       // that passes every pair the exact test passes -- the narrowphase decides
+      int p = SGT_FIRST;
+      SgGenPair nxt;
+      nxt.kind = SGP_UNSUPPORTED; nxt.g1 = nxt.g2 = nxt.pad = 0;
+      if (p < H.ngpair) nxt = A.gpairs[p];
+      for (; p < H.ngpair; p += SGT_STRIDE) {
+        const SgGenPair gp = nxt;
+        if (p + SGT_STRIDE < H.ngpair) nxt = A.gpairs[p + SGT_STRIDE];
+        const int i1 = sgg_index(gp.g1), i2 = sgg_index(gp.g2), k2 = sgg_kind(gp.g2);
+        float bf;
+        memcpy(&bf, &gp.pad, 4);
+        const double bound = (double)bf;
+        bool hit = false;
+        if (gp.kind == SGP_PLANE_CAP || gp.kind == SGP_PLANE_BOX) {
+          const double* c = gp.kind == SGP_PLANE_CAP ? S.ecen + 3 * i2 : (k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[i2]);
+          const double dif[3] = {c[0] - H.plane_pos[0], c[1] - H.plane_pos[1], c[2] - H.plane_pos[2]};
+          hit = !(dot3(dif, H.plane_normal) > bound);
+        } else if (gp.kind != SGP_UNSUPPORTED) {
+          // geom2 is a box (finger or static); geom1 the centre sphere, an element capsule or a box
+          const double* bp = k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[i2];
+          const int k1 = sgg_kind(gp.g1);
+          const double* c = k1 == SGG_CENTER ? H.center_pos : (k1 == SGG_ELEM ? S.ecen + 3 * i1 : (k1 == SGG_BOX ? S.gpos + 3 * i1 : H.st_pos[i1]));
+          const double dif[3] = {bp[0] - c[0], bp[1] - c[1], bp[2] - c[2]};
+          hit = !(dot3(dif, dif) > bound * bound);
+          if (hit && k1 == SGG_ELEM) {   // tighter: the capsule's bounding sphere against the box itself
+            const double* bm = k2 == SGG_BOX ? S.gmat + 9 * i2 : H.st_mat[i2];
+            const double* sz = k2 == SGG_BOX ? T.g_size[i2] : H.st_size[i2];
+            const double t[3] = {-dif[0], -dif[1], -dif[2]};
+            double loc[3];
+            mulmatT3(loc, bm, t);
+            hit = !(box_sdist(loc, sz) - H.cap_rbound > H.con_margin);
+          }
+        }   // (a pair with other contact parameters, SGP_UNSUPPORTED, keeps its place in the table only: never generated)
+        if (hit) {
+          const int idx = lds_inc(&S.icnt[IC_NHIT]);
+          if (idx < SGT_MAXHIT) S.hit_pair[idx] = p;
         }
-      } else {
-        hit = false;   // a pair with other contact parameters: never generated (plan: SGP_UNSUPPORTED keeps its place only)
-      }
-      if (hit) {
-        const int idx = lds_inc(&S.icnt[IC_NHIT]);
-        if (idx < SGT_MAXHIT) S.hit_pair[idx] = p;
       }
     }
     SGT_SYNC();
+    SGT_STAMP(7);
     int nhit = S.icnt[IC_NHIT];
     if (nhit > SGT_MAXHIT) { nhit = SGT_MAXHIT; flags |= SG_FLAG_CONTACTFULL; }
     SGT_PAR(i, nhit) {   // rank by pair index = mj_collision's order
@@ -565,6 +665,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         if (S.hit_off[i] + k < SGT_MAXCON) S.con_src[S.hit_off[i] + k] = i * SGT_HITREC + k;
     SGT_SYNC();
 
+    SGT_STAMP(8);
     // ---------------------------------------------------------------- stage 6: constraint rows
     // (a) equality rows: one joint-fix row per element, the tendon-fix row over all sliders
     double tj_pos = 0, tj_vel = 0, tj_asm = 0, tj_warm = 0, tj_A = 0;
@@ -574,7 +675,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       const double aref = -H.eqj_B * S.ve[e] - H.eqj_K * imp * pos;
       S.Rfix[e] = R; S.bfix[e] = S.asme[e] - aref;
       S.ffix[e] = -(S.we[e] - aref) / R;
-      const double co = E(SGE_COEF, e), invm = 1.0 / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
+      const double co = S.ecoef[e], invm = S.einvm[e];
+      S.Ifix[e] = 1.0 / (invm + R);
       tj_pos += co * S.qe[e]; tj_vel += co * S.ve[e]; tj_asm += co * S.asme[e]; tj_warm += co * S.we[e]; tj_A += co * co * invm;
       // (d) limit rows of the slider: slot 0 lower side, slot 1 upper side (MuJoCo's order)
       for (int sd = 0; sd < 2; sd++) {
@@ -592,6 +694,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           }
         }
         S.Rlim[2 * e + sd] = Rl; S.blim[2 * e + sd] = bl; S.flim[2 * e + sd] = fl;
+        S.Ilim[2 * e + sd] = 1.0 / (invm + Rl);
       }
     }
     tj_pos = wsum(tj_pos); tj_vel = wsum(tj_vel); tj_asm = wsum(tj_asm); tj_warm = wsum(tj_warm); tj_A = wsum(tj_A);
@@ -603,10 +706,11 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       ten_b = tj_asm - aref;
       ten_f = -(tj_warm - aref) / ten_R;
     }
+    const double ten_I = 1.0 / (tj_A + ten_R);
     // (c) limit rows of the chain dofs, one lane per chain: compact list in dof order, lower side first
     SGT_PAR(c, K) {
       int n = 0;
-      double* rows = S.lrow + 5 * 2 * T.c_dof0[c];
+      double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
       for (int dl = 0; dl < T.c_ndof[c]; dl++) {
         const int d = T.c_dof0[c] + dl;
         if (!T.d_limited[d]) continue;
@@ -618,12 +722,14 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           const double R = fmax(SG_MINVAL, (1 - imp) / imp * T.d_invw[d]);
           const double aref = -T.d_limB[d] * sg * S.v[d] - T.d_limK[d] * imp * (dist - T.d_margin[d]);
           const double jar = sg * S.warm[d] - aref;
-          double* r = rows + 5 * n++;
+          double* r = rows + SGT_LROW * n++;
           r[0] = dl; r[1] = sg; r[2] = R; r[3] = sg * S.asm_[d] - aref; r[4] = jar < 0 ? -jar / R : 0.0;
+          r[5] = 1.0 / (S.Minv[T.c_mat0[c] + dl * T.c_ndof[c] + dl] + R);
         }
       }
       S.icnt[IC_NLIM0 + c] = n;
     }
+    SGT_STAMP(9);
     // (e) contact rows, one lane per contact
     SGT_PAR(ci, ncon) {
       const int src = S.con_src[ci], hi = src / SGT_HITREC;
@@ -741,8 +847,28 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       sc[CS_C1] = ch[0]; sc[CS_N1] = nd[0]; sc[CS_C2] = ch[1]; sc[CS_N2] = nd[1];
       sc[CS_ROWS] = rows ? 1.0 : 0.0;
       sc[CS_TOUCH] = (obj && touchbit >= 0) ? touchbit : -1;
+      // the contact's stream in the sweep: its one chain; -1 = no rows; -2 = not exactly one chain block (both fingers, or a slider
+      // against a static geom): such a list is swept serially
+      S.con_chain[ci] = !rows ? -1 : (nblk == 1 ? ch[0] : -2);
+    }
+    SGT_ONE { S.icnt[IC_SERIAL] = 0; }
+    SGT_SYNC();
+    // Contacts of different chains commute exactly unless they share a slider; mj_solPGS's order within a chain is kept by that
+    // chain's stream.  One lane per chain then sweeps its own contacts (a serial list is the fallback, decided here per substep).
+    SGT_PAR(ci, ncon) {
+      const int c = S.con_chain[ci];
+      bool serial = c == -2;
+      if (c >= 0) {
+        const int sl = (int)cscal(ci)[CS_SL];
+        if (sl >= 0)
+          for (int cj = 0; cj < ncon; cj++)
+            if (S.con_chain[cj] >= 0 && S.con_chain[cj] != c && (int)cscal(cj)[CS_SL] == sl) serial = true;
+      }
+      if (serial) S.icnt[IC_SERIAL] = 1;
     }
     SGT_SYNC();
+    const bool serial_contacts = S.icnt[IC_SERIAL] != 0;
+    SGT_STAMP(10);
     // row count (nefc) and the touch bits of this contact list
     {
       int nl = 0;
@@ -762,15 +888,12 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     // ---------------------------------------------------------------- stage 10: warmstart (kept only if it beats f = 0), PGS
     // a = M^-1 J' f of the current forces: chains in aF, sliders in ae
     auto apply_all = [&]() {
-      SGT_PAR(e, N) {
-        const double invm = 1.0 / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
-        S.ae[e] = invm * (S.ffix[e] + E(SGE_COEF, e) * ten_f + S.flim[2 * e] - S.flim[2 * e + 1]);
-      }
+      SGT_PAR(e, N) S.ae[e] = S.einvm[e] * (S.ffix[e] + S.ecoef[e] * ten_f + S.flim[2 * e] - S.flim[2 * e + 1]);
       SGT_PAR(d, ND) {
         const int c = T.d_chain[d], ndc = T.c_ndof[c], dl = d - T.c_dof0[c];
-        const double* rows = S.lrow + 5 * 2 * T.c_dof0[c];
+        const double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
         double s = 0;
-        for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) s += S.Minv[T.c_mat0[c] + (int)rows[5 * i] * ndc + dl] * rows[5 * i + 1] * rows[5 * i + 4];
+        for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) s += S.Minv[T.c_mat0[c] + (int)rows[SGT_LROW * i] * ndc + dl] * rows[SGT_LROW * i + 1] * rows[SGT_LROW * i + 4];
         S.aF[d] = s;
       }
       SGT_SYNC();
@@ -796,15 +919,15 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     {
       double cost = 0, S_ae = 0;
       SGT_PAR(e, N) {
-        S_ae += E(SGE_COEF, e) * S.ae[e];
+        S_ae += S.ecoef[e] * S.ae[e];
         cost += S.ffix[e] * (0.5 * (S.ae[e] + S.Rfix[e] * S.ffix[e]) + S.bfix[e]);
         cost += S.flim[2 * e] * (0.5 * (S.ae[e] + S.Rlim[2 * e] * S.flim[2 * e]) + S.blim[2 * e]);
         cost += S.flim[2 * e + 1] * (0.5 * (-S.ae[e] + S.Rlim[2 * e + 1] * S.flim[2 * e + 1]) + S.blim[2 * e + 1]);
       }
       SGT_PAR(c, K) {
-        const double* rows = S.lrow + 5 * 2 * T.c_dof0[c];
+        const double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
         for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) {
-          const double* r = rows + 5 * i;
+          const double* r = rows + SGT_LROW * i;
           cost += r[4] * (0.5 * (r[1] * S.aF[T.c_dof0[c] + (int)r[0]] + r[2] * r[4]) + r[3]);
         }
       }
@@ -831,66 +954,108 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         SGT_PAR(e, N) { S.ffix[e] = 0; S.flim[2 * e] = 0; S.flim[2 * e + 1] = 0; S.ae[e] = 0; }
         SGT_PAR(d, ND) S.aF[d] = 0;
         SGT_PAR(c, K)
-          for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) S.lrow[5 * (2 * T.c_dof0[c] + i) + 4] = 0;
+          for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) S.lrow[SGT_LROW * (2 * T.c_dof0[c] + i) + 4] = 0;
         SGT_PAR(i, 3 * ncon) S.cf[i] = 0;
       }
       SGT_SYNC();
     }
     iters = 0;
+    SGT_STAMP(11);
     for (int it = 0; it < H.iterations; it++) {
       double imp_par = 0, imp_uni = 0;
       // joint-fix rows: each on its own slider
       double S_ae = 0;
       SGT_PAR(e, N) {
-        const double invm = 1.0 / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
+        const double invm = S.einvm[e];
         double f = S.ffix[e];
         const double old = f;
-        imp_par -= scalar_update(f, S.bfix[e], S.ae[e], S.Rfix[e], invm + S.Rfix[e], false);
+        imp_par -= scalar_update_rcp(f, S.bfix[e], S.ae[e], S.Rfix[e], invm + S.Rfix[e], S.Ifix[e], false);
         S.ffix[e] = f;
         S.ae[e] += invm * (f - old);
-        S_ae += E(SGE_COEF, e) * S.ae[e];
+        S_ae += S.ecoef[e] * S.ae[e];
       }
       S_ae = wsum(S_ae);
       {  // the tendon-fix row over all sliders
         const double old = ten_f;
-        imp_uni -= scalar_update(ten_f, ten_b, S_ae, ten_R, tj_A + ten_R, false);
+        imp_uni -= scalar_update_rcp(ten_f, ten_b, S_ae, ten_R, tj_A + ten_R, ten_I, false);
         const double dfl = ten_f - old;
-        SGT_PAR(e, N) S.ae[e] += E(SGE_COEF, e) * dfl / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
+        SGT_PAR(e, N) S.ae[e] += S.ecoef[e] * dfl * S.einvm[e];
       }
       // chain limit rows: serial within a chain, the chains side by side
       SGT_PAR(c, K) {
         const int ndc = T.c_ndof[c], d0 = T.c_dof0[c];
-        double* rows = S.lrow + 5 * 2 * d0;
+        double* rows = S.lrow + SGT_LROW * 2 * d0;
         const double* Mi = S.Minv + T.c_mat0[c];
         for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) {
-          double* r = rows + 5 * i;
+          double* r = rows + SGT_LROW * i;
           const int dl = (int)r[0];
           double f = r[4];
           const double old = f;
-          imp_par -= scalar_update(f, r[3], r[1] * S.aF[d0 + dl], r[2], Mi[dl * ndc + dl] + r[2], true);
+          imp_par -= scalar_update_rcp(f, r[3], r[1] * S.aF[d0 + dl], r[2], Mi[dl * ndc + dl] + r[2], r[5], true);
           r[4] = f;
           const double dfl = r[1] * (f - old);
-          if (dfl != 0.0)
-            for (int k = 0; k < ndc; k++) S.aF[d0 + k] += Mi[dl * ndc + k] * dfl;
+          if (dfl != 0.0) {   // all loads before the stores: a load-store chain through LDS costs a round trip per element
+            double an[SGT_CHD];
+#pragma unroll
+            for (int k = 0; k < SGT_CHD; k++)
+              if (k < ndc) an[k] = S.aF[d0 + k] + Mi[dl * ndc + k] * dfl;
+#pragma unroll
+            for (int k = 0; k < SGT_CHD; k++)
+              if (k < ndc) S.aF[d0 + k] = an[k];
+          }
         }
       }
       // slider limit rows
       SGT_PAR(e, N) {
-        const double invm = 1.0 / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
+        const double invm = S.einvm[e];
         for (int sd = 0; sd < 2; sd++) {
           const double R = S.Rlim[2 * e + sd];
           if (R == 0.0) continue;
           const double sg = sd ? -1.0 : 1.0;
           double f = S.flim[2 * e + sd];
           const double old = f;
-          imp_par -= scalar_update(f, S.blim[2 * e + sd], sg * S.ae[e], R, invm + R, true);
+          imp_par -= scalar_update_rcp(f, S.blim[2 * e + sd], sg * S.ae[e], R, invm + R, S.Ilim[2 * e + sd], true);
           S.flim[2 * e + sd] = f;
           S.ae[e] += invm * sg * (f - old);
         }
       }
       SGT_SYNC();
-      // contacts, in order
-      for (int ci = 0; ci < ncon; ci++) {
+      SGT_STAMP(12);
+      // contacts: one stream per chain ...
+      if (!serial_contacts) {
+        SGT_PAR(c, K) {
+          const int d0 = T.c_dof0[c], ndc = T.c_ndof[c];
+          for (int ci = 0; ci < ncon; ci++) {
+            if (S.con_chain[ci] != c) continue;
+            const double* sc = cscal(ci);
+            const double* J = crow(ci);
+            const double* W = J + 3 * CS;
+            const int n1 = (int)sc[CS_N1], sl = (int)sc[CS_SL];
+            double p0 = 0, p1 = 0, p2 = 0;
+            for (int dl = 0; dl < n1; dl++) {
+              const double a = S.aF[d0 + dl];
+              p0 += J[dl] * a; p1 += J[CS + dl] * a; p2 += J[2 * CS + dl] * a;
+            }
+            const double as_ = sl >= 0 ? S.ae[sl] : 0.0;
+            double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
+            const double res[3] = {sc[CS_B] + sc[CS_JS] * as_ + p0 + sc[CS_R] * f[0], sc[CS_B + 1] + sc[CS_JS + 1] * as_ + p1 + sc[CS_R] * f[1],
+                                   sc[CS_B + 2] + sc[CS_JS + 2] * as_ + p2 + sc[CS_R] * f[2]};
+            imp_par -= contact_block_update(sc + CS_A, res, f, H.con_mu, df);
+            double an[SGT_CHD];
+#pragma unroll
+            for (int k = 0; k < SGT_CHD; k++)
+              if (k < ndc) an[k] = S.aF[d0 + k] + (W[k] * df[0] + W[CS + k] * df[1] + W[2 * CS + k] * df[2]);
+#pragma unroll
+            for (int k = 0; k < SGT_CHD; k++)
+              if (k < ndc) S.aF[d0 + k] = an[k];
+            S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
+            if (sl >= 0) S.ae[sl] += sc[CS_INVM] * (sc[CS_JS] * df[0] + sc[CS_JS + 1] * df[1] + sc[CS_JS + 2] * df[2]);
+          }
+        }
+        SGT_SYNC();
+      }
+      // ... or one serial list, the lanes spread over the dofs of a contact's chain block(s)
+      for (int ci = 0; serial_contacts && ci < ncon; ci++) {
         const double* sc = cscal(ci);
         if (sc[CS_ROWS] == 0.0) continue;
         const int c1 = (int)sc[CS_C1], c2 = (int)sc[CS_C2], n1 = (int)sc[CS_N1], n2 = (int)sc[CS_N2], sl = (int)sc[CS_SL];
@@ -922,18 +1087,20 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         }
         SGT_SYNC();
       }
+      SGT_STAMP(13);
       const double improvement = (wsum(imp_par) + imp_uni) * H.pgs_scale;
       iters = it + 1;
       if (improvement < H.tolerance) break;
     }
 
+    SGT_STAMP(14);
     // ---------------------------------------------------------------- qacc, qfrc_constraint, warmstart, sensors
     SGT_PAR(d, ND) {
       const int c = T.d_chain[d], dl = d - T.c_dof0[c];
       double s = 0;
-      const double* rows = S.lrow + 5 * 2 * T.c_dof0[c];
+      const double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
       for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++)
-        if ((int)rows[5 * i] == dl) s += rows[5 * i + 1] * rows[5 * i + 4];
+        if ((int)rows[SGT_LROW * i] == dl) s += rows[SGT_LROW * i + 1] * rows[SGT_LROW * i + 4];
       for (int ci = 0; ci < ncon; ci++) {
         const double* sc = cscal(ci);
         if (sc[CS_ROWS] == 0.0) continue;
@@ -979,6 +1146,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     }
     if (badacc > 0) { flags |= SG_FLAG_BADQACC; break; }
     if (!integrate) continue;
+    SGT_STAMP(15);
     // ---------------------------------------------------------------- stage 12: Euler with implicit joint damping
     SGT_PAR(i, T.NMAT) {
       int c = 0;
@@ -988,15 +1156,15 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     }
     SGT_PAR(d, ND) S.bias[d] = S.fs[d] + S.fc[d];   // right-hand side (the bias array is free now)
     SGT_SYNC();
+    factor_all();
     SGT_PAR(c, K) {
-      chain_factor(S.L + T.c_mat0[c], T.c_ndof[c]);
-      chain_solve(S.L + T.c_mat0[c], T.c_ndof[c], S.bias + T.c_dof0[c]);
+      chain_solve_reg(S.L + T.c_mat0[c], T.c_ndof[c], S.bias + T.c_dof0[c]);
       double* cs = S.chs + c * CHS_N;
       cs[CHS_ACT] += h * cs[CHS_ACTDOT];
     }
     double Jx = 0, Jy = 0;
     SGT_PAR(e, N) {
-      const double m = E(SGE_MASS, e) + E(SGE_ARMATURE, e), fce = m * S.ae[e], den = m + h * E(SGE_DAMPING, e), co = E(SGE_COEF, e);
+      const double m = E(SGE_MASS, e) + E(SGE_ARMATURE, e), fce = m * S.ae[e], den = m + h * E(SGE_DAMPING, e), co = S.ecoef[e];
       const double x = (S.fse[e] + fce) / den;
       S.asme[e] = x;   // (asme is rebuilt by the next forward pass)
       Jx += co * x; Jy += co * co / den;
@@ -1015,6 +1183,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       S.q[d] += h * S.v[d];
     }
     SGT_SYNC();
+    SGT_STAMP(16);
   }
 
   // ---------------------------------------------------------------- state and outputs back

@@ -78,7 +78,7 @@ void temu_run(TreeEmu* E, int mode, int nsub) {
   A.mask = nullptr; A.sens = E->sens.data(); A.sens_stride = E->P.h.nsensordata;
   A.flags = &E->flags; A.touch = &E->touch; A.touch_words = E->touchw; A.ncon = &E->ncon; A.nefc = &E->nefc; A.iters = &E->iters;
   A.cws = E->cws.data(); A.cws_stride = (long long)E->cws.size();
-  A.nenv = 1; A.nsub = nsub; A.mode = mode;
+  A.nenv = 1; A.nsub = nsub; A.mode = mode; A.secprof = nullptr;
   sgt::tree_env(A, 0, E->lds.data());
 }
 

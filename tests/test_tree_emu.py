@@ -95,3 +95,39 @@ def test_tree_plan_refuses_what_it_cannot_run():
     with pytest.raises(RuntimeError) as ei:
         TreeEmu(m)
     assert "fix-rows-only" in str(ei.value)
+
+
+# ---- every pair kind of the candidate-pair table, and the serial contact list (a slider under both fingers, both chains in one row) ----
+@pytest.mark.parametrize("kind", ["thin", "fingers", "stop", "shelf", "rest", "sledge"])
+def test_special_scenes_pair_kinds_and_the_serial_list(tmp_path, kind):
+    """the scenes of tests/test_emu_vs_oracle.py that leave the fast kernels' two pair kinds, on the tree pipeline's source: box - box
+    (finger x finger: both chains in one row; finger x static block), plane - box, plane - capsule, static box - capsule, and one
+    slider carrying contacts of both fingers -- the cases in which the sweep runs the contacts as one serial list instead of one
+    stream per chain.  Sensors, contact, row and sweep counts per env step; the oracle's contact list confirms the special pair."""
+    from test_emu_vs_oracle import elements_touching_both_fingers, general_path_scene, special_contacts, thin_shell_scene
+    path = thin_shell_scene(tmp_path / "thin.xml") if kind == "thin" else general_path_scene(kind, tmp_path / (kind + ".xml"))
+    m = sg.compile_mjcf(path, composite_neighbors=False)
+    jids = list(range(8, m.nv))
+    s = oracle_sim(m)
+    k = 640.0
+    s.jnt_stiffness[jids] = k
+    s.tendon_stiffness[0] = k
+    s.reset(); s.forward(); s.step()
+    e = TreeEmu(m)
+    e.set_stiffness(k, jids, [0])
+    assert e.reset(1) == 0
+    worst, special = 0.0, 0
+    for t, c in enumerate(episode_schedule()[:150]):
+        if c is not None:
+            e.ctrl[:] = c
+            s.ctrl[:] = c
+        for _ in range(7):
+            assert s.step() == 0
+        assert e.step(7) == 0, t
+        assert (e.ncon, e.nefc, e.iters) == (s.ncon, s.nefc, s.solver_iter), t
+        special += elements_touching_both_fingers(m, s.contacts()) if kind == "thin" else special_contacts(m, s.contacts(), kind)
+        worst = max(worst, np.abs(e.sensordata - s.sensordata).max())
+        if kind in ("shelf", "rest", "sledge"):   # dozens of standing contacts from the first step on: these scenes amplify round-off
+            e.qpos[:] = s.qpos; e.qvel[:] = s.qvel; e.warm[:] = s.qacc_warmstart; e.act[:] = s.act
+    assert special > (40 if kind == "thin" else 100), special
+    assert worst < 1e-7, worst
