@@ -245,11 +245,11 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
       }
     }
     if (T.K == 0) FAIL("model has no finger chain");
-    T.NMAT = 0; T.CS = 0;
-    for (int c = 0; c < T.K; c++) {
-      T.c_mat0[c] = T.NMAT; T.NMAT += T.c_ndof[c] * T.c_ndof[c];
-      T.CS = std::max(T.CS, T.c_ndof[c]);
-    }
+    T.CS = 0;
+    for (int c = 0; c < T.K; c++) T.CS = std::max(T.CS, T.c_ndof[c]);
+    T.CS = (T.CS + 3) & ~3;   // every chain's vectors and matrix blocks are padded to this stride: uniform loop counts on the device
+    for (int c = 0; c < T.K; c++) T.c_mat0[c] = c * T.CS * T.CS;
+    T.NMAT = T.K * T.CS * T.CS;
     if (T.ND + nelem != nv) FAIL("the model has dofs that belong neither to a finger chain nor to a composite element");
   }
   for (int b = 1; b < nbody && !tree; b++) {

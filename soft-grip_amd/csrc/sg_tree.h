@@ -61,9 +61,11 @@ struct TreeArgs {
   unsigned long long* secprof;   // profiling build (-DSG_SECTION_PROF) only: cycle sums per section, else unused
 };
 
-// work-space layout (doubles): staged narrowphase records | contact rows
+// work-space layout (doubles): staged narrowphase records | contact rows | the chains' mass-matrix blocks
 SG_HD long long cws_row_doubles(int CS) { return 12LL * CS + SGT_CSC; }   // 2 blocks x (J, W) x 3 rows x CS + scalars
-SG_HD long long cws_doubles(int CS) { return (long long)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (long long)SGT_MAXCON * cws_row_doubles(CS); }
+SG_HD long long cws_doubles(const SgTreeDev& T) {
+  return (long long)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (long long)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT;
+}
 
 // scalar part of a contact record
 enum { CS_A = 0, CS_B = 6, CS_F0 = 9, CS_R = 12, CS_INVM = 13, CS_JS = 14, CS_SL = 17, CS_C1 = 18, CS_N1 = 19, CS_C2 = 20, CS_N2 = 21,
@@ -73,7 +75,7 @@ struct Lds {
   double *q, *v, *warm, *asm_, *aF, *fs, *fc, *bias, *tenJ, *kd, *qacc;
   double *xpos, *xmat, *xipos, *ximat, *bw, *bal, *ba, *bf, *bn;
   double *anchor, *axis, *gpos, *gmat, *spos;
-  double *M, *L, *Minv;
+  double *L, *Minv, *tmpP;
   double *qe, *ve, *we, *asme, *ae, *fse, *ffix, *bfix, *Rfix, *flim, *blim, *Rlim, *ke;
   double *einvm, *ecoef, *ecen, *Ifix, *Ilim;   // 1 / (m + armature), tendon coefficient, capsule centres [3][N], 1 / (A + R) of the fix / limit rows
   double *lrow, *seg, *chs, *cf, *red;
@@ -87,12 +89,12 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N) {
   double* p = base;
   auto take = [&](size_t n) { double* r = p; p += (n + 1) & ~(size_t)1; return r; };
   const int ND = T.ND, NB = T.NB;
-  L.q = take(ND); L.v = take(ND); L.warm = take(ND); L.asm_ = take(ND); L.aF = take(ND); L.fs = take(ND); L.fc = take(ND);
+  L.q = take(ND); L.v = take(ND); L.warm = take(ND); L.asm_ = take(ND); L.aF = take(T.K * T.CS); L.fs = take(ND); L.fc = take(ND);
   L.bias = take(ND); L.tenJ = take(ND); L.kd = take(ND); L.qacc = take(ND);
   L.xpos = take(3 * NB); L.xmat = take(9 * NB); L.xipos = take(3 * NB); L.ximat = take(9 * NB); L.bw = take(3 * NB);
   L.bal = take(3 * NB); L.ba = take(3 * NB); L.bf = take(3 * NB); L.bn = take(3 * NB);
   L.anchor = take(3 * ND); L.axis = take(3 * ND); L.gpos = take(3 * T.NG); L.gmat = take(9 * T.NG); L.spos = take(3 * T.NS);
-  L.M = take(T.NMAT); L.L = take(T.NMAT); L.Minv = take(T.NMAT);
+  L.L = take(T.NMAT); L.Minv = take(T.NMAT); L.tmpP = take(T.K * T.CS);
   L.qe = take(N); L.ve = take(N); L.we = take(N); L.asme = take(N); L.ae = take(N); L.fse = take(N); L.ffix = take(N);
   L.bfix = take(N); L.Rfix = take(N); L.flim = take(2 * N); L.blim = take(2 * N); L.Rlim = take(2 * N); L.ke = take(N);
   L.einvm = take(N); L.ecoef = take(N); L.ecen = take(3 * N); L.Ifix = take(N); L.Ilim = take(2 * N);
@@ -168,31 +170,34 @@ SG_HD void chain_solve(const double* Lc, int nd, double* x) {
 }
 // the same solve with x in registers: fully unrolled over the SGT_CHD capacity, guarded by nd (LDS reads of L only, no dependent
 // read-modify-write chain through LDS: 9 k instead of 100 k cycles for the M^-1 columns).  Same operations in the same order.
-SG_HD void chain_solve_reg(const double* Lc, int nd, double* xmem) {
+// Lc: a padded block [P][P] (identity beyond the chain's dofs), xmem: a padded vector [P]; P is the same on every lane, so the guards
+// are scalar branches around straight-line blocks
+SG_HD void chain_solve_reg(const double* Lc, int P, double* xmem) {
   double x[SGT_CHD];
 #pragma unroll
-  for (int k = 0; k < SGT_CHD; k++) x[k] = k < nd ? xmem[k] : 0.0;
+  for (int k = 0; k < SGT_CHD; k += 4)
+    if (k < P) { x[k] = xmem[k]; x[k + 1] = xmem[k + 1]; x[k + 2] = xmem[k + 2]; x[k + 3] = xmem[k + 3]; }
 #pragma unroll
   for (int k = SGT_CHD - 1; k >= 1; k--)
-    if (k < nd) {
+    if (k < P) {
       const double xk = x[k];
 #pragma unroll
-      for (int i = k - 1; i >= 0; i--) x[i] -= Lc[k * nd + i] * xk;
+      for (int i = k - 1; i >= 0; i--) x[i] -= Lc[k * P + i] * xk;
     }
 #pragma unroll
-  for (int k = 0; k < SGT_CHD; k++)
-    if (k < nd) x[k] /= Lc[k * nd + k];
+  for (int k = 0; k < SGT_CHD; k += 4)
+    if (k < P) { x[k] /= Lc[k * P + k]; x[k + 1] /= Lc[(k + 1) * P + k + 1]; x[k + 2] /= Lc[(k + 2) * P + k + 2]; x[k + 3] /= Lc[(k + 3) * P + k + 3]; }
 #pragma unroll
   for (int k = 1; k < SGT_CHD; k++)
-    if (k < nd) {
+    if (k < P) {
       double s = x[k];
 #pragma unroll
-      for (int i = k - 1; i >= 0; i--) s -= Lc[k * nd + i] * x[i];
+      for (int i = k - 1; i >= 0; i--) s -= Lc[k * P + i] * x[i];
       x[k] = s;
     }
 #pragma unroll
-  for (int k = 0; k < SGT_CHD; k++)
-    if (k < nd) xmem[k] = x[k];
+  for (int k = 0; k < SGT_CHD; k += 4)
+    if (k < P) { xmem[k] = x[k]; xmem[k + 1] = x[k + 1]; xmem[k + 2] = x[k + 2]; xmem[k + 3] = x[k + 3]; }
 }
 // scalar row update with the reciprocal of the row's diagonal A + R precomputed (as the fast kernels' equality rows)
 SG_HD double scalar_update_rcp(double& f, double b, double Ja, double R, double Adiag, double Ainv, bool inequality) {
@@ -232,6 +237,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   const long long CW = cws_row_doubles(CS);
   auto crow = [&](int c) { return crow0 + (size_t)c * CW; };                 // J1[3][CS] | W1[3][CS] | J2[3][CS] | W2[3][CS] | scalars
   auto cscal = [&](int c) { return crow0 + (size_t)c * CW + 12 * CS; };
+  double* const Mg = crow0 + (size_t)SGT_MAXCON * CW;    // the chains' mass-matrix blocks [K][CS][CS], identity-padded
+  auto pidx = [&](int d) { const int c = T.d_chain[d]; return c * CS + d - T.c_dof0[c]; };   // flat chain dof -> index in a padded [K][CS] vector
 
   if (A.mode == 1 && A.mask && !A.mask[env]) return;   // masked reset: the other envs keep everything
   double* const gq = A.qpos + (size_t)env * nv;
@@ -279,22 +286,28 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   SGT_STAMP_INIT();
   // L'DL of every chain block in S.L at once (mj_factorM on serial chains): step s eliminates dof k = nd - 1 - s of each chain, one lane
   // per row i < k: L[i][j] -= (L[k][i] / L[k][k]) L[k][j] for j <= i, then row k is scaled.  Same operations as chain_factor.
+  // The blocks are padded to [CS][CS]; a row's update runs over the whole row (the entries right of the diagonal are never read), so
+  // that every lane's loop has the same count.
   auto factor_all = [&]() {
     for (int st = 0; st + 1 < CS; st++) {
-      SGT_PAR(d, ND) {
-        const int c = T.d_chain[d], nd = T.c_ndof[c], i = d - T.c_dof0[c], k = nd - 1 - st;
+      SGT_PAR(idx, K * CS) {
+        const int c = idx / CS, i = idx % CS, k = T.c_ndof[c] - 1 - st;
         if (k >= 1 && i < k) {
-          double* Lc = S.L + T.c_mat0[c];
-          const double a = Lc[k * nd + i] / Lc[k * nd + k];
-          for (int j = i; j >= 0; j--) Lc[i * nd + j] -= a * Lc[k * nd + j];
+          double* Lc = S.L + c * CS * CS;
+          const double a = Lc[k * CS + i] / Lc[k * CS + k];
+          for (int j = 0; j < CS; j += 4) {
+            const double l0 = Lc[k * CS + j], l1 = Lc[k * CS + j + 1], l2 = Lc[k * CS + j + 2], l3 = Lc[k * CS + j + 3];
+            const double r0 = Lc[i * CS + j], r1 = Lc[i * CS + j + 1], r2 = Lc[i * CS + j + 2], r3 = Lc[i * CS + j + 3];
+            Lc[i * CS + j] = r0 - a * l0; Lc[i * CS + j + 1] = r1 - a * l1; Lc[i * CS + j + 2] = r2 - a * l2; Lc[i * CS + j + 3] = r3 - a * l3;
+          }
         }
       }
       SGT_SYNC();
-      SGT_PAR(d, ND) {
-        const int c = T.d_chain[d], nd = T.c_ndof[c], i = d - T.c_dof0[c], k = nd - 1 - st;
+      SGT_PAR(idx, K * CS) {
+        const int c = idx / CS, i = idx % CS, k = T.c_ndof[c] - 1 - st;
         if (k >= 1 && i < k) {
-          double* Lc = S.L + T.c_mat0[c];
-          Lc[k * nd + i] = Lc[k * nd + i] / Lc[k * nd + k];
+          double* Lc = S.L + c * CS * CS;
+          Lc[k * CS + i] = Lc[k * CS + i] / Lc[k * CS + k];
         }
       }
       SGT_SYNC();
@@ -437,10 +450,10 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     SGT_STAMP(2);
     // ---------------------------------------------------------------- stage 4: mass matrix, one lane per entry of the lower triangles
     SGT_PAR(i, T.NMAT) {
-      int c = 0;
-      while (c + 1 < K && i >= T.c_mat0[c + 1]) c++;
-      const int nd = T.c_ndof[c], a = (i - T.c_mat0[c]) / nd, b = (i - T.c_mat0[c]) % nd;
-      if (b <= a) {
+      const int c = i / (CS * CS), a = (i % (CS * CS)) / CS, b = i % CS, nd = T.c_ndof[c];
+      if (a >= nd || b >= nd) {
+        Mg[i] = a == b ? 1.0 : 0.0;   // identity padding
+      } else if (b <= a) {
         const int da = T.c_dof0[c] + a, db = T.c_dof0[c] + b;
         double s = a == b ? T.d_armature[da] : 0.0;
         for (int tb = T.d_body[da]; tb < T.c_body0[c] + T.c_nbody[c]; tb++) {
@@ -453,20 +466,20 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           mulmat3(Ir, S.ximat + 9 * tb, S.axis + 3 * da);
           s += mass * dot3(ja, jb) + dot3(Ir, S.axis + 3 * db);
         }
-        S.M[T.c_mat0[c] + a * nd + b] = s;
-        S.M[T.c_mat0[c] + b * nd + a] = s;
+        Mg[c * CS * CS + a * CS + b] = s;
+        Mg[c * CS * CS + b * CS + a] = s;
       }
     }
     SGT_SYNC();
     SGT_STAMP(3);
-    SGT_PAR(i, T.NMAT) S.L[i] = S.M[i];
+    SGT_PAR(i, T.NMAT) S.L[i] = Mg[i];
     SGT_SYNC();
     factor_all();
-    SGT_PAR(d, ND) {   // M^-1 by columns (= rows): solve for the unit vector of dof d
-      const int c = T.d_chain[d], nd = T.c_ndof[c], dl = d - T.c_dof0[c];
-      double* x = S.Minv + T.c_mat0[c] + dl * nd;
-      for (int k = 0; k < nd; k++) x[k] = k == dl ? 1.0 : 0.0;
-      chain_solve_reg(S.L + T.c_mat0[c], nd, x);
+    SGT_PAR(idx, K * CS) {   // M^-1 by columns (= rows): solve for the unit vectors (the padding rows come out as unit vectors too)
+      const int c = idx / CS, dl = idx % CS;
+      double* x = S.Minv + c * CS * CS + dl * CS;
+      for (int k = 0; k < CS; k++) x[k] = k == dl ? 1.0 : 0.0;
+      chain_solve_reg(S.L + c * CS * CS, CS, x);
     }
     SGT_STAMP(4);
     // ---------------------------------------------------------------- stage 7: bias forces (RNE with qacc = 0), body velocities
@@ -526,10 +539,14 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       const double* cs = S.chs + c * CHS_N;
       const double pas = -S.kd[d] * (S.q[d] - T.d_springref[d]) - T.d_damping[d] * S.v[d] + S.tenJ[d] * cs[CHS_TFRC];
       S.fs[d] = pas - s + S.tenJ[d] * cs[CHS_AFRC];
-      S.asm_[d] = S.fs[d];
     }
+    SGT_PAR(i, K * CS) S.tmpP[i] = 0;
     SGT_SYNC();
-    SGT_PAR(c, K) chain_solve_reg(S.L + T.c_mat0[c], T.c_ndof[c], S.asm_ + T.c_dof0[c]);
+    SGT_PAR(d, ND) S.tmpP[pidx(d)] = S.fs[d];
+    SGT_SYNC();
+    SGT_PAR(c, K) chain_solve_reg(S.L + c * CS * CS, CS, S.tmpP + c * CS);
+    SGT_SYNC();
+    SGT_PAR(d, ND) S.asm_[d] = S.tmpP[pidx(d)];
     SGT_STAMP(5);
     // ---------------------------------------------------------------- the composite's sliders: smooth forces (stages 7 - 9)
     double t0_len = 0, t0_vel = 0;
@@ -724,7 +741,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           const double jar = sg * S.warm[d] - aref;
           double* r = rows + SGT_LROW * n++;
           r[0] = dl; r[1] = sg; r[2] = R; r[3] = sg * S.asm_[d] - aref; r[4] = jar < 0 ? -jar / R : 0.0;
-          r[5] = 1.0 / (S.Minv[T.c_mat0[c] + dl * T.c_ndof[c] + dl] + R);
+          r[5] = 1.0 / (S.Minv[c * CS * CS + dl * CS + dl] + R);
         }
       }
       S.icnt[IC_NLIM0 + c] = n;
@@ -759,6 +776,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           if (fresh) { blk = nblk++; ch[blk] = c; nd[blk] = 0; }
           double* J = blk ? J2 : J1;
           const int nold = nd[blk];
+          if (fresh)
+            for (int k = 0; k < 3 * CS; k++) J[k] = 0.0;   // the sweep reads whole padded rows
           for (int dl = 0; dl < (n > nold ? n : nold); dl++) {
             double jp[3] = {0, 0, 0};
             if (dl < n) {
@@ -790,14 +809,14 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         jw[rr] = sl >= 0 ? Js[rr] * S.we[sl] : 0.0;
       }
       for (int b = 0; b < nblk; b++) {
-        const int c = ch[b], ndc = T.c_ndof[c], d0 = T.c_dof0[c], n = nd[b];
-        const double* Mi = S.Minv + T.c_mat0[c];
+        const int c = ch[b], d0 = T.c_dof0[c], n = nd[b];
+        const double* Mi = S.Minv + c * CS * CS;
         double* J = b ? J2 : J1;
         double* W = b ? W2 : W1;
         for (int rr = 0; rr < 3; rr++) {
-          for (int dl = 0; dl < ndc; dl++) {
+          for (int dl = 0; dl < CS; dl++) {   // (M^-1's padding columns are zero in the rows of real dofs)
             double s = 0;
-            for (int e2 = 0; e2 < n; e2++) s += J[rr * CS + e2] * Mi[e2 * ndc + dl];
+            for (int e2 = 0; e2 < n; e2++) s += J[rr * CS + e2] * Mi[e2 * CS + dl];
             W[rr * CS + dl] = s;
           }
           for (int dl = 0; dl < n; dl++) {
@@ -889,24 +908,24 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     // a = M^-1 J' f of the current forces: chains in aF, sliders in ae
     auto apply_all = [&]() {
       SGT_PAR(e, N) S.ae[e] = S.einvm[e] * (S.ffix[e] + S.ecoef[e] * ten_f + S.flim[2 * e] - S.flim[2 * e + 1]);
-      SGT_PAR(d, ND) {
-        const int c = T.d_chain[d], ndc = T.c_ndof[c], dl = d - T.c_dof0[c];
+      SGT_PAR(idx, K * CS) {
+        const int c = idx / CS, dl = idx % CS;
         const double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
         double s = 0;
-        for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) s += S.Minv[T.c_mat0[c] + (int)rows[SGT_LROW * i] * ndc + dl] * rows[SGT_LROW * i + 1] * rows[SGT_LROW * i + 4];
-        S.aF[d] = s;
+        for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) s += S.Minv[c * CS * CS + (int)rows[SGT_LROW * i] * CS + dl] * rows[SGT_LROW * i + 1] * rows[SGT_LROW * i + 4];
+        S.aF[idx] = s;
       }
       SGT_SYNC();
       for (int ci = 0; ci < ncon; ci++) {   // contacts add their pushes one after the other (a slider / chain may be shared)
         const double* sc = cscal(ci);
         if (sc[CS_ROWS] == 0.0) continue;
         const double* f = S.cf + 3 * ci;
-        const int c1 = (int)sc[CS_C1], c2 = (int)sc[CS_C2], n1c = c1 >= 0 ? T.c_ndof[c1] : 0, n2c = c2 >= 0 ? T.c_ndof[c2] : 0;
+        const int c1 = (int)sc[CS_C1], c2 = (int)sc[CS_C2], n1c = c1 >= 0 ? CS : 0, n2c = c2 >= 0 ? CS : 0;
         SGT_PAR(i, n1c + n2c) {
           const bool second = i >= n1c;
           const int dl = second ? i - n1c : i;
           const double* W = crow(ci) + (second ? 9 * CS : 3 * CS);
-          S.aF[T.c_dof0[second ? c2 : c1] + dl] += W[dl] * f[0] + W[CS + dl] * f[1] + W[2 * CS + dl] * f[2];
+          S.aF[(second ? c2 : c1) * CS + dl] += W[dl] * f[0] + W[CS + dl] * f[1] + W[2 * CS + dl] * f[2];
         }
         SGT_ONE {
           const int sl = (int)sc[CS_SL];
@@ -928,7 +947,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         const double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
         for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) {
           const double* r = rows + SGT_LROW * i;
-          cost += r[4] * (0.5 * (r[1] * S.aF[T.c_dof0[c] + (int)r[0]] + r[2] * r[4]) + r[3]);
+          cost += r[4] * (0.5 * (r[1] * S.aF[c * CS + (int)r[0]] + r[2] * r[4]) + r[3]);
         }
       }
       SGT_PAR(ci, ncon) {
@@ -942,7 +961,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
             const int c = (int)sc[b ? CS_C2 : CS_C1], n = (int)sc[b ? CS_N2 : CS_N1];
             if (c < 0) continue;
             const double* J = crow(ci) + (b ? 6 * CS : 0) + rr * CS;
-            for (int dl = 0; dl < n; dl++) ja += J[dl] * S.aF[T.c_dof0[c] + dl];
+            for (int dl = 0; dl < n; dl++) ja += J[dl] * S.aF[c * CS + dl];
           }
           cost += f[rr] * (0.5 * (ja + sc[CS_R] * f[rr]) + sc[CS_B + rr]);
         }
@@ -952,7 +971,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       if (cost > 0) {   // uniform
         ten_f = 0;
         SGT_PAR(e, N) { S.ffix[e] = 0; S.flim[2 * e] = 0; S.flim[2 * e + 1] = 0; S.ae[e] = 0; }
-        SGT_PAR(d, ND) S.aF[d] = 0;
+        SGT_PAR(i, K * CS) S.aF[i] = 0;
         SGT_PAR(c, K)
           for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) S.lrow[SGT_LROW * (2 * T.c_dof0[c] + i) + 4] = 0;
         SGT_PAR(i, 3 * ncon) S.cf[i] = 0;
@@ -975,36 +994,40 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         S_ae += S.ecoef[e] * S.ae[e];
       }
       S_ae = wsum(S_ae);
+      SGT_STAMP(17);
       {  // the tendon-fix row over all sliders
         const double old = ten_f;
         imp_uni -= scalar_update_rcp(ten_f, ten_b, S_ae, ten_R, tj_A + ten_R, ten_I, false);
         const double dfl = ten_f - old;
         SGT_PAR(e, N) S.ae[e] += S.ecoef[e] * dfl * S.einvm[e];
       }
+      SGT_STAMP(18);
       // chain limit rows: serial within a chain, the chains side by side
       SGT_PAR(c, K) {
-        const int ndc = T.c_ndof[c], d0 = T.c_dof0[c];
-        double* rows = S.lrow + SGT_LROW * 2 * d0;
-        const double* Mi = S.Minv + T.c_mat0[c];
-        for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) {
+        double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
+        const double* Mi = S.Minv + c * CS * CS;
+        double* aFc = S.aF + c * CS;
+        const int nrow = S.icnt[IC_NLIM0 + c];
+        for (int i = 0; i < nrow; i++) {
           double* r = rows + SGT_LROW * i;
           const int dl = (int)r[0];
           double f = r[4];
           const double old = f;
-          imp_par -= scalar_update_rcp(f, r[3], r[1] * S.aF[d0 + dl], r[2], Mi[dl * ndc + dl] + r[2], r[5], true);
+          imp_par -= scalar_update_rcp(f, r[3], r[1] * aFc[dl], r[2], Mi[dl * CS + dl] + r[2], r[5], true);
           r[4] = f;
           const double dfl = r[1] * (f - old);
-          if (dfl != 0.0) {   // all loads before the stores: a load-store chain through LDS costs a round trip per element
-            double an[SGT_CHD];
+          // every load before the first store (a load-store chain through LDS costs a round trip per element): unrolled over the
+          // capacity, the loads unguarded (beyond the padded stride CS they hit other LDS words and are dropped), the stores behind
+          // scalar branches on CS, which is the same on every lane
+          double an[SGT_CHD];
 #pragma unroll
-            for (int k = 0; k < SGT_CHD; k++)
-              if (k < ndc) an[k] = S.aF[d0 + k] + Mi[dl * ndc + k] * dfl;
+          for (int k = 0; k < SGT_CHD; k++) an[k] = aFc[k] + Mi[dl * CS + k] * dfl;
 #pragma unroll
-            for (int k = 0; k < SGT_CHD; k++)
-              if (k < ndc) S.aF[d0 + k] = an[k];
-          }
+          for (int k = 0; k < SGT_CHD; k += 4)
+            if (k < CS) { aFc[k] = an[k]; aFc[k + 1] = an[k + 1]; aFc[k + 2] = an[k + 2]; aFc[k + 3] = an[k + 3]; }
         }
       }
+      SGT_STAMP(19);
       // slider limit rows
       SGT_PAR(e, N) {
         const double invm = S.einvm[e];
@@ -1024,18 +1047,26 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       // contacts: one stream per chain ...
       if (!serial_contacts) {
         SGT_PAR(c, K) {
-          const int d0 = T.c_dof0[c], ndc = T.c_ndof[c];
+          double* aFc = S.aF + c * CS;
           for (int ci = 0; ci < ncon; ci++) {
             if (S.con_chain[ci] != c) continue;
             const double* sc = cscal(ci);
             const double* J = crow(ci);
             const double* W = J + 3 * CS;
-            const int n1 = (int)sc[CS_N1], sl = (int)sc[CS_SL];
+            const int sl = (int)sc[CS_SL];
             double p0 = 0, p1 = 0, p2 = 0;
-            for (int dl = 0; dl < n1; dl++) {
-              const double a = S.aF[d0 + dl];
-              p0 += J[dl] * a; p1 += J[CS + dl] * a; p2 += J[2 * CS + dl] * a;
+            // whole padded rows (J is zero beyond the body's dofs), unrolled over the capacity with every load issued up front: the rows
+            // sit in global memory (L2), and a loop would pay that latency once per trip.  Beyond the padded stride CS (uniform) the
+            // loads hit the record's other words and are dropped by the select.
+#pragma unroll
+            for (int k = 0; k < SGT_CHD; k++) {
+              const double a = aFc[k], j0 = J[k], j1 = J[CS + k], j2 = J[2 * CS + k];
+              const bool in = k < CS;
+              p0 += in ? j0 * a : 0.0; p1 += in ? j1 * a : 0.0; p2 += in ? j2 * a : 0.0;
             }
+            double w0[SGT_CHD], w1[SGT_CHD], w2[SGT_CHD];   // the W rows are on their way while the block update runs
+#pragma unroll
+            for (int k = 0; k < SGT_CHD; k++) { w0[k] = W[k]; w1[k] = W[CS + k]; w2[k] = W[2 * CS + k]; }
             const double as_ = sl >= 0 ? S.ae[sl] : 0.0;
             double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
             const double res[3] = {sc[CS_B] + sc[CS_JS] * as_ + p0 + sc[CS_R] * f[0], sc[CS_B + 1] + sc[CS_JS + 1] * as_ + p1 + sc[CS_R] * f[1],
@@ -1043,11 +1074,10 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
             imp_par -= contact_block_update(sc + CS_A, res, f, H.con_mu, df);
             double an[SGT_CHD];
 #pragma unroll
-            for (int k = 0; k < SGT_CHD; k++)
-              if (k < ndc) an[k] = S.aF[d0 + k] + (W[k] * df[0] + W[CS + k] * df[1] + W[2 * CS + k] * df[2]);
+            for (int k = 0; k < SGT_CHD; k++) an[k] = aFc[k] + (w0[k] * df[0] + w1[k] * df[1] + w2[k] * df[2]);
 #pragma unroll
-            for (int k = 0; k < SGT_CHD; k++)
-              if (k < ndc) S.aF[d0 + k] = an[k];
+            for (int k = 0; k < SGT_CHD; k += 4)
+              if (k < CS) { aFc[k] = an[k]; aFc[k + 1] = an[k + 1]; aFc[k + 2] = an[k + 2]; aFc[k + 3] = an[k + 3]; }
             S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
             if (sl >= 0) S.ae[sl] += sc[CS_INVM] * (sc[CS_JS] * df[0] + sc[CS_JS + 1] * df[1] + sc[CS_JS + 2] * df[2]);
           }
@@ -1064,7 +1094,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           const bool second = i >= n1;
           const int dl = second ? i - n1 : i;
           const double* J = crow(ci) + (second ? 6 * CS : 0);
-          const double a = S.aF[T.c_dof0[second ? c2 : c1] + dl];
+          const double a = S.aF[(second ? c2 : c1) * CS + dl];
           p0 += J[dl] * a; p1 += J[CS + dl] * a; p2 += J[2 * CS + dl] * a;
         }
         p0 = wsum(p0); p1 = wsum(p1); p2 = wsum(p2);
@@ -1074,12 +1104,12 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
                                sc[CS_B + 2] + sc[CS_JS + 2] * as_ + p2 + sc[CS_R] * f[2]};
         imp_uni -= contact_block_update(sc + CS_A, res, f, H.con_mu, df);
         SGT_SYNC();   // every lane has read the old forces and accelerations
-        const int n1c = c1 >= 0 ? T.c_ndof[c1] : 0, n2c = c2 >= 0 ? T.c_ndof[c2] : 0;
+        const int n1c = c1 >= 0 ? CS : 0, n2c = c2 >= 0 ? CS : 0;
         SGT_PAR(i, n1c + n2c) {
           const bool second = i >= n1c;
           const int dl = second ? i - n1c : i;
           const double* W = crow(ci) + (second ? 9 * CS : 3 * CS);
-          S.aF[T.c_dof0[second ? c2 : c1] + dl] += W[dl] * df[0] + W[CS + dl] * df[1] + W[2 * CS + dl] * df[2];
+          S.aF[(second ? c2 : c1) * CS + dl] += W[dl] * df[0] + W[CS + dl] * df[1] + W[2 * CS + dl] * df[2];
         }
         SGT_ONE {
           S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
@@ -1111,7 +1141,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           }
       }
       S.fc[d] = s;
-      S.qacc[d] = S.asm_[d] + S.aF[d];
+      S.qacc[d] = S.asm_[d] + S.aF[pidx(d)];
       S.warm[d] = S.qacc[d];
     }
     double badacc = 0;
@@ -1149,16 +1179,15 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     SGT_STAMP(15);
     // ---------------------------------------------------------------- stage 12: Euler with implicit joint damping
     SGT_PAR(i, T.NMAT) {
-      int c = 0;
-      while (c + 1 < K && i >= T.c_mat0[c + 1]) c++;
-      const int nd = T.c_ndof[c], a = (i - T.c_mat0[c]) / nd, b = (i - T.c_mat0[c]) % nd;
-      S.L[i] = S.M[i] + (a == b ? h * T.d_damping[T.c_dof0[c] + a] : 0.0);
+      const int c = i / (CS * CS), a = (i % (CS * CS)) / CS, b = i % CS;
+      S.L[i] = Mg[i] + ((a == b && a < T.c_ndof[c]) ? h * T.d_damping[T.c_dof0[c] + a] : 0.0);
     }
-    SGT_PAR(d, ND) S.bias[d] = S.fs[d] + S.fc[d];   // right-hand side (the bias array is free now)
+    SGT_PAR(i, K * CS) S.tmpP[i] = 0;
     SGT_SYNC();
+    SGT_PAR(d, ND) S.tmpP[pidx(d)] = S.fs[d] + S.fc[d];   // right-hand side, padded
     factor_all();
     SGT_PAR(c, K) {
-      chain_solve_reg(S.L + T.c_mat0[c], T.c_ndof[c], S.bias + T.c_dof0[c]);
+      chain_solve_reg(S.L + c * CS * CS, CS, S.tmpP + c * CS);
       double* cs = S.chs + c * CHS_N;
       cs[CHS_ACT] += h * cs[CHS_ACTDOT];
     }
@@ -1179,7 +1208,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       S.qe[e] += h * S.ve[e];
     }
     SGT_PAR(d, ND) {
-      S.v[d] += h * S.bias[d];
+      S.v[d] += h * S.tmpP[pidx(d)];
       S.q[d] += h * S.v[d];
     }
     SGT_SYNC();

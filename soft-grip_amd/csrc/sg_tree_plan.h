@@ -26,8 +26,9 @@
 
 struct SgTreeDev {
   int K, NB, ND, NG, NS, NSENS;
-  int NMAT;    // sum over chains of ndof^2: doubles of one set of dense per-chain blocks
-  int CS;      // row stride of a contact's chain block = max ndof over the chains
+  int CS;      // padded stride of a chain: max ndof over the chains rounded up to a multiple of 4.  Chain vectors are [K][CS], matrix
+               // blocks [K][CS][CS] (identity / zero padding), a contact's J / W rows [3][CS]: the hot loops run to CS on every lane
+  int NMAT;    // K * CS * CS: doubles of one set of per-chain blocks
   // ---- chains
   int c_body0[SGT_MAXCH], c_nbody[SGT_MAXCH], c_dof0[SGT_MAXCH], c_ndof[SGT_MAXCH], c_mat0[SGT_MAXCH];
   double c_root_pos[SGT_MAXCH][3], c_root_quat[SGT_MAXCH][4];
