@@ -43,7 +43,7 @@ typedef struct sg_blob_record {
 } sg_blob_record;
 
 /* enums (MuJoCo numbering) */
-enum { SG_JNT_SLIDE = 2, SG_JNT_HINGE = 3 };
+enum { SG_JNT_FREE = 0, SG_JNT_SLIDE = 2, SG_JNT_HINGE = 3 };  /* FREE: compiled by mjcf.py and run by the oracle only: 7 positions, 6 dofs; records jnt_qposadr / jnt_dofadr / dof_jntid map the three index spaces */
 enum { SG_GEOM_PLANE = 0, SG_GEOM_SPHERE = 2, SG_GEOM_CAPSULE = 3, SG_GEOM_BOX = 6 };
 enum { SG_EQ_JOINT = 2, SG_EQ_TENDON = 3 };
 enum { SG_WRAP_JOINT = 1, SG_WRAP_SITE = 3 };

@@ -34,7 +34,7 @@ def lib():
         L.sgo_data_new.restype = vp
         L.sgo_data_new.argtypes = [vp]
         L.sgo_data_free.argtypes = [vp]
-        for f in ("sgo_nv", "sgo_nu", "sgo_nsensordata", "sgo_ntendon"):
+        for f in ("sgo_nv", "sgo_nq", "sgo_njnt", "sgo_nu", "sgo_nsensordata", "sgo_ntendon"):
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [vp]
         L.sgo_reset.argtypes = [vp, vp]
@@ -71,6 +71,7 @@ class OracleModel:
         if not self.ptr:
             raise RuntimeError("oracle: " + err.value.decode())
         self.nv, self.nu = L.sgo_nv(self.ptr), L.sgo_nu(self.ptr)
+        self.nq, self.njnt = L.sgo_nq(self.ptr), L.sgo_njnt(self.ptr)      # = nv unless the model has a free joint
         self.nsensordata, self.ntendon = L.sgo_nsensordata(self.ptr), L.sgo_ntendon(self.ptr)
 
     def __del__(self):
@@ -91,11 +92,11 @@ class OracleSim:
             return np.ctypeslib.as_array(getattr(L, fn)(self.ptr), shape=(n,))
 
         m = model
-        self.qpos, self.qvel, self.qacc = view("sgo_qpos", m.nv), view("sgo_qvel", m.nv), view("sgo_qacc", m.nv)
+        self.qpos, self.qvel, self.qacc = view("sgo_qpos", m.nq), view("sgo_qvel", m.nv), view("sgo_qacc", m.nv)
         self.qacc_warmstart = view("sgo_qacc_warmstart", m.nv)
         self.act, self.ctrl = view("sgo_act", m.nu), view("sgo_ctrl", m.nu)
         self.sensordata = view("sgo_sensordata", m.nsensordata)
-        self.jnt_stiffness, self.tendon_stiffness = view("sgo_jnt_stiffness", m.nv), view("sgo_tendon_stiffness", m.ntendon)
+        self.jnt_stiffness, self.tendon_stiffness = view("sgo_jnt_stiffness", m.njnt), view("sgo_tendon_stiffness", m.ntendon)
         self.ten_length, self.qfrc_bias = view("sgo_ten_length", m.ntendon), view("sgo_qfrc_bias", m.nv)
         self.qM = np.ctypeslib.as_array(L.sgo_qM(self.ptr), shape=(m.nv, m.nv))
 

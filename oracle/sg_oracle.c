@@ -57,7 +57,7 @@ typedef struct {
 
 struct sgo_model {
   void* blob;
-  int nbody, nv, ngeom, nsite, ntendon, nwrap, neq, nu, nsensor;
+  int nbody, nv, nq, njnt, ngeom, nsite, ntendon, nwrap, neq, nu, nsensor;   /* nq = nv = njnt unless the model has a free joint (7 positions, 6 dofs) */
   double timestep, gravity[3], tolerance, impratio, meaninertia;
   int iterations, nconmax, njmax;
   /* views into blob */
@@ -80,6 +80,9 @@ struct sgo_model {
   double* site_lmat;
   int npair;
   int* pair; /* npair x 2 candidate geom pairs in MuJoCo's body-pair order */
+  /* joint -> first position / first dof, dof -> joint (identity unless the blob brings them: free joints), and per dof / body:
+   * rotational? (hinge, free rotation: jp = axis x r, jr = axis; else slide / free translation: jp = axis), the body's dof range */
+  int *jnt_qposadr, *jnt_dofadr, *dof_jntid, *dof_rot, *body_dofadr, *body_dofnum;
   int dof_damping_any;
   int implicit_tendon_damping; /* model flag opt_i[3] (0 when the blob has only three): see sgo_step */
 };
@@ -205,9 +208,12 @@ sgo_model* sgo_model_load(const void* blob, size_t nbytes, char* err, size_t err
   m->implicit_tendon_damping = cnt > 3 ? oi[3] : 0;
   GETF(body_pos); m->nbody = (int)(cnt / 3);
   GETF(body_quat); GETF(body_ipos); GETF(body_imat); GETF(body_mass); GETF(body_invweight0);
-  GETF(jnt_pos); m->nv = (int)(cnt / 3);
+  GETF(jnt_pos); m->njnt = (int)(cnt / 3);
   GETF(jnt_axis); GETF(jnt_range); GETF(jnt_stiffness); GETF(jnt_margin); GETF(jnt_solref); GETF(jnt_solimp);
-  GETF(qpos0); GETF(qpos_spring); GETF(dof_damping); GETF(dof_armature); GETF(dof_invweight0);
+  GETF(qpos0); m->nq = (int)cnt;
+  GETF(qpos_spring);
+  GETF(dof_damping); m->nv = (int)cnt;
+  GETF(dof_armature); GETF(dof_invweight0);
   GETF(geom_size); m->ngeom = (int)(cnt / 3);
   GETF(geom_pos); GETF(geom_quat); GETF(geom_friction); GETF(geom_solref); GETF(geom_solimp); GETF(geom_solmix);
   GETF(geom_margin); GETF(geom_gap); GETF(geom_rbound);
@@ -228,6 +234,30 @@ sgo_model* sgo_model_load(const void* blob, size_t nbytes, char* err, size_t err
   GETI(sensor_type); m->nsensor = (int)cnt;
   GETI(sensor_objid); GETI(sensor_adr);
 
+  { /* index maps: the blob carries them only when a free joint makes joints, positions and dofs differ */
+    const int* qa = (const int*)blob_find(m->blob, "jnt_qposadr", SG_DT_I32, &cnt);
+    const int* da = (const int*)blob_find(m->blob, "jnt_dofadr", SG_DT_I32, &cnt);
+    const int* dj = (const int*)blob_find(m->blob, "dof_jntid", SG_DT_I32, &cnt);
+    if ((!qa || !da || !dj) && (m->nq != m->njnt || m->nv != m->njnt)) { snprintf(err, errlen, "blob lacks the joint address maps"); goto fail; }
+    m->jnt_qposadr = (int*)malloc(sizeof(int) * (m->njnt + 1)); m->jnt_dofadr = (int*)malloc(sizeof(int) * (m->njnt + 1));
+    m->dof_jntid = (int*)malloc(sizeof(int) * (m->nv + 1)); m->dof_rot = (int*)malloc(sizeof(int) * (m->nv + 1));
+    m->body_dofadr = (int*)malloc(sizeof(int) * m->nbody); m->body_dofnum = (int*)calloc(m->nbody, sizeof(int));
+    for (int j = 0; j < m->njnt; j++) { m->jnt_qposadr[j] = qa ? qa[j] : j; m->jnt_dofadr[j] = da ? da[j] : j; }
+    for (int i = 0; i < m->nv; i++) m->dof_jntid[i] = dj ? dj[i] : i;
+    for (int i = 0; i < m->nv; i++) {
+      int j = m->dof_jntid[i], ty = m->jnt_type[j];
+      if (ty != SG_JNT_HINGE && ty != SG_JNT_SLIDE && ty != SG_JNT_FREE) { snprintf(err, errlen, "unsupported joint type %d", ty); goto fail; }
+      m->dof_rot[i] = ty == SG_JNT_HINGE || (ty == SG_JNT_FREE && i - m->jnt_dofadr[j] >= 3);
+    }
+    for (int b = 0; b < m->nbody; b++) {
+      m->body_dofadr[b] = m->body_jntnum[b] > 0 ? m->jnt_dofadr[m->body_jntadr[b]] : -1;
+      for (int k = 0; k < m->body_jntnum[b]; k++) {
+        int j = m->body_jntadr[b] + k;
+        m->body_dofnum[b] += m->jnt_type[j] == SG_JNT_FREE ? 6 : 1;
+        if (m->jnt_type[j] == SG_JNT_FREE && (m->body_parentid[b] != 0 || m->body_jntnum[b] != 1)) { snprintf(err, errlen, "a free joint must be the only joint of a child of the world"); goto fail; }
+      }
+    }
+  }
   m->geom_lmat = (double*)malloc(sizeof(double) * 9 * (m->ngeom + 1));
   for (int g = 0; g < m->ngeom; g++) quat2mat(m->geom_lmat + 9 * g, m->geom_quat + 4 * g);
   m->site_lmat = (double*)malloc(sizeof(double) * 9 * (m->nsite + 1));
@@ -237,7 +267,7 @@ sgo_model* sgo_model_load(const void* blob, size_t nbytes, char* err, size_t err
   /* chain depth check */
   for (int b = 1; b < m->nbody; b++) {
     int n = 0;
-    for (int a = b; a > 0; a = m->body_parentid[a]) n += m->body_jntnum[a];
+    for (int a = b; a > 0; a = m->body_parentid[a]) n += m->body_dofnum[a];
     if (n > MAXCHAIN) { snprintf(err, errlen, "kinematic chain too deep"); goto fail; }
   }
   /* candidate geom pairs: body pairs (b1<b2) ascending, geoms of b1 outer, geoms of b2 inner */
@@ -270,9 +300,13 @@ fail:
 
 void sgo_model_free(sgo_model* m) {
   if (!m) return;
-  free(m->blob); free(m->geom_lmat); free(m->site_lmat); free(m->pair); free(m);
+  free(m->blob); free(m->geom_lmat); free(m->site_lmat); free(m->pair);
+  free(m->jnt_qposadr); free(m->jnt_dofadr); free(m->dof_jntid); free(m->dof_rot); free(m->body_dofadr); free(m->body_dofnum);
+  free(m);
 }
 int sgo_nv(const sgo_model* m) { return m->nv; }
+int sgo_nq(const sgo_model* m) { return m->nq; }
+int sgo_njnt(const sgo_model* m) { return m->njnt; }
 int sgo_nu(const sgo_model* m) { return m->nu; }
 int sgo_nsensordata(const sgo_model* m) { return 3 * m->nsensor; }
 int sgo_ntendon(const sgo_model* m) { return m->ntendon; }
@@ -305,9 +339,9 @@ sgo_data* sgo_data_new(const sgo_model* m) {
   sgo_data* d = (sgo_data*)calloc(1, sizeof *d);
   int nv = m->nv, nb = m->nbody;
   d->m = m;
-  d->qpos = dalloc(nv); d->qvel = dalloc(nv); d->act = dalloc(m->nu); d->ctrl = dalloc(m->nu); d->qacc_warmstart = dalloc(nv);
-  d->jnt_stiffness = dalloc(nv); d->tendon_stiffness = dalloc(m->ntendon);
-  memcpy(d->jnt_stiffness, m->jnt_stiffness, sizeof(double) * nv);
+  d->qpos = dalloc(m->nq); d->qvel = dalloc(nv); d->act = dalloc(m->nu); d->ctrl = dalloc(m->nu); d->qacc_warmstart = dalloc(nv);
+  d->jnt_stiffness = dalloc(m->njnt); d->tendon_stiffness = dalloc(m->ntendon);
+  memcpy(d->jnt_stiffness, m->jnt_stiffness, sizeof(double) * m->njnt);
   memcpy(d->tendon_stiffness, m->tendon_stiffness, sizeof(double) * m->ntendon);
   d->xpos = dalloc(3 * nb); d->xquat = dalloc(4 * nb); d->xmat = dalloc(9 * nb); d->xipos = dalloc(3 * nb); d->ximat = dalloc(9 * nb);
   d->xanchor = dalloc(3 * nv); d->xaxis = dalloc(3 * nv);
@@ -379,7 +413,7 @@ void sgo_contact(const sgo_data* d, int i, int* g1, int* g2, double* dist, doubl
 
 /* mj_resetData (manenv.py:57): qpos=qpos0, everything else zero; model parameters untouched */
 void sgo_reset(const sgo_model* m, sgo_data* d) {
-  memcpy(d->qpos, m->qpos0, sizeof(double) * m->nv);
+  memcpy(d->qpos, m->qpos0, sizeof(double) * m->nq);
   memset(d->qvel, 0, sizeof(double) * m->nv);
   memset(d->qacc_warmstart, 0, sizeof(double) * m->nv);
   memset(d->qacc, 0, sizeof(double) * m->nv);
@@ -401,21 +435,34 @@ static void kinematics(const sgo_model* m, sgo_data* d) {
     mulmat3(t, d->xmat + 9 * p, m->body_pos + 3 * i);
     for (int k = 0; k < 3; k++) pos[k] = d->xpos[3 * p + k] + t[k];
     quatmul(quat, d->xquat + 4 * p, m->body_quat + 4 * i);
-    for (int k = 0; k < m->body_jntnum[i]; k++) {
-      int j = m->body_jntadr[i] + k;
+    for (int k = 0; k < m->body_jntnum[i]; k++) { /* xanchor / xaxis are indexed by DOF */
+      int j = m->body_jntadr[i] + k, qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+      if (m->jnt_type[j] == SG_JNT_FREE) { /* the 7 positions ARE the body's pose (a child of the world) */
+        memcpy(pos, d->qpos + qa, 24); memcpy(quat, d->qpos + qa + 3, 32);
+        double nq = sqrt(quat[0] * quat[0] + quat[1] * quat[1] + quat[2] * quat[2] + quat[3] * quat[3]);
+        for (int c = 0; c < 4; c++) quat[c] /= nq;
+        quat2mat(mat, quat);
+        for (int c = 0; c < 3; c++) /* dofs 0-2: translation along the world axes; 3-5: rotation about the body's own axes */
+          for (int r = 0; r < 3; r++) {
+            d->xanchor[3 * (da + c) + r] = d->xanchor[3 * (da + 3 + c) + r] = pos[r];
+            d->xaxis[3 * (da + c) + r] = r == c ? 1.0 : 0.0;
+            d->xaxis[3 * (da + 3 + c) + r] = mat[3 * r + c];
+          }
+        continue;
+      }
       quat2mat(mat, quat);
       mulmat3(t, mat, m->jnt_pos + 3 * j);
-      for (int c = 0; c < 3; c++) d->xanchor[3 * j + c] = pos[c] + t[c];
-      mulmat3(d->xaxis + 3 * j, mat, m->jnt_axis + 3 * j);
-      double dq = d->qpos[j] - m->qpos0[j];
+      for (int c = 0; c < 3; c++) d->xanchor[3 * da + c] = pos[c] + t[c];
+      mulmat3(d->xaxis + 3 * da, mat, m->jnt_axis + 3 * j);
+      double dq = d->qpos[qa] - m->qpos0[qa];
       if (m->jnt_type[j] == SG_JNT_SLIDE) {
-        addscl3(pos, d->xaxis + 3 * j, dq);
+        addscl3(pos, d->xaxis + 3 * da, dq);
       } else {
         double s = sin(0.5 * dq), ql[4] = {cos(0.5 * dq), m->jnt_axis[3 * j] * s, m->jnt_axis[3 * j + 1] * s, m->jnt_axis[3 * j + 2] * s};
         quatmul(quat, quat, ql);
         quat2mat(mat, quat);
         mulmat3(t, mat, m->jnt_pos + 3 * j);
-        for (int c = 0; c < 3; c++) pos[c] = d->xanchor[3 * j + c] - t[c];
+        for (int c = 0; c < 3; c++) pos[c] = d->xanchor[3 * da + c] - t[c];
       }
     }
     double n = sqrt(quat[0] * quat[0] + quat[1] * quat[1] + quat[2] * quat[2] + quat[3] * quat[3]);
@@ -452,11 +499,11 @@ typedef struct { int n; int dof[MAXCHAIN]; double jp[MAXCHAIN][3], jr[MAXCHAIN][
 static void jac_chain(const sgo_model* m, const sgo_data* d, int body, const double* point, chainjac* cj) {
   cj->n = 0;
   for (int b = body; b > 0; b = m->body_parentid[b])
-    for (int k = m->body_jntnum[b] - 1; k >= 0; k--) {
-      int j = m->body_jntadr[b] + k, n = cj->n++;
+    for (int k = m->body_dofnum[b] - 1; k >= 0; k--) {
+      int j = m->body_dofadr[b] + k, n = cj->n++;   /* j: a dof */
       const double* ax = d->xaxis + 3 * j;
       cj->dof[n] = j;
-      if (m->jnt_type[j] == SG_JNT_SLIDE) {
+      if (!m->dof_rot[j]) {
         memcpy(cj->jp[n], ax, 24);
         cj->jr[n][0] = cj->jr[n][1] = cj->jr[n][2] = 0;
       } else {
@@ -475,7 +522,10 @@ static void tendons(const sgo_model* m, sgo_data* d) {
     int a = m->tendon_adr[t], n = m->tendon_num[t];
     double L = 0, *J = d->ten_J + (size_t)t * nv;
     if (m->wrap_type[a] == SG_WRAP_JOINT) {
-      for (int w = a; w < a + n; w++) { L += m->wrap_prm[w] * d->qpos[m->wrap_objid[w]]; J[m->wrap_objid[w]] = m->wrap_prm[w]; }
+      for (int w = a; w < a + n; w++) { /* wrap_objid: a joint id */
+        L += m->wrap_prm[w] * d->qpos[m->jnt_qposadr[m->wrap_objid[w]]];
+        J[m->jnt_dofadr[m->wrap_objid[w]]] = m->wrap_prm[w];
+      }
     } else {
       for (int w = a; w < a + n - 1; w++) {
         int s0 = m->wrap_objid[w], s1 = m->wrap_objid[w + 1];
@@ -898,18 +948,20 @@ static void make_constraint(const sgo_model* m, sgo_data* d) {
   /* equality rows, by id */
   for (int e = 0; e < m->neq; e++) {
     if (m->eq_type[e] == SG_EQ_JOINT) {
-      int j = m->eq_obj1id[e], j2 = m->eq_obj2id[e];
+      int j = m->eq_obj1id[e], j2 = m->eq_obj2id[e]; /* joint ids (scalar joints) */
+      int q1 = m->jnt_qposadr[j], d1 = m->jnt_dofadr[j];
       const double* pc = m->eq_data + 5 * e; /* polycoef */
       if (j2 < 0) {
         double one = 1.0;
-        add_row(d, EFC_EQUALITY, e, d->qpos[j] - m->qpos0[j] - pc[0], 0, 1, &j, &one);
+        add_row(d, EFC_EQUALITY, e, d->qpos[q1] - m->qpos0[q1] - pc[0], 0, 1, &d1, &one);
       } else { /* two joints: (q1 - q1_0) = poly(q2 - q2_0), J = (+1 on joint 1, -poly' on joint 2) */
-        double dif = d->qpos[j2] - m->qpos0[j2];
+        int q2 = m->jnt_qposadr[j2];
+        double dif = d->qpos[q2] - m->qpos0[q2];
         double poly = pc[0] + dif * (pc[1] + dif * (pc[2] + dif * (pc[3] + dif * pc[4])));
         double der = pc[1] + dif * (2 * pc[2] + dif * (3 * pc[3] + dif * 4 * pc[4]));
-        int cc[2] = {j, j2};
+        int cc[2] = {d1, m->jnt_dofadr[j2]};
         double vv[2] = {1.0, -der};
-        add_row(d, EFC_EQUALITY, e, d->qpos[j] - m->qpos0[j] - poly, 0, 2, cc, vv);
+        add_row(d, EFC_EQUALITY, e, d->qpos[q1] - m->qpos0[q1] - poly, 0, 2, cc, vv);
       }
     } else {
       int t = m->eq_obj1id[e], n = 0;
@@ -919,11 +971,12 @@ static void make_constraint(const sgo_model* m, sgo_data* d) {
     }
   }
   /* joint limits, by joint id, lower side first */
-  for (int j = 0; j < nv; j++) {
-    if (!m->jnt_limited[j]) continue;
+  for (int j = 0; j < m->njnt; j++) {
+    if (!m->jnt_limited[j] || m->jnt_type[j] == SG_JNT_FREE) continue;
+    int dj = m->jnt_dofadr[j];
     for (int side = -1; side <= 1; side += 2) {
-      double dist = side * (m->jnt_range[2 * j + (side + 1) / 2] - d->qpos[j]);
-      if (dist < m->jnt_margin[j]) { double v = -side; add_row(d, EFC_LIMIT, j, dist, m->jnt_margin[j], 1, &j, &v); }
+      double dist = side * (m->jnt_range[2 * j + (side + 1) / 2] - d->qpos[m->jnt_qposadr[j]]);
+      if (dist < m->jnt_margin[j]) { double v = -side; add_row(d, EFC_LIMIT, j, dist, m->jnt_margin[j], 1, &dj, &v); }
     }
   }
   /* contacts, in detection order */
@@ -952,7 +1005,7 @@ static void make_constraint(const sgo_model* m, sgo_data* d) {
     if (d->efc_type[i] == EFC_EQUALITY) {
       solref = m->eq_solref + 2 * id; solimp = m->eq_solimp + 5 * id;
       if (m->eq_type[id] == SG_EQ_JOINT) /* joint equality: the invweights of its one or two dofs */
-        dA = m->dof_invweight0[m->eq_obj1id[id]] + (m->eq_obj2id[id] >= 0 ? m->dof_invweight0[m->eq_obj2id[id]] : 0.0);
+        dA = m->dof_invweight0[m->jnt_dofadr[m->eq_obj1id[id]]] + (m->eq_obj2id[id] >= 0 ? m->dof_invweight0[m->jnt_dofadr[m->eq_obj2id[id]]] : 0.0);
       else {
         dA = m->tendon_invweight0[m->eq_obj1id[id]];
         if (g_variant & 8) {
@@ -961,7 +1014,7 @@ static void make_constraint(const sgo_model* m, sgo_data* d) {
         }
       }
     } else if (d->efc_type[i] == EFC_LIMIT) {
-      solref = m->jnt_solref + 2 * id; solimp = m->jnt_solimp + 5 * id; dA = m->dof_invweight0[id];
+      solref = m->jnt_solref + 2 * id; solimp = m->jnt_solimp + 5 * id; dA = m->dof_invweight0[m->jnt_dofadr[id]];
     } else {
       const contact_t* con = d->contact + id;
       solref = con->solref; solimp = con->solimp;
@@ -1068,8 +1121,9 @@ static void tree_motion(const sgo_model* m, sgo_data* d, const double* qacc, int
     memcpy(w, d->bw + 3 * p, 24); memcpy(v, d->bv + 3 * p, 24); memcpy(al, d->bal + 3 * p, 24); memcpy(a, d->ba + 3 * p, 24);
     memcpy(P, d->xpos + 3 * p, 24);
     for (int k = 0; k <= m->body_jntnum[i]; k++) {
-      int last = k == m->body_jntnum[i], j = last ? -1 : m->body_jntadr[i] + k;
-      if (last || m->jnt_type[j] == SG_JNT_HINGE) { /* move the reference point (to the anchor, or finally the body origin) */
+      int last = k == m->body_jntnum[i], jn = last ? -1 : m->body_jntadr[i] + k, j = last ? -1 : m->jnt_dofadr[jn]; /* j: the joint's (first) dof */
+      int ty = last ? -1 : m->jnt_type[jn];
+      if (last || ty == SG_JNT_HINGE || ty == SG_JNT_FREE) { /* move the reference point (to the anchor, or finally the body origin) */
         const double* Q = last ? d->xpos + 3 * i : d->xanchor + 3 * j;
         for (int c = 0; c < 3; c++) r[c] = Q[c] - P[c];
         cross3(t, w, r);
@@ -1078,10 +1132,32 @@ static void tree_motion(const sgo_model* m, sgo_data* d, const double* qacc, int
         memcpy(P, Q, 24);
       }
       if (last) break;
+      if (ty == SG_JNT_FREE) {
+        /* dofs 0-2: the origin's velocity along the world axes (constant axes: no velocity-product term, mj_comVel zeroes
+         * cdof_dot for them); dofs 3-5: angular velocity about the body's own axes -- all three axes turn with the body, so each
+         * one's rate of change is taken with the angular velocity BEFORE the joint (the three terms of the joint's own velocity
+         * cancel: w_joint x w_joint = 0), as mj_comVel does for ball / free joints */
+        double w0[3] = {w[0], w[1], w[2]};
+        for (int c = 0; c < 3; c++) {
+          const double* u = d->xaxis + 3 * (j + c);
+          double qd = d->qvel[j + c], qdd = qacc ? qacc[j + c] : 0.0;
+          cross3(t, w0, u);
+          if (with_acc) { addscl3(a, u, qdd); addscl3(a, t, 2 * qd); }
+          addscl3(v, u, qd);
+        }
+        for (int c = 0; c < 3; c++) {
+          const double* u = d->xaxis + 3 * (j + 3 + c);
+          double qd = d->qvel[j + 3 + c], qdd = qacc ? qacc[j + 3 + c] : 0.0;
+          cross3(t, w0, u);
+          if (with_acc) { addscl3(al, u, qdd); addscl3(al, t, qd); }
+          addscl3(w, u, qd);
+        }
+        continue;
+      }
       const double* u = d->xaxis + 3 * j;
       double qd = d->qvel[j], qdd = qacc ? qacc[j] : 0.0;
       cross3(t, w, u); /* du/dt */
-      if (m->jnt_type[j] == SG_JNT_HINGE) {
+      if (ty == SG_JNT_HINGE) {
         if (with_acc) { addscl3(al, u, qdd); addscl3(al, t, qd); }
         addscl3(w, u, qd);
       } else {
@@ -1269,8 +1345,11 @@ int sgo_forward(const sgo_model* m, sgo_data* d) {
     for (int i = 0; i < nv; i++) s += d->ten_J[(size_t)t * nv + i] * d->qvel[i];
     d->ten_velocity[t] = s;
   }
-  for (int i = 0; i < nv; i++) /* joint springs and dampers */
-    d->qfrc_passive[i] = -d->jnt_stiffness[i] * (d->qpos[i] - m->qpos_spring[i]) - m->dof_damping[i] * d->qvel[i];
+  for (int i = 0; i < nv; i++) { /* joint springs (scalar joints; a free joint has none) and dampers */
+    int j = m->dof_jntid[i], qa = m->jnt_qposadr[j];
+    double spring = m->jnt_type[j] == SG_JNT_FREE ? 0.0 : -d->jnt_stiffness[j] * (d->qpos[qa] - m->qpos_spring[qa]);
+    d->qfrc_passive[i] = spring - m->dof_damping[i] * d->qvel[i];
+  }
   for (int t = 0; t < m->ntendon; t++) { /* tendon springs and dampers */
     double frc = -d->tendon_stiffness[t] * (d->ten_length[t] - m->tendon_lengthspring[t]) - m->tendon_damping[t] * d->ten_velocity[t];
     if (frc != 0)
@@ -1351,10 +1430,10 @@ int sgo_step(const sgo_model* m, sgo_data* d) {
   int nv = m->nv;
   double h = m->timestep;
   d->warnings = 0;
-  for (int i = 0; i < nv; i++) {
+  for (int i = 0; i < m->nq; i++)
     if (isbad(d->qpos[i])) d->warnings |= SGO_WARN_BADQPOS;
+  for (int i = 0; i < nv; i++)
     if (isbad(d->qvel[i])) d->warnings |= SGO_WARN_BADQVEL;
-  }
   if (d->warnings) return d->warnings;
   sgo_forward(m, d);
   for (int i = 0; i < nv; i++)
@@ -1389,7 +1468,20 @@ int sgo_step(const sgo_model* m, sgo_data* d) {
   if (g_variant & 1) memcpy(d->qacc_warmstart, qacc, sizeof(double) * nv);
   for (int u = 0; u < m->nu; u++) d->act[u] += h * d->act_dot[u];
   for (int i = 0; i < nv; i++) d->qvel[i] += h * qacc[i];
-  for (int i = 0; i < nv; i++) d->qpos[i] += h * d->qvel[i];
+  for (int j = 0; j < m->njnt; j++) { /* mj_integratePos */
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (m->jnt_type[j] != SG_JNT_FREE) { d->qpos[qa] += h * d->qvel[da]; continue; }
+    for (int c = 0; c < 3; c++) d->qpos[qa + c] += h * d->qvel[da + c];
+    /* mju_quatIntegrate: turn by |w| h about w / |w|, w = the angular velocity in the BODY frame: q <- q * (cos, axis sin) */
+    const double* wl = d->qvel + da + 3;
+    double nw = sqrt(dot3(wl, wl)), ang = h * nw;
+    if (nw > MINVAL) {
+      double sn = sin(0.5 * ang), qr[4] = {cos(0.5 * ang), wl[0] / nw * sn, wl[1] / nw * sn, wl[2] / nw * sn}, *q = d->qpos + qa + 3;
+      quatmul(q, q, qr);
+      double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      for (int c = 0; c < 4; c++) q[c] /= nq;
+    }
+  }
   d->time += h;
   return d->warnings;
 }

@@ -33,6 +33,8 @@ sgo_data* sgo_data_new(const sgo_model*);
 void sgo_data_free(sgo_data*);
 
 int sgo_nv(const sgo_model*);
+int sgo_nq(const sgo_model*);    /* = nv unless the model has a free joint (7 positions, 6 dofs) */
+int sgo_njnt(const sgo_model*);
 int sgo_nu(const sgo_model*);
 int sgo_nsensordata(const sgo_model*);
 int sgo_ntendon(const sgo_model*);

@@ -34,7 +34,7 @@ from typing import Dict, List, Optional
 import numpy as np
 
 # ---- enums (MuJoCo numbering, so dumps can be diffed against mj_printModel) ----
-JNT_SLIDE, JNT_HINGE = 2, 3
+JNT_FREE, JNT_SLIDE, JNT_HINGE = 0, 2, 3
 GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX = 0, 2, 3, 6
 EQ_JOINT, EQ_TENDON = 2, 3
 WRAP_JOINT, WRAP_SITE = 1, 3
@@ -398,7 +398,15 @@ class _Compiler:
                 if c.tag == "inertial":
                     raise ValueError("<inertial> is not supported (inertiafromgeom only)")
             elif c.tag == "freejoint":
-                raise ValueError("free joints are out of scope (SURVEY.md item 4b)")
+                # SURVEY.md 8(f) rank 4 (reference data/gripper/soft_experiments_softball.xml:8): 7 positions (world position +
+                # quaternion), 6 dofs (linear velocity in the world frame, angular velocity in the body frame); no spring, damper,
+                # armature or limit.  Compiled here and run by the oracle; the kernels' plans refuse it with a reason.
+                if body.parent != 0 or body.joints:
+                    raise ValueError("a free joint must be the only joint of a child of the world body")
+                body.joints.append(_Joint(
+                    name=c.attrib.get("name", ""), type=JNT_FREE, pos=np.zeros(3), axis=np.array([0.0, 0.0, 1.0]), limited=False,
+                    range=np.zeros(2), stiffness=0.0, damping=0.0, armature=0.0, margin=0.0, ref=0.0, springref=0.0,
+                    solreflimit=_DEF_SOLREF.copy(), solimplimit=_DEF_SOLIMP.copy()))
             else:
                 raise ValueError("unsupported worldbody element <%s>" % c.tag)
 
@@ -586,19 +594,31 @@ class _Compiler:
         m.jnt_margin = np.array([j.margin for _, j in joints])
         m.jnt_solref = np.array([j.solreflimit for _, j in joints]).reshape(nj, 2)
         m.jnt_solimp = np.array([j.solimplimit for _, j in joints]).reshape(nj, 5)
-        m.qpos0 = np.array([j.ref for _, j in joints])
-        m.qpos_spring = np.array([j.springref for _, j in joints])
-        m.dof_damping = np.array([j.damping for _, j in joints])
-        m.dof_armature = np.array([j.armature for _, j in joints])
-        # dof tree: previous joint on the same body, else last joint of the nearest jointed ancestor
-        m.dof_parentid = np.full(nj, -1, np.int32)
+        # positions (nq) and dofs (nv): one each for a hinge / slide; a free joint has 7 positions (the body's world position and
+        # quaternion: a child of the world) and 6 dofs
+        q0, qs, dd, da, qadr, dadr, djnt = [], [], [], [], [], [], []
+        for k, (i, j) in enumerate(joints):
+            qadr.append(len(q0)); dadr.append(len(dd))
+            if j.type == JNT_FREE:
+                pose = list(B[i].pos) + list(B[i].quat)
+                q0 += pose; qs += pose
+                dd += [j.damping] * 6; da += [j.armature] * 6; djnt += [k] * 6
+            else:
+                q0.append(j.ref); qs.append(j.springref); dd.append(j.damping); da.append(j.armature); djnt.append(k)
+        m.qpos0, m.qpos_spring = np.array(q0, dtype=np.float64), np.array(qs, dtype=np.float64)
+        m.dof_damping, m.dof_armature = np.array(dd, dtype=np.float64), np.array(da, dtype=np.float64)
+        m.jnt_qposadr, m.jnt_dofadr, m.dof_jntid = np.array(qadr, np.int32), np.array(dadr, np.int32), np.array(djnt, np.int32)
+        nvd = len(dd)
+        # dof tree: previous dof on the same body, else last dof of the nearest jointed ancestor
+        m.dof_parentid = np.full(nvd, -1, np.int32)
         last_dof_of_body = np.full(nbody, -1, np.int32)
         for i in range(1, nbody):
             prev = last_dof_of_body[B[i].parent]
             for k in range(m.body_jntnum[i]):
-                d = m.body_jntadr[i] + k
-                m.dof_parentid[d] = prev
-                prev = d
+                jj = m.body_jntadr[i] + k
+                for d in range(dadr[jj], dadr[jj] + (6 if joints[jj][1].type == JNT_FREE else 1)):
+                    m.dof_parentid[d] = prev
+                    prev = d
             last_dof_of_body[i] = prev
 
         m.geom_type = np.array([g.type for _, g in geoms], np.int32)
@@ -749,6 +769,7 @@ class Model:
         nj = len(self.jnt_type)
         xanchor = np.zeros((nj, 3))
         xaxis = np.zeros((nj, 3))
+        qa = self.jnt_qposadr
         for i in range(1, nb):
             p = self.body_parentid[i]
             R = quat_to_mat(xquat[p])
@@ -756,10 +777,15 @@ class Model:
             quat = quat_mul(xquat[p], self.body_quat[i])
             for k in range(self.body_jntnum[i]):
                 j = self.body_jntadr[i] + k
+                if self.jnt_type[j] == JNT_FREE:     # the pose IS the joint's 7 positions
+                    pos = np.array(qpos[qa[j]:qa[j] + 3], dtype=np.float64)
+                    quat = quat_normalize(np.array(qpos[qa[j] + 3:qa[j] + 7], dtype=np.float64))
+                    xanchor[j] = pos
+                    continue
                 R = quat_to_mat(quat)
                 xanchor[j] = pos + R @ self.jnt_pos[j]
                 xaxis[j] = R @ self.jnt_axis[j]
-                dq = qpos[j] - self.qpos0[j]
+                dq = qpos[qa[j]] - self.qpos0[qa[j]]
                 if self.jnt_type[j] == JNT_SLIDE:
                     pos = pos + xaxis[j] * dq
                 else:
@@ -773,25 +799,32 @@ class Model:
 
     def _jac_point(self, kin, body, point):
         """3 x nv translational and rotational Jacobians of ``point`` fixed to ``body``."""
-        nv = len(self.jnt_type)
+        nv = self.nv
         jp = np.zeros((3, nv))
         jr = np.zeros((3, nv))
+        da = self.jnt_dofadr
         b = body
         while b > 0:
             for k in range(self.body_jntnum[b]):
                 j = self.body_jntadr[b] + k
+                d = da[j]
                 ax = kin["xaxis"][j]
-                if self.jnt_type[j] == JNT_SLIDE:
-                    jp[:, j] = ax
+                if self.jnt_type[j] == JNT_FREE:    # translations along the world axes, rotations about the body's own axes
+                    R = kin["xmat"][b]
+                    for c in range(3):
+                        jp[c, d + c] = 1.0
+                        jr[:, d + 3 + c] = R[:, c]
+                        jp[:, d + 3 + c] = np.cross(R[:, c], point - kin["xpos"][b])
+                elif self.jnt_type[j] == JNT_SLIDE:
+                    jp[:, d] = ax
                 else:
-                    jr[:, j] = ax
-                    jp[:, j] = np.cross(ax, point - kin["xanchor"][j])
+                    jr[:, d] = ax
+                    jp[:, d] = np.cross(ax, point - kin["xanchor"][j])
             b = self.body_parentid[b]
         return jp, jr
 
     def mass_matrix(self, qpos):
         kin = self.kinematics(qpos)
-        nv = len(self.jnt_type)
         M = np.diag(self.dof_armature.astype(np.float64))
         for b in range(1, len(self.body_parentid)):
             if self.body_mass[b] <= 0 or self.body_weldid[b] == 0:
@@ -808,7 +841,7 @@ class Model:
 
     def tendon_length_jac(self, qpos, kin=None):
         kin = kin or self.kinematics(qpos)
-        nv = len(self.jnt_type)
+        nv = self.nv
         nt = len(self.tendon_adr)
         L = np.zeros(nt)
         J = np.zeros((nt, nv))
@@ -816,9 +849,9 @@ class Model:
         for t in range(nt):
             a, n = self.tendon_adr[t], self.tendon_num[t]
             if self.wrap_type[a] == WRAP_JOINT:
-                for w in range(a, a + n):
-                    L[t] += self.wrap_prm[w] * qpos[self.wrap_objid[w]]
-                    J[t, self.wrap_objid[w]] = self.wrap_prm[w]
+                for w in range(a, a + n):     # (wrap_objid is a JOINT id)
+                    L[t] += self.wrap_prm[w] * qpos[self.jnt_qposadr[self.wrap_objid[w]]]
+                    J[t, self.jnt_dofadr[self.wrap_objid[w]]] = self.wrap_prm[w]
             else:
                 for w in range(a, a + n - 1):
                     s0, s1 = self.wrap_objid[w], self.wrap_objid[w + 1]
@@ -839,6 +872,10 @@ class Model:
         Minv = np.linalg.inv(M)
         self.meaninertia = float(np.trace(M) / max(1, nv))
         self.dof_invweight0 = np.diag(Minv).copy()
+        for j in np.flatnonzero(np.asarray(self.jnt_type) == JNT_FREE):   # mj_setConst: one value for the 3 translations, one for the 3 rotations
+            d = self.jnt_dofadr[j]
+            self.dof_invweight0[d:d + 3] = self.dof_invweight0[d:d + 3].mean()
+            self.dof_invweight0[d + 3:d + 6] = self.dof_invweight0[d + 3:d + 6].mean()
         nb = len(self.body_parentid)
         self.body_invweight0 = np.zeros((nb, 2))
         for b in range(1, nb):
@@ -863,10 +900,29 @@ class Model:
 
     @property
     def nv(self):
+        return len(self.dof_damping)
+
+    @property
+    def nq(self):
+        return len(self.qpos0)
+
+    @property
+    def njnt(self):
         return len(self.jnt_type)
 
-    nq = nv
-    njnt = nv      # every joint of the subset is scalar (hinge / slide)
+    # address maps joint -> first position / first dof, dof -> joint.  Identity for models of scalar joints (hinge / slide), whose
+    # blobs do not carry them; a free joint (7 positions, 6 dofs) makes the three index spaces differ.
+    def _adr(self, name, n):
+        v = self.__dict__.get(name)
+        return v if v is not None and len(v) == n else np.arange(n, dtype=np.int32)
+
+    jnt_qposadr = property(lambda self: self._adr("_jnt_qposadr", len(self.jnt_type)), lambda self, v: self.__dict__.__setitem__("_jnt_qposadr", np.asarray(v, np.int32)))
+    jnt_dofadr = property(lambda self: self._adr("_jnt_dofadr", len(self.jnt_type)), lambda self, v: self.__dict__.__setitem__("_jnt_dofadr", np.asarray(v, np.int32)))
+    dof_jntid = property(lambda self: self._adr("_dof_jntid", len(self.dof_damping)), lambda self, v: self.__dict__.__setitem__("_dof_jntid", np.asarray(v, np.int32)))
+
+    @property
+    def has_free_joint(self):
+        return bool((np.asarray(self.jnt_type) == JNT_FREE).any())
 
     @property
     def nsite(self):
@@ -939,6 +995,9 @@ class Model:
             add(f, np.asarray(getattr(self, f), dtype=np.float64), 1)
         for f in self._FIELDS_I32:
             add(f, np.asarray(getattr(self, f), dtype=np.int32), 2)
+        if self.has_free_joint:   # only then do joint, position and dof indices differ (blobs of scalar-joint models stay as they were)
+            for f in ("jnt_qposadr", "jnt_dofadr", "dof_jntid"):
+                add(f, np.asarray(getattr(self, f), dtype=np.int32), 2)
         names = "\n".join(["|".join(self.body_names), "|".join(self.jnt_names), "|".join(self.geom_names),
                            "|".join(self.site_names), "|".join(self.tendon_names), "|".join(self.sensor_names)])
         add("names", np.frombuffer(names.encode(), dtype=np.uint8), 3)
