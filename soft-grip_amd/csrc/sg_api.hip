@@ -132,7 +132,7 @@ static int launch_tree(sg_batch* b, int mode, const uint8_t* mask, int nsub, dou
   a.ncon = b->ncon; a.nefc = b->nefc; a.iters = b->iters;
   a.cws = b->tcws; a.cws_stride = sgt::cws_doubles(m->tree);
   a.nenv = b->n; a.nsub = nsub; a.mode = mode; a.secprof = b->w.secprof;
-  const size_t lds = sgt::lds_bytes(m->tree, m->tplan.h.nelem);
+  const size_t lds = sgt::lds_bytes(m->tree, m->tplan.h.nelem, m->tplan.h.has_free);
   if (!b->tree_attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)sg_tree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     b->tree_attr_set = true;
@@ -156,7 +156,7 @@ int sg_model_create(const void* blob, size_t nbytes, sg_model** out) {
   std::string err, terr;
   m->has_fast = sg_plan_build(blob, nbytes, &m->plan, &err);
   m->has_tree = sg_tree_plan_build(blob, nbytes, &m->tplan, &m->tree, &terr);
-  if (m->has_tree && sgt::lds_bytes(m->tree, m->tplan.h.nelem) > 160 * 1024) {
+  if (m->has_tree && sgt::lds_bytes(m->tree, m->tplan.h.nelem, m->tplan.h.has_free) > 160 * 1024) {
     m->has_tree = false;
     terr = "the env's state does not fit the 160 KB of LDS";
   }

@@ -25,7 +25,8 @@ SG_HD int sgg_kind(int ref) { return ref >> 16; }
 SG_HD int sgg_index(int ref) { return ref & 0xFFFF; }
 
 // narrowphase routine of a candidate pair (geom1 / geom2 in mj_collideGeoms' order: by type, plane < sphere < capsule < box)
-enum { SGP_PLANE_CAP = 0, SGP_PLANE_BOX = 1, SGP_SPH_BOX = 2, SGP_CAP_BOX = 3, SGP_BOX_BOX = 4, SGP_UNSUPPORTED = 5 };
+enum { SGP_PLANE_CAP = 0, SGP_PLANE_BOX = 1, SGP_SPH_BOX = 2, SGP_CAP_BOX = 3, SGP_BOX_BOX = 4, SGP_UNSUPPORTED = 5,
+       SGP_PLANE_SPH = 6 /* tree plans with a free object only */ };
 #define SG_GEN_MAXCON 112   // contacts of an env on the general path (the fast path: 64 per finger); with the box - box work space
                             // the list fills the phase kernel's 8 KB contact staging area
 #define SG_GEN_ROUNDS ((SG_GEN_MAXCON + 63) / 64)

@@ -90,17 +90,29 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
   const int nbody = (int)(cnt / 3);
   NEEDF(body_quat, "body_quat"); NEEDF(body_ipos, "body_ipos"); NEEDF(body_imat, "body_imat"); NEEDF(body_mass, "body_mass");
   NEEDF(body_invweight0, "body_invweight0");
+  int free_jnt = -1;   // tree plans: the joint id of the object's free joint (soft_experiments_softball.xml:8), else -1
   NEEDF(jnt_pos, "jnt_pos");
-  const int nv = (int)(cnt / 3);
+  const int nv = (int)(cnt / 3);   // joints (= dofs = positions unless there is a free joint: 7 positions, 6 dofs)
   {  // a free joint (7 positions, 6 dofs: mjcf.py compiles it, the oracle runs it) makes joint, position and dof indices differ
     long long nj = 0;
     const int* jt = (const int*)B.find("jnt_type", SG_DT_I32, &nj);
     for (long long j = 0; jt && j < nj; j++)
-      if (jt[j] == SG_JNT_FREE) FAIL("the model has a free joint: not built in the kernels yet (compiled by mjcf.py, run by the oracle; DESIGN.md 7)");
+      if (jt[j] == SG_JNT_FREE) {
+        if (!tree) FAIL("the model has a free joint: the two-finger kernels do not run it (the tree pipeline's object block does: DESIGN.md 4.8)");
+        if (free_jnt >= 0) FAIL("more than one free joint");
+        free_jnt = (int)j;
+      }
   }
   NEEDF(jnt_axis, "jnt_axis"); NEEDF(jnt_range, "jnt_range"); NEEDF(jnt_stiffness, "jnt_stiffness"); NEEDF(jnt_margin, "jnt_margin");
   NEEDF(jnt_solref, "jnt_solref"); NEEDF(jnt_solimp, "jnt_solimp"); NEEDF(qpos0, "qpos0"); NEEDF(qpos_spring, "qpos_spring");
-  NEEDF(dof_damping, "dof_damping"); NEEDF(dof_armature, "dof_armature"); NEEDF(dof_invweight0, "dof_invweight0");
+  const long long nq_model = cnt;   // (count of qpos_spring)
+  NEEDF(dof_damping, "dof_damping");
+  const long long nv_model = cnt;
+  NEEDF(dof_armature, "dof_armature"); NEEDF(dof_invweight0, "dof_invweight0");
+  // joint -> first position / first dof: one free joint shifts everything behind it by 6 / 5
+  auto JQ = [&](int j) { return (free_jnt >= 0 && j > free_jnt) ? j + 6 : j; };
+  auto JD = [&](int j) { return (free_jnt >= 0 && j > free_jnt) ? j + 5 : j; };
+  if (nq_model != nv + (free_jnt >= 0 ? 6 : 0) || nv_model != nv + (free_jnt >= 0 ? 5 : 0)) FAIL("position / dof counts do not match the joints");
   NEEDF(geom_size, "geom_size");
   const int ngeom = (int)(cnt / 3);
   NEEDF(geom_pos, "geom_pos"); NEEDF(geom_quat, "geom_quat"); NEEDF(geom_friction, "geom_friction"); NEEDF(geom_solref, "geom_solref");
@@ -135,10 +147,10 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
   P = SgPlan();
   SgPlanHeader& H = P.h;
   memset(&H, 0, sizeof H);
-  H.nv = nv; H.nu = nu; H.nsensordata = 3 * nsensor; H.ntendon = ntendon;
+  H.nv = (int)nv_model; H.nq = (int)nq_model; H.njnt = nv; H.nu = nu; H.nsensordata = 3 * nsensor; H.ntendon = ntendon;
   H.timestep = opt_d[0]; memcpy(H.gravity, opt_d + 1, 24); H.tolerance = opt_d[4]; H.impratio = opt_d[5]; H.meaninertia = opt_d[6];
   H.iterations = opt_i[0];
-  H.pgs_scale = 1.0 / (H.meaninertia * (nv > 1 ? nv : 1));
+  H.pgs_scale = 1.0 / (H.meaninertia * (H.nv > 1 ? H.nv : 1));
   if (H.impratio != 1.0) FAIL("impratio != 1 is not supported by the kernels");
 
   // world poses of world-welded (static) bodies
@@ -163,12 +175,16 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
 
   // ---- classify moving bodies: elements vs chain bodies ----
   std::vector<int> is_elem(nbody, 0), chain_of(nbody, -1), cbidx(nbody, -1);
-  int first_elem = -1, nelem = 0;
+  int first_elem = -1, nelem = 0, free_body = -1;
+  for (int b = 1; b < nbody && free_jnt >= 0; b++)
+    if (body_jntnum[b] > 0 && body_jntadr[b] == free_jnt) free_body = b;
+  if (free_jnt >= 0 && (free_body < 0 || body_jntnum[free_body] != 1 || body_parentid[free_body] != 0)) FAIL("a free joint must be the only joint of a child of the world");
   for (int b = 1; b < nbody; b++) {
     if (body_weldid[b] == 0) continue;
     bool slider = body_jntnum[b] == 1 && jnt_type[body_jntadr[b]] == SG_JNT_SLIDE;
     if (slider) {
-      if (body_weldid[body_parentid[b]] != 0 || nchild[b] != 0) FAIL("slide joints are only supported on leaf bodies with a static parent");
+      if ((body_weldid[body_parentid[b]] != 0 && body_parentid[b] != free_body) || nchild[b] != 0)
+        FAIL("slide joints are only supported on leaf bodies with a static parent (tree plans: or the free body)");
       if (body_geomnum[b] != 1 || geom_type[body_geomadr[b]] != SG_GEOM_CAPSULE) FAIL("element bodies must carry exactly one capsule");
       if (first_elem < 0) first_elem = b;
       if (b != first_elem + nelem) FAIL("element bodies must be contiguous");
@@ -179,8 +195,20 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
   }
   if (nelem == 0) FAIL("model has no composite elements");
   H.nelem = nelem;
-  H.elem_dof0 = body_jntadr[first_elem];
-  if (H.elem_dof0 + nelem != nv) FAIL("element dofs must be the last dofs of the model");
+  const int elem_jnt0 = body_jntadr[first_elem];   // joint id of the first element (kmask_jnt, tendon wraps and equalities speak joint ids)
+  H.elem_jnt0 = elem_jnt0; H.elem_dof0 = JD(elem_jnt0); H.elem_qpos0 = JQ(elem_jnt0);
+  if (elem_jnt0 + nelem != nv) FAIL("element dofs must be the last dofs of the model");
+  H.has_free = free_jnt >= 0;
+  if (H.has_free) {
+    for (int e = 0; e < nelem; e++)
+      if (body_parentid[first_elem + e] != free_body) FAIL("with a free joint every composite element must hang off the free body");
+    if (free_jnt != elem_jnt0 - 1 || free_body != first_elem - 1) FAIL("the free body must come right before the composite elements");
+    H.free_jnt = free_jnt; H.free_qadr = free_jnt; H.free_dadr = free_jnt;   // (every joint before it is scalar)
+    memcpy(H.free_q0, qpos0 + free_jnt, 56);
+    H.free_mass = body_mass[free_body];
+    memcpy(H.free_com, body_ipos + 3 * free_body, 24); memcpy(H.free_inertia, body_imat + 9 * free_body, 72);
+    H.free_binvw = body_invweight0[2 * free_body];
+  }
 
   int nchain = 0;
   auto lim_kb = [&](int j, double* K, double* Bd) {
@@ -199,8 +227,9 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
   if (tree) {
     SgTreeDev& T = *tree;
     for (int b = 1; b < nbody; b++) {
-      if (body_weldid[b] == 0 || is_elem[b]) continue;
+      if (body_weldid[b] == 0 || is_elem[b] || b == free_body) continue;
       if (b >= first_elem) FAIL("chain bodies must precede the composite elements");
+      if (free_jnt >= 0 && body_jntadr[b] + body_jntnum[b] > free_jnt) FAIL("finger joints must precede the free joint");
       if (body_jntnum[b] < 1) FAIL("a moving chain body without a joint");
       for (int k = 0; k < body_jntnum[b]; k++)
         if (jnt_type[body_jntadr[b] + k] != SG_JNT_HINGE) FAIL("chain bodies may only have hinge joints");
@@ -256,7 +285,7 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
     T.CS = (T.CS + 3) & ~3;   // every chain's vectors and matrix blocks are padded to this stride: uniform loop counts on the device
     for (int c = 0; c < T.K; c++) T.c_mat0[c] = c * T.CS * T.CS;
     T.NMAT = T.K * T.CS * T.CS;
-    if (T.ND + nelem != nv) FAIL("the model has dofs that belong neither to a finger chain nor to a composite element");
+    if (T.ND + nelem + (free_jnt >= 0 ? 1 : 0) != nv) FAIL("the model has dofs that belong neither to a finger chain nor to a composite element");
   }
   for (int b = 1; b < nbody && !tree; b++) {
     if (body_weldid[b] == 0 || is_elem[b]) continue;
@@ -332,14 +361,27 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
   P.elem_dofmap.resize(nelem);
   auto E = [&](int f, int e) -> double& { return P.elem[(size_t)f * nelem + e]; };
   for (int e = 0; e < nelem; e++) {
-    int b = first_elem + e, j = H.elem_dof0 + e, g = body_geomadr[b], p = body_parentid[b];
-    P.elem_geom[e] = g; P.elem_dofmap[e] = j;
-    // body frame in the world at q = qpos0
+    int b = first_elem + e, j = elem_jnt0 + e, jd = JD(j), jq = JQ(j), g = body_geomadr[b], p = body_parentid[b];
+    P.elem_geom[e] = g; P.elem_dofmap[e] = jd;
+    // body frame in the world at q = qpos0 -- in the frame of the FREE body when the elements hang off one (H.has_free: every
+    // "world" field below is then local to that body, and the kernel turns it with the body's pose)
     double bp[3], bq[4], bm[9], t[3];
-    mulmat3(t, &wmat[9 * p], body_pos + 3 * b);
-    for (int c = 0; c < 3; c++) bp[c] = wpos[3 * p + c] + t[c];
-    qmul(bq, &wquat[4 * p], body_quat + 4 * b);
+    static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z3[3] = {0, 0, 0}, Q1[4] = {1, 0, 0, 0};
+    const double *pm = p == free_body ? I9 : &wmat[9 * p], *pp = p == free_body ? Z3 : &wpos[3 * p], *pq = p == free_body ? Q1 : &wquat[4 * p];
+    mulmat3(t, pm, body_pos + 3 * b);
+    for (int c = 0; c < 3; c++) bp[c] = pp[c] + t[c];
+    qmul(bq, pq, body_quat + 4 * b);
     quat2mat(bm, bq);
+    {  // the element's centre of mass at q = qpos0 and its inertia about it, same frame (the free object's mass matrix and bias)
+      double kc[3], RI[9], Rt[9], Iw[9];
+      mulmat3(kc, bm, body_ipos + 3 * b);
+      mulmat33(RI, bm, body_imat + 9 * b);
+      for (int a = 0; a < 3; a++)
+        for (int c = 0; c < 3; c++) Rt[3 * a + c] = bm[3 * c + a];
+      mulmat33(Iw, RI, Rt);
+      E(SGE_KX, e) = bp[0] + kc[0]; E(SGE_KY, e) = bp[1] + kc[1]; E(SGE_KZ, e) = bp[2] + kc[2];
+      E(SGE_I00, e) = Iw[0]; E(SGE_I01, e) = Iw[1]; E(SGE_I02, e) = Iw[2]; E(SGE_I11, e) = Iw[4]; E(SGE_I12, e) = Iw[5]; E(SGE_I22, e) = Iw[8];
+    }
     double ax[3], gp[3], gm[9], gl[9];
     mulmat3(ax, bm, jnt_axis + 3 * j);
     mulmat3(t, bm, geom_pos + 3 * g);
@@ -349,9 +391,9 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
     E(SGE_AX, e) = ax[0]; E(SGE_AY, e) = ax[1]; E(SGE_AZ, e) = ax[2];
     E(SGE_GX, e) = gp[0]; E(SGE_GY, e) = gp[1]; E(SGE_GZ, e) = gp[2];
     E(SGE_CX, e) = gm[2]; E(SGE_CY, e) = gm[5]; E(SGE_CZ, e) = gm[8];
-    E(SGE_MASS, e) = body_mass[b]; E(SGE_ARMATURE, e) = dof_armature[j]; E(SGE_DAMPING, e) = dof_damping[j];
-    E(SGE_K0, e) = jnt_stiffness[j]; E(SGE_SPRINGREF, e) = qpos_spring[j]; E(SGE_QPOS0, e) = qpos0[j];
-    E(SGE_INVW, e) = dof_invweight0[j]; E(SGE_BINVW, e) = body_invweight0[2 * b];
+    E(SGE_MASS, e) = body_mass[b]; E(SGE_ARMATURE, e) = dof_armature[jd]; E(SGE_DAMPING, e) = dof_damping[jd];
+    E(SGE_K0, e) = jnt_stiffness[j]; E(SGE_SPRINGREF, e) = qpos_spring[jq]; E(SGE_QPOS0, e) = qpos0[jq];
+    E(SGE_INVW, e) = dof_invweight0[jd]; E(SGE_BINVW, e) = body_invweight0[2 * b];
     if (jnt_limited[j]) {
       if (!tree) FAIL("limited element sliders are not supported");
       double K, Bd;
@@ -376,7 +418,7 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
       if (H.t0_id >= 0) FAIL("more than one fixed tendon");
       if (n != nelem) FAIL("the fixed tendon must wrap every element slider exactly once");
       for (int w = 0; w < n; w++) {
-        if (wrap_objid[a + w] != H.elem_dof0 + w) FAIL("the fixed tendon must list the element sliders in order");
+        if (wrap_objid[a + w] != elem_jnt0 + w) FAIL("the fixed tendon must list the element sliders in order");
         E(SGE_COEF, w) = wrap_prm[a + w];
       }
       H.t0_id = t; H.t0_k0 = tendon_stiffness[t]; H.t0_damping = tendon_damping[t]; H.t0_lspring = tendon_lengthspring[t];
@@ -469,7 +511,7 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
     for (int q = 0; q < neq - 1; q++) {
       if (eq_type[q] != SG_EQ_JOINT) FAIL("only the last equality may be a tendon equality");
       if (memcmp(eq_solref + 2 * q, eq_solref, 16) || memcmp(eq_solimp + 5 * q, eq_solimp, 40)) FAIL("joint equalities must share solref/solimp");
-      const int e1 = eq_obj1id[q] - H.elem_dof0, e2 = eq_obj2id[q] < 0 ? -1 : eq_obj2id[q] - H.elem_dof0;
+      const int e1 = eq_obj1id[q] - elem_jnt0, e2 = eq_obj2id[q] < 0 ? -1 : eq_obj2id[q] - elem_jnt0;
       if (e1 < 0 || e1 >= nelem) FAIL("joint equalities must act on element sliders");
       if (eq_obj2id[q] < 0) {
         if (e1 != nfix) FAIL("the joint-fix equalities must come in element order");
@@ -702,11 +744,39 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
       FAIL("unsupported static geom type");
     }
   }
+  if (H.has_free) {   // the free body's own geoms: the composite's centre sphere (its position stays LOCAL to the body)
+    for (int k = 0; k < body_geomnum[free_body]; k++) {
+      const int g = body_geomadr[free_body] + k;
+      bool hits_chain = false;
+      for (int cg : chain_geoms) hits_chain |= allowed(g, cg);
+      if (geom_type[g] != SG_GEOM_SPHERE) FAIL("the free body may only carry a sphere");
+      if (H.has_center) FAIL("more than one centre sphere");
+      if (hits_chain && !check_pair(g, chain_geoms[0])) FAIL("contact parameters must be uniform over all finger/object pairs");
+      H.has_center = 1; H.center_on_free = 1; H.center_geom = g; H.center_radius = geom_size[3 * g];
+      memcpy(H.center_pos, geom_pos + 3 * g, 24);
+    }
+    // constants of the object's mass matrix (header comment)
+    const int N = nelem;
+    for (int k = 0; k < 21; k++) H.obj_BBD[k] = H.obj_BBDh[k] = 0;
+    for (int k = 0; k < 6; k++) H.obj_tenB[k] = H.obj_tenBh[k] = 0;
+    H.obj_msum = H.free_mass;
+    for (int c = 0; c < 3; c++) H.obj_mk0[c] = H.free_mass * H.free_com[c];
+    for (int e = 0; e < N; e++) {
+      const double m = E(SGE_MASS, e), a[3] = {E(SGE_AX, e), E(SGE_AY, e), E(SGE_AZ, e)}, k0[3] = {E(SGE_KX, e), E(SGE_KY, e), E(SGE_KZ, e)};
+      const double Bv[6] = {m * a[0], m * a[1], m * a[2], m * (k0[1] * a[2] - k0[2] * a[1]), m * (k0[2] * a[0] - k0[0] * a[2]), m * (k0[0] * a[1] - k0[1] * a[0])};
+      const double D = m + E(SGE_ARMATURE, e), Dh = D + H.timestep * E(SGE_DAMPING, e), co = E(SGE_COEF, e);
+      int q = 0;
+      for (int r = 0; r < 6; r++)
+        for (int c = r; c < 6; c++) { H.obj_BBD[q] += Bv[r] * Bv[c] / D; H.obj_BBDh[q] += Bv[r] * Bv[c] / Dh; q++; }
+      for (int r = 0; r < 6; r++) { H.obj_tenB[r] += co * Bv[r] / D; H.obj_tenBh[r] += co * Bv[r] / Dh; }
+      H.obj_msum += m;
+    }
+  }
   // Safe slider range per element: while q stays inside (QLO, QHI) the capsule cannot touch the plane (exact: the lower of its two
   // end spheres) and its bounding sphere cannot touch a static box, so those pairs (legal in the model, never active in the reference
   // scenes) need no narrowphase on the fast path; outside it the env's substep runs on the general contact path (sg_general.h).
   // The distance to a convex static geom is convex in q, so the unsafe set is one interval.
-  for (int e = 0; e < nelem; e++) {
+  for (int e = 0; e < nelem && !H.has_free; e++) {   // (a free object's element fields are local: no fixed range exists)
     double ax[3] = {E(SGE_AX, e), E(SGE_AY, e), E(SGE_AZ, e)}, g0[3] = {E(SGE_GX, e), E(SGE_GY, e), E(SGE_GZ, e)}, q0 = E(SGE_QPOS0, e);
     double qlo = -1e30, qhi = 1e30;
     auto clearance = [&](int kind, int k, double q) {  // >0: bounding sphere clear of static geom k
@@ -771,6 +841,7 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
       for (int k = 0; k < H.chain[c].ngeom; k++) ref_of[H.chain[c].g_id[k]] = (4 << 16) | (c * SG_CG + k);
     for (int g = 0; tree && g < tree->NG; g++) ref_of[tree->g_id[g]] = (4 << 16) | g;
     for (int e = 0; e < nelem; e++) ref_of[P.elem_geom[e]] = (5 << 16) | e;
+    if (H.has_free && H.has_center) ref_of[H.center_geom] = 3 << 16;
     auto pair_allowed = [&](int g1, int g2) {
       const int b1 = geom_bodyid[g1], b2 = geom_bodyid[g2];
       if (!allowed(g1, g2)) return false;
@@ -795,6 +866,7 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
             else if (t1 == SG_GEOM_SPHERE && t2 == SG_GEOM_BOX) gp.kind = 2;
             else if (t1 == SG_GEOM_CAPSULE && t2 == SG_GEOM_BOX) gp.kind = 3;
             else if (t1 == SG_GEOM_BOX && t2 == SG_GEOM_BOX) gp.kind = 4;
+            else if (t1 == 0 && t2 == SG_GEOM_SPHERE && tree) gp.kind = 6;   // SGP_PLANE_SPH: the free object's centre sphere on the ground
             else FAIL("unsupported collision pair types");
             if (gp.g1 == 0 || gp.g2 == 0) FAIL("a collision pair involves a geom outside the plan class");
             if (!check_pair(g1, g2)) gp.kind = 5;   // SGP_UNSUPPORTED

@@ -61,6 +61,8 @@ enum {
   SGE_COEF,                          // coefficient in the fixed tendon
   SGE_QLO, SGE_QHI,                  // slider range inside which the capsule cannot reach any static geom
   SGE_LIMITED, SGE_RLO, SGE_RHI,     // limited slider (tree plans only: sg_tree_plan.h) and its range
+  SGE_KX, SGE_KY, SGE_KZ,            // centre of mass at q = qpos0 (tree plans)
+  SGE_I00, SGE_I01, SGE_I02, SGE_I11, SGE_I12, SGE_I22,   // inertia about it, same frame (tree plans)
   SGE_NFIELD
 };
 
@@ -75,6 +77,16 @@ struct SgPlanHeader {
   double eqj_K, eqj_B, eqj_solimp[5];            // joint-fix equality rows
   double eqt_K, eqt_B, eqt_solimp[5], eqt_invw;  // tendon-fix equality row
   double t0_k0, t0_damping, t0_lspring, t0_L0;   // the fixed tendon's own spring/damper
+  // the object's FREE body (tree plans only; soft_experiments_softball.xml:8): the composite's elements hang off a body with a free
+  // joint -- 7 positions (world position + quaternion), 6 dofs (world-frame linear, body-frame angular velocity).  Every element
+  // field that is "world" for a static parent (axis, capsule centre / axis, centre of mass, inertia) and center_pos are then LOCAL to
+  // that body.  obj_*: constants of the object's arrow-shaped mass matrix [[M_ff, B], [B', D]] (B_e = m_e (a_e ; k_e x a_e) in the
+  // body frame, D_e = m_e + armature_e): sum_e B_e B_e' / D_e (upper triangle, row-major), sum_e coef_e B_e / D_e, and both with
+  // D_e + h damping_e (the Euler step's M + h B)
+  int nq, njnt, elem_jnt0, elem_qpos0;
+  int has_free, free_jnt, free_qadr, free_dadr, center_on_free, pad_free;
+  double free_q0[7], free_mass, free_com[3], free_inertia[9], free_binvw;
+  double obj_BBD[21], obj_BBDh[21], obj_tenB[6], obj_tenBh[6], obj_msum, obj_mk0[3];
   // limit rows of the element sliders (tree plans only; uniform over the limited sliders, checked at build)
   double lime_K, lime_B, lime_solimp[5], lime_margin;
   int nlimited_elem;

@@ -40,7 +40,7 @@ using namespace sgm;
 #define SGT_MAXHIT 256   // candidate pairs that pass the bounding tests
 #define SGT_HITREC 8     // contacts one pair can produce (box - box)
 #define SGT_RECW 10      // doubles of a staged narrowphase record: dist, pos[3], n[3], tangent hint[3]
-#define SGT_CSC 32       // scalar doubles of a contact record in the work space
+#define SGT_CSC 56       // scalar doubles of a contact record in the work space
 #define SGT_LROW 6       // doubles of a chain limit row: dof, sign, R, b, f, 1 / (A + R)
 
 struct TreeArgs {
@@ -69,7 +69,11 @@ SG_HD long long cws_doubles(const SgTreeDev& T) {
 
 // scalar part of a contact record
 enum { CS_A = 0, CS_B = 6, CS_F0 = 9, CS_R = 12, CS_INVM = 13, CS_JS = 14, CS_SL = 17, CS_C1 = 18, CS_N1 = 19, CS_C2 = 20, CS_N2 = 21,
-       CS_ROWS = 22, CS_TOUCH = 23 };
+       CS_ROWS = 22, CS_TOUCH = 23, CS_OBJ = 24 /* the contact touches the free object */, CS_JO = 25 /* [3][6]: its rows on the object's free dofs, body frame */ };
+// the free object's block in LDS (S.of[..]); body frame unless said otherwise
+enum { OF_P = 0, OF_Q = 3, OF_R = 7, OF_VW = 16 /* world */, OF_VL = 19, OF_WL = 22 /* (v, w) contiguous */, OF_WARM = 25, OF_ASM = 31, OF_AF = 37, OF_GF = 43, OF_SINV = 49,
+       OF_CEN = 85 /* world */, OF_GL = 88, OF_CTEN = 91, OF_BIAS = 97, OF_X = 103, OF_Y = 109, OF_WB = 115 /* OF_WARM: dof coordinates (world translations), kept
+       across substeps; OF_WB: the same in the body frame of this substep */, OF_MFF = 121 /* upper triangle of M_ff, 21 */, OF_TMP = 142, OF_N = 160 };
 
 struct Lds {
   double *q, *v, *warm, *asm_, *aF, *fs, *fc, *bias, *tenJ, *kd, *qacc;
@@ -79,13 +83,14 @@ struct Lds {
   double *qe, *ve, *we, *asme, *ae, *fse, *ffix, *bfix, *Rfix, *flim, *blim, *Rlim, *ke;
   double *einvm, *ecoef, *ecen, *Ifix, *Ilim;   // 1 / (m + armature), tendon coefficient, capsule centres [3][N], 1 / (A + R) of the fix / limit rows
   double *lrow, *seg, *chs, *cf, *red;
+  double *of, *Be, *Ce, *Afix;   // free object (plans with has_free): scalars (OF_*), B_e [N][6], C_e = -S^-1 B_e / D_e [N][6], the fix rows' diagonals A + R
   int *hit_pair, *hit_sorted, *hit_cnt, *hit_off, *con_src, *con_chain, *icnt;
 };
 enum { IC_NHIT = 0, IC_NCON, IC_SERIAL, IC_NLIM0 /* + chain */, IC_N = IC_NLIM0 + SGT_MAXCH };
 // per-chain scalars in LDS (chs[c * CHS_N + ..])
 enum { CHS_TLEN = 0, CHS_TVEL, CHS_TFRC, CHS_AFRC, CHS_ACTDOT, CHS_ACT, CHS_CTRL, CHS_KT, CHS_N };
 
-SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N) {
+SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_free = 0) {
   double* p = base;
   auto take = [&](size_t n) { double* r = p; p += (n + 1) & ~(size_t)1; return r; };
   const int ND = T.ND, NB = T.NB;
@@ -100,6 +105,7 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N) {
   L.einvm = take(N); L.ecoef = take(N); L.ecen = take(3 * N); L.Ifix = take(N); L.Ilim = take(2 * N);
   L.lrow = take(SGT_LROW * 2 * ND); L.seg = take(4 * SGT_MAXCH * SGT_MAXTS); L.chs = take(CHS_N * SGT_MAXCH); L.cf = take(3 * SGT_MAXCON);
   L.red = take(16);
+  L.of = take(has_free ? OF_N : 0); L.Be = take(has_free ? 6 * N : 0); L.Ce = take(has_free ? 6 * N : 0); L.Afix = take(has_free ? N : 0);
   int* ip = (int*)p;
   L.hit_pair = ip; ip += SGT_MAXHIT;
   L.hit_sorted = ip; ip += SGT_MAXHIT;
@@ -110,9 +116,9 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N) {
   L.icnt = ip; ip += 32;
   return (size_t)((char*)ip - (char*)base);
 }
-SG_HD size_t lds_bytes(const SgTreeDev& T, int N) {
+SG_HD size_t lds_bytes(const SgTreeDev& T, int N, int has_free = 0) {
   Lds L;
-  return lds_carve(L, reinterpret_cast<double*>((uintptr_t)4096), T, N);
+  return lds_carve(L, reinterpret_cast<double*>((uintptr_t)4096), T, N, has_free);
 }
 
 // section stamps (profiling build only: build_native.py --prof, scripts/tree_section_profile.py): lane 0 adds the cycles since the
@@ -210,6 +216,27 @@ SG_HD double scalar_update_rcp(double& f, double b, double Ja, double R, double 
   f = fn;
   return change;
 }
+// inverse of a symmetric positive definite 6 x 6 matrix (Gauss-Jordan without pivoting: the free object's Schur complement)
+SG_HD void spd_inverse6(const double* Sm, double* Si) {
+  double a[6][12];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) { a[i][j] = Sm[6 * i + j]; a[i][6 + j] = i == j ? 1.0 : 0.0; }
+  for (int k = 0; k < 6; k++) {
+    const double pv = 1.0 / a[k][k];
+    for (int j = 0; j < 12; j++) a[k][j] *= pv;
+    for (int i = 0; i < 6; i++) {
+      if (i == k) continue;
+      const double f = a[i][k];
+      for (int j = 0; j < 12; j++) a[i][j] -= f * a[k][j];
+    }
+  }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) Si[6 * i + j] = a[i][6 + j];
+}
+SG_HD double dot6(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
+SG_HD void mat6vec(double* r, const double* M, const double* v) {
+  for (int i = 0; i < 6; i++) r[i] = dot6(M + 6 * i, v);
+}
 // in-place L'DL of a chain block (mj_factorM restricted to a serial chain)
 SG_HD void chain_factor(double* Lc, int nd) {
   for (int k = nd - 1; k >= 1; k--) {
@@ -229,7 +256,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   const int N = H.nelem, ND = T.ND, NB = T.NB, K = T.K, nv = H.nv, nu = H.nu, CS = T.CS;
   const double h = H.timestep;
   Lds S;
-  lds_carve(S, lds_base, T, N);
+  lds_carve(S, lds_base, T, N, H.has_free);
   auto E = [&](int f, int e) { return A.elem[(size_t)f * N + e]; };
   double* const cw = A.cws + (size_t)env * A.cws_stride;
   double* const stage = cw;
@@ -241,7 +268,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   auto pidx = [&](int d) { const int c = T.d_chain[d]; return c * CS + d - T.c_dof0[c]; };   // flat chain dof -> index in a padded [K][CS] vector
 
   if (A.mode == 1 && A.mask && !A.mask[env]) return;   // masked reset: the other envs keep everything
-  double* const gq = A.qpos + (size_t)env * nv;
+  const bool FR = H.has_free != 0;   // the composite's elements hang off a free body (6 dofs): the "object block" below
+  double* const gq = A.qpos + (size_t)env * H.nq;
   double* const gv = A.qvel + (size_t)env * nv;
   double* const gw = A.warm + (size_t)env * nv;
   double* const gact = A.act + (size_t)env * (nu > 0 ? nu : 1);
@@ -259,14 +287,28 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     S.qacc[d] = 0;
   }
   SGT_PAR(e, N) {
-    const int j = H.elem_dof0 + e;
+    const int jd = H.elem_dof0 + e, jq = H.elem_qpos0 + e;
     const bool rs = A.mode == 1;
-    S.qe[e] = rs ? E(SGE_QPOS0, e) : gq[j];
-    S.ve[e] = rs ? 0.0 : gv[j];
-    S.we[e] = rs ? 0.0 : gw[j];
-    S.ke[e] = A.kmask_jnt[j] ? kenv : E(SGE_K0, e);
+    S.qe[e] = rs ? E(SGE_QPOS0, e) : gq[jq];
+    S.ve[e] = rs ? 0.0 : gv[jd];
+    S.we[e] = rs ? 0.0 : gw[jd];
+    S.ke[e] = A.kmask_jnt[H.elem_jnt0 + e] ? kenv : E(SGE_K0, e);
     S.einvm[e] = 1.0 / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
     S.ecoef[e] = E(SGE_COEF, e);
+    if (FR) {   // B_e = m_e (a_e ; k_e x a_e): the slider's column of the object's mass matrix, body frame (constant)
+      const double m = E(SGE_MASS, e), a[3] = {E(SGE_AX, e), E(SGE_AY, e), E(SGE_AZ, e)}, k0[3] = {E(SGE_KX, e), E(SGE_KY, e), E(SGE_KZ, e)};
+      double kxa[3];
+      cross3(kxa, k0, a);
+      for (int c = 0; c < 3; c++) { S.Be[6 * e + c] = m * a[c]; S.Be[6 * e + 3 + c] = m * kxa[c]; }
+    }
+  }
+  if (FR) {
+    SGT_ONE {
+      const bool rs = A.mode == 1;
+      for (int c = 0; c < 7; c++) S.of[OF_P + c] = rs ? H.free_q0[c] : gq[H.free_qadr + c];
+      for (int c = 0; c < 3; c++) { S.of[OF_VW + c] = rs ? 0.0 : gv[H.free_dadr + c]; S.of[OF_WL + c] = rs ? 0.0 : gv[H.free_dadr + 3 + c]; }
+      for (int c = 0; c < 6; c++) S.of[OF_WARM + c] = rs ? 0.0 : gw[H.free_dadr + c];   // warmstart in dof coordinates (world translations)
+    }
   }
   SGT_PAR(c, K) {
     double* cs = S.chs + c * CHS_N;
@@ -324,6 +366,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       double bad = 0;
       SGT_PAR(d, ND) bad += (isbad(S.q[d]) ? 1.0 : 0.0) + (isbad(S.v[d]) ? 1024.0 : 0.0);
       SGT_PAR(e, N) bad += (isbad(S.qe[e]) ? 1.0 : 0.0) + (isbad(S.ve[e]) ? 1024.0 : 0.0);
+      if (FR) SGT_PAR(c, 7) bad += (isbad(S.of[OF_P + c]) ? 1.0 : 0.0) + ((c < 6 && isbad(S.of[OF_VW + c])) ? 1024.0 : 0.0);
       bad = wsum(bad);
       if (bad > 0) {
         const int nb = (int)bad;
@@ -373,6 +416,19 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         for (int k = 0; k < 4; k++) pquat[k] = quat[k];
         for (int k = 0; k < 9; k++) pmat[k] = mat[k];
       }
+    }
+    if (FR) SGT_ONE {   // the free body's pose IS its 7 positions; velocities, gravity and the warmstart in its frame
+      double* o = S.of;
+      const double nq = sqrt(o[OF_Q] * o[OF_Q] + o[OF_Q + 1] * o[OF_Q + 1] + o[OF_Q + 2] * o[OF_Q + 2] + o[OF_Q + 3] * o[OF_Q + 3]);
+      double qn[4] = {o[OF_Q] / nq, o[OF_Q + 1] / nq, o[OF_Q + 2] / nq, o[OF_Q + 3] / nq};
+      quat2mat(o + OF_R, qn);
+      mulmatT3(o + OF_VL, o + OF_R, o + OF_VW);
+      mulmatT3(o + OF_GL, o + OF_R, H.gravity);
+      mulmatT3(o + OF_WB, o + OF_R, o + OF_WARM);
+      for (int c = 0; c < 3; c++) o[OF_WB + 3 + c] = o[OF_WARM + 3 + c];
+      double t[3];
+      mulmat3(t, o + OF_R, H.center_pos);
+      for (int c = 0; c < 3; c++) o[OF_CEN + c] = o[OF_P + c] + t[c];
     }
     SGT_SYNC();
     SGT_PAR(g, T.NG) {
@@ -553,7 +609,81 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     SGT_PAR(e, N) { t0_len += E(SGE_COEF, e) * S.qe[e]; t0_vel += E(SGE_COEF, e) * S.ve[e]; }
     t0_len = wsum(t0_len); t0_vel = wsum(t0_vel);
     const double t0_frc = -kt0 * (t0_len - H.t0_lspring) - H.t0_damping * t0_vel;
-    SGT_PAR(e, N) {
+    if (FR) {
+      // ---- the free object, everything in the body's frame.  Dofs: (v, w) of the body -- v turned into its frame --
+      // and the sliders.  Mass matrix [[M_ff, B], [B', D]]: M_ff from the total mass, first moment and inertia about the body's
+      // origin (they move with the sliders: three reductions), B_e constant, D diagonal.  Bias: RNE over a star -- the body
+      // and its leaves (oracle tree_motion / rne_bias): a leaf's centre of mass accelerates with -g + 2 (w x a_e) s'_e + w x (w x k_e).
+      const double* o = S.of;
+      const double w[3] = {o[OF_WL], o[OF_WL + 1], o[OF_WL + 2]}, gl[3] = {o[OF_GL], o[OF_GL + 1], o[OF_GL + 2]};
+      double acc[15];   // force (3), torque about the origin (3), first moment (3), inertia about the origin (6: 00 01 02 11 12 22)
+      for (int k = 0; k < 15; k++) acc[k] = 0;
+      SGT_PAR(e, N) {
+        const double m = E(SGE_MASS, e), sd = S.qe[e] - E(SGE_QPOS0, e), a[3] = {E(SGE_AX, e), E(SGE_AY, e), E(SGE_AZ, e)};
+        const double k[3] = {E(SGE_KX, e) + a[0] * sd, E(SGE_KY, e) + a[1] * sd, E(SGE_KZ, e) + a[2] * sd};
+        const double Ie[9] = {E(SGE_I00, e), E(SGE_I01, e), E(SGE_I02, e), E(SGE_I01, e), E(SGE_I11, e), E(SGE_I12, e), E(SGE_I02, e), E(SGE_I12, e), E(SGE_I22, e)};
+        double t[3], t2[3], f[3], n[3], Iw[3], kxf[3];
+        cross3(t, w, a);
+        cross3(t2, w, k); cross3(f, w, t2);
+        for (int c = 0; c < 3; c++) f[c] = m * (f[c] - gl[c] + 2 * t[c] * S.ve[e]);
+        mulmat3(Iw, Ie, w);
+        cross3(n, w, Iw);
+        cross3(kxf, k, f);
+        const double pas = -S.ke[e] * (S.qe[e] - E(SGE_SPRINGREF, e)) - E(SGE_DAMPING, e) * S.ve[e] + E(SGE_COEF, e) * t0_frc;
+        S.fse[e] = pas - dot3(a, f);
+        const double kk = dot3(k, k);
+        for (int c = 0; c < 3; c++) { acc[c] += f[c]; acc[3 + c] += kxf[c] + n[c]; acc[6 + c] += m * k[c]; }
+        acc[9] += Ie[0] + m * (kk - k[0] * k[0]); acc[10] += Ie[1] - m * k[0] * k[1]; acc[11] += Ie[2] - m * k[0] * k[2];
+        acc[12] += Ie[4] + m * (kk - k[1] * k[1]); acc[13] += Ie[5] - m * k[1] * k[2]; acc[14] += Ie[8] + m * (kk - k[2] * k[2]);
+        double cl[3] = {E(SGE_GX, e) + a[0] * sd, E(SGE_GY, e) + a[1] * sd, E(SGE_GZ, e) + a[2] * sd}, cw[3];   // the capsule's centre, world
+        mulmat3(cw, o + OF_R, cl);
+        for (int c = 0; c < 3; c++) S.ecen[3 * e + c] = o[OF_P + c] + cw[c];
+      }
+      for (int k = 0; k < 15; k++) acc[k] = wsum(acc[k]);
+      SGT_SYNC();
+      SGT_ONE {
+        double* ow = S.of;
+        const double mF = H.free_mass, *c = H.free_com;
+        double t2[3], f[3], n[3], Iw[3], cxf[3];
+        cross3(t2, w, c); cross3(f, w, t2);
+        for (int q = 0; q < 3; q++) f[q] = mF * (f[q] - gl[q]);
+        mulmat3(Iw, H.free_inertia, w);
+        cross3(n, w, Iw);
+        cross3(cxf, c, f);
+        const double cc = dot3(c, c);
+        double F6[6], mk[3], I6[6];
+        for (int q = 0; q < 3; q++) { F6[q] = acc[q] + f[q]; F6[3 + q] = acc[3 + q] + cxf[q] + n[q]; mk[q] = acc[6 + q] + mF * c[q]; }
+        I6[0] = acc[9] + H.free_inertia[0] + mF * (cc - c[0] * c[0]); I6[1] = acc[10] + H.free_inertia[1] - mF * c[0] * c[1];
+        I6[2] = acc[11] + H.free_inertia[2] - mF * c[0] * c[2]; I6[3] = acc[12] + H.free_inertia[4] + mF * (cc - c[1] * c[1]);
+        I6[4] = acc[13] + H.free_inertia[5] - mF * c[1] * c[2]; I6[5] = acc[14] + H.free_inertia[8] + mF * (cc - c[2] * c[2]);
+        for (int q = 0; q < 6; q++) ow[OF_BIAS + q] = F6[q];
+        // M_ff = [[m I, -[mk]x], [[mk]x, I_o]]; kept (21 numbers) for the Euler step's S' = M_ff - sum B B' / (D + h d)
+        double Mff[36];
+        for (int q = 0; q < 36; q++) Mff[q] = 0;
+        Mff[0] = Mff[7] = Mff[14] = H.obj_msum;
+        Mff[0 * 6 + 4] = mk[2]; Mff[0 * 6 + 5] = -mk[1]; Mff[1 * 6 + 3] = -mk[2]; Mff[1 * 6 + 5] = mk[0]; Mff[2 * 6 + 3] = mk[1]; Mff[2 * 6 + 4] = -mk[0];
+        Mff[21] = I6[0]; Mff[22] = I6[1]; Mff[23] = I6[2]; Mff[28] = I6[3]; Mff[29] = I6[4]; Mff[35] = I6[5];
+        for (int r = 0; r < 6; r++)
+          for (int q = 0; q < r; q++) Mff[6 * r + q] = Mff[6 * q + r];
+        double Sm[36];
+        int qq = 0;
+        for (int r = 0; r < 6; r++)
+          for (int q = r; q < 6; q++) { Sm[6 * r + q] = Sm[6 * q + r] = Mff[6 * r + q] - H.obj_BBD[qq]; ow[OF_MFF + qq] = Mff[6 * r + q]; qq++; }
+        spd_inverse6(Sm, ow + OF_SINV);
+      }
+      SGT_SYNC();
+      double red[6] = {0, 0, 0, 0, 0, 0};
+      SGT_PAR(e, N)
+        for (int q = 0; q < 6; q++) red[q] += S.Be[6 * e + q] * S.fse[e] * S.einvm[e];
+      for (int q = 0; q < 6; q++) red[q] = wsum(red[q]);
+      double rhs[6], af6[6];
+      for (int q = 0; q < 6; q++) rhs[q] = -o[OF_BIAS + q] - red[q];
+      mat6vec(af6, o + OF_SINV, rhs);
+      SGT_SYNC();
+      SGT_ONE { for (int q = 0; q < 6; q++) S.of[OF_ASM + q] = af6[q]; }
+      SGT_PAR(e, N) S.asme[e] = (S.fse[e] - dot6(S.Be + 6 * e, af6)) * S.einvm[e];
+    }
+    if (!FR) SGT_PAR(e, N) {
       const double m = E(SGE_MASS, e), ga = H.gravity[0] * E(SGE_AX, e) + H.gravity[1] * E(SGE_AY, e) + H.gravity[2] * E(SGE_AZ, e);
       const double pas = -S.ke[e] * (S.qe[e] - E(SGE_SPRINGREF, e)) - E(SGE_DAMPING, e) * S.ve[e] + E(SGE_COEF, e) * t0_frc;
       S.fse[e] = pas + m * ga;   // - bias, bias = -m g . axis
@@ -583,15 +713,16 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         memcpy(&bf, &gp.pad, 4);
         const double bound = (double)bf;
         bool hit = false;
-        if (gp.kind == SGP_PLANE_CAP || gp.kind == SGP_PLANE_BOX) {
-          const double* c = gp.kind == SGP_PLANE_CAP ? S.ecen + 3 * i2 : (k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[i2]);
+        const double* cenw = FR ? S.of + OF_CEN : H.center_pos;   // the centre sphere (on the free body when there is one)
+        if (gp.kind == SGP_PLANE_CAP || gp.kind == SGP_PLANE_BOX || gp.kind == SGP_PLANE_SPH) {
+          const double* c = gp.kind == SGP_PLANE_SPH ? cenw : gp.kind == SGP_PLANE_CAP ? S.ecen + 3 * i2 : (k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[i2]);
           const double dif[3] = {c[0] - H.plane_pos[0], c[1] - H.plane_pos[1], c[2] - H.plane_pos[2]};
           hit = !(dot3(dif, H.plane_normal) > bound);
         } else if (gp.kind != SGP_UNSUPPORTED) {
           // geom2 is a box (finger or static); geom1 the centre sphere, an element capsule or a box
           const double* bp = k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[i2];
           const int k1 = sgg_kind(gp.g1);
-          const double* c = k1 == SGG_CENTER ? H.center_pos : (k1 == SGG_ELEM ? S.ecen + 3 * i1 : (k1 == SGG_BOX ? S.gpos + 3 * i1 : H.st_pos[i1]));
+          const double* c = k1 == SGG_CENTER ? cenw : (k1 == SGG_ELEM ? S.ecen + 3 * i1 : (k1 == SGG_BOX ? S.gpos + 3 * i1 : H.st_pos[i1]));
           const double dif[3] = {bp[0] - c[0], bp[1] - c[1], bp[2] - c[2]};
           hit = !(dot3(dif, dif) > bound * bound);
           if (hit && k1 == SGG_ELEM) {   // tighter: the capsule's bounding sphere against the box itself
@@ -634,10 +765,25 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       const double* bp = k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[i2];
       const double* bm = k2 == SGG_BOX ? S.gmat + 9 * i2 : H.st_mat[i2];
       const double* sz = k2 == SGG_BOX ? T.g_size[i2] : H.st_size[i2];
-      if (gp.kind == SGP_PLANE_CAP) {
-        double c[3];
+      const double* cenw = FR ? S.of + OF_CEN : H.center_pos;
+      auto elem_axis = [&](int e, double* cax) {   // the capsule's axis in the world (it turns with a free body)
+        const double cl[3] = {E(SGE_CX, e), E(SGE_CY, e), E(SGE_CZ, e)};
+        if (FR) mulmat3(cax, S.of + OF_R, cl);
+        else { cax[0] = cl[0]; cax[1] = cl[1]; cax[2] = cl[2]; }
+      };
+      if (gp.kind == SGP_PLANE_SPH) {   // oracle collision(), plane - sphere branch
+        const double e3[3] = {cenw[0] - H.plane_pos[0], cenw[1] - H.plane_pos[1], cenw[2] - H.plane_pos[2]};
+        const double dist = dot3(e3, H.plane_normal) - H.center_radius;
+        if (!(dist > H.con_margin)) {
+          ConRec r0;
+          r0.dist = dist;
+          for (int k = 0; k < 3; k++) { r0.pos[k] = cenw[k] - H.plane_normal[k] * (H.center_radius + 0.5 * dist); r0.n[k] = H.plane_normal[k]; }
+          put(r0, nullptr);
+        }
+      } else if (gp.kind == SGP_PLANE_CAP) {
+        double c[3], cax[3];
         elem_center(i2, c);
-        const double cax[3] = {E(SGE_CX, i2), E(SGE_CY, i2), E(SGE_CZ, i2)};
+        elem_axis(i2, cax);
         ConRec r0, r1;
         const int m = gen_plane_capsule(H.plane_pos, H.plane_normal, c, cax, H.cap_radius, H.cap_hl, H.con_margin, r0, r1);
         if (m > 0) put(r0, cax);
@@ -648,11 +794,11 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         for (int k = 0; k < m; k++) put(r[k], nullptr);
       } else if (gp.kind == SGP_SPH_BOX) {
         ConRec r0;
-        if (sphere_box(H.center_pos, H.center_radius, bp, bm, sz, H.con_margin, r0)) put(r0, nullptr);
+        if (sphere_box(cenw, H.center_radius, bp, bm, sz, H.con_margin, r0)) put(r0, nullptr);
       } else if (gp.kind == SGP_CAP_BOX) {
-        double c[3];
+        double c[3], cax[3];
         elem_center(i1, c);
-        const double cax[3] = {E(SGE_CX, i1), E(SGE_CY, i1), E(SGE_CZ, i1)};
+        elem_axis(i1, cax);
         ConRec r0, r1;
         const int m = capsule_box(c, cax, H.cap_radius, H.cap_hl, bp, bm, sz, H.con_margin, r0, r1);
         if (m & 1) put(r0, nullptr);
@@ -693,7 +839,15 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       S.Rfix[e] = R; S.bfix[e] = S.asme[e] - aref;
       S.ffix[e] = -(S.we[e] - aref) / R;
       const double co = S.ecoef[e], invm = S.einvm[e];
-      S.Ifix[e] = 1.0 / (invm + R);
+      double Aee = invm;
+      if (FR) {   // the row reaches every slider through the body: [M^-1]_ee = 1/D + B' S^-1 B / D^2; C_e = -S^-1 B_e / D
+        double Bs[6];
+        mat6vec(Bs, S.of + OF_SINV, S.Be + 6 * e);
+        Aee = invm + dot6(S.Be + 6 * e, Bs) * invm * invm;
+        for (int q = 0; q < 6; q++) S.Ce[6 * e + q] = -Bs[q] * invm;
+        S.Afix[e] = Aee + R;
+      }
+      S.Ifix[e] = 1.0 / (Aee + R);
       tj_pos += co * S.qe[e]; tj_vel += co * S.ve[e]; tj_asm += co * S.asme[e]; tj_warm += co * S.we[e]; tj_A += co * co * invm;
       // (d) limit rows of the slider: slot 0 lower side, slot 1 upper side (MuJoCo's order)
       for (int sd = 0; sd < 2; sd++) {
@@ -715,6 +869,13 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       }
     }
     tj_pos = wsum(tj_pos); tj_vel = wsum(tj_vel); tj_asm = wsum(tj_asm); tj_warm = wsum(tj_warm); tj_A = wsum(tj_A);
+    double cten[6] = {0, 0, 0, 0, 0, 0};   // free object: the tendon row's push on the body, C_ten = -S^-1 sum_e coef_e B_e / D_e
+    if (FR) {
+      double Bs[6];
+      mat6vec(Bs, S.of + OF_SINV, H.obj_tenB);
+      tj_A += dot6(H.obj_tenB, Bs);
+      for (int q = 0; q < 6; q++) cten[q] = -Bs[q];
+    }
     double ten_R, ten_b, ten_f;
     {
       const double pos = tj_pos - H.t0_L0, imp = impedance(H.eqt_solimp, pos, 0.0);
@@ -760,8 +921,22 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       // the two sides: geom1's body enters the row with -, geom2's with +
       int ch[2] = {-1, -1}, nd[2] = {0, 0}, sl = -1, touchbit = -1;
       double binvw = 0, Js[3] = {0, 0, 0}, invm = 0;
-      bool obj = false;
+      bool obj = false, onfree = false;
       int nblk = 0;
+      double Jo[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}}, fl[9], xl[3];   // free object: frame rows and contact point in the body's frame
+      if (FR) {
+        const double d3[3] = {rec[1] - S.of[OF_P], rec[2] - S.of[OF_P + 1], rec[3] - S.of[OF_P + 2]};
+        mulmatT3(xl, S.of + OF_R, d3);
+        for (int rr = 0; rr < 3; rr++) mulmatT3(fl + 3 * rr, S.of + OF_R, fr + 3 * rr);
+      }
+      auto object_side = [&](double sg) {   // a point of the free body (or of one of its leaves): translation n, rotation x x n
+        onfree = true;
+        for (int rr = 0; rr < 3; rr++) {
+          double xn[3];
+          cross3(xn, xl, fl + 3 * rr);
+          for (int c = 0; c < 3; c++) { Jo[rr][c] += sg * fl[3 * rr + c]; Jo[rr][3 + c] += sg * xn[c]; }
+        }
+      };
       for (int side = 0; side < 2; side++) {
         const int ref = side ? gp.g2 : gp.g1, kind = sgg_kind(ref), idx = sgg_index(ref);
         const double sg = side ? 1.0 : -1.0;
@@ -795,10 +970,12 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           sl = idx; obj = true;
           binvw += E(SGE_BINVW, idx);
           invm = 1.0 / (E(SGE_MASS, idx) + E(SGE_ARMATURE, idx));
-          const double ax[3] = {E(SGE_AX, idx), E(SGE_AY, idx), E(SGE_AZ, idx)};
-          for (int rr = 0; rr < 3; rr++) Js[rr] += sg * dot3(fr + 3 * rr, ax);
+          const double ax[3] = {E(SGE_AX, idx), E(SGE_AY, idx), E(SGE_AZ, idx)};   // (local to the free body when there is one)
+          for (int rr = 0; rr < 3; rr++) Js[rr] += sg * dot3((FR ? fl : fr) + 3 * rr, ax);
+          if (FR) object_side(sg);
         } else if (kind == SGG_CENTER) {
           obj = true;
+          if (FR) { object_side(sg); binvw += H.free_binvw; }
         }
       }
       // W = J M^-1 over the whole chain, A = J M^-1 J' + R
@@ -807,6 +984,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         vel[rr] = sl >= 0 ? Js[rr] * S.ve[sl] : 0.0;
         js[rr] = sl >= 0 ? Js[rr] * S.asme[sl] : 0.0;
         jw[rr] = sl >= 0 ? Js[rr] * S.we[sl] : 0.0;
+        if (onfree) { vel[rr] += dot6(Jo[rr], S.of + OF_VL); js[rr] += dot6(Jo[rr], S.of + OF_ASM); jw[rr] += dot6(Jo[rr], S.of + OF_WB); }
       }
       for (int b = 0; b < nblk; b++) {
         const int c = ch[b], d0 = T.c_dof0[c], n = nd[b];
@@ -835,7 +1013,18 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       }
       const double dist = rec[0], imp = impedance(H.con_solimp, dist, H.con_margin);
       const double R = fmax(SG_MINVAL, (1 - imp) / imp * binvw), D = 1 / R;
-      {
+      if (onfree) {   // the object's share of J M^-1 J' through the arrow matrix: y = M^-1 J_r' = (y_f ; y_e)
+        double yf[3][6], ye[3];
+        for (int rr = 0; rr < 3; rr++) {
+          double t6[6];
+          for (int q = 0; q < 6; q++) t6[q] = Jo[rr][q] - (sl >= 0 ? S.Be[6 * sl + q] * Js[rr] * invm : 0.0);
+          mat6vec(yf[rr], S.of + OF_SINV, t6);
+          ye[rr] = sl >= 0 ? (Js[rr] - dot6(S.Be + 6 * sl, yf[rr])) * invm : 0.0;
+        }
+        int k = 0;
+        for (int rr = 0; rr < 3; rr++)
+          for (int s2 = rr; s2 < 3; s2++) { Am[k] += dot6(Jo[s2], yf[rr]) + Js[s2] * ye[rr] + (rr == s2 ? R : 0.0); k++; }
+      } else {
         int k = 0;
         for (int rr = 0; rr < 3; rr++)
           for (int s2 = rr; s2 < 3; s2++) { Am[k] += Js[rr] * Js[s2] * invm + (rr == s2 ? R : 0.0); k++; }
@@ -866,9 +1055,12 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       sc[CS_C1] = ch[0]; sc[CS_N1] = nd[0]; sc[CS_C2] = ch[1]; sc[CS_N2] = nd[1];
       sc[CS_ROWS] = rows ? 1.0 : 0.0;
       sc[CS_TOUCH] = (obj && touchbit >= 0) ? touchbit : -1;
+      sc[CS_OBJ] = onfree ? 1.0 : 0.0;
+      for (int rr = 0; rr < 3; rr++)
+        for (int q = 0; q < 6; q++) sc[CS_JO + 6 * rr + q] = Jo[rr][q];
       // the contact's stream in the sweep: its one chain; -1 = no rows; -2 = not exactly one chain block (both fingers, or a slider
       // against a static geom): such a list is swept serially
-      S.con_chain[ci] = !rows ? -1 : (nblk == 1 ? ch[0] : -2);
+      S.con_chain[ci] = !rows ? -1 : ((nblk == 1 && !onfree) ? ch[0] : -2);   // (a free object couples every contact on it: serial list)
     }
     SGT_ONE { S.icnt[IC_SERIAL] = 0; }
     SGT_SYNC();
@@ -930,18 +1122,35 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         SGT_ONE {
           const int sl = (int)sc[CS_SL];
           if (sl >= 0) S.ae[sl] += sc[CS_INVM] * (sc[CS_JS] * f[0] + sc[CS_JS + 1] * f[1] + sc[CS_JS + 2] * f[2]);
+          if (FR && sc[CS_OBJ] != 0.0)
+            for (int q = 0; q < 6; q++) S.of[OF_GF + q] += sc[CS_JO + q] * f[0] + sc[CS_JO + 6 + q] * f[1] + sc[CS_JO + 12 + q] * f[2];
         }
         SGT_SYNC();
       }
+      if (FR) {   // S.ae holds the sliders' LOCAL part g_e / D_e; the body: a_f = S^-1 (g_f - sum_e B_e g_e / D_e)
+        double red[6] = {0, 0, 0, 0, 0, 0}, rhs[6], af6[6];
+        SGT_PAR(e, N)
+          for (int q = 0; q < 6; q++) red[q] += S.Be[6 * e + q] * S.ae[e];
+        for (int q = 0; q < 6; q++) rhs[q] = S.of[OF_GF + q] - wsum(red[q]);
+        mat6vec(af6, S.of + OF_SINV, rhs);
+        SGT_SYNC();
+        SGT_ONE { for (int q = 0; q < 6; q++) S.of[OF_AF + q] = af6[q]; }
+        SGT_SYNC();
+      }
+    };
+    if (FR) { SGT_ONE { for (int q = 0; q < 6; q++) S.of[OF_GF + q] = 0; } }
+    auto slider_acc = [&](int e) {   // a slider's constraint acceleration: with a free object its local part minus the body's share
+      return FR ? S.ae[e] - dot6(S.Be + 6 * e, S.of + OF_AF) * S.einvm[e] : S.ae[e];
     };
     apply_all();
     {
       double cost = 0, S_ae = 0;
       SGT_PAR(e, N) {
-        S_ae += S.ecoef[e] * S.ae[e];
-        cost += S.ffix[e] * (0.5 * (S.ae[e] + S.Rfix[e] * S.ffix[e]) + S.bfix[e]);
-        cost += S.flim[2 * e] * (0.5 * (S.ae[e] + S.Rlim[2 * e] * S.flim[2 * e]) + S.blim[2 * e]);
-        cost += S.flim[2 * e + 1] * (0.5 * (-S.ae[e] + S.Rlim[2 * e + 1] * S.flim[2 * e + 1]) + S.blim[2 * e + 1]);
+        const double ae_ = slider_acc(e);
+        S_ae += S.ecoef[e] * ae_;
+        cost += S.ffix[e] * (0.5 * (ae_ + S.Rfix[e] * S.ffix[e]) + S.bfix[e]);
+        cost += S.flim[2 * e] * (0.5 * (ae_ + S.Rlim[2 * e] * S.flim[2 * e]) + S.blim[2 * e]);
+        cost += S.flim[2 * e + 1] * (0.5 * (-ae_ + S.Rlim[2 * e + 1] * S.flim[2 * e + 1]) + S.blim[2 * e + 1]);
       }
       SGT_PAR(c, K) {
         const double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
@@ -956,7 +1165,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         const double* f = S.cf + 3 * ci;
         const int sl = (int)sc[CS_SL];
         for (int rr = 0; rr < 3; rr++) {
-          double ja = sl >= 0 ? sc[CS_JS + rr] * S.ae[sl] : 0.0;
+          double ja = sl >= 0 ? sc[CS_JS + rr] * slider_acc(sl) : 0.0;
+          if (FR && sc[CS_OBJ] != 0.0) ja += dot6(sc + CS_JO + 6 * rr, S.of + OF_AF);
           for (int b = 0; b < 2; b++) {
             const int c = (int)sc[b ? CS_C2 : CS_C1], n = (int)sc[b ? CS_N2 : CS_N1];
             if (c < 0) continue;
@@ -972,6 +1182,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         ten_f = 0;
         SGT_PAR(e, N) { S.ffix[e] = 0; S.flim[2 * e] = 0; S.flim[2 * e + 1] = 0; S.ae[e] = 0; }
         SGT_PAR(i, K * CS) S.aF[i] = 0;
+        if (FR) SGT_ONE { for (int q = 0; q < 6; q++) S.of[OF_AF + q] = S.of[OF_GF + q] = 0; }
         SGT_PAR(c, K)
           for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) S.lrow[SGT_LROW * (2 * T.c_dof0[c] + i) + 4] = 0;
         SGT_PAR(i, 3 * ncon) S.cf[i] = 0;
@@ -984,22 +1195,52 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       double imp_par = 0, imp_uni = 0;
       // joint-fix rows: each on its own slider
       double S_ae = 0;
-      SGT_PAR(e, N) {
-        const double invm = S.einvm[e];
-        double f = S.ffix[e];
-        const double old = f;
-        imp_par -= scalar_update_rcp(f, S.bfix[e], S.ae[e], S.Rfix[e], invm + S.Rfix[e], S.Ifix[e], false);
-        S.ffix[e] = f;
-        S.ae[e] += invm * (f - old);
-        S_ae += S.ecoef[e] * S.ae[e];
+      if (FR) {
+        // with a free object a joint-fix row moves the body and through it every slider: the rows run one after the other (mj_solPGS's
+        // order), the body's acceleration a_f in registers, a row's own slider from its local part and a_f
+        SGT_ONE {
+          double af6[6], imp = 0;
+          for (int q = 0; q < 6; q++) af6[q] = S.of[OF_AF + q];
+          for (int e = 0; e < N; e++) {
+            const double invm = S.einvm[e];
+            double f = S.ffix[e];
+            const double old = f;
+            imp -= scalar_update_rcp(f, S.bfix[e], S.ae[e] - dot6(S.Be + 6 * e, af6) * invm, S.Rfix[e], S.Afix[e], S.Ifix[e], false);
+            const double dfl = f - old;
+            S.ffix[e] = f;
+            S.ae[e] += invm * dfl;
+            for (int q = 0; q < 6; q++) af6[q] += S.Ce[6 * e + q] * dfl;
+          }
+          for (int q = 0; q < 6; q++) S.of[OF_AF + q] = af6[q];
+          S.red[0] = imp;
+        }
+        SGT_SYNC();
+        imp_uni += S.red[0];
+        SGT_PAR(e, N) S_ae += S.ecoef[e] * S.ae[e];
+        S_ae = wsum(S_ae) - dot6(H.obj_tenB, S.of + OF_AF);   // sum coef_e a_e, a_e = local part - B_e . a_f / D_e
+      } else {
+        SGT_PAR(e, N) {
+          const double invm = S.einvm[e];
+          double f = S.ffix[e];
+          const double old = f;
+          imp_par -= scalar_update_rcp(f, S.bfix[e], S.ae[e], S.Rfix[e], invm + S.Rfix[e], S.Ifix[e], false);
+          S.ffix[e] = f;
+          S.ae[e] += invm * (f - old);
+          S_ae += S.ecoef[e] * S.ae[e];
+        }
+        S_ae = wsum(S_ae);
       }
-      S_ae = wsum(S_ae);
       SGT_STAMP(17);
       {  // the tendon-fix row over all sliders
         const double old = ten_f;
         imp_uni -= scalar_update_rcp(ten_f, ten_b, S_ae, ten_R, tj_A + ten_R, ten_I, false);
         const double dfl = ten_f - old;
         SGT_PAR(e, N) S.ae[e] += S.ecoef[e] * dfl * S.einvm[e];
+        if (FR) {
+          SGT_SYNC();
+          SGT_ONE { for (int q = 0; q < 6; q++) S.of[OF_AF + q] += cten[q] * dfl; }
+          SGT_SYNC();
+        }
       }
       SGT_STAMP(18);
       // chain limit rows: serial within a chain, the chains side by side
@@ -1098,7 +1339,9 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           p0 += J[dl] * a; p1 += J[CS + dl] * a; p2 += J[2 * CS + dl] * a;
         }
         p0 = wsum(p0); p1 = wsum(p1); p2 = wsum(p2);
-        const double as_ = sl >= 0 ? S.ae[sl] : 0.0;
+        const bool ob = FR && sc[CS_OBJ] != 0.0;
+        if (ob) { p0 += dot6(sc + CS_JO, S.of + OF_AF); p1 += dot6(sc + CS_JO + 6, S.of + OF_AF); p2 += dot6(sc + CS_JO + 12, S.of + OF_AF); }
+        const double as_ = sl >= 0 ? slider_acc(sl) : 0.0;
         double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
         const double res[3] = {sc[CS_B] + sc[CS_JS] * as_ + p0 + sc[CS_R] * f[0], sc[CS_B + 1] + sc[CS_JS + 1] * as_ + p1 + sc[CS_R] * f[1],
                                sc[CS_B + 2] + sc[CS_JS + 2] * as_ + p2 + sc[CS_R] * f[2]};
@@ -1113,7 +1356,14 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         }
         SGT_ONE {
           S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
-          if (sl >= 0) S.ae[sl] += sc[CS_INVM] * (sc[CS_JS] * df[0] + sc[CS_JS + 1] * df[1] + sc[CS_JS + 2] * df[2]);
+          const double dge = sl >= 0 ? sc[CS_JS] * df[0] + sc[CS_JS + 1] * df[1] + sc[CS_JS + 2] * df[2] : 0.0;
+          if (sl >= 0) S.ae[sl] += sc[CS_INVM] * dge;
+          if (ob) {   // the push on the body: g_f += J_o' df; a_f += S^-1 J_o' df + C_sl dg_e
+            double dg[6], da[6];
+            for (int q = 0; q < 6; q++) dg[q] = sc[CS_JO + q] * df[0] + sc[CS_JO + 6 + q] * df[1] + sc[CS_JO + 12 + q] * df[2];
+            mat6vec(da, S.of + OF_SINV, dg);
+            for (int q = 0; q < 6; q++) { S.of[OF_GF + q] += dg[q]; S.of[OF_AF + q] += da[q] + (sl >= 0 ? S.Ce[6 * sl + q] * dge : 0.0); }
+          }
         }
         SGT_SYNC();
       }
@@ -1147,9 +1397,16 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     double badacc = 0;
     SGT_PAR(d, ND) badacc += isbad(S.qacc[d]) ? 1.0 : 0.0;
     SGT_PAR(e, N) {
-      const double qa = S.asme[e] + S.ae[e];
+      const double qa = S.asme[e] + slider_acc(e);
       S.we[e] = qa;
       badacc += isbad(qa) ? 1.0 : 0.0;
+    }
+    if (FR) {   // the body: qacc in dof coordinates (translations along the world axes) is what the next solve warmstarts from
+      double qf[6], tw[3];
+      for (int q = 0; q < 6; q++) { qf[q] = S.of[OF_ASM + q] + S.of[OF_AF + q]; badacc += isbad(qf[q]) ? 1.0 / 64 : 0.0; }
+      mulmat3(tw, S.of + OF_R, qf);
+      SGT_SYNC();
+      SGT_ONE { for (int q = 0; q < 3; q++) { S.of[OF_WARM + q] = tw[q]; S.of[OF_WARM + 3 + q] = qf[3 + q]; } }
     }
     badacc = wsum(badacc);
     SGT_SYNC();
@@ -1192,20 +1449,73 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       cs[CHS_ACT] += h * cs[CHS_ACTDOT];
     }
     double Jx = 0, Jy = 0;
-    SGT_PAR(e, N) {
-      const double m = E(SGE_MASS, e) + E(SGE_ARMATURE, e), fce = m * S.ae[e], den = m + h * E(SGE_DAMPING, e), co = S.ecoef[e];
-      const double x = (S.fse[e] + fce) / den;
-      S.asme[e] = x;   // (asme is rebuilt by the next forward pass)
-      Jx += co * x; Jy += co * co / den;
-    }
-    Jx = wsum(Jx); Jy = wsum(Jy);
-    const double kk = H.t0_implicit ? h * H.t0_damping * Jx / (1 + h * H.t0_damping * Jy) : 0.0;   // D5: Sherman-Morrison
-    SGT_SYNC();
-    SGT_PAR(e, N) {
-      const double den = E(SGE_MASS, e) + E(SGE_ARMATURE, e) + h * E(SGE_DAMPING, e);
-      const double x = S.asme[e] - kk * E(SGE_COEF, e) / den;
-      S.ve[e] += h * x;
-      S.qe[e] += h * S.ve[e];
+    if (FR) {
+      // (M + h B) x = f for the arrow matrix: D' = D + h d, S' = M_ff - sum B B' / D' (the sum is a plan constant); the same solve for
+      // y = (M + h B)^-1 J' of the volume tendon (D5: Sherman-Morrison on top of it)
+      double Sh[36], Shi[36], rf[6] = {0, 0, 0, 0, 0, 0}, xf[6], yf[6], t6[6];
+      {
+        int qq = 0;
+        for (int r = 0; r < 6; r++)
+          for (int q = r; q < 6; q++) { Sh[6 * r + q] = Sh[6 * q + r] = S.of[OF_MFF + qq] - H.obj_BBDh[qq]; qq++; }
+      }
+      spd_inverse6(Sh, Shi);
+      SGT_PAR(e, N) {
+        const double D = E(SGE_MASS, e) + E(SGE_ARMATURE, e), den = D + h * E(SGE_DAMPING, e), r = (S.fse[e] + D * S.ae[e]) / den;   // (g_e = D x the local part)
+        for (int q = 0; q < 6; q++) rf[q] += S.Be[6 * e + q] * r;
+      }
+      for (int q = 0; q < 6; q++) t6[q] = -S.of[OF_BIAS + q] + S.of[OF_GF + q] - wsum(rf[q]);
+      mat6vec(xf, Shi, t6);
+      for (int q = 0; q < 6; q++) t6[q] = -H.obj_tenBh[q];
+      mat6vec(yf, Shi, t6);
+      SGT_PAR(e, N) {
+        const double D = E(SGE_MASS, e) + E(SGE_ARMATURE, e), den = D + h * E(SGE_DAMPING, e), co = S.ecoef[e];
+        const double x = (S.fse[e] + D * S.ae[e] - dot6(S.Be + 6 * e, xf)) / den, y = (co - dot6(S.Be + 6 * e, yf)) / den;
+        S.asme[e] = x; S.Ifix[e] = y;   // (both arrays are rebuilt by the next forward pass)
+        Jx += co * x; Jy += co * y;
+      }
+      Jx = wsum(Jx); Jy = wsum(Jy);
+      const double kf = H.t0_implicit ? h * H.t0_damping * Jx / (1 + h * H.t0_damping * Jy) : 0.0;
+      SGT_SYNC();
+      SGT_PAR(e, N) {
+        S.ve[e] += h * (S.asme[e] - kf * S.Ifix[e]);
+        S.qe[e] += h * S.ve[e];
+      }
+      SGT_ONE {   // the body: velocities (world translations, body-frame rotations), then mj_integratePos with the new velocity
+        double* o = S.of;
+        double xw[3], xb[3] = {xf[0] - kf * yf[0], xf[1] - kf * yf[1], xf[2] - kf * yf[2]};
+        mulmat3(xw, o + OF_R, xb);
+        for (int q = 0; q < 3; q++) {
+          o[OF_VW + q] += h * xw[q];
+          o[OF_WL + q] += h * (xf[3 + q] - kf * yf[3 + q]);
+          o[OF_P + q] += h * o[OF_VW + q];
+        }
+        const double* wl = o + OF_WL;
+        const double nw = sqrt(dot3(wl, wl)), ang = h * nw;
+        if (nw > SG_MINVAL) {   // mju_quatIntegrate: q <- q * (cos, axis sin), the axis in the body frame
+          const double sn = sin(0.5 * ang), qr[4] = {cos(0.5 * ang), wl[0] / nw * sn, wl[1] / nw * sn, wl[2] / nw * sn};
+          const double nq0 = sqrt(o[OF_Q] * o[OF_Q] + o[OF_Q + 1] * o[OF_Q + 1] + o[OF_Q + 2] * o[OF_Q + 2] + o[OF_Q + 3] * o[OF_Q + 3]);
+          (void)nq0;
+          quatmul(o + OF_Q, o + OF_Q, qr);
+          const double nq = sqrt(o[OF_Q] * o[OF_Q] + o[OF_Q + 1] * o[OF_Q + 1] + o[OF_Q + 2] * o[OF_Q + 2] + o[OF_Q + 3] * o[OF_Q + 3]);
+          for (int q = 0; q < 4; q++) o[OF_Q + q] /= nq;
+        }
+      }
+    } else {
+      SGT_PAR(e, N) {
+        const double m = E(SGE_MASS, e) + E(SGE_ARMATURE, e), fce = m * S.ae[e], den = m + h * E(SGE_DAMPING, e), co = S.ecoef[e];
+        const double x = (S.fse[e] + fce) / den;
+        S.asme[e] = x;   // (asme is rebuilt by the next forward pass)
+        Jx += co * x; Jy += co * co / den;
+      }
+      Jx = wsum(Jx); Jy = wsum(Jy);
+      const double kk = H.t0_implicit ? h * H.t0_damping * Jx / (1 + h * H.t0_damping * Jy) : 0.0;   // D5: Sherman-Morrison
+      SGT_SYNC();
+      SGT_PAR(e, N) {
+        const double den = E(SGE_MASS, e) + E(SGE_ARMATURE, e) + h * E(SGE_DAMPING, e);
+        const double x = S.asme[e] - kk * E(SGE_COEF, e) / den;
+        S.ve[e] += h * x;
+        S.qe[e] += h * S.ve[e];
+      }
     }
     SGT_PAR(d, ND) {
       S.v[d] += h * S.tmpP[pidx(d)];
@@ -1222,8 +1532,13 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     gq[j] = S.q[d]; gv[j] = S.v[d]; gw[j] = S.warm[d];
   }
   SGT_PAR(e, N) {
-    const int j = H.elem_dof0 + e;
-    gq[j] = S.qe[e]; gv[j] = S.ve[e]; gw[j] = S.we[e];
+    const int jd = H.elem_dof0 + e;
+    gq[H.elem_qpos0 + e] = S.qe[e]; gv[jd] = S.ve[e]; gw[jd] = S.we[e];
+  }
+  if (FR) SGT_ONE {
+    for (int c = 0; c < 7; c++) gq[H.free_qadr + c] = S.of[OF_P + c];
+    for (int c = 0; c < 3; c++) { gv[H.free_dadr + c] = S.of[OF_VW + c]; gv[H.free_dadr + 3 + c] = S.of[OF_WL + c]; }
+    for (int c = 0; c < 6; c++) gw[H.free_dadr + c] = S.of[OF_WARM + c];
   }
   SGT_PAR(c, K)
     if (T.a_has[c]) gact[T.a_id[c]] = S.chs[c * CHS_N + CHS_ACT];

@@ -33,23 +33,26 @@ TreeEmu* temu_new(const void* blob, size_t n, char* err, size_t errlen) {
   }
   const SgPlanHeader& H = E->P.h;
   const int nu = H.nu > 0 ? H.nu : 1;
-  E->qpos.assign(H.nv, 0.0); E->qvel.assign(H.nv, 0.0); E->warm.assign(H.nv, 0.0); E->act.assign(nu, 0.0); E->ctrl.assign(nu, 0.0);
+  E->qpos.assign(H.nq, 0.0); E->qvel.assign(H.nv, 0.0); E->warm.assign(H.nv, 0.0); E->act.assign(nu, 0.0); E->ctrl.assign(nu, 0.0);
   E->sens.assign(H.nsensordata, 0.0);
-  E->kmask_jnt.assign(H.nv, 0); E->kmask_ten.assign(H.ntendon, 0);
+  E->kmask_jnt.assign(H.njnt, 0); E->kmask_ten.assign(H.ntendon, 0);
   E->kenv = 0;
   E->cws.assign((size_t)sgt::cws_doubles(E->T), 0.0);
-  E->lds.assign(sgt::lds_bytes(E->T, H.nelem) / 8 + 8, 0.0);
+  E->lds.assign(sgt::lds_bytes(E->T, H.nelem, H.has_free) / 8 + 8, 0.0);
   for (int d = 0; d < E->T.ND; d++) E->qpos[E->T.d_gid[d]] = E->T.d_qpos0[d];
-  for (int e2 = 0; e2 < H.nelem; e2++) E->qpos[H.elem_dof0 + e2] = E->P.elem[(size_t)SGE_QPOS0 * H.nelem + e2];
+  for (int e2 = 0; e2 < H.nelem; e2++) E->qpos[H.elem_qpos0 + e2] = E->P.elem[(size_t)SGE_QPOS0 * H.nelem + e2];
+  if (H.has_free)
+    for (int c = 0; c < 7; c++) E->qpos[H.free_qadr + c] = H.free_q0[c];
   E->flags = E->touch = E->ncon = E->nefc = E->iters = 0;
   E->touchw[0] = E->touchw[1] = 0;
   return E;
 }
 void temu_free(TreeEmu* E) { delete E; }
 int temu_nv(TreeEmu* E) { return E->P.h.nv; }
+int temu_nq(TreeEmu* E) { return E->P.h.nq; }
 int temu_nu(TreeEmu* E) { return E->P.h.nu; }
 int temu_nsens(TreeEmu* E) { return E->P.h.nsensordata; }
-size_t temu_lds_bytes(TreeEmu* E) { return sgt::lds_bytes(E->T, E->P.h.nelem); }
+size_t temu_lds_bytes(TreeEmu* E) { return sgt::lds_bytes(E->T, E->P.h.nelem, E->P.h.has_free); }
 double* temu_qpos(TreeEmu* E) { return E->qpos.data(); }
 double* temu_qvel(TreeEmu* E) { return E->qvel.data(); }
 double* temu_warm(TreeEmu* E) { return E->warm.data(); }

@@ -171,7 +171,7 @@ class TreeEmu:
         L.temu_new.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.temu_free.argtypes = [C.c_void_p]
         L.temu_lds_bytes.restype = C.c_size_t
-        for f in ("temu_nv", "temu_nu", "temu_nsens", "temu_flags", "temu_ncon", "temu_nefc", "temu_iters", "temu_lds_bytes"):
+        for f in ("temu_nv", "temu_nq", "temu_nu", "temu_nsens", "temu_flags", "temu_ncon", "temu_nefc", "temu_iters", "temu_lds_bytes"):
             getattr(L, f).argtypes = [C.c_void_p]
         for f in ("temu_qpos", "temu_qvel", "temu_warm", "temu_act", "temu_ctrl", "temu_sens"):
             getattr(L, f).restype = C.POINTER(C.c_double)
@@ -187,7 +187,7 @@ class TreeEmu:
             raise RuntimeError(err.value.decode())
         nv, nu, ns = L.temu_nv(self.p), L.temu_nu(self.p), L.temu_nsens(self.p)
         arr = lambda f, n: np.ctypeslib.as_array(getattr(L, f)(self.p), shape=(n,))  # noqa: E731
-        self.qpos, self.qvel, self.warm = arr("temu_qpos", nv), arr("temu_qvel", nv), arr("temu_warm", nv)
+        self.qpos, self.qvel, self.warm = arr("temu_qpos", L.temu_nq(self.p)), arr("temu_qvel", nv), arr("temu_warm", nv)
         self.act, self.ctrl, self.sensordata = arr("temu_act", nu), arr("temu_ctrl", nu), arr("temu_sens", ns)
 
     def __del__(self):
