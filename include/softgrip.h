@@ -63,7 +63,9 @@ int sg_mjcf_compile(const char* xml_path, int flags, void** blob, size_t* nbytes
 void sg_blob_free(void* blob);
 int sg_model_create(const void* blob, size_t nbytes, sg_model** out);
 void sg_model_destroy(sg_model* m);
-int sg_model_nq(const sg_model* m);           /* == nv */
+int sg_model_nq(const sg_model* m);           /* positions; == nv unless the model has a free joint (7 positions, 6 dofs) */
+int sg_model_nv(const sg_model* m);           /* dofs: the width of qvel / qacc_warmstart */
+int sg_model_njnt(const sg_model* m);         /* joints: what the ids of sg_set_stiffness count */
 int sg_model_nu(const sg_model* m);           /* == na */
 int sg_model_nsensordata(const sg_model* m);
 int sg_model_ntendon(const sg_model* m);
@@ -105,8 +107,9 @@ int sg_reset(sg_batch* b, const uint8_t* mask, int sim_start, double* sens_out, 
 int sg_step(sg_batch* b, int n_substeps, double* sens_out, long long sens_stride, int32_t* flags_out, int32_t* touch_out,
             void* stream);
 
-/* state access for tests and checkpointing: [n_envs][nq] (qpos, qvel, qacc_warmstart) and
- * [n_envs][nu] (act, ctrl); device pointers, any may be NULL. */
+/* state access for tests and checkpointing: [n_envs][nq] (qpos), [n_envs][nv] (qvel, qacc_warmstart) and
+ * [n_envs][nu] (act, ctrl); device pointers, any may be NULL.  A free joint's seven positions are the body's world position and
+ * quaternion, its six velocities the linear velocity in the world frame and the angular velocity in the body frame (MuJoCo's layout). */
 int sg_get_state(sg_batch* b, double* qpos, double* qvel, double* act, double* qacc_warmstart, double* ctrl, void* stream);
 int sg_set_state(sg_batch* b, const double* qpos, const double* qvel, const double* act, const double* qacc_warmstart,
                  const double* ctrl, void* stream);
@@ -117,7 +120,8 @@ int sg_get_solver_stats(sg_batch* b, int32_t* ncon, int32_t* nefc, int32_t* iter
 
 /* kernel pipeline (same results to round-off, all parity-tested): 3 = tree (csrc/sg_tree.h: one env per wavefront, state in LDS;
  * the only pipeline for grippers outside the two-finger class -- any number of serial finger chains up to 24 dofs, multi-site
- * tendons, limited sliders: the reference's soft_grip_four_fingers.xml -- and selectable for fix-rows-only two-finger models),
+ * tendons, limited sliders: the reference's soft_grip_four_fingers.xml -- and for an object on a free joint: the reference's
+ * soft_experiments_softball.xml; selectable for fix-rows-only two-finger models),
  * 2 = rows (default for the two-finger class: chain / phase / row-parallel PGS
  * kernels, a lane quad per finger stream in the solver), 1 = split (same chain with one lane per finger stream),
  * 0 = fused (one kernel per call, everything on chip).  The env var SG_PIPELINE=fused|split|rows sets the default of

@@ -38,7 +38,13 @@ def fourfinger_scene(tmpdir):
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "models"), exist_ok=True)
     import tempfile
-    with tempfile.TemporaryDirectory() as tmp:   # oracle / compiler scope only: the kernels' plan class is two 4-dof fingers
+    # the free-floating ball (reference data/gripper/soft_experiments_softball.xml: <freejoint/> on the composite's body)
+    m = sg.compile_mjcf(os.path.join(REF, "soft_experiments_softball.xml"), composite_neighbors=False)
+    out = os.path.join(ROOT, "models", "freeball_fix.sgmodel")
+    with open(out, "wb") as f:
+        f.write(m.to_blob())
+    print("freeball_fix nq", m.nq, "nv", m.nv, "neq", m.neq, "->", out, os.path.getsize(out), "bytes")
+    with tempfile.TemporaryDirectory() as tmp:   # the four-finger gripper (tree pipeline)
         m = sg.compile_mjcf(fourfinger_scene(tmp), composite_neighbors=False)
         out = os.path.join(ROOT, "models", "fourfinger_softball_fix.sgmodel")
         with open(out, "wb") as f:

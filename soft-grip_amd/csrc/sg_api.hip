@@ -204,7 +204,9 @@ int sg_model_compile(const char* xml_path, int flags, sg_model** out) {
   free(blob);
   return rc;
 }
-int sg_model_nq(const sg_model* m) { return m->plan.h.nv; }
+int sg_model_nq(const sg_model* m) { return m->plan.h.nq; }
+int sg_model_nv(const sg_model* m) { return m->plan.h.nv; }
+int sg_model_njnt(const sg_model* m) { return m->plan.h.njnt; }
 int sg_model_nu(const sg_model* m) { return m->plan.h.nu; }
 int sg_model_nsensordata(const sg_model* m) { return m->plan.h.nsensordata; }
 int sg_model_ntendon(const sg_model* m) { return m->plan.h.ntendon; }
@@ -241,7 +243,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   b->dH = nullptr; b->delem = b->qpos = b->qvel = b->warm = b->act = b->ctrl = b->kenv = b->ctrl_row = nullptr;
   b->kmask_jnt = b->kmask_ten = b->flags = b->touch = b->ncon = b->nefc = b->iters = nullptr;
   const SgPlanHeader& H = m->plan.h;
-  const size_t n = n_envs, nv = H.nv, nu = H.nu > 0 ? H.nu : 1, nt = H.ntendon;
+  const size_t n = n_envs, nv = H.nv, nq = H.nq, njnt = H.njnt, nu = H.nu > 0 ? H.nu : 1, nt = H.ntendon;   // nq = nv = njnt unless the model has a free joint
 #define ALLOC(p, bytes)                                   \
   do {                                                    \
     hipError_t e_ = hipMalloc((void**)&(p), (bytes));     \
@@ -252,10 +254,10 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   } while (0)
   ALLOC(b->dH, sizeof(SgPlanHeader));
   ALLOC(b->delem, sizeof(double) * m->plan.elem.size());
-  ALLOC(b->qpos, sizeof(double) * n * nv); ALLOC(b->qvel, sizeof(double) * n * nv); ALLOC(b->warm, sizeof(double) * n * nv);
+  ALLOC(b->qpos, sizeof(double) * n * nq); ALLOC(b->qvel, sizeof(double) * n * nv); ALLOC(b->warm, sizeof(double) * n * nv);
   ALLOC(b->act, sizeof(double) * n * nu); ALLOC(b->ctrl, sizeof(double) * n * nu); ALLOC(b->kenv, sizeof(double) * n);
   ALLOC(b->ctrl_row, sizeof(double) * nu);
-  ALLOC(b->kmask_jnt, sizeof(int) * nv); ALLOC(b->kmask_ten, sizeof(int) * nt);
+  ALLOC(b->kmask_jnt, sizeof(int) * njnt); ALLOC(b->kmask_ten, sizeof(int) * nt);
   ALLOC(b->flags, sizeof(int) * n); ALLOC(b->touch, sizeof(int) * n); ALLOC(b->ncon, sizeof(int) * n); ALLOC(b->nefc, sizeof(int) * n);
   ALLOC(b->iters, sizeof(int) * n);
   memset(&b->w, 0, sizeof b->w);
@@ -316,19 +318,21 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   HIPCHK(hipMemcpy(b->dH, &H, sizeof H, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->delem, m->plan.elem.data(), sizeof(double) * m->plan.elem.size(), hipMemcpyHostToDevice));
   // state as after mj_resetData
-  std::vector<double> q0(nv, 0.0);
+  std::vector<double> q0(nq, 0.0);
   for (int c = 0; c < H.nchain; c++)
     for (int d = 0; d < H.chain[c].ndof; d++) q0[H.chain[c].dof0 + d] = H.chain[c].qpos0[d];
   if (!m->has_fast)
     for (int d = 0; d < m->tree.ND; d++) q0[m->tree.d_gid[d]] = m->tree.d_qpos0[d];
-  for (int e = 0; e < H.nelem; e++) q0[H.elem_dof0 + e] = m->plan.elem[(size_t)SGE_QPOS0 * H.nelem + e];
-  std::vector<double> qall(n * nv);
-  for (size_t i = 0; i < n; i++) memcpy(&qall[i * nv], q0.data(), sizeof(double) * nv);
-  HIPCHK(hipMemcpy(b->qpos, qall.data(), sizeof(double) * n * nv, hipMemcpyHostToDevice));
+  for (int e = 0; e < H.nelem; e++) q0[H.elem_qpos0 + e] = m->plan.elem[(size_t)SGE_QPOS0 * H.nelem + e];
+  if (H.has_free)
+    for (int c = 0; c < 7; c++) q0[H.free_qadr + c] = H.free_q0[c];
+  std::vector<double> qall(n * nq);
+  for (size_t i = 0; i < n; i++) memcpy(&qall[i * nq], q0.data(), sizeof(double) * nq);
+  HIPCHK(hipMemcpy(b->qpos, qall.data(), sizeof(double) * n * nq, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(b->qvel, 0, sizeof(double) * n * nv)); HIPCHK(hipMemset(b->warm, 0, sizeof(double) * n * nv));
   HIPCHK(hipMemset(b->act, 0, sizeof(double) * n * nu)); HIPCHK(hipMemset(b->ctrl, 0, sizeof(double) * n * nu));
   HIPCHK(hipMemset(b->kenv, 0, sizeof(double) * n));
-  HIPCHK(hipMemset(b->kmask_jnt, 0, sizeof(int) * nv)); HIPCHK(hipMemset(b->kmask_ten, 0, sizeof(int) * nt));
+  HIPCHK(hipMemset(b->kmask_jnt, 0, sizeof(int) * njnt)); HIPCHK(hipMemset(b->kmask_ten, 0, sizeof(int) * nt));
   HIPCHK(hipMemset(b->flags, 0, sizeof(int) * n)); HIPCHK(hipMemset(b->touch, 0, sizeof(int) * n));
   HIPCHK(hipMemset(b->ncon, 0, sizeof(int) * n)); HIPCHK(hipMemset(b->nefc, 0, sizeof(int) * n)); HIPCHK(hipMemset(b->iters, 0, sizeof(int) * n));
   if (b->pipeline == 3)
@@ -343,9 +347,9 @@ int sg_set_stiffness(sg_batch* b, const double* k, int k_on_host, const int* jnt
   if (!b || !k || nj < 0 || nt < 0 || (nj && !jnt_ids) || (nt && !ten_ids)) return fail(SG_ERR_INVALID, "sg_set_stiffness: bad argument");
   HIPCHK(hipSetDevice(b->device));
   const SgPlanHeader& H = b->m->plan.h;
-  std::vector<int> mj(H.nv, 0), mt(H.ntendon, 0);
+  std::vector<int> mj(H.njnt, 0), mt(H.ntendon, 0);
   for (int i = 0; i < nj; i++) {
-    if (jnt_ids[i] < 0 || jnt_ids[i] >= H.nv) return fail(SG_ERR_INVALID, "sg_set_stiffness: joint id out of range");
+    if (jnt_ids[i] < 0 || jnt_ids[i] >= H.njnt) return fail(SG_ERR_INVALID, "sg_set_stiffness: joint id out of range");
     mj[jnt_ids[i]] = 1;
   }
   for (int i = 0; i < nt; i++) {
@@ -355,7 +359,7 @@ int sg_set_stiffness(sg_batch* b, const double* k, int k_on_host, const int* jnt
   hipStream_t s = (hipStream_t)stream;
   // the masks are tiny; a synchronous copy keeps the host vectors' lifetime trivial
   HIPCHK(hipStreamSynchronize(s));
-  HIPCHK(hipMemcpy(b->kmask_jnt, mj.data(), sizeof(int) * H.nv, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->kmask_jnt, mj.data(), sizeof(int) * H.njnt, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->kmask_ten, mt.data(), sizeof(int) * H.ntendon, hipMemcpyHostToDevice));
   if (k_on_host) HIPCHK(hipMemcpy(b->kenv, k, sizeof(double) * b->n, hipMemcpyHostToDevice));
   else HIPCHK(hipMemcpyAsync(b->kenv, k, sizeof(double) * b->n, hipMemcpyDeviceToDevice, s));
@@ -567,7 +571,7 @@ int sg_get_state(sg_batch* b, double* qpos, double* qvel, double* act, double* w
   HIPCHK(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t n = b->n, nv = b->m->plan.h.nv, nu = b->m->plan.h.nu;
-  if (qpos) HIPCHK(hipMemcpyAsync(qpos, b->qpos, sizeof(double) * n * nv, hipMemcpyDeviceToDevice, s));
+  if (qpos) HIPCHK(hipMemcpyAsync(qpos, b->qpos, sizeof(double) * n * b->m->plan.h.nq, hipMemcpyDeviceToDevice, s));
   if (qvel) HIPCHK(hipMemcpyAsync(qvel, b->qvel, sizeof(double) * n * nv, hipMemcpyDeviceToDevice, s));
   if (warm) HIPCHK(hipMemcpyAsync(warm, b->warm, sizeof(double) * n * nv, hipMemcpyDeviceToDevice, s));
   if (act && nu) HIPCHK(hipMemcpyAsync(act, b->act, sizeof(double) * n * nu, hipMemcpyDeviceToDevice, s));
@@ -580,7 +584,7 @@ int sg_set_state(sg_batch* b, const double* qpos, const double* qvel, const doub
   HIPCHK(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t n = b->n, nv = b->m->plan.h.nv, nu = b->m->plan.h.nu;
-  if (qpos) HIPCHK(hipMemcpyAsync(b->qpos, qpos, sizeof(double) * n * nv, hipMemcpyDeviceToDevice, s));
+  if (qpos) HIPCHK(hipMemcpyAsync(b->qpos, qpos, sizeof(double) * n * b->m->plan.h.nq, hipMemcpyDeviceToDevice, s));
   if (qvel) HIPCHK(hipMemcpyAsync(b->qvel, qvel, sizeof(double) * n * nv, hipMemcpyDeviceToDevice, s));
   if (warm) HIPCHK(hipMemcpyAsync(b->warm, warm, sizeof(double) * n * nv, hipMemcpyDeviceToDevice, s));
   if (act && nu) HIPCHK(hipMemcpyAsync(b->act, act, sizeof(double) * n * nu, hipMemcpyDeviceToDevice, s));

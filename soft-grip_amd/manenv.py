@@ -77,7 +77,7 @@ class ManEnv(Env):
         want = _damper or self._tendon_damper_arg
         self.model = load_model(path, None if want == "auto" else want)
         self.tendon_damper = "implicit" if self.model.opt_implicit_tendon_damping else "explicit"
-        if max(self.joint_ids) >= self.model.nv or max(self.tendon_ids) >= self.model.ntendon:
+        if max(self.joint_ids) >= self.model.njnt or max(self.tendon_ids) >= self.model.ntendon:
             raise ValueError("scene %s has %d joints and %d tendons: the stiffness ids (joints %d..%d, tendons %s) do not fit it -- pass "
                              "joint_ids / tendon_ids" % (path, self.model.nv, self.model.ntendon, min(self.joint_ids), max(self.joint_ids),
                                                          self.tendon_ids))

@@ -19,7 +19,7 @@ SYMBOLS = [
     "sg_batch_nenvs", "sg_batch_device", "sg_set_stiffness", "sg_set_ctrl", "sg_reset", "sg_step", "sg_get_state",
     "sg_set_state", "sg_get_solver_stats", "sg_set_pipeline", "sg_profile_enable", "sg_profile_read", "sg_profile_read_solver",
     "sg_model_compile", "sg_mjcf_compile", "sg_blob_free", "sg_set_solver_envs_per_wavefront", "sg_solver_envs_per_wavefront",
-    "sg_get_touch_words", "sg_model_nboxes",
+    "sg_get_touch_words", "sg_model_nboxes", "sg_model_nv", "sg_model_njnt",
 ]
 SG_COMPILE_NO_NEIGHBORS, SG_COMPILE_IMPLICIT_TENDON_DAMPER = 1, 2
 
@@ -52,7 +52,7 @@ def lib():
     L.sg_blob_free.argtypes = [vp]
     L.sg_blob_free.restype = None
     L.sg_get_touch_words.argtypes = [vp, ip, C.c_int, vp]
-    for f in ("sg_model_nq", "sg_model_nu", "sg_model_nsensordata", "sg_model_ntendon", "sg_model_nelem", "sg_model_nboxes"):
+    for f in ("sg_model_nq", "sg_model_nv", "sg_model_njnt", "sg_model_nu", "sg_model_nsensordata", "sg_model_ntendon", "sg_model_nelem", "sg_model_nboxes"):
         getattr(L, f).argtypes = [vp]
     L.sg_batch_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.sg_batch_destroy.argtypes = [vp]
@@ -103,6 +103,7 @@ class NativeModel:
         check(lib().sg_model_create(blob, len(blob), C.byref(self.ptr)))
         L = lib()
         self.nq = L.sg_model_nq(self.ptr)
+        self.nv = L.sg_model_nv(self.ptr)        # == nq unless the model has a free joint (7 positions, 6 dofs)
         self.nu = L.sg_model_nu(self.ptr)
         self.nsensordata = L.sg_model_nsensordata(self.ptr)
         self.ntendon = L.sg_model_ntendon(self.ptr)
@@ -163,8 +164,8 @@ class NativeBatch:
     def get_state(self):
         t, m = self.torch, self.nmodel
         kw = dict(dtype=t.float64, device=self.device)
-        out = dict(qpos=t.empty(self.n, m.nq, **kw), qvel=t.empty(self.n, m.nq, **kw), act=t.empty(self.n, m.nu, **kw),
-                   qacc_warmstart=t.empty(self.n, m.nq, **kw), ctrl=t.empty(self.n, m.nu, **kw))
+        out = dict(qpos=t.empty(self.n, m.nq, **kw), qvel=t.empty(self.n, m.nv, **kw), act=t.empty(self.n, m.nu, **kw),
+                   qacc_warmstart=t.empty(self.n, m.nv, **kw), ctrl=t.empty(self.n, m.nu, **kw))
         check(lib().sg_get_state(self.ptr, _ptr(out["qpos"]), _ptr(out["qvel"]), _ptr(out["act"]), _ptr(out["qacc_warmstart"]),
                                  _ptr(out["ctrl"]), self._stream()))
         return out

@@ -159,6 +159,44 @@ def test_four_finger_manenv_contact_flag_and_masked_reset():
     assert float((after[[0, 1, 3, 4, 5]] - before[[0, 1, 3, 4, 5]]).abs().max()) < 0.05     # they went on with their episode
 
 
+def test_free_ball_episode_matches_oracle():
+    """the reference's free-floating ball (soft_experiments_softball.xml: the composite on a body with a free joint, nq = 233, nv = 232)
+    in the tree pipeline's object block on the GPU: the whole squeeze episode FREE-RUNNING against the oracle, 4 envs over the stiffness
+    range -- sensors 1e-6, contact / row / sweep counts exact at every step, the ball's pose at the end to 1e-6, unit quaternions"""
+    torch = _torch()
+    m = sg.load_model(model_path("freeball_fix"), "implicit")
+    assert (m.nq, m.nv, m.njnt) == (233, 232, 227)
+    jids = list(range(9, 227))              # joint ids of the ball's 218 sliders (joint 8 is the free joint)
+    ks = [300.0, 700.0, 1050.0, 1400.0]
+    nm, b, sens, flags = _batch(m, ks, jids, [0])
+    assert (nm.nq, nm.nv) == (233, 232)
+    sims = _oracles(m, ks, jids, [0])
+    b.reset(1, sens=sens, flags=flags)
+    assert int(flags.abs().sum()) == 0
+    worst = 0.0
+    for t, c in enumerate(episode_schedule()):
+        if c is not None:
+            b.set_ctrl_broadcast(np.full(2, c))
+            for s in sims:
+                s.ctrl[:] = c
+        for s in sims:
+            for _ in range(7):
+                assert s.step() == 0
+        b.step(7, sens=sens, flags=flags)
+        assert int(flags.abs().sum()) == 0, t
+        worst = max(worst, np.abs(sens.cpu().numpy() - np.stack([s.sensordata for s in sims])).max())
+        stats = {k: v.cpu().numpy() for k, v in b.solver_stats().items()}
+        for i, s in enumerate(sims):
+            assert (stats["ncon"][i], stats["nefc"][i], stats["iters"][i]) == (s.ncon, s.nefc, s.solver_iter), (t, i)
+    st = b.get_state()
+    q = st["qpos"].cpu().numpy()
+    assert q.shape == (4, 233) and st["qvel"].shape == (4, 232)
+    np.testing.assert_allclose(q, np.stack([s.qpos for s in sims]), atol=1e-6)
+    assert np.abs(np.linalg.norm(q[:, 11:15], axis=1) - 1).max() < 1e-12
+    assert worst < 1e-6, worst
+    print("free ball episode: max |sensor - oracle| = %.2e free-running" % worst)
+
+
 def test_model_outside_both_classes_is_refused_with_both_reasons():
     from softgrip_amd import native
     m = sg.load_model(model_path("fourfinger_softball_fix"), "implicit")

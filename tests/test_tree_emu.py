@@ -131,3 +131,106 @@ def test_special_scenes_pair_kinds_and_the_serial_list(tmp_path, kind):
             e.qpos[:] = s.qpos; e.qvel[:] = s.qvel; e.warm[:] = s.qacc_warmstart; e.act[:] = s.act
     assert special > (40 if kind == "thin" else 100), special
     assert worst < 1e-7, worst
+
+
+# ---- the free object (soft_experiments_softball.xml:8): the composite's elements on a body with a free joint ----
+def _free_mini(tmp_path, far):
+    """the own scene with a <freejoint/> on the object's body; far: lifted out of the gripper's reach and tilted (no contacts ever)"""
+    import os
+    from helpers import ROOT
+    x = open(os.path.join(ROOT, "tests", "data", "mini_gripper.xml")).read()
+    # near: the gripper lowered to the ground, the object resting on it between the fingers (the "rest" scene of test_emu_vs_oracle.py)
+    new = '<body pos="1.15 0 6.0" quat="0.9 0.2 -0.1 0.3">' if far else '<body pos="1.15 0 0.236">'
+    x = x.replace('<body pos="1.15 0 1.0">\n      <composite', new + '\n      <freejoint/>\n      <composite')
+    if not far:
+        x = x.replace('<body pos="0 0 1.0">', '<body pos="0 0 0.3">')
+    path = str(tmp_path / ("free_far.xml" if far else "free_near.xml"))
+    with open(path, "w") as f:
+        f.write(x)
+    return sg.compile_mjcf(path, composite_neighbors=False)
+
+
+def test_free_object_tumbling_without_contacts(tmp_path):
+    """a composite on a free body, thrown, spinning, its sliders moving: the object block of the tree pipeline (arrow-shaped mass matrix
+    through a 6 x 6 Schur complement, star-shaped RNE, the joint-fix rows one after the other, quaternion integration) against the
+    oracle's general tree algorithms, free-running for 150 substeps: 1e-12"""
+    m = _free_mini(tmp_path, far=True)
+    assert (m.nq, m.nv, m.njnt) == (49, 48, 43)
+    fj = int(np.flatnonzero(m.jnt_type == 0)[0])
+    jids = list(range(fj + 1, m.njnt))
+    s = oracle_sim(m)
+    s.jnt_stiffness[jids] = 640.0
+    s.tendon_stiffness[0] = 640.0
+    e = TreeEmu(m)
+    e.set_stiffness(640.0, jids, [0])
+    s.reset()
+    s.qvel[fj:fj + 3] = [0.3, -0.2, 0.5]
+    s.qvel[fj + 3:fj + 6] = [1.0, -2.0, 0.7]
+    s.qvel[fj + 6:] = 0.05 * np.random.RandomState(0).randn(m.nv - fj - 6)
+    s.qpos[fj + 7:] += 0.01 * np.random.RandomState(1).randn(m.nq - fj - 7)
+    e.qpos[:] = s.qpos; e.qvel[:] = s.qvel
+    for t in range(150):
+        assert s.step() == 0 and e.step(1) == 0
+        assert (e.ncon, e.nefc, e.iters) == (s.ncon, s.nefc, s.solver_iter), t
+    np.testing.assert_allclose(e.qpos, s.qpos, atol=1e-12)
+    np.testing.assert_allclose(e.qvel, s.qvel, atol=1e-12)
+    assert abs(np.linalg.norm(e.qpos[fj + 3:fj + 7]) - 1) < 1e-14 and np.abs(e.qpos[fj + 3:fj + 7] - m.qpos0[fj + 3:fj + 7]).max() > 0.1
+
+
+def test_free_object_squeezed_by_the_own_gripper(tmp_path):
+    """the same object resting on the ground between the fingers (plane - capsule contacts with the capsule axis as tangent hint),
+    squeezed and pushed around by them -- every contact carries six object columns and all of them go through the body; free-running
+    over the schedule, counts exact"""
+    m = _free_mini(tmp_path, far=False)
+    fj = int(np.flatnonzero(m.jnt_type == 0)[0])
+    jids = list(range(fj + 1, m.njnt))
+    s = oracle_sim(m)
+    s.jnt_stiffness[jids] = 640.0
+    s.tendon_stiffness[0] = 640.0
+    s.reset(); s.forward(); s.step()
+    e = TreeEmu(m)
+    e.set_stiffness(640.0, jids, [0])
+    assert e.reset(1) == 0
+    worst, ground, fingers = 0.0, 0, 0
+    for t, c in enumerate(episode_schedule()[:140]):
+        if c is not None:
+            e.ctrl[:] = c
+            s.ctrl[:] = c
+        for _ in range(7):
+            assert s.step() == 0
+        assert e.step(7) == 0
+        assert (e.ncon, e.nefc, e.iters) == (s.ncon, s.nefc, s.solver_iter), t
+        worst = max(worst, np.abs(e.sensordata - s.sensordata).max())
+        names = [(m.geom_names[cc["geom1"]][:4], m.geom_names[cc["geom2"]][:4]) for cc in s.contacts()]
+        ground += sum(1 for n in names if n[0] == "grou")
+        fingers += sum(1 for n in names if n[1][:1] == "f" or n[0][:1] == "f")
+    assert ground > 100 and fingers > 100 and worst < 1e-7, (ground, fingers, worst)
+    np.testing.assert_allclose(e.qpos, s.qpos, atol=1e-7)
+
+
+@pytest.mark.skipif(not __import__("os").path.exists("/root/reference/data/gripper/soft_experiments_softball.xml"), reason="needs the reference's MJCF files (build container only)")
+def test_reference_free_ball_scene_free_running():
+    """soft_experiments_softball.xml as the reference ships it (8 gripper dofs + 6 + 218 sliders, the shell inside the fingers at the
+    start, D5 damper): the whole squeeze episode free-running against the oracle -- sensors 1e-7, contact / row / sweep counts exact"""
+    m = sg.compile_mjcf("/root/reference/data/gripper/soft_experiments_softball.xml", composite_neighbors=False)
+    m.opt_implicit_tendon_damping = 1
+    jids = list(range(9, 227))
+    s = oracle_sim(m)
+    s.jnt_stiffness[jids] = 700.0
+    s.tendon_stiffness[0] = 700.0
+    s.reset(); s.forward(); s.step()
+    e = TreeEmu(m)
+    e.set_stiffness(700.0, jids, [0])
+    assert e.reset(1) == 0
+    worst = 0.0
+    for t, c in enumerate(episode_schedule()):
+        if c is not None:
+            e.ctrl[:] = c
+            s.ctrl[:] = c
+        for _ in range(7):
+            assert s.step() == 0
+        assert e.step(7) == 0
+        assert (e.ncon, e.nefc, e.iters) == (s.ncon, s.nefc, s.solver_iter), t
+        worst = max(worst, np.abs(e.sensordata - s.sensordata).max())
+    assert worst < 1e-7, worst
+    np.testing.assert_allclose(e.qpos, s.qpos, atol=1e-8)
