@@ -66,6 +66,8 @@ def stiffness_ids(scene):
     """(joint ids, tendon ids) that carry the per-env stiffness: the reference's class attributes (environment/manenv.py:12-13) for the
     two-finger scenes; the ball's 218 sliders behind the 65 gripper joints for the four-finger scene (manenv.py:11's commented ids
     belong to an older gripper file)"""
+    if scene.startswith("freeball"):       # soft_experiments_softball.xml: joint 8 is the ball's free joint, joints 9 .. 226 its sliders
+        return list(range(9, 227)), [0]
     return (list(range(65, 283)) if scene.startswith("fourfinger") else list(range(11, 64))), [0]
 
 
@@ -320,10 +322,10 @@ def main():
 
     if rank == 0:
         value = world * n * nsteps / dt
-        abytes = algorithmic_bytes_per_env_step(nm.nq, nm.nq, nm.nu, nm.nu, R.nsd)
+        abytes = algorithmic_bytes_per_env_step(nm.nq, nm.nv, nm.nu, nm.nu, R.nsd)
         ach = abytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         pipe = os.environ.get("SG_PIPELINE", "rows")
-        if args.scene.startswith("fourfinger"):
+        if args.scene.startswith(("fourfinger", "freeball")):
             pipe = "tree"   # outside the two-finger class: the tree pipeline is the only one that runs it
         nb_on = bool((model.eq_obj2id >= 0).any())
         res = {

@@ -366,7 +366,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       double bad = 0;
       SGT_PAR(d, ND) bad += (isbad(S.q[d]) ? 1.0 : 0.0) + (isbad(S.v[d]) ? 1024.0 : 0.0);
       SGT_PAR(e, N) bad += (isbad(S.qe[e]) ? 1.0 : 0.0) + (isbad(S.ve[e]) ? 1024.0 : 0.0);
-      if (FR) SGT_PAR(c, 7) bad += (isbad(S.of[OF_P + c]) ? 1.0 : 0.0) + ((c < 6 && isbad(S.of[OF_VW + c])) ? 1024.0 : 0.0);
+      if (FR) SGT_PAR(c, 7) bad += (isbad(S.of[OF_P + c]) ? 1.0 : 0.0) + ((c < 3 && (isbad(S.of[OF_VW + c]) || isbad(S.of[OF_WL + c]))) ? 1024.0 : 0.0);
       bad = wsum(bad);
       if (bad > 0) {
         const int nb = (int)bad;

@@ -8,6 +8,7 @@ class FakeModel:
     def __init__(self, model):
         self.model, self.nq, self.nu, self.nsensordata, self.ntendon, self.nelem = model, model.nv, model.nu, 12, 3, 110
         self.nboxes = 4
+        self.nv = model.nv
 
 
 class FakeBatch:
