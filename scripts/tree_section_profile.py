@@ -33,7 +33,7 @@ def main():
     L = native.lib()
     L.sg_debug_sections.argtypes = [C.c_void_p, C.c_void_p]
     buf = (C.c_ulonglong * 48)()
-    jids = list(range(65, 283)) if scene.startswith("fourfinger") else list(range(11, 64))
+    jids = list(range(65, 283)) if scene.startswith("fourfinger") else list(range(9, 227)) if scene.startswith("freeball") else list(range(11, 64))
     b.set_stiffness(np.random.RandomState(0).uniform(300, 1400, n), jids, [0])
     b.reset(1)
     ctrl = np.zeros(nm.nu)

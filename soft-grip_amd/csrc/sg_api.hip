@@ -90,7 +90,7 @@ static int tree_alloc(sg_batch* b) {
   const sg_model* m = b->m;
   if (!m->has_tree) return fail(SG_ERR_MODEL, "the tree pipeline does not run this model");
   const size_t n = b->n;
-  const long long cwd = sgt::cws_doubles(m->tree);
+  const long long cwd = sgt::cws_doubles(m->tree, m->tplan.h.nelem, m->tplan.h.has_free);
 #define TALLOC(p, bytes)                                                                  \
   do {                                                                                    \
     hipError_t e_ = hipMalloc((void**)&(p), (bytes));                                     \
@@ -130,7 +130,7 @@ static int launch_tree(sg_batch* b, int mode, const uint8_t* mask, int nsub, dou
   a.mask = mask; a.sens = sens; a.sens_stride = stride > 0 ? stride : m->tplan.h.nsensordata;
   a.flags = flags ? flags : b->flags; a.touch = touch ? touch : b->touch; a.touch_words = b->touch_words;
   a.ncon = b->ncon; a.nefc = b->nefc; a.iters = b->iters;
-  a.cws = b->tcws; a.cws_stride = sgt::cws_doubles(m->tree);
+  a.cws = b->tcws; a.cws_stride = sgt::cws_doubles(m->tree, m->tplan.h.nelem, m->tplan.h.has_free);
   a.nenv = b->n; a.nsub = nsub; a.mode = mode; a.secprof = b->w.secprof;
   const size_t lds = sgt::lds_bytes(m->tree, m->tplan.h.nelem, m->tplan.h.has_free);
   if (!b->tree_attr_set) {

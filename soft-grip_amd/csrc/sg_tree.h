@@ -63,9 +63,7 @@ struct TreeArgs {
 
 // work-space layout (doubles): staged narrowphase records | contact rows | the chains' mass-matrix blocks
 SG_HD long long cws_row_doubles(int CS) { return 12LL * CS + SGT_CSC; }   // 2 blocks x (J, W) x 3 rows x CS + scalars
-SG_HD long long cws_doubles(const SgTreeDev& T) {
-  return (long long)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (long long)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT;
-}
+
 
 // scalar part of a contact record
 enum { CS_A = 0, CS_B = 6, CS_F0 = 9, CS_R = 12, CS_INVM = 13, CS_JS = 14, CS_SL = 17, CS_C1 = 18, CS_N1 = 19, CS_C2 = 20, CS_N2 = 21,
@@ -90,22 +88,28 @@ enum { IC_NHIT = 0, IC_NCON, IC_SERIAL, IC_NLIM0 /* + chain */, IC_N = IC_NLIM0 
 // per-chain scalars in LDS (chs[c * CHS_N + ..])
 enum { CHS_TLEN = 0, CHS_TVEL, CHS_TFRC, CHS_AFRC, CHS_ACTDOT, CHS_ACT, CHS_CTRL, CHS_KT, CHS_N };
 
-SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_free = 0) {
-  double* p = base;
+// The env's arrays.  base: its LDS block; gbase: the part of its work space that backs the arrays only their own lane (or a later
+// phase behind a barrier) touches -- the L'DL blocks, the sliders' sweep constants and build-only state: 35 KB of the four-finger
+// scene's 113 KB, which is what lets two workgroups share a CU's LDS (the loads are coalesced and L2-resident).  Returns the LDS
+// bytes; *gdoubles the doubles taken from gbase.
+SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_free, double* gbase, size_t* gdoubles) {
+  double *p = base, *g = gbase;
   auto take = [&](size_t n) { double* r = p; p += (n + 1) & ~(size_t)1; return r; };
+  auto takeg = [&](size_t n) { double* r = g; g += (n + 1) & ~(size_t)1; return r; };
   const int ND = T.ND, NB = T.NB;
   L.q = take(ND); L.v = take(ND); L.warm = take(ND); L.asm_ = take(ND); L.aF = take(T.K * T.CS); L.fs = take(ND); L.fc = take(ND);
   L.bias = take(ND); L.tenJ = take(ND); L.kd = take(ND); L.qacc = take(ND);
   L.xpos = take(3 * NB); L.xmat = take(9 * NB); L.xipos = take(3 * NB); L.ximat = take(9 * NB); L.bw = take(3 * NB);
   L.bal = take(3 * NB); L.ba = take(3 * NB); L.bf = take(3 * NB); L.bn = take(3 * NB);
   L.anchor = take(3 * ND); L.axis = take(3 * ND); L.gpos = take(3 * T.NG); L.gmat = take(9 * T.NG); L.spos = take(3 * T.NS);
-  L.L = take(T.NMAT); L.Minv = take(T.NMAT); L.tmpP = take(T.K * T.CS);
-  L.qe = take(N); L.ve = take(N); L.we = take(N); L.asme = take(N); L.ae = take(N); L.fse = take(N); L.ffix = take(N);
-  L.bfix = take(N); L.Rfix = take(N); L.flim = take(2 * N); L.blim = take(2 * N); L.Rlim = take(2 * N); L.ke = take(N);
-  L.einvm = take(N); L.ecoef = take(N); L.ecen = take(3 * N); L.Ifix = take(N); L.Ilim = take(2 * N);
-  L.lrow = take(SGT_LROW * 2 * ND); L.seg = take(4 * SGT_MAXCH * SGT_MAXTS); L.chs = take(CHS_N * SGT_MAXCH); L.cf = take(3 * SGT_MAXCON);
+  L.L = takeg(T.NMAT); L.Minv = take(T.NMAT); L.tmpP = take(T.K * T.CS);
+  L.qe = takeg(N); L.ve = take(N); L.we = take(N); L.asme = take(N); L.ae = take(N); L.fse = takeg(N); L.ffix = take(N);
+  L.bfix = takeg(N); L.Rfix = takeg(N); L.flim = take(2 * N); L.blim = takeg(2 * N); L.Rlim = takeg(2 * N); L.ke = takeg(N);
+  L.einvm = take(N); L.ecoef = takeg(N); L.ecen = take(3 * N); L.Ifix = takeg(N); L.Ilim = takeg(2 * N);
+  L.lrow = take(SGT_LROW * 2 * ND); L.seg = take(4 * T.K * SGT_MAXTS); L.chs = take(CHS_N * SGT_MAXCH); L.cf = take(3 * SGT_MAXCON);
   L.red = take(16);
-  L.of = take(has_free ? OF_N : 0); L.Be = take(has_free ? 6 * N : 0); L.Ce = take(has_free ? 6 * N : 0); L.Afix = take(has_free ? N : 0);
+  L.of = take(has_free ? OF_N : 0); L.Be = take(has_free ? 6 * N : 0); L.Ce = take(has_free ? 6 * N : 0); L.Afix = takeg(has_free ? N : 0);
+  if (gdoubles) *gdoubles = (size_t)(g - gbase);
   int* ip = (int*)p;
   L.hit_pair = ip; ip += SGT_MAXHIT;
   L.hit_sorted = ip; ip += SGT_MAXHIT;
@@ -118,7 +122,17 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
 }
 SG_HD size_t lds_bytes(const SgTreeDev& T, int N, int has_free = 0) {
   Lds L;
-  return lds_carve(L, reinterpret_cast<double*>((uintptr_t)4096), T, N, has_free);
+  return lds_carve(L, reinterpret_cast<double*>((uintptr_t)4096), T, N, has_free, reinterpret_cast<double*>((uintptr_t)4096), nullptr);
+}
+SG_HD size_t gws_doubles(const SgTreeDev& T, int N, int has_free);
+SG_HD long long cws_doubles(const SgTreeDev& T, int N, int has_free) {
+  return (long long)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (long long)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT + (long long)gws_doubles(T, N, has_free);
+}
+SG_HD size_t gws_doubles(const SgTreeDev& T, int N, int has_free) {   // the work-space doubles behind the global-backed arrays
+  Lds L;
+  size_t n = 0;
+  lds_carve(L, reinterpret_cast<double*>((uintptr_t)4096), T, N, has_free, reinterpret_cast<double*>((uintptr_t)4096), &n);
+  return n;
 }
 
 // section stamps (profiling build only: build_native.py --prof, scripts/tree_section_profile.py): lane 0 adds the cycles since the
@@ -256,7 +270,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   const int N = H.nelem, ND = T.ND, NB = T.NB, K = T.K, nv = H.nv, nu = H.nu, CS = T.CS;
   const double h = H.timestep;
   Lds S;
-  lds_carve(S, lds_base, T, N, H.has_free);
+  lds_carve(S, lds_base, T, N, H.has_free, A.cws + (size_t)env * A.cws_stride + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (size_t)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT, nullptr);
   auto E = [&](int f, int e) { return A.elem[(size_t)f * N + e]; };
   double* const cw = A.cws + (size_t)env * A.cws_stride;
   double* const stage = cw;

@@ -37,7 +37,7 @@ TreeEmu* temu_new(const void* blob, size_t n, char* err, size_t errlen) {
   E->sens.assign(H.nsensordata, 0.0);
   E->kmask_jnt.assign(H.njnt, 0); E->kmask_ten.assign(H.ntendon, 0);
   E->kenv = 0;
-  E->cws.assign((size_t)sgt::cws_doubles(E->T), 0.0);
+  E->cws.assign((size_t)sgt::cws_doubles(E->T, H.nelem, H.has_free), 0.0);
   E->lds.assign(sgt::lds_bytes(E->T, H.nelem, H.has_free) / 8 + 8, 0.0);
   for (int d = 0; d < E->T.ND; d++) E->qpos[E->T.d_gid[d]] = E->T.d_qpos0[d];
   for (int e2 = 0; e2 < H.nelem; e2++) E->qpos[H.elem_qpos0 + e2] = E->P.elem[(size_t)SGE_QPOS0 * H.nelem + e2];
