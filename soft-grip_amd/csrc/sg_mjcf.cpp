@@ -457,7 +457,14 @@ struct Compiler {
       } else if (c.tag == "inertial") {
         fail("<inertial> is not supported (inertiafromgeom only)");
       } else if (c.tag == "freejoint") {
-        fail("free joints are out of scope (SURVEY.md item 4b)");
+        // SURVEY 8(f) rank 4 (reference data/gripper/soft_experiments_softball.xml:8), as mjcf.py: 7 positions (world position +
+        // quaternion), 6 dofs; no spring, damper, armature or limit
+        if (bodies[bid].parent != 0 || !bodies[bid].joints.empty()) fail("a free joint must be the only joint of a child of the world body");
+        Joint j;
+        j.name = c.gets("name", "");
+        j.type = SG_JNT_FREE;
+        j.pos = V3(); j.axis = V3(); j.axis[2] = 1;
+        bodies[bid].joints.push_back(j);
       } else {
         fail("unsupported worldbody element <" + c.tag + ">");
       }
@@ -743,10 +750,25 @@ std::string finalize(Compiler& C, bool implicit_tendon_damping) {
   }
   const int nj = (int)joints.size(), ng = (int)geoms.size(), ns = (int)sites.size();
   for (int i = 1; i < nbody; i++) body_weldid[i] = B[i].joints.empty() ? body_weldid[B[i].parent] : i;
-  std::vector<int> dof_parentid(nj, -1), last_dof(nbody, -1);
+  // joint -> first position / first dof (a free joint: 7 / 6), dof -> joint
+  std::vector<int> jnt_qposadr(nj), jnt_dofadr(nj), dof_jntid;
+  int nq = 0;
+  bool has_free = false;
+  for (int k = 0; k < nj; k++) {
+    const bool fr = joints[k].j->type == SG_JNT_FREE;
+    has_free = has_free || fr;
+    jnt_qposadr[k] = nq; jnt_dofadr[k] = (int)dof_jntid.size();
+    nq += fr ? 7 : 1;
+    for (int d = 0; d < (fr ? 6 : 1); d++) dof_jntid.push_back(k);
+  }
+  const int nvd = (int)dof_jntid.size();
+  std::vector<int> dof_parentid(nvd, -1), last_dof(nbody, -1);
   for (int i = 1; i < nbody; i++) {
     int prev = last_dof[B[i].parent];
-    for (int k = 0; k < body_jntnum[i]; k++) { const int d = body_jntadr[i] + k; dof_parentid[d] = prev; prev = d; }
+    for (int k = 0; k < body_jntnum[i]; k++) {
+      const int jj = body_jntadr[i] + k;
+      for (int d = jnt_dofadr[jj]; d < jnt_dofadr[jj] + (joints[jj].j->type == SG_JNT_FREE ? 6 : 1); d++) { dof_parentid[d] = prev; prev = d; }
+    }
     last_dof[i] = prev;
   }
 
@@ -811,7 +833,7 @@ std::string finalize(Compiler& C, bool implicit_tendon_damping) {
     for (int a = 0; a < 4; a++) body_quat[4 * i + a] = B[i].quat[a];
   }
   std::vector<double> jnt_pos(3 * nj), jnt_axis(3 * nj), jnt_range(2 * nj), jnt_stiffness(nj), jnt_margin(nj), jnt_solref(2 * nj), jnt_solimp(5 * nj),
-      qpos0(nj), qpos_spring(nj), dof_damping(nj), dof_armature(nj);
+      qpos0(nq), qpos_spring(nq), dof_damping(nvd), dof_armature(nvd);
   std::vector<int> jnt_type(nj), jnt_bodyid(nj), jnt_limited(nj);
   for (int k = 0; k < nj; k++) {
     const Joint& j = *joints[k].j;
@@ -821,7 +843,15 @@ std::string finalize(Compiler& C, bool implicit_tendon_damping) {
     jnt_stiffness[k] = j.stiffness; jnt_margin[k] = j.margin;
     jnt_solref[2 * k] = j.solref[0]; jnt_solref[2 * k + 1] = j.solref[1];
     for (int a = 0; a < 5; a++) jnt_solimp[5 * k + a] = j.solimp[a];
-    qpos0[k] = j.ref; qpos_spring[k] = j.springref; dof_damping[k] = j.damping; dof_armature[k] = j.armature;
+    const int qa = jnt_qposadr[k], da = jnt_dofadr[k];
+    if (j.type == SG_JNT_FREE) {   // the body's pose (a child of the world)
+      const Body& bb = B[joints[k].body];
+      for (int a = 0; a < 3; a++) qpos0[qa + a] = qpos_spring[qa + a] = bb.pos[a];
+      for (int a = 0; a < 4; a++) qpos0[qa + 3 + a] = qpos_spring[qa + 3 + a] = bb.quat[a];
+      for (int d = 0; d < 6; d++) { dof_damping[da + d] = j.damping; dof_armature[da + d] = j.armature; }
+    } else {
+      qpos0[qa] = j.ref; qpos_spring[qa] = j.springref; dof_damping[da] = j.damping; dof_armature[da] = j.armature;
+    }
   }
   std::vector<double> geom_size(3 * ng), geom_pos(3 * ng), geom_quat(4 * ng), geom_friction(3 * ng), geom_solref(2 * ng), geom_solimp(5 * ng),
       geom_solmix(ng), geom_margin(ng), geom_gap(ng), geom_rbound(ng, 0.0);
@@ -887,8 +917,9 @@ std::string finalize(Compiler& C, bool implicit_tendon_damping) {
   }
 
   // ---- qpos0-dependent constants (MuJoCo's mj_setConst; mjcf.py Model._set_const) ----
-  const int nv = nj;
-  std::vector<V3> xpos(nbody), xanchor(nj), xaxis(nj);
+  const int nv = nvd;
+  std::vector<V3> xpos(nbody), xanchor(nv), xaxis(nv);   // anchors / axes by DOF
+  std::vector<int> dof_rot(nv, 0);
   std::vector<Q4> xquat(nbody);
   std::vector<M3> xmat(nbody);
   xmat[0] = quat_to_mat(xquat[0]);
@@ -901,16 +932,28 @@ std::string finalize(Compiler& C, bool implicit_tendon_damping) {
     Q4 bq; for (int a = 0; a < 4; a++) bq[a] = body_quat[4 * i + a];
     Q4 quat = quat_mul(xquat[p], bq);
     for (int k = 0; k < body_jntnum[i]; k++) {
-      const int j = body_jntadr[i] + k;
+      const int jn = body_jntadr[i] + k, j = jnt_dofadr[jn];
+      if (jnt_type[jn] == SG_JNT_FREE) {   // at qpos0 the free body sits where the XML puts it; dofs: world translations, body-axis rotations
+        R = quat_to_mat(quat_normalize(quat));
+        for (int c = 0; c < 3; c++) {
+          xanchor[j + c] = pos; xanchor[j + 3 + c] = pos;
+          V3 e; e[c] = 1; xaxis[j + c] = e;
+          V3 u; for (int a = 0; a < 3; a++) u[a] = R.m[a][c];
+          xaxis[j + 3 + c] = u;
+          dof_rot[j + 3 + c] = 1;
+        }
+        continue;
+      }
       R = quat_to_mat(quat);
-      V3 jp, ja; for (int a = 0; a < 3; a++) { jp[a] = jnt_pos[3 * j + a]; ja[a] = jnt_axis[3 * j + a]; }
+      V3 jp, ja; for (int a = 0; a < 3; a++) { jp[a] = jnt_pos[3 * jn + a]; ja[a] = jnt_axis[3 * jn + a]; }
       V3 rj = mul(R, jp);
       for (int a = 0; a < 3; a++) xanchor[j][a] = pos[a] + rj[a];
       xaxis[j] = mul(R, ja);
       const double dq = 0.0;  // at qpos0
-      if (jnt_type[j] == SG_JNT_SLIDE) {
+      if (jnt_type[jn] == SG_JNT_SLIDE) {
         for (int a = 0; a < 3; a++) pos[a] = pos[a] + xaxis[j][a] * dq;
       } else {
+        dof_rot[j] = 1;
         Q4 ql; ql[0] = std::cos(dq / 2);
         for (int a = 0; a < 3; a++) ql[1 + a] = ja[a] * std::sin(dq / 2);
         quat = quat_mul(quat, ql);
@@ -928,15 +971,17 @@ std::string finalize(Compiler& C, bool implicit_tendon_damping) {
     std::vector<Jcol> cols;
     for (int b = body; b > 0; b = body_parentid[b])
       for (int k = 0; k < body_jntnum[b]; k++) {
-        const int j = body_jntadr[b] + k;
-        Jcol c; c.dof = j;
-        if (jnt_type[j] == SG_JNT_SLIDE) { c.jp = xaxis[j]; }
-        else {
-          c.jr = xaxis[j];
-          V3 d; for (int a = 0; a < 3; a++) d[a] = point[a] - xanchor[j][a];
-          c.jp = cross(xaxis[j], d);
+        const int jn = body_jntadr[b] + k;
+        for (int j = jnt_dofadr[jn]; j < jnt_dofadr[jn] + (jnt_type[jn] == SG_JNT_FREE ? 6 : 1); j++) {
+          Jcol c; c.dof = j;
+          if (!dof_rot[j]) { c.jp = xaxis[j]; }
+          else {
+            c.jr = xaxis[j];
+            V3 d; for (int a = 0; a < 3; a++) d[a] = point[a] - xanchor[j][a];
+            c.jp = cross(xaxis[j], d);
+          }
+          cols.push_back(c);
         }
-        cols.push_back(c);
       }
     return cols;
   };
@@ -1000,6 +1045,13 @@ std::string finalize(Compiler& C, bool implicit_tendon_damping) {
   const double meaninertia = tr / (nv > 1 ? nv : 1);
   std::vector<double> dof_invweight0(nv), body_invweight0(2 * nbody, 0.0);
   for (int j = 0; j < nv; j++) dof_invweight0[j] = Minv[(size_t)j * nv + j];
+  for (int k = 0; k < nj; k++)   // mj_setConst: one value for a free joint's three translations, one for its three rotations
+    if (jnt_type[k] == SG_JNT_FREE)
+      for (int h3 = 0; h3 < 2; h3++) {
+        const int d0 = jnt_dofadr[k] + 3 * h3;
+        const double av = (dof_invweight0[d0] + dof_invweight0[d0 + 1] + dof_invweight0[d0 + 2]) / 3;
+        dof_invweight0[d0] = dof_invweight0[d0 + 1] = dof_invweight0[d0 + 2] = av;
+      }
   for (int b = 1; b < nbody; b++) {
     if (body_weldid[b] == 0) continue;
     auto cols = jac_point(b, com[b]);
@@ -1028,7 +1080,10 @@ std::string finalize(Compiler& C, bool implicit_tendon_damping) {
       std::vector<double> J(nv, 0.0);
       const int a0 = tendon_adr[t], n = tendon_num[t];
       if (wrap_type[a0] == SG_WRAP_JOINT) {
-        for (int w = a0; w < a0 + n; w++) { tendon_length0[t] += wrap_prm[w] * qpos0[wrap_objid[w]]; J[wrap_objid[w]] = wrap_prm[w]; }
+        for (int w = a0; w < a0 + n; w++) {   // (wrap_objid: a joint id)
+          tendon_length0[t] += wrap_prm[w] * qpos0[jnt_qposadr[wrap_objid[w]]];
+          J[jnt_dofadr[wrap_objid[w]]] = wrap_prm[w];
+        }
       } else {
         for (int w = a0; w < a0 + n - 1; w++) {
           const int s0 = wrap_objid[w], s1 = wrap_objid[w + 1];
@@ -1085,6 +1140,7 @@ std::string finalize(Compiler& C, bool implicit_tendon_damping) {
   addI("wrap_objid", wrap_objid);
   addI("eq_type", eq_type); addI("eq_obj1id", eq_obj1id); addI("eq_obj2id", eq_obj2id); addI("actuator_trnid", actuator_trnid);
   addI("sensor_type", sensor_type); addI("sensor_objid", sensor_objid); addI("sensor_adr", sensor_adr);
+  if (has_free) { addI("jnt_qposadr", jnt_qposadr); addI("jnt_dofadr", jnt_dofadr); addI("dof_jntid", dof_jntid); }   // (only then do the three index spaces differ)
   std::vector<std::string> bn, jn, gn, sn, tn, sen;
   for (auto& b : B) bn.push_back(b.name);
   for (auto& j : joints) jn.push_back(j.j->name);

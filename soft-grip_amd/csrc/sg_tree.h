@@ -81,8 +81,11 @@ struct Lds {
   double *qe, *ve, *we, *asme, *ae, *fse, *ffix, *bfix, *Rfix, *flim, *blim, *Rlim, *ke;
   double *einvm, *ecoef, *ecen, *Ifix, *Ilim;   // 1 / (m + armature), tendon coefficient, capsule centres [3][N], 1 / (A + R) of the fix / limit rows
   double *lrow, *seg, *chs, *cf, *red;
+  double *frow;   // free object: the joint-fix rows' constants for the serial sweep, [N][5]: b, R, A + R, 1 / (A + R), 1 / D
   double *of, *Be, *Ce, *Afix;   // free object (plans with has_free): scalars (OF_*), B_e [N][6], C_e = -S^-1 B_e / D_e [N][6], the fix rows' diagonals A + R
   int *hit_pair, *hit_sorted, *hit_cnt, *hit_off, *con_src, *con_chain, *icnt;
+  double* csc;   // LDS copies of the first `ncache` contacts' scalar records (the sweeps read them 30 times; the rest stay in the work space)
+  int ncache;
 };
 enum { IC_NHIT = 0, IC_NCON, IC_SERIAL, IC_NLIM0 /* + chain */, IC_N = IC_NLIM0 + SGT_MAXCH };
 // per-chain scalars in LDS (chs[c * CHS_N + ..])
@@ -109,6 +112,7 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
   L.lrow = take(SGT_LROW * 2 * ND); L.seg = take(4 * T.K * SGT_MAXTS); L.chs = take(CHS_N * SGT_MAXCH); L.cf = take(3 * SGT_MAXCON);
   L.red = take(16);
   L.of = take(has_free ? OF_N : 0); L.Be = take(has_free ? 6 * N : 0); L.Ce = take(has_free ? 6 * N : 0); L.Afix = takeg(has_free ? N : 0);
+  L.frow = take(has_free ? 5 * N : 0);
   if (gdoubles) *gdoubles = (size_t)(g - gbase);
   int* ip = (int*)p;
   L.hit_pair = ip; ip += SGT_MAXHIT;
@@ -118,7 +122,14 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
   L.con_src = ip; ip += SGT_MAXCON;
   L.con_chain = ip; ip += SGT_MAXCON;
   L.icnt = ip; ip += 32;
-  return (size_t)((char*)ip - (char*)base);
+  // what is left of the LDS up to the next occupancy step (160 KB / k workgroups per CU) caches contact scalars
+  const size_t used = (size_t)((char*)ip - (char*)base), total = 160 * 1024 - 2048;
+  const size_t kper = used < total ? total / used : 1, room = total / (kper ? kper : 1) - used;
+  size_t nc = room / (SGT_CSC * sizeof(double));
+  if (nc > SGT_MAXCON) nc = SGT_MAXCON;
+  L.ncache = (int)nc;
+  L.csc = (double*)ip;
+  return used + nc * SGT_CSC * sizeof(double);
 }
 SG_HD size_t lds_bytes(const SgTreeDev& T, int N, int has_free = 0) {
   Lds L;
@@ -278,6 +289,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   const long long CW = cws_row_doubles(CS);
   auto crow = [&](int c) { return crow0 + (size_t)c * CW; };                 // J1[3][CS] | W1[3][CS] | J2[3][CS] | W2[3][CS] | scalars
   auto cscal = [&](int c) { return crow0 + (size_t)c * CW + 12 * CS; };
+  auto cscr = [&](int c) -> const double* { return c < S.ncache ? S.csc + (size_t)c * SGT_CSC : crow0 + (size_t)c * CW + 12 * CS; };   // for the sweeps: the LDS copy when there is one
   double* const Mg = crow0 + (size_t)SGT_MAXCON * CW;    // the chains' mass-matrix blocks [K][CS][CS], identity-padded
   auto pidx = [&](int d) { const int c = T.d_chain[d]; return c * CS + d - T.c_dof0[c]; };   // flat chain dof -> index in a padded [K][CS] vector
 
@@ -860,6 +872,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         Aee = invm + dot6(S.Be + 6 * e, Bs) * invm * invm;
         for (int q = 0; q < 6; q++) S.Ce[6 * e + q] = -Bs[q] * invm;
         S.Afix[e] = Aee + R;
+        double* fr5 = S.frow + 5 * e;
+        fr5[0] = S.bfix[e]; fr5[1] = R; fr5[2] = Aee + R; fr5[3] = 1.0 / (Aee + R); fr5[4] = invm;
       }
       S.Ifix[e] = 1.0 / (Aee + R);
       tj_pos += co * S.qe[e]; tj_vel += co * S.ve[e]; tj_asm += co * S.asme[e]; tj_warm += co * S.we[e]; tj_A += co * co * invm;
@@ -1078,6 +1092,10 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     }
     SGT_ONE { S.icnt[IC_SERIAL] = 0; }
     SGT_SYNC();
+    {
+      const int ncc = ncon < S.ncache ? ncon : S.ncache;
+      SGT_PAR(i, ncc * SGT_CSC) S.csc[i] = cscal(i / SGT_CSC)[i % SGT_CSC];
+    }
     // Contacts of different chains commute exactly unless they share a slider; mj_solPGS's order within a chain is kept by that
     // chain's stream.  One lane per chain then sweeps its own contacts (a serial list is the fallback, decided here per substep).
     SGT_PAR(ci, ncon) {
@@ -1123,7 +1141,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       }
       SGT_SYNC();
       for (int ci = 0; ci < ncon; ci++) {   // contacts add their pushes one after the other (a slider / chain may be shared)
-        const double* sc = cscal(ci);
+        const double* sc = cscr(ci);
         if (sc[CS_ROWS] == 0.0) continue;
         const double* f = S.cf + 3 * ci;
         const int c1 = (int)sc[CS_C1], c2 = (int)sc[CS_C2], n1c = c1 >= 0 ? CS : 0, n2c = c2 >= 0 ? CS : 0;
@@ -1174,7 +1192,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         }
       }
       SGT_PAR(ci, ncon) {
-        const double* sc = cscal(ci);
+        const double* sc = cscr(ci);
         if (sc[CS_ROWS] == 0.0) continue;
         const double* f = S.cf + 3 * ci;
         const int sl = (int)sc[CS_SL];
@@ -1215,15 +1233,27 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         SGT_ONE {
           double af6[6], imp = 0;
           for (int q = 0; q < 6; q++) af6[q] = S.of[OF_AF + q];
+          // the next row's 19 words are loaded before this row's dependent arithmetic (the chain a_f -> residual -> force -> a_f is
+          // what a row costs; its loads would otherwise sit in front of it: 626 -> ... cycles per row)
+          double nr[5], nB[6], nC[6], nf = S.ffix[0], na = S.ae[0];
+          for (int q = 0; q < 5; q++) nr[q] = S.frow[q];
+          for (int q = 0; q < 6; q++) { nB[q] = S.Be[q]; nC[q] = S.Ce[q]; }
           for (int e = 0; e < N; e++) {
-            const double invm = S.einvm[e];
-            double f = S.ffix[e];
+            double r5[5], B6[6], C6[6], f = nf;
+            const double ael = na;
+            for (int q = 0; q < 5; q++) r5[q] = nr[q];
+            for (int q = 0; q < 6; q++) { B6[q] = nB[q]; C6[q] = nC[q]; }
+            if (e + 1 < N) {
+              for (int q = 0; q < 5; q++) nr[q] = S.frow[5 * (e + 1) + q];
+              for (int q = 0; q < 6; q++) { nB[q] = S.Be[6 * (e + 1) + q]; nC[q] = S.Ce[6 * (e + 1) + q]; }
+              nf = S.ffix[e + 1]; na = S.ae[e + 1];
+            }
             const double old = f;
-            imp -= scalar_update_rcp(f, S.bfix[e], S.ae[e] - dot6(S.Be + 6 * e, af6) * invm, S.Rfix[e], S.Afix[e], S.Ifix[e], false);
+            imp -= scalar_update_rcp(f, r5[0], ael - dot6(B6, af6) * r5[4], r5[1], r5[2], r5[3], false);
             const double dfl = f - old;
             S.ffix[e] = f;
-            S.ae[e] += invm * dfl;
-            for (int q = 0; q < 6; q++) af6[q] += S.Ce[6 * e + q] * dfl;
+            S.ae[e] = ael + r5[4] * dfl;
+            for (int q = 0; q < 6; q++) af6[q] += C6[q] * dfl;
           }
           for (int q = 0; q < 6; q++) S.of[OF_AF + q] = af6[q];
           S.red[0] = imp;
@@ -1305,7 +1335,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           double* aFc = S.aF + c * CS;
           for (int ci = 0; ci < ncon; ci++) {
             if (S.con_chain[ci] != c) continue;
-            const double* sc = cscal(ci);
+            const double* sc = cscr(ci);
             const double* J = crow(ci);
             const double* W = J + 3 * CS;
             const int sl = (int)sc[CS_SL];
@@ -1341,7 +1371,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       }
       // ... or one serial list, the lanes spread over the dofs of a contact's chain block(s)
       for (int ci = 0; serial_contacts && ci < ncon; ci++) {
-        const double* sc = cscal(ci);
+        const double* sc = cscr(ci);
         if (sc[CS_ROWS] == 0.0) continue;
         const int c1 = (int)sc[CS_C1], c2 = (int)sc[CS_C2], n1 = (int)sc[CS_N1], n2 = (int)sc[CS_N2], sl = (int)sc[CS_SL];
         double p0 = 0, p1 = 0, p2 = 0;
@@ -1396,7 +1426,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++)
         if ((int)rows[SGT_LROW * i] == dl) s += rows[SGT_LROW * i + 1] * rows[SGT_LROW * i + 4];
       for (int ci = 0; ci < ncon; ci++) {
-        const double* sc = cscal(ci);
+        const double* sc = cscr(ci);
         if (sc[CS_ROWS] == 0.0) continue;
         for (int b = 0; b < 2; b++)
           if ((int)sc[b ? CS_C2 : CS_C1] == c && dl < (int)sc[b ? CS_N2 : CS_N1]) {

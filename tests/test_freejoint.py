@@ -137,3 +137,22 @@ def test_reference_free_ball_scene_on_the_oracle():
     from softgrip_amd import native
     nm = native.NativeModel(m)
     assert (nm.nq, nm.nv) == (233, 232)
+
+
+def test_both_compilers_agree_on_free_joint_scenes():
+    """the library's own MJCF compiler (csrc/sg_mjcf.cpp, sg_mjcf_compile) takes <freejoint/> like mjcf.py: sizes, address maps and the
+    dof tree equal, reals to 1e-12 relative -- on the own scene and (build container) on the reference's free ball"""
+    from softgrip_amd import native
+    paths = [os.path.join(ROOT, "tests", "data", "free_body.xml")] + ([REF] if os.path.exists(REF) else [])
+    for path in paths:
+        a = sg.compile_mjcf(path, composite_neighbors=False)
+        b = sg.Model.from_blob(native.compile_mjcf_native(path, composite_neighbors=False))
+        assert (a.nq, a.nv, a.njnt, a.neq) == (b.nq, b.nv, b.njnt, b.neq) and b.has_free_joint
+        for f in ("dof_parentid", "jnt_qposadr", "jnt_dofadr", "dof_jntid", "jnt_type", "jnt_bodyid", "eq_obj1id", "wrap_objid", "body_jntadr"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+        for f in ("body_mass", "body_pos", "body_imat", "qpos0", "qpos_spring", "dof_damping", "dof_armature", "dof_invweight0", "body_invweight0",
+                  "tendon_length0", "tendon_invweight0", "jnt_axis", "geom_pos"):
+            x, y = np.asarray(getattr(a, f), float), np.asarray(getattr(b, f), float)
+            if x.size:
+                np.testing.assert_allclose(x, y, rtol=1e-12, atol=1e-14 * max(1.0, float(np.abs(x).max())), err_msg=f)
+        assert abs(a.meaninertia - b.meaninertia) < 1e-14
