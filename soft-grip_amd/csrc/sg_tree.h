@@ -262,6 +262,49 @@ SG_HD double dot6(const double* a, const double* b) { return a[0] * b[0] + a[1] 
 SG_HD void mat6vec(double* r, const double* M, const double* v) {
   for (int i = 0; i < 6; i++) r[i] = dot6(M + 6 * i, v);
 }
+#if defined(__HIPCC__)
+#define SGT_NOINLINE __host__ __device__ __attribute__((noinline))
+#else
+#define SGT_NOINLINE __attribute__((noinline))
+#endif
+// pointers into the env's LDS block, typed as such for an out-of-line function: through generic pointers the loads are FLAT, whose
+// completion the compiler can only wait for all at once -- which turns a prefetch into a stall
+#if SGT_DEVICE
+#define SGT_LDSP __attribute__((address_space(3)))
+#else
+#define SGT_LDSP
+#endif
+// The free object's joint-fix rows, one after the other (one lane).  A function of its own ON PURPOSE: inlined into the step kernel --
+// 256 + 256 registers and spilling -- the loop's 40 live values went to scratch memory and a row cost 600 cycles; called, it gets a
+// register allocation of its own.  The next row's 19 words are loaded before this row's dependent arithmetic.
+static SGT_NOINLINE double free_fix_rows(const SGT_LDSP double* frow, const SGT_LDSP double* Be, const SGT_LDSP double* Ce, SGT_LDSP double* ffix, SGT_LDSP double* ae,
+                                         SGT_LDSP double* af, int N) {
+  double af6[6], imp = 0;
+  for (int q = 0; q < 6; q++) af6[q] = af[q];
+  double nr[5], nB[6], nC[6], nf = ffix[0], na = ae[0];
+  for (int q = 0; q < 5; q++) nr[q] = frow[q];
+  for (int q = 0; q < 6; q++) { nB[q] = Be[q]; nC[q] = Ce[q]; }
+#pragma unroll 2
+  for (int e = 0; e < N; e++) {
+    double r5[5], B6[6], C6[6], f = nf;
+    const double ael = na;
+    for (int q = 0; q < 5; q++) r5[q] = nr[q];
+    for (int q = 0; q < 6; q++) { B6[q] = nB[q]; C6[q] = nC[q]; }
+    {  // (the row behind the last one is read too: the arrays are followed by other words of the block, and the values are dropped)
+      for (int q = 0; q < 5; q++) nr[q] = frow[5 * (e + 1) + q];
+      for (int q = 0; q < 6; q++) { nB[q] = Be[6 * (e + 1) + q]; nC[q] = Ce[6 * (e + 1) + q]; }
+      nf = ffix[e + 1]; na = ae[e + 1];
+    }
+    const double old = f;
+    imp -= scalar_update_rcp(f, r5[0], ael - dot6(B6, af6) * r5[4], r5[1], r5[2], r5[3], false);
+    const double dfl = f - old;
+    ffix[e] = f;
+    ae[e] = ael + r5[4] * dfl;
+    for (int q = 0; q < 6; q++) af6[q] += C6[q] * dfl;
+  }
+  for (int q = 0; q < 6; q++) af[q] = af6[q];
+  return imp;
+}
 // in-place L'DL of a chain block (mj_factorM restricted to a serial chain)
 SG_HD void chain_factor(double* Lc, int nd) {
   for (int k = nd - 1; k >= 1; k--) {
@@ -1231,32 +1274,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         // with a free object a joint-fix row moves the body and through it every slider: the rows run one after the other (mj_solPGS's
         // order), the body's acceleration a_f in registers, a row's own slider from its local part and a_f
         SGT_ONE {
-          double af6[6], imp = 0;
-          for (int q = 0; q < 6; q++) af6[q] = S.of[OF_AF + q];
-          // the next row's 19 words are loaded before this row's dependent arithmetic (the chain a_f -> residual -> force -> a_f is
-          // what a row costs; its loads would otherwise sit in front of it: 626 -> ... cycles per row)
-          double nr[5], nB[6], nC[6], nf = S.ffix[0], na = S.ae[0];
-          for (int q = 0; q < 5; q++) nr[q] = S.frow[q];
-          for (int q = 0; q < 6; q++) { nB[q] = S.Be[q]; nC[q] = S.Ce[q]; }
-          for (int e = 0; e < N; e++) {
-            double r5[5], B6[6], C6[6], f = nf;
-            const double ael = na;
-            for (int q = 0; q < 5; q++) r5[q] = nr[q];
-            for (int q = 0; q < 6; q++) { B6[q] = nB[q]; C6[q] = nC[q]; }
-            if (e + 1 < N) {
-              for (int q = 0; q < 5; q++) nr[q] = S.frow[5 * (e + 1) + q];
-              for (int q = 0; q < 6; q++) { nB[q] = S.Be[6 * (e + 1) + q]; nC[q] = S.Ce[6 * (e + 1) + q]; }
-              nf = S.ffix[e + 1]; na = S.ae[e + 1];
-            }
-            const double old = f;
-            imp -= scalar_update_rcp(f, r5[0], ael - dot6(B6, af6) * r5[4], r5[1], r5[2], r5[3], false);
-            const double dfl = f - old;
-            S.ffix[e] = f;
-            S.ae[e] = ael + r5[4] * dfl;
-            for (int q = 0; q < 6; q++) af6[q] += C6[q] * dfl;
-          }
-          for (int q = 0; q < 6; q++) S.of[OF_AF + q] = af6[q];
-          S.red[0] = imp;
+          S.red[0] = free_fix_rows((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.Ce, (SGT_LDSP double*)S.ffix,
+                                   (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N);
         }
         SGT_SYNC();
         imp_uni += S.red[0];

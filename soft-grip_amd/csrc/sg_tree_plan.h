@@ -18,7 +18,9 @@
 #define SGT_MAXCH 8     // chains
 #define SGT_MAXB 64     // chain bodies, all chains
 #define SGT_MAXD 128    // chain dofs, all chains
+#ifndef SGT_CHD
 #define SGT_CHD 24      // dofs of one chain
+#endif
 #define SGT_MAXG 128    // finger boxes
 #define SGT_MAXS 64     // sites on chain bodies (tendon / sensor sites)
 #define SGT_MAXTS 16    // sites of one spatial tendon

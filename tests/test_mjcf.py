@@ -237,8 +237,8 @@ _COMPOSITE_XML = ("<mujoco><compiler angle='radian'/><option solver='PGS' cone='
 def test_native_compiler_errors_are_reported(tmp_path):
     """same refusals as mjcf.py, as SG_ERR_MODEL with a message (no exception crosses the C ABI)"""
     from softgrip_amd import native
-    cases = {"free.xml": ("<mujoco><compiler angle='radian'/><option solver='PGS' cone='elliptic'/><worldbody><body><freejoint/>"
-                          "<geom type='sphere' size='1'/></body></worldbody></mujoco>", "free joints"),
+    cases = {"free.xml": ("<mujoco><compiler angle='radian'/><option solver='PGS' cone='elliptic'/><worldbody><body><body><freejoint/>"
+                          "<geom type='sphere' size='1'/></body></body></worldbody></mujoco>", "free joint must be the only joint of a child of the world"),
              "newton.xml": ("<mujoco><compiler angle='radian'/><worldbody/></mujoco>", "solver='PGS'"),
              "degree.xml": ("<mujoco><option solver='PGS' cone='elliptic'/><compiler angle='degree'/></mujoco>", "radian"),
              "broken.xml": ("<mujoco><worldbody><body></worldbody></mujoco>", "XML error"),
