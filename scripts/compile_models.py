@@ -45,11 +45,12 @@ if __name__ == "__main__":
         f.write(m.to_blob())
     print("freeball_fix nq", m.nq, "nv", m.nv, "neq", m.neq, "->", out, os.path.getsize(out), "bytes")
     with tempfile.TemporaryDirectory() as tmp:   # the four-finger gripper (tree pipeline)
-        m = sg.compile_mjcf(fourfinger_scene(tmp), composite_neighbors=False)
-        out = os.path.join(ROOT, "models", "fourfinger_softball_fix.sgmodel")
-        with open(out, "wb") as f:
-            f.write(m.to_blob())
-        print("fourfinger_softball_fix nv", m.nv, "neq", m.neq, "->", out, os.path.getsize(out), "bytes")
+        for suffix, nb in (("_fix", False), ("", True)):   # fix rows only / with the composite's neighbour equalities (651 rows)
+            m = sg.compile_mjcf(fourfinger_scene(tmp), composite_neighbors=nb)
+            out = os.path.join(ROOT, "models", "fourfinger_softball" + suffix + ".sgmodel")
+            with open(out, "wb") as f:
+                f.write(m.to_blob())
+            print("fourfinger_softball" + suffix, "nv", m.nv, "neq", m.neq, "->", out, os.path.getsize(out), "bytes")
     # <scene>.sgmodel: the composite as MuJoCo's documentation describes it -- fix rows, neighbour equalities, tendon row (the
     # default; rows pipeline only); <scene>_fix.sgmodel: the same scene without the neighbour equalities (opt-in)
     for suffix, nb in (("", True), ("_fix", False)):

@@ -66,6 +66,8 @@ struct sg_batch {
   SgTreeDev* dT;
   double *dtelem, *tcws;
   SgGenPair* dtpairs;
+  SgEqSlot* dtsched;  // neighbour-row models: the tree plan's block schedule and neighbour tables
+  int* dtnbtab;
   int* touch_words;   // [n][2]
   bool tree_attr_set;
   SgWork w;
@@ -90,7 +92,7 @@ static int tree_alloc(sg_batch* b) {
   const sg_model* m = b->m;
   if (!m->has_tree) return fail(SG_ERR_MODEL, "the tree pipeline does not run this model");
   const size_t n = b->n;
-  const long long cwd = sgt::cws_doubles(m->tree, m->tplan.h.nelem, m->tplan.h.has_free);
+  const long long cwd = sgt::cws_doubles(m->tree, m->tplan.h.nelem, m->tplan.h.has_free, m->tplan.h.nnb);
 #define TALLOC(p, bytes)                                                                  \
   do {                                                                                    \
     hipError_t e_ = hipMalloc((void**)&(p), (bytes));                                     \
@@ -102,7 +104,11 @@ static int tree_alloc(sg_batch* b) {
   TALLOC(b->dtpairs, sizeof(SgGenPair) * (m->tplan.gpairs.size() + 1));
   TALLOC(b->tcws, sizeof(double) * n * (size_t)cwd);
   TALLOC(b->touch_words, sizeof(int) * 2 * n);
+  TALLOC(b->dtsched, sizeof(SgEqSlot) * (m->tplan.sched.size() + 1));
+  TALLOC(b->dtnbtab, sizeof(int) * (m->tplan.nbtab.size() + 1));
 #undef TALLOC
+  HIPCHK(hipMemcpy(b->dtsched, m->tplan.sched.data(), sizeof(SgEqSlot) * m->tplan.sched.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->dtnbtab, m->tplan.nbtab.data(), sizeof(int) * m->tplan.nbtab.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->dTH, &m->tplan.h, sizeof(SgPlanHeader), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->dT, &m->tree, sizeof(SgTreeDev), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->dtelem, m->tplan.elem.data(), sizeof(double) * m->tplan.elem.size(), hipMemcpyHostToDevice));
@@ -124,15 +130,15 @@ static int launch_tree(sg_batch* b, int mode, const uint8_t* mask, int nsub, dou
                        hipStream_t s) {
   const sg_model* m = b->m;
   sgt::TreeArgs a;
-  a.H = b->dTH; a.T = b->dT; a.elem = b->dtelem; a.gpairs = b->dtpairs;
+  a.H = b->dTH; a.T = b->dT; a.elem = b->dtelem; a.gpairs = b->dtpairs; a.sched = b->dtsched; a.nbtab = b->dtnbtab;
   a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.act = b->act; a.ctrl = b->ctrl;
   a.kenv = b->kenv; a.kmask_jnt = b->kmask_jnt; a.kmask_ten = b->kmask_ten;
   a.mask = mask; a.sens = sens; a.sens_stride = stride > 0 ? stride : m->tplan.h.nsensordata;
   a.flags = flags ? flags : b->flags; a.touch = touch ? touch : b->touch; a.touch_words = b->touch_words;
   a.ncon = b->ncon; a.nefc = b->nefc; a.iters = b->iters;
-  a.cws = b->tcws; a.cws_stride = sgt::cws_doubles(m->tree, m->tplan.h.nelem, m->tplan.h.has_free);
+  a.cws = b->tcws; a.cws_stride = sgt::cws_doubles(m->tree, m->tplan.h.nelem, m->tplan.h.has_free, m->tplan.h.nnb);
   a.nenv = b->n; a.nsub = nsub; a.mode = mode; a.secprof = b->w.secprof;
-  const size_t lds = sgt::lds_bytes(m->tree, m->tplan.h.nelem, m->tplan.h.has_free);
+  const size_t lds = sgt::lds_bytes(m->tree, m->tplan.h.nelem, m->tplan.h.has_free, m->tplan.h.nnb);
   if (!b->tree_attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)sg_tree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     b->tree_attr_set = true;
@@ -156,7 +162,7 @@ int sg_model_create(const void* blob, size_t nbytes, sg_model** out) {
   std::string err, terr;
   m->has_fast = sg_plan_build(blob, nbytes, &m->plan, &err);
   m->has_tree = sg_tree_plan_build(blob, nbytes, &m->tplan, &m->tree, &terr);
-  if (m->has_tree && sgt::lds_bytes(m->tree, m->tplan.h.nelem, m->tplan.h.has_free) > 160 * 1024) {
+  if (m->has_tree && sgt::lds_bytes(m->tree, m->tplan.h.nelem, m->tplan.h.has_free, m->tplan.h.nnb) > 160 * 1024) {
     m->has_tree = false;
     terr = "the env's state does not fit the 160 KB of LDS";
   }
@@ -215,7 +221,7 @@ int sg_model_nelem(const sg_model* m) { return m->plan.h.nelem; }
 void sg_batch_destroy(sg_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  void* tptrs[] = {b->dTH, b->dT, b->dtelem, b->tcws, b->dtpairs, b->touch_words};
+  void* tptrs[] = {b->dTH, b->dT, b->dtelem, b->tcws, b->dtpairs, b->touch_words, b->dtsched, b->dtnbtab};
   for (void* p : tptrs)
     if (p) (void)hipFree(p);
   void* ptrs[] = {b->dtab, b->dgpairs, b->dnbtab, b->dsched, b->dH, b->delem, b->qpos, b->qvel, b->warm, b->act, b->ctrl, b->kenv, b->ctrl_row, b->kmask_jnt, b->kmask_ten,
@@ -239,7 +245,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   sg_batch* b = new sg_batch();
   b->m = m; b->n = n_envs; b->device = device; b->lds_attr_set = false; b->prof = false; b->prof_ms = 0; b->prof_n = 0; b->prof_pgs_ms = 0; b->prof_pgs_n = 0;
   b->dnbtab = nullptr; b->dsched = nullptr; b->dgpairs = nullptr; b->dtab = nullptr; b->epw_override = 0;
-  b->dTH = nullptr; b->dT = nullptr; b->dtelem = b->tcws = nullptr; b->dtpairs = nullptr; b->touch_words = nullptr; b->tree_attr_set = false;
+  b->dTH = nullptr; b->dT = nullptr; b->dtelem = b->tcws = nullptr; b->dtpairs = nullptr; b->touch_words = nullptr; b->tree_attr_set = false; b->dtsched = nullptr; b->dtnbtab = nullptr;
   b->dH = nullptr; b->delem = b->qpos = b->qvel = b->warm = b->act = b->ctrl = b->kenv = b->ctrl_row = nullptr;
   b->kmask_jnt = b->kmask_ten = b->flags = b->touch = b->ncon = b->nefc = b->iters = nullptr;
   const SgPlanHeader& H = m->plan.h;

@@ -529,7 +529,9 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
   }
   H.nnb = neq - 1 - nelem;
   H.eq_rounds = 0;
-  if (tree && H.nnb > 0) FAIL("the tree pipeline runs fix-rows-only models (compile the scene without the composite's neighbour equalities)");
+  if (tree && H.nnb > 0 && H.has_free) FAIL("the tree pipeline runs a free object with fix rows only (compile the scene without the composite's neighbour equalities)");
+  const int eq_slots = tree ? 64 : SG_EQ_SLOTS;   // blocks per round: a lane each in the tree pipeline, a lane pair of the 16-lane group in the solver
+  H.eq_slots = eq_slots;
   if (H.nnb > 0) {
     const int N = nelem, nnb = H.nnb;
     P.nbtab.assign((size_t)9 * N + 3 * nnb, -1);
@@ -588,7 +590,7 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
         if (ok) ready.push_back(e);
       }
       std::stable_sort(ready.begin(), ready.end(), [&](int a, int b) { return height[a] > height[b]; });
-      for (int g = 0; g < SG_EQ_SLOTS; g++) {
+      for (int g = 0; g < eq_slots; g++) {
         SgEqSlot sl;
         sl.e = sl.p[0] = sl.p[1] = sl.p[2] = N;  // idle slot: the zero word and the dummy records
         if (g < (int)ready.size()) {
@@ -602,9 +604,9 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
       rnd++;
     }
     H.eq_rounds = rnd;
-    for (int e = 1; e < N; e++)
+    for (int e = 1; e < N && !tree; e++)
       if (invm(e) != invm(0)) FAIL("neighbour-row models need elements of equal mass (the solver keeps 1 / m as a constant)");
-    for (int e = 0; e < N; e++)
+    for (int e = 0; e < N && !tree; e++)
       if (P.elem[(size_t)SGE_COEF * N + e] != 1.0) FAIL("neighbour-row models need the element tendon with coefficients 1 (the solver tracks the sum of the slider accelerations)");
   }
   kb(eq_solref, eq_solimp, &H.eqj_K, &H.eqj_B);

@@ -71,6 +71,7 @@ struct SgPlanHeader {
   int ngpair;     // entries of SgPlan::gpairs (the general contact path's candidate pairs)
   int nnb;        // neighbour equality rows (0: the model has none)
   int eq_rounds;  // rounds of the equality-row schedule (SgPlan::sched), 0 when nnb == 0
+  int eq_slots;   // blocks per round of that schedule: SG_EQ_SLOTS (solver kernel) or 64 (tree plans: a lane each)
   double timestep, gravity[3], tolerance, impratio, meaninertia, pgs_scale;
   // element-uniform parameters
   double cap_radius, cap_hl, cap_rbound;
@@ -129,7 +130,7 @@ struct SgPlan {
   //   workspace arrays nbf / nbb / nbR have 3 * nelem slots, so the phase kernel's lanes (= elements) store them coalesced
   //   out_*: the (up to 3) neighbour rows of element e: partner element / slot, -1 = none; in_slot: the (up to 3) rows that have e as second joint
   std::vector<int> nbtab;
-  std::vector<SgEqSlot> sched;     // eq_rounds x SG_EQ_SLOTS
+  std::vector<SgEqSlot> sched;     // eq_rounds x eq_slots
   std::vector<double> elem;        // SGE_NFIELD x nelem
   std::vector<int> elem_geom;      // geom id of each element's capsule
   std::vector<int> elem_dofmap;    // (informational) global dof of element e = elem_dof0 + e

@@ -48,7 +48,9 @@ struct TreeArgs {
   const SgTreeDev* T;
   const double* elem;        // SgPlan::elem (SoA over elements)
   const SgGenPair* gpairs;
-  double *qpos, *qvel, *warm, *act, *ctrl;   // [n][nv], [n][nu]
+  const SgEqSlot* sched;     // neighbour-row models: SgPlan::sched (eq_rounds x 64 blocks) and SgPlan::nbtab (out_e2 | out_slot | in_slot, [3][N] each)
+  const int* nbtab;
+  double *qpos, *qvel, *warm, *act, *ctrl;   // [n][nq] / [n][nv], [n][nu]
   const double* kenv;
   const int *kmask_jnt, *kmask_ten;
   const unsigned char* mask;  // mode 1: envs to reset (nullptr = all)
@@ -81,6 +83,7 @@ struct Lds {
   double *qe, *ve, *we, *asme, *ae, *fse, *ffix, *bfix, *Rfix, *flim, *blim, *Rlim, *ke;
   double *einvm, *ecoef, *ecen, *Ifix, *Ilim;   // 1 / (m + armature), tendon coefficient, capsule centres [3][N], 1 / (A + R) of the fix / limit rows
   double *lrow, *seg, *chs, *cf, *red;
+  double *nbf, *nbb, *nbR, *nbI;   // neighbour equality rows by slot d * N + e (the d-th row registered for element e): force, b, R, 1 / (A + R)
   double *frow;   // free object: the joint-fix rows' constants for the serial sweep, [N][5]: b, R, A + R, 1 / (A + R), 1 / D
   double *of, *Be, *Ce, *Afix;   // free object (plans with has_free): scalars (OF_*), B_e [N][6], C_e = -S^-1 B_e / D_e [N][6], the fix rows' diagonals A + R
   int *hit_pair, *hit_sorted, *hit_cnt, *hit_off, *con_src, *con_chain, *icnt;
@@ -95,7 +98,7 @@ enum { CHS_TLEN = 0, CHS_TVEL, CHS_TFRC, CHS_AFRC, CHS_ACTDOT, CHS_ACT, CHS_CTRL
 // phase behind a barrier) touches -- the L'DL blocks, the sliders' sweep constants and build-only state: 35 KB of the four-finger
 // scene's 113 KB, which is what lets two workgroups share a CU's LDS (the loads are coalesced and L2-resident).  Returns the LDS
 // bytes; *gdoubles the doubles taken from gbase.
-SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_free, double* gbase, size_t* gdoubles) {
+SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_free, double* gbase, size_t* gdoubles, int nnb = 0) {
   double *p = base, *g = gbase;
   auto take = [&](size_t n) { double* r = p; p += (n + 1) & ~(size_t)1; return r; };
   auto takeg = [&](size_t n) { double* r = g; g += (n + 1) & ~(size_t)1; return r; };
@@ -113,6 +116,7 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
   L.red = take(16);
   L.of = take(has_free ? OF_N : 0); L.Be = take(has_free ? 6 * N : 0); L.Ce = take(has_free ? 6 * N : 0); L.Afix = takeg(has_free ? N : 0);
   L.frow = take(has_free ? 5 * N : 0);
+  L.nbf = takeg(nnb ? 3 * N : 0); L.nbb = takeg(nnb ? 3 * N : 0); L.nbR = takeg(nnb ? 3 * N : 0); L.nbI = takeg(nnb ? 3 * N : 0);
   if (gdoubles) *gdoubles = (size_t)(g - gbase);
   int* ip = (int*)p;
   L.hit_pair = ip; ip += SGT_MAXHIT;
@@ -131,18 +135,18 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
   L.csc = (double*)ip;
   return used + nc * SGT_CSC * sizeof(double);
 }
-SG_HD size_t lds_bytes(const SgTreeDev& T, int N, int has_free = 0) {
+SG_HD size_t lds_bytes(const SgTreeDev& T, int N, int has_free = 0, int nnb = 0) {
   Lds L;
-  return lds_carve(L, reinterpret_cast<double*>((uintptr_t)4096), T, N, has_free, reinterpret_cast<double*>((uintptr_t)4096), nullptr);
+  return lds_carve(L, reinterpret_cast<double*>((uintptr_t)4096), T, N, has_free, reinterpret_cast<double*>((uintptr_t)4096), nullptr, nnb);
 }
-SG_HD size_t gws_doubles(const SgTreeDev& T, int N, int has_free);
-SG_HD long long cws_doubles(const SgTreeDev& T, int N, int has_free) {
-  return (long long)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (long long)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT + (long long)gws_doubles(T, N, has_free);
+SG_HD size_t gws_doubles(const SgTreeDev& T, int N, int has_free, int nnb);
+SG_HD long long cws_doubles(const SgTreeDev& T, int N, int has_free, int nnb = 0) {
+  return (long long)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (long long)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT + (long long)gws_doubles(T, N, has_free, nnb);
 }
-SG_HD size_t gws_doubles(const SgTreeDev& T, int N, int has_free) {   // the work-space doubles behind the global-backed arrays
+SG_HD size_t gws_doubles(const SgTreeDev& T, int N, int has_free, int nnb) {   // the work-space doubles behind the global-backed arrays
   Lds L;
   size_t n = 0;
-  lds_carve(L, reinterpret_cast<double*>((uintptr_t)4096), T, N, has_free, reinterpret_cast<double*>((uintptr_t)4096), &n);
+  lds_carve(L, reinterpret_cast<double*>((uintptr_t)4096), T, N, has_free, reinterpret_cast<double*>((uintptr_t)4096), &n, nnb);
   return n;
 }
 
@@ -324,7 +328,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   const int N = H.nelem, ND = T.ND, NB = T.NB, K = T.K, nv = H.nv, nu = H.nu, CS = T.CS;
   const double h = H.timestep;
   Lds S;
-  lds_carve(S, lds_base, T, N, H.has_free, A.cws + (size_t)env * A.cws_stride + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (size_t)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT, nullptr);
+  lds_carve(S, lds_base, T, N, H.has_free, A.cws + (size_t)env * A.cws_stride + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (size_t)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT, nullptr, H.nnb);
   auto E = [&](int f, int e) { return A.elem[(size_t)f * N + e]; };
   double* const cw = A.cws + (size_t)env * A.cws_stride;
   double* const stage = cw;
@@ -956,6 +960,25 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       ten_f = -(tj_warm - aref) / ten_R;
     }
     const double ten_I = 1.0 / (tj_A + ten_R);
+    // (a') the composite's neighbour equalities q_e1 - q0_e1 = q_e2 - q0_e2 (MuJoCo's documented composite): slot
+    //      d * N + e = the d-th row registered for element e (its partner: nbtab's out_e2); J = +1 on e, -1 on the partner
+    const bool NB = H.nnb > 0;
+    if (NB) {
+      SGT_SYNC();   // (asme / we of other lanes' elements)
+      SGT_PAR(k, 3 * N) {
+        const int e = k % N, pe = A.nbtab[k];
+        double R = 0, b = 0, f = 0, I = 0;   // R = 0 marks an empty slot
+        if (pe >= 0) {
+          const double pos = (S.qe[e] - E(SGE_QPOS0, e)) - (S.qe[pe] - E(SGE_QPOS0, pe)), imp = impedance(H.eqj_solimp, pos, 0.0);
+          R = fmax(SG_MINVAL, (1 - imp) / imp * (E(SGE_INVW, e) + E(SGE_INVW, pe)));
+          const double aref = -H.eqj_B * (S.ve[e] - S.ve[pe]) - H.eqj_K * imp * pos;
+          b = (S.asme[e] - S.asme[pe]) - aref;
+          f = -((S.we[e] - S.we[pe]) - aref) / R;
+          I = 1.0 / (S.einvm[e] + S.einvm[pe] + R);
+        }
+        S.nbR[k] = R; S.nbb[k] = b; S.nbf[k] = f; S.nbI[k] = I;
+      }
+    }
     // (c) limit rows of the chain dofs, one lane per chain: compact list in dof order, lower side first
     SGT_PAR(c, K) {
       int n = 0;
@@ -1162,7 +1185,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       double cnt = 0;
       SGT_PAR(e, N) cnt += (S.Rlim[2 * e] != 0.0 ? 1.0 : 0.0) + (S.Rlim[2 * e + 1] != 0.0 ? 1.0 : 0.0);
       SGT_PAR(ci, ncon) cnt += cscal(ci)[CS_ROWS] != 0.0 ? 3.0 : 0.0;
-      nefc = N + 1 + nl + (int)wsum(cnt);
+      nefc = N + 1 + nl + H.nnb + (int)wsum(cnt);
       touch_lo = touch_hi = 0;
       for (int ci = 0; ci < ncon; ci++) {   // uniform loop: every lane ends up with the same words
         const int tbit = (int)cscal(ci)[CS_TOUCH];
@@ -1174,7 +1197,16 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     // ---------------------------------------------------------------- stage 10: warmstart (kept only if it beats f = 0), PGS
     // a = M^-1 J' f of the current forces: chains in aF, sliders in ae
     auto apply_all = [&]() {
-      SGT_PAR(e, N) S.ae[e] = S.einvm[e] * (S.ffix[e] + S.ecoef[e] * ten_f + S.flim[2 * e] - S.flim[2 * e + 1]);
+      SGT_PAR(e, N) {
+        double g = S.ffix[e] + S.ecoef[e] * ten_f + S.flim[2 * e] - S.flim[2 * e + 1];
+        if (NB)
+          for (int d = 0; d < 3; d++) {   // its own rows push it with +f, the rows that have it as partner (nbtab's in_slot) with -f
+            if (A.nbtab[d * N + e] >= 0) g += S.nbf[d * N + e];
+            const int in = A.nbtab[6 * N + d * N + e];
+            if (in >= 0) g -= S.nbf[in];
+          }
+        S.ae[e] = S.einvm[e] * g;
+      }
       SGT_PAR(idx, K * CS) {
         const int c = idx / CS, dl = idx % CS;
         const double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
@@ -1227,6 +1259,10 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         cost += S.flim[2 * e] * (0.5 * (ae_ + S.Rlim[2 * e] * S.flim[2 * e]) + S.blim[2 * e]);
         cost += S.flim[2 * e + 1] * (0.5 * (-ae_ + S.Rlim[2 * e + 1] * S.flim[2 * e + 1]) + S.blim[2 * e + 1]);
       }
+      if (NB) SGT_PAR(k, 3 * N) {
+        const int pe = A.nbtab[k];
+        if (pe >= 0) cost += S.nbf[k] * (0.5 * ((S.ae[k % N] - S.ae[pe]) + S.nbR[k] * S.nbf[k]) + S.nbb[k]);
+      }
       SGT_PAR(c, K) {
         const double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
         for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) {
@@ -1256,6 +1292,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       if (cost > 0) {   // uniform
         ten_f = 0;
         SGT_PAR(e, N) { S.ffix[e] = 0; S.flim[2 * e] = 0; S.flim[2 * e + 1] = 0; S.ae[e] = 0; }
+        if (NB) SGT_PAR(k, 3 * N) S.nbf[k] = 0;
         SGT_PAR(i, K * CS) S.aF[i] = 0;
         if (FR) SGT_ONE { for (int q = 0; q < 6; q++) S.of[OF_AF + q] = S.of[OF_GF + q] = 0; }
         SGT_PAR(c, K)
@@ -1281,6 +1318,39 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         imp_uni += S.red[0];
         SGT_PAR(e, N) S_ae += S.ecoef[e] * S.ae[e];
         S_ae = wsum(S_ae) - dot6(H.obj_tenB, S.of + OF_AF);   // sum coef_e a_e, a_e = local part - B_e . a_f / D_e
+      } else if (NB) {
+        // equality BLOCKS [fix_e, e's neighbour rows] in the plan's list schedule: the blocks of a round share no slider (they
+        // commute exactly), every block sits in a later round than the blocks it depends on -- the rounds in order ARE mj_solPGS's
+        // sequential sweep (sg_plan.h); 64 blocks per round, a lane each
+        for (int r = 0; r < H.eq_rounds; r++) {
+          SGT_PAR(sl, 64) {
+            const SgEqSlot slot = A.sched[r * 64 + sl];
+            const int e = slot.e;
+            if (e < N) {
+              const double invm = S.einvm[e];
+              double ae_ = S.ae[e], f = S.ffix[e];
+              double old = f;
+              imp_par -= scalar_update_rcp(f, S.bfix[e], ae_, S.Rfix[e], invm + S.Rfix[e], S.Ifix[e], false);
+              S.ffix[e] = f;
+              ae_ += invm * (f - old);
+              for (int d = 0; d < 3; d++) {
+                const int pe = slot.p[d];
+                if (pe >= N) continue;
+                const int k = d * N + e;
+                const double ap = S.ae[pe], ipm = S.einvm[pe], R = S.nbR[k];
+                f = S.nbf[k]; old = f;
+                imp_par -= scalar_update_rcp(f, S.nbb[k], ae_ - ap, R, invm + ipm + R, S.nbI[k], false);
+                S.nbf[k] = f;
+                ae_ += invm * (f - old);
+                S.ae[pe] = ap - ipm * (f - old);
+              }
+              S.ae[e] = ae_;
+            }
+          }
+          SGT_SYNC();
+        }
+        SGT_PAR(e, N) S_ae += S.ecoef[e] * S.ae[e];
+        S_ae = wsum(S_ae);
       } else {
         SGT_PAR(e, N) {
           const double invm = S.einvm[e];

@@ -37,8 +37,8 @@ TreeEmu* temu_new(const void* blob, size_t n, char* err, size_t errlen) {
   E->sens.assign(H.nsensordata, 0.0);
   E->kmask_jnt.assign(H.njnt, 0); E->kmask_ten.assign(H.ntendon, 0);
   E->kenv = 0;
-  E->cws.assign((size_t)sgt::cws_doubles(E->T, H.nelem, H.has_free), 0.0);
-  E->lds.assign(sgt::lds_bytes(E->T, H.nelem, H.has_free) / 8 + 8, 0.0);
+  E->cws.assign((size_t)sgt::cws_doubles(E->T, H.nelem, H.has_free, H.nnb), 0.0);
+  E->lds.assign(sgt::lds_bytes(E->T, H.nelem, H.has_free, H.nnb) / 8 + 8, 0.0);
   for (int d = 0; d < E->T.ND; d++) E->qpos[E->T.d_gid[d]] = E->T.d_qpos0[d];
   for (int e2 = 0; e2 < H.nelem; e2++) E->qpos[H.elem_qpos0 + e2] = E->P.elem[(size_t)SGE_QPOS0 * H.nelem + e2];
   if (H.has_free)
@@ -52,7 +52,7 @@ int temu_nv(TreeEmu* E) { return E->P.h.nv; }
 int temu_nq(TreeEmu* E) { return E->P.h.nq; }
 int temu_nu(TreeEmu* E) { return E->P.h.nu; }
 int temu_nsens(TreeEmu* E) { return E->P.h.nsensordata; }
-size_t temu_lds_bytes(TreeEmu* E) { return sgt::lds_bytes(E->T, E->P.h.nelem, E->P.h.has_free); }
+size_t temu_lds_bytes(TreeEmu* E) { return sgt::lds_bytes(E->T, E->P.h.nelem, E->P.h.has_free, E->P.h.nnb); }
 double* temu_qpos(TreeEmu* E) { return E->qpos.data(); }
 double* temu_qvel(TreeEmu* E) { return E->qvel.data(); }
 double* temu_warm(TreeEmu* E) { return E->warm.data(); }
@@ -76,6 +76,7 @@ void temu_set_stiffness(TreeEmu* E, double k, const int* jnt, int nj, const int*
 void temu_run(TreeEmu* E, int mode, int nsub) {
   sgt::TreeArgs A;
   A.H = &E->P.h; A.T = &E->T; A.elem = E->P.elem.data(); A.gpairs = E->P.gpairs.data();
+  A.sched = E->P.sched.data(); A.nbtab = E->P.nbtab.data();
   A.qpos = E->qpos.data(); A.qvel = E->qvel.data(); A.warm = E->warm.data(); A.act = E->act.data(); A.ctrl = E->ctrl.data();
   A.kenv = &E->kenv; A.kmask_jnt = E->kmask_jnt.data(); A.kmask_ten = E->kmask_ten.data();
   A.mask = nullptr; A.sens = E->sens.data(); A.sens_stride = E->P.h.nsensordata;

@@ -42,13 +42,15 @@ def _oracles(model, ks, jids, tids):
     return sims
 
 
-def test_four_finger_episode_matches_oracle():
-    """the whole squeeze schedule, 5 envs over the stiffness range, along the oracle's trajectories (the batch re-seated on the oracles'
+@pytest.mark.parametrize("scene", ["fourfinger_softball_fix", "fourfinger_softball"])
+def test_four_finger_episode_matches_oracle(scene):
+    """(fix rows only: 219 equality rows; with the composite's neighbour equalities: 651 -- the blocks run by the plan's 64-slot schedule)
+    the whole squeeze schedule, 5 envs over the stiffness range, along the oracle's trajectories (the batch re-seated on the oracles'
     states after every env step: 218 active limit rows make this scene amplify round-off, tests/test_tree_emu.py): every sensor
     sample of the 24 channels at 1e-7, contact / row / sweep counts and the 64 touch bits exact at every step"""
     torch = _torch()
-    m = sg.load_model(model_path("fourfinger_softball_fix"), "implicit")
-    ks = [300.0, 575.0, 850.0, 1125.0, 1400.0]
+    m = sg.load_model(model_path(scene), "implicit")
+    ks = [300.0, 575.0, 850.0, 1125.0, 1400.0] if scene.endswith("_fix") else [400.0, 1000.0]
     nm, b, sens, flags = _batch(m, ks, FF_JOINTS, [0])
     assert nm.nboxes == 64 and nm.nsensordata == 24
     sims = _oracles(m, ks, FF_JOINTS, [0])
@@ -88,7 +90,7 @@ def test_four_finger_episode_matches_oracle():
     assert worst < 1e-7, worst
     for f in range(4):
         assert touched >> (16 * f) & 0xFFFF, f
-    print("four-finger episode: max |sensor - oracle| = %.2e" % worst)
+    print("four-finger episode (%s): max |sensor - oracle| = %.2e" % (scene, worst))
 
 
 @pytest.mark.parametrize("scene,damper", [("softbox_fix", None), ("softball_fix", "implicit")])
@@ -124,6 +126,44 @@ def test_tree_pipeline_on_two_finger_scenes(scene, damper):
         for i, s in enumerate(sims):
             assert (int(st["ncon"][i]), int(st["nefc"][i]), int(st["iters"][i])) == (s.ncon, s.nefc, s.solver_iter), (t, i)
         assert torch.equal(st["ncon"], st2["ncon"]) and torch.equal(touch, touch2), t
+    assert worst < 1e-7 and worst2 < 1e-7, (worst, worst2)
+
+
+def test_default_two_finger_model_in_the_tree_pipeline():
+    """models/softbox.sgmodel (327 equality rows: the benchmark model) through pipeline 3 against the rows pipeline and the oracle, along
+    the oracle's trajectory for 120 env steps: sensors 1e-7, counts exact, both pipelines"""
+    torch = _torch()
+    m = sg.load_model(model_path("softbox"))
+    ks = [320.0, 903.6948543200572, 1390.0]
+    nm, b, sens, flags = _batch(m, ks, JOINT_IDS, TENDON_IDS, "tree")
+    nm2, b2, sens2, flags2 = _batch(m, ks, JOINT_IDS, TENDON_IDS, "rows")
+    sims = _oracles(m, ks, JOINT_IDS, TENDON_IDS)
+    b.reset(1, sens=sens, flags=flags)
+    b2.reset(1, sens=sens2, flags=flags2)
+    dev = dict(device=b.device, dtype=torch.float64)
+    worst = worst2 = 0.0
+    for t, c in enumerate(episode_schedule()[:120]):
+        if c is not None:
+            for x in (b, b2):
+                x.set_ctrl_broadcast(np.full(2, c))
+            for s in sims:
+                s.ctrl[:] = c
+        st = dict(qpos=torch.tensor(np.stack([s.qpos for s in sims]), **dev), qvel=torch.tensor(np.stack([s.qvel for s in sims]), **dev),
+                  act=torch.tensor(np.stack([s.act for s in sims]), **dev), qacc_warmstart=torch.tensor(np.stack([s.qacc_warmstart for s in sims]), **dev))
+        b.set_state(**st); b2.set_state(**st)
+        for s in sims:
+            for _ in range(7):
+                assert s.step() == 0
+        b.step(7, sens=sens, flags=flags)
+        b2.step(7, sens=sens2, flags=flags2)
+        assert int(flags.abs().sum()) == 0 and int(flags2.abs().sum()) == 0
+        ref = np.stack([s.sensordata for s in sims])
+        worst = max(worst, np.abs(sens.cpu().numpy() - ref).max())
+        worst2 = max(worst2, np.abs(sens2.cpu().numpy() - ref).max())
+        st1, st2 = b.solver_stats(), b2.solver_stats()
+        for i, s in enumerate(sims):
+            assert (int(st1["ncon"][i]), int(st1["nefc"][i]), int(st1["iters"][i])) == (s.ncon, s.nefc, s.solver_iter), (t, i)
+            assert (int(st2["ncon"][i]), int(st2["nefc"][i]), int(st2["iters"][i])) == (s.ncon, s.nefc, s.solver_iter), (t, i)
     assert worst < 1e-7 and worst2 < 1e-7, (worst, worst2)
 
 
