@@ -214,6 +214,9 @@ def make_parser():
                         help="integration of the composite volume tendon's damper (DESIGN.md D5); auto = explicit, implicit for scenes that need it")
     parser.add_argument('--joint-ids', type=int, nargs="+", default=None, help="joints whose stiffness is randomised (default: the reference's 11..63)")
     parser.add_argument('--tendon-ids', type=int, nargs="+", default=None, help="tendons whose stiffness is randomised (default: the reference's 0)")
+    parser.add_argument('--finger-names', nargs="+", default=None, help="geom name fragments of the fingers for the contact flag (default: the reference's "
+                        "['g12', 'g2']; four-finger gripper: g11 g12 g13 g2, reference manenv.py:16)")
+    parser.add_argument('--n-actuated', type=int, default=None, help="actuators close_hand / loose_hand drive (default 2; four-finger gripper: 4)")
     parser.add_argument('--no-check-scene', dest="check_scene", action='store_false', default=True,
                         help="skip the load-time dry run that rejects scenes which cannot survive their own idle phase")
     parser.add_argument('--gpus', type=int, default=1,

@@ -280,6 +280,7 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
       }
     }
     if (T.K == 0) FAIL("model has no finger chain");
+    if (T.NG > 64) FAIL("more than 64 finger boxes (the contact read-out has 64 bits)");
     T.CS = 0;
     for (int c = 0; c < T.K; c++) T.CS = std::max(T.CS, T.c_ndof[c]);
     T.CS = (T.CS + 3) & ~3;   // every chain's vectors and matrix blocks are padded to this stride: uniform loop counts on the device

@@ -258,3 +258,29 @@ def test_model_outside_both_classes_is_refused_with_both_reasons():
     with pytest.raises(native.SoftgripError) as ei:
         native.NativeModel(m)
     assert ei.value.code == native.SG_ERR_MODEL and "two-finger kernels" in str(ei.value) and "tree pipeline" in str(ei.value)
+
+
+def test_datasets_from_the_four_finger_and_the_free_ball_scenes(tmp_path):
+    """the dataset host (create_dataset: reference create_dataset.py:23-79) on the two scenes of SURVEY 8(f) rank 4: one episode-batch of
+    8 envs each; the four-finger rows are [200, 24] (reference manenv.py:11,16: the commented ids), the free ball's [200, 12]; all finite;
+    each scene's first env reproduces the oracle's first rows for its label"""
+    import pickle
+    from softgrip_amd import create_dataset as cd
+    cases = [("fourfinger_softball_fix", FF_JOINTS, 24, ["--finger-names"] + FINGERS + ["--n-actuated", "4"]),
+             ("freeball_fix", list(range(9, 227)), 12, [])]
+    for scene, jids, width, extra in cases:
+        args = cd.make_parser().parse_args(["--mujoco-model-paths", model_path(scene), "--n-envs", "8", "--data-folder", str(tmp_path), "--data-name", scene,
+                                            "--tendon-damper", "implicit", "--joint-ids"] + [str(j) for j in jids] + ["--tendon-ids", "0"] + extra)
+        np.random.seed(11)
+        d = pickle.load(open(cd.log_into_file(args), "rb"))
+        X = np.array(d["data"])
+        assert X.shape == (8, 200, width) and np.isfinite(X).all() and len(d["stiffness"]) == 8
+        m = sg.load_model(model_path(scene), "implicit")
+        s = oracle_sim(m)
+        s.jnt_stiffness[jids] = d["stiffness"][0]
+        s.tendon_stiffness[0] = d["stiffness"][0]
+        s.reset(); s.forward(); s.step()
+        for t in range(8):
+            for _ in range(7):
+                assert s.step() == 0
+            assert np.abs(X[0, t] - s.sensordata).max() < 1e-6, (scene, t)
