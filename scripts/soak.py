@@ -21,23 +21,26 @@ damper = sys.argv[3] if len(sys.argv) > 3 else ("explicit" if scene.startswith("
 m = sg.load_model(os.path.join(ROOT, "models", scene + ".sgmodel"), damper)
 nm = native.NativeModel(m)
 sched = episode_schedule()
+# which joints / tendons carry the per-env stiffness (bench.py stiffness_ids): the four-finger and free-ball scenes have their own
+jids = list(range(65, 283)) if scene.startswith("fourfinger") else list(range(9, 227)) if scene.startswith("freeball") else list(range(11, 64))
+nsd = nm.nsensordata
 digests = []
 for run in range(2):
     b = native.NativeBatch(nm, n, 0)
     rng = np.random.RandomState(7)
-    out = torch.zeros(n, len(sched), 12, dtype=torch.float64, device=b.device)
+    out = torch.zeros(n, len(sched), nsd, dtype=torch.float64, device=b.device)
     flags = torch.zeros(n, dtype=torch.int32, device=b.device)
     h = hashlib.sha256()
     nbad = 0
     for ep in range(episodes):
-        b.set_stiffness(rng.uniform(300, 1400, n), list(range(11, 64)), [0])
+        b.set_stiffness(rng.uniform(300, 1400, n), jids, [0])
         b.reset(1, flags=flags)
-        ctrl = np.zeros(2)
+        ctrl = np.zeros(nm.nu)
         for t, c in enumerate(sched):
             if c is not None:
                 ctrl[:] = c
                 b.set_ctrl_broadcast(ctrl)
-            b.step(7, sens=out[:, t], sens_stride=len(sched) * 12, flags=flags)
+            b.step(7, sens=out[:, t], sens_stride=len(sched) * nsd, flags=flags)
             nbad += int((flags != 0).sum())
         a = out.cpu().numpy()
         assert np.isfinite(a).all()
