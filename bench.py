@@ -366,12 +366,12 @@ def main():
         # Episode-average counters of this very workload from committed rocprofv3 PMC passes (profiles/<tag>_<scene>_*.json).  They
         # describe the whole 200-step episode, which is what both kinds of timed region measure or estimate; they are attached
         # only for the workload they were collected on.
-        attach = n == 4096 and pipe == "rows" and not args.with_regressor
+        attach = n == 4096 and pipe in ("rows", "tree") and not args.with_regressor
         tp = os.path.join(ROOT, "profiles", "%s_%s_hbm_traffic.json" % (PROFILE_TAG, args.scene))
         if attach and os.path.exists(tp):
             res["roofline"]["traffic"] = json.load(open(tp))["per_sg_step_call_bytes"]
             res["roofline"]["traffic_source"] = ("profiles/%s: episode average per sg_step call (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; gfx950 x2 "
-                                                 "correction on the 16-B-per-lane reads of the PGS kernel; fabric-side: Infinity-Cache hits included)" % os.path.basename(tp))
+                                                 "correction on the 16-B-per-lane reads of the PGS kernel, none on the tree kernel's 8-B reads; fabric-side: Infinity-Cache hits included)" % os.path.basename(tp))
         sp = os.path.join(ROOT, "profiles", "%s_%s_sq_totals.json" % (PROFILE_TAG, args.scene))
         if attach and os.path.exists(sp):
             # secondary roofline (the binding limit is instruction issue, not HBM): VALU wavefront-instructions per env
@@ -384,7 +384,9 @@ def main():
                 "valu_insts_per_env_step": sq["SQ_INSTS_VALU"], "salu_insts_per_env_step": sq["SQ_INSTS_SALU"],
                 "lds_insts_per_env_step": sq["SQ_INSTS_LDS"],
                 "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_*, own pass, episode average); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per "
-                          "fp64 wavefront instruction; the PGS kernel runs one wavefront per SIMD (1024 at 4096 envs: 4 envs per wavefront) and a wavefront alone on its SIMD issues one instruction per ~7-8 cycles, so ~0.5 is this design's ceiling for it" % os.path.basename(sp)}
+                          "fp64 wavefront instruction; %s" % (os.path.basename(sp),
+                          "the tree kernel runs one env per wavefront, two workgroups per CU (half the SIMDs), one instruction per ~7 cycles: ~0.25 is its ceiling at this occupancy" if pipe == "tree" else
+                          "the PGS kernel runs one wavefront per SIMD (1024 at 4096 envs: 4 envs per wavefront) and a wavefront alone on its SIMD issues one instruction per ~7-8 cycles, so ~0.5 is this design's ceiling for it")}
         if world == 1 and nb_on and not args.fake_native_for_tests and not args.no_fix_variant and not args.with_regressor and args.scene.endswith(("softbox", "softball", "softcylinder")):
             # labelled secondary: the same workload on the fix-rows-only model (composite_neighbors=False)
             del R

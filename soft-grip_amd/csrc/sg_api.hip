@@ -295,7 +295,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
     if (!ok) { sg_batch_destroy(b); return fail(SG_ERR_NOMEM, "hipMalloc (split-pipeline workspace)"); }
     const char* pm = getenv("SG_PIPELINE");
     b->pipeline = (pm && strcmp(pm, "fused") == 0) ? 0 : (pm && strcmp(pm, "split") == 0) ? 1 : (pm && strcmp(pm, "tree") == 0 && m->has_tree) ? 3 : 2;
-    if (H.nnb > 0) b->pipeline = 2;  // neighbour equality rows exist in the rows pipeline only
+    if (H.nnb > 0 && b->pipeline != 3) b->pipeline = 2;  // neighbour equality rows: the rows pipeline (or the tree pipeline when asked for)
   }
   if (m->has_fast && H.nnb > 0) {
     std::vector<SgEqSlot> sch = m->plan.sched;
