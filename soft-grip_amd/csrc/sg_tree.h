@@ -8,11 +8,16 @@
 //   * a dense mass-matrix block per finger chain (<= 24 x 24) with MuJoCo's L'DL, its inverse by columns; the composite's sliders
 //     are 1 x 1 blocks;
 //   * A = J M^-1 J' is never formed: a constraint row keeps J and W = M^-1 J', the sweep keeps the accelerations a = M^-1 J' f;
-//   * the equality / limit rows of the sliders commute among themselves (each touches its own slider): one row per lane;
-//     a chain's limit rows run serially on one lane per chain; contacts run serially in mj_collision's order, the lanes of the
-//     wavefront spread over the dofs of the contact's chain block(s);
+//   * the joint-fix / limit rows of the sliders commute among themselves (each touches its own slider): one row per lane; with the
+//     composite's neighbour equalities the equality BLOCKS [fix_e, e's neighbour rows] run by the plan's list schedule, 64 blocks a
+//     round; a chain's limit rows run serially on one lane per chain; contacts run as one stream per chain (they commute across
+//     chains unless they share a slider) or, when they do not, serially in mj_collision's order with the lanes of the wavefront
+//     spread over the dofs of the contact's chain block(s);
 //   * collision walks the plan's candidate-pair table (SgPlan::gpairs = mj_collision's pair order) 64 pairs at a time:
-//     bounding tests per lane, hits ranked by pair index, one lane per hit in the narrowphase (sg_math.h / sg_general.h).
+//     bounding tests per lane, hits ranked by pair index, one lane per hit in the narrowphase (sg_math.h / sg_general.h);
+//   * a FREE OBJECT (reference data/gripper/soft_experiments_softball.xml:8: the composite on a body with a free joint) is an object
+//     block with an arrow-shaped mass matrix, solved through a 6 x 6 Schur complement in the body's frame; its joint-fix rows run one
+//     after the other (every one moves the body), its contacts carry six object columns.
 //
 // The code is BULK-SYNCHRONOUS: parallel loops over work items (SGT_PAR), single-lane sections (SGT_ONE) and barriers (SGT_SYNC)
 // between them; lanes talk through the env's LDS block and its global work space only.  That is what lets tests/emu run the very

@@ -11,7 +11,9 @@
 //   * accelerometers / gyros on chain sites;
 //   * the composite ELEMENTS, their equalities, the static geoms and the candidate-pair table exactly as in SgPlan (sg_plan.h) --
 //     the tree plan is an SgPlan whose header has nchain = 0 plus this table.  Element sliders may be limited here
-//     (the four-finger file's <joint limited="true"/> default reaches the composite's sliders).
+//     (the four-finger file's <joint limited="true"/> default reaches the composite's sliders), the composite may sit on a body
+//     with a free joint (SgPlanHeader::has_free: soft_experiments_softball.xml), and the neighbour equalities are scheduled 64 blocks
+//     a round (SgPlanHeader::eq_slots).
 // Everything is a fixed-size POD so that one hipMemcpy puts it on the device.
 #pragma once
 
