@@ -747,6 +747,7 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
       FAIL("unsupported static geom type");
     }
   }
+  if (H.has_free && H.nlimited_elem > 0) FAIL("limited sliders on a free object are not built (the object block sweeps joint-fix rows only)");
   if (H.has_free) {   // the free body's own geoms: the composite's centre sphere (its position stays LOCAL to the body)
     for (int k = 0; k < body_geomnum[free_body]; k++) {
       const int g = body_geomadr[free_body] + k;
