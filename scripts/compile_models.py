@@ -39,11 +39,12 @@ if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "models"), exist_ok=True)
     import tempfile
     # the free-floating ball (reference data/gripper/soft_experiments_softball.xml: <freejoint/> on the composite's body)
-    m = sg.compile_mjcf(os.path.join(REF, "soft_experiments_softball.xml"), composite_neighbors=False)
-    out = os.path.join(ROOT, "models", "freeball_fix.sgmodel")
-    with open(out, "wb") as f:
-        f.write(m.to_blob())
-    print("freeball_fix nq", m.nq, "nv", m.nv, "neq", m.neq, "->", out, os.path.getsize(out), "bytes")
+    for suffix, nb in (("_fix", False), ("", True)):
+        m = sg.compile_mjcf(os.path.join(REF, "soft_experiments_softball.xml"), composite_neighbors=nb)
+        out = os.path.join(ROOT, "models", "freeball" + suffix + ".sgmodel")
+        with open(out, "wb") as f:
+            f.write(m.to_blob())
+        print("freeball" + suffix, "nq", m.nq, "nv", m.nv, "neq", m.neq, "->", out, os.path.getsize(out), "bytes")
     with tempfile.TemporaryDirectory() as tmp:   # the four-finger gripper (tree pipeline)
         for suffix, nb in (("_fix", False), ("", True)):   # fix rows only / with the composite's neighbour equalities (651 rows)
             m = sg.compile_mjcf(fourfinger_scene(tmp), composite_neighbors=nb)

@@ -530,7 +530,6 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
   }
   H.nnb = neq - 1 - nelem;
   H.eq_rounds = 0;
-  if (tree && H.nnb > 0 && H.has_free) FAIL("the tree pipeline runs a free object with fix rows only (compile the scene without the composite's neighbour equalities)");
   const int eq_slots = tree ? 64 : SG_EQ_SLOTS;   // blocks per round: a lane each in the tree pipeline, a lane pair of the 16-lane group in the solver
   H.eq_slots = eq_slots;
   if (H.nnb > 0) {

@@ -88,7 +88,7 @@ struct Lds {
   double *qe, *ve, *we, *asme, *ae, *fse, *ffix, *bfix, *Rfix, *flim, *blim, *Rlim, *ke;
   double *einvm, *ecoef, *ecen, *Ifix, *Ilim;   // 1 / (m + armature), tendon coefficient, capsule centres [3][N], 1 / (A + R) of the fix / limit rows
   double *lrow, *seg, *chs, *cf, *red;
-  double *nbf, *nbb, *nbR, *nbI;   // neighbour equality rows by slot d * N + e (the d-th row registered for element e): force, b, R, 1 / (A + R)
+  double *nbf, *nbb, *nbR, *nbI, *nbA;   // neighbour equality rows by slot d * N + e (the d-th row registered for element e): force, b, R, 1 / (A + R); free object: A + R
   double *frow;   // free object: the joint-fix rows' constants for the serial sweep, [N][5]: b, R, A + R, 1 / (A + R), 1 / D
   double *of, *Be, *Ce, *Afix;   // free object (plans with has_free): scalars (OF_*), B_e [N][6], C_e = -S^-1 B_e / D_e [N][6], the fix rows' diagonals A + R
   int *hit_pair, *hit_sorted, *hit_cnt, *hit_off, *con_src, *con_chain, *icnt;
@@ -122,6 +122,7 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
   L.of = take(has_free ? OF_N : 0); L.Be = take(has_free ? 6 * N : 0); L.Ce = take(has_free ? 6 * N : 0); L.Afix = takeg(has_free ? N : 0);
   L.frow = take(has_free ? 5 * N : 0);
   L.nbf = takeg(nnb ? 3 * N : 0); L.nbb = takeg(nnb ? 3 * N : 0); L.nbR = takeg(nnb ? 3 * N : 0); L.nbI = takeg(nnb ? 3 * N : 0);
+  L.nbA = takeg((nnb && has_free) ? 3 * N : 0);
   if (gdoubles) *gdoubles = (size_t)(g - gbase);
   int* ip = (int*)p;
   L.hit_pair = ip; ip += SGT_MAXHIT;
@@ -310,6 +311,43 @@ static SGT_NOINLINE double free_fix_rows(const SGT_LDSP double* frow, const SGT_
     ffix[e] = f;
     ae[e] = ael + r5[4] * dfl;
     for (int q = 0; q < 6; q++) af6[q] += C6[q] * dfl;
+  }
+  for (int q = 0; q < 6; q++) af[q] = af6[q];
+  return imp;
+}
+// The same with the composite's neighbour equalities: the equality BLOCKS [fix_e, e's neighbour rows (partner p: J = +1 on e, -1 on p)] in
+// mj_solPGS's order.  A neighbour row moves two sliders and, through both, the body: a_f += (C_e - C_p) df.  (The neighbour rows' words
+// sit in the work space: generic pointers.)
+static SGT_NOINLINE double free_eq_blocks(const SGT_LDSP double* frow, const SGT_LDSP double* Be, const SGT_LDSP double* Ce, SGT_LDSP double* ffix, SGT_LDSP double* ae,
+                                          SGT_LDSP double* af, int N, const int* nbtab, double* nbf, const double* nbb, const double* nbR, const double* nbA,
+                                          const double* nbI) {
+  double af6[6], imp = 0;
+  for (int q = 0; q < 6; q++) af6[q] = af[q];
+  for (int e = 0; e < N; e++) {
+    double B6[6], C6[6];
+    for (int q = 0; q < 6; q++) { B6[q] = Be[6 * e + q]; C6[q] = Ce[6 * e + q]; }
+    const double invm = frow[5 * e + 4];
+    double f = ffix[e], old = f, ael = ae[e];
+    imp -= scalar_update_rcp(f, frow[5 * e], ael - dot6(B6, af6) * invm, frow[5 * e + 1], frow[5 * e + 2], frow[5 * e + 3], false);
+    double dfl = f - old;
+    ffix[e] = f;
+    ael += invm * dfl;
+    for (int q = 0; q < 6; q++) af6[q] += C6[q] * dfl;
+    for (int d = 0; d < 3; d++) {
+      const int k = d * N + e, pe = nbtab[k];
+      if (pe < 0) continue;
+      double Bp[6], Cp[6];
+      for (int q = 0; q < 6; q++) { Bp[q] = Be[6 * pe + q]; Cp[q] = Ce[6 * pe + q]; }
+      const double ipm = frow[5 * pe + 4], apl = ae[pe];
+      f = nbf[k]; old = f;
+      imp -= scalar_update_rcp(f, nbb[k], (ael - dot6(B6, af6) * invm) - (apl - dot6(Bp, af6) * ipm), nbR[k], nbA[k], nbI[k], false);
+      dfl = f - old;
+      nbf[k] = f;
+      ael += invm * dfl;
+      ae[pe] = apl - ipm * dfl;
+      for (int q = 0; q < 6; q++) af6[q] += (C6[q] - Cp[q]) * dfl;
+    }
+    ae[e] = ael;
   }
   for (int q = 0; q < 6; q++) af[q] = af6[q];
   return imp;
@@ -979,7 +1017,16 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           const double aref = -H.eqj_B * (S.ve[e] - S.ve[pe]) - H.eqj_K * imp * pos;
           b = (S.asme[e] - S.asme[pe]) - aref;
           f = -((S.we[e] - S.we[pe]) - aref) / R;
-          I = 1.0 / (S.einvm[e] + S.einvm[pe] + R);
+          double Arow = S.einvm[e] + S.einvm[pe];
+          if (FR) {   // through the body too: [M^-1]_ee + [M^-1]_pp - 2 [M^-1]_ep, [M^-1]_xy = delta_xy / D_x + B_x' S^-1 B_y / (D_x D_y)
+            double Se[6], Sp[6];
+            mat6vec(Se, S.of + OF_SINV, S.Be + 6 * e);
+            mat6vec(Sp, S.of + OF_SINV, S.Be + 6 * pe);
+            const double ie = S.einvm[e], ip = S.einvm[pe];
+            Arow += dot6(S.Be + 6 * e, Se) * ie * ie + dot6(S.Be + 6 * pe, Sp) * ip * ip - 2 * dot6(S.Be + 6 * e, Sp) * ie * ip;
+            S.nbA[k] = Arow + R;
+          }
+          I = 1.0 / (Arow + R);
         }
         S.nbR[k] = R; S.nbb[k] = b; S.nbf[k] = f; S.nbI[k] = I;
       }
@@ -1266,7 +1313,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       }
       if (NB) SGT_PAR(k, 3 * N) {
         const int pe = A.nbtab[k];
-        if (pe >= 0) cost += S.nbf[k] * (0.5 * ((S.ae[k % N] - S.ae[pe]) + S.nbR[k] * S.nbf[k]) + S.nbb[k]);
+        if (pe >= 0) cost += S.nbf[k] * (0.5 * ((slider_acc(k % N) - slider_acc(pe)) + S.nbR[k] * S.nbf[k]) + S.nbb[k]);
       }
       SGT_PAR(c, K) {
         const double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
@@ -1315,7 +1362,11 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       if (FR) {
         // with a free object a joint-fix row moves the body and through it every slider: the rows run one after the other (mj_solPGS's
         // order), the body's acceleration a_f in registers, a row's own slider from its local part and a_f
-        SGT_ONE {
+        if (NB) SGT_ONE {
+          S.red[0] = free_eq_blocks((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.Ce, (SGT_LDSP double*)S.ffix,
+                                    (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N, A.nbtab, S.nbf, S.nbb, S.nbR, S.nbA, S.nbI);
+        }
+        if (!NB) SGT_ONE {
           S.red[0] = free_fix_rows((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.Ce, (SGT_LDSP double*)S.ffix,
                                    (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N);
         }

@@ -128,12 +128,43 @@ def test_default_softbox_first_steps_free_running():
     np.testing.assert_allclose(e.qpos, s.qpos, atol=1e-10)
 
 
-@pytest.mark.skipif(not __import__("os").path.exists("/root/reference/data/gripper/soft_experiments_softball.xml"), reason="needs the reference's MJCF files (build container only)")
 def test_tree_plan_refuses_what_it_cannot_run():
-    m = sg.compile_mjcf("/root/reference/data/gripper/soft_experiments_softball.xml")       # a free object WITH neighbour equalities
+    m = sg.load_model(model_path("fourfinger_softball_fix"), "implicit")
+    m.jnt_type = m.jnt_type.copy()
+    m.jnt_type[3] = 2                      # a slide joint in a finger chain
     with pytest.raises(RuntimeError) as ei:
         TreeEmu(m)
-    assert "fix rows only" in str(ei.value)
+    assert "hinge" in str(ei.value)
+
+
+def test_free_ball_with_neighbour_equalities():
+    """models/freeball.sgmodel: the free-floating ball as MuJoCo's documentation describes the composite (651 equality rows) -- the
+    equality blocks [fix_e, e's neighbour rows] swept one after the other with the body's acceleration carried along, a neighbour row
+    pushing the body through both of its sliders -- along the oracle's trajectory for 100 env steps: sensors, contact, row and sweep
+    counts"""
+    m = sg.load_model(model_path("freeball"), "implicit")
+    assert m.neq == 651 and m.has_free_joint
+    jids = list(range(9, 227))
+    s = oracle_sim(m)
+    s.jnt_stiffness[jids] = 700.0
+    s.tendon_stiffness[0] = 700.0
+    s.reset(); s.forward(); s.step()
+    e = TreeEmu(m)
+    e.set_stiffness(700.0, jids, [0])
+    assert e.reset(1) == 0
+    np.testing.assert_allclose(e.qvel, s.qvel, atol=1e-12)
+    worst = 0.0
+    for t, c in enumerate(episode_schedule()[:100]):
+        if c is not None:
+            e.ctrl[:] = c
+            s.ctrl[:] = c
+        e.qpos[:] = s.qpos; e.qvel[:] = s.qvel; e.warm[:] = s.qacc_warmstart; e.act[:] = s.act
+        for _ in range(7):
+            assert s.step() == 0
+        assert e.step(7) == 0
+        assert (e.ncon, e.nefc, e.iters) == (s.ncon, s.nefc, s.solver_iter), t
+        worst = max(worst, np.abs(e.sensordata - s.sensordata).max())
+    assert worst < 1e-8, worst
 
 
 # ---- every pair kind of the candidate-pair table, and the serial contact list (a slider under both fingers, both chains in one row) ----
