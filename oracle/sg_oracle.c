@@ -934,7 +934,12 @@ static void add_row(sgo_data* d, int type, int id, double pos, double margin, in
   d->efc_type[r] = type; d->efc_id[r] = id; d->efc_pos[r] = pos; d->efc_margin[r] = margin;
   int k = 0;
   for (int i = 0; i < nnz; i++)
-    if (val[i] != 0.0) { d->J_col[a + k] = col[i]; d->J_val[a + k] = val[i]; k++; }
+    if (val[i] != 0.0) {
+      int j = 0; /* a contact between two bodies of one chain names their common dofs twice: one entry per column (mj_jacDifPair) */
+      while (j < k && d->J_col[a + j] != col[i]) j++;
+      if (j < k) { d->J_val[a + j] += val[i]; continue; }
+      d->J_col[a + k] = col[i]; d->J_val[a + k] = val[i]; k++;
+    }
   d->J_rowadr[r + 1] = a + k;
   d->nefc = r + 1;
 }

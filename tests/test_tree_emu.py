@@ -304,3 +304,174 @@ def test_reference_free_ball_scene_free_running():
         worst = max(worst, np.abs(e.sensordata - s.sensordata).max())
     assert worst < 1e-7, worst
     np.testing.assert_allclose(e.qpos, s.qpos, atol=1e-8)
+
+
+# ---- fuzzing the tree class: random grippers against the oracle ----
+def random_gripper_xml(rng, free=False):
+    """a random member of the tree pipeline's model class: 1 - 4 fingers around the object, 1 - 5 links each with 1 - 3 hinges and 1 - 2
+    boxes per link, a tendon through a random subset of the links' sites (>= 2 sites, the base's first), an actuator on it, an
+    accelerometer + gyro pair on a random link; a box / ellipsoid / cylinder shell, optionally on a free joint; random time step, sweep
+    count, masses, ranges"""
+    nf = rng.randint(1, 5)
+    angles = rng.permutation(4)[:nf] * (np.pi / 2) + rng.uniform(-0.2, 0.2, nf)
+    fingers, tendons, acts, sens = [], [], [], []
+    for f in range(nf):
+        nl = rng.randint(1, 6)
+        ca, sa = np.cos(angles[f]), np.sin(angles[f])
+        # a finger starts on a ring around the object and points down along -z with its flexion axis tangent to the ring
+        body = '<body pos="%.4g %.4g 0.9" quat="%.6g 0 0 %.6g">\n' % (1.2 + 0.75 * ca, 0.75 * sa, np.cos(angles[f] / 2), np.sin(angles[f] / 2))
+        sites = []
+        depth = 0
+        for l in range(nl):
+            length = rng.uniform(0.25, 0.45)
+            body += '  ' * l + '<body pos="0 0 %.4g">\n' % (-0.1 if l == 0 else -lengths_prev)
+            nj = rng.randint(1, 4)
+            axes = ["0 1 0", "1 0 0", "0 0 1"]
+            for j in range(nj):
+                lo, hi = (-0.6, 0.15) if j == 0 else (-0.03, 0.03)
+                body += '  ' * l + '  <joint type="hinge" axis="%s" limited="true" range="%.4g %.4g" stiffness="%.3g" damping="%.3g"/>\n' % (
+                    axes[j], lo * rng.uniform(.7, 1.2), hi * rng.uniform(.7, 1.2), rng.choice([0, 4, 9]), rng.choice([0, 5, 20]))
+            for g in range(rng.randint(1, 3)):
+                body += '  ' * l + '  <geom class="link" name="f%dl%dg%d" pos="%.4g 0 %.4g" size="%.4g %.4g %.4g" mass="%.4g"/>\n' % (
+                    f, l, g, -0.07 * g, -length / 2, rng.uniform(0.04, 0.08), rng.uniform(0.12, 0.2), length / 2, rng.uniform(0.03, 0.1))
+            body += '  ' * l + '  <site name="s%d_%d" pos="-0.12 0 %.4g"/>\n' % (f, l, -length / 2)
+            sites.append("s%d_%d" % (f, l))
+            lengths_prev = length
+            depth += 1
+        body += ''.join('  ' * (depth - 1 - l) + '</body>\n' for l in range(depth)) + '</body>\n'
+        fingers.append(body)
+        keep = [s for s in sites if rng.rand() < 0.7] or sites[-1:]
+        tendons.append('<spatial name="t%d"><site site="anchor%d"/>%s</spatial>' % (f, f, "".join('<site site="%s"/>' % s for s in keep)))
+        acts.append('<cylinder tendon="t%d" area="%.4g"/>' % (f, rng.uniform(150, 350)))
+        imu = sites[rng.randint(len(sites))]
+        sens.append('<accelerometer name="acc%d" site="%s"/>' % (f, imu))
+        sens.append('<gyro name="gyr%d" site="%s"/>' % (f, imu))
+    anchors = "".join('<site name="anchor%d" pos="%.4g %.4g 1.35"/>' % (f, 1.2 + 0.5 * np.cos(angles[f]), 0.5 * np.sin(angles[f])) for f in range(nf))
+    ctype = ["box", "ellipsoid", "cylinder"][rng.randint(3)]
+    return """<mujoco model="random gripper (tests/test_tree_emu.py)">
+  <compiler angle="radian" inertiafromgeom="auto" settotalmass="%.4g"/>
+  <option timestep="%.4g" solver="PGS" iterations="%d" tolerance="1e-7" cone="elliptic"/>
+  <size nconmax="300" njmax="3000"/>
+  <default><geom density="1"/><site size="0.01"/><default class="link"><geom type="box" contype="1" conaffinity="1"/></default></default>
+  <worldbody>
+    <geom name="ground" type="plane" size="0 0 1" condim="1"/>
+    <body pos="0 0 0">%s<geom class="link" name="roof" pos="1.2 0 1.5" size="0.9 0.9 0.04" mass="0.2"/>
+%s    </body>
+    <body pos="1.2 0 %.4g">%s
+      <composite prefix="OBJ" type="%s" count="%d %d %d" spacing="%.4g">
+        <geom type="capsule" size=".07 0.05" mass="0.001" contype="0" conaffinity="1"/>
+        <joint kind="main" stiffness="500" damping="%.4g" solreffix="-100 -10" solimpfix="0.9 0.97 0.000001 0.9 2"/>
+        <tendon kind="main" stiffness="500" damping="2" solreffix="-100 -10" solimpfix="0.9 0.97 0.000001 0.9 2"/>
+      </composite>
+    </body>
+  </worldbody>
+  <tendon>%s</tendon>
+  <actuator>%s</actuator>
+  <sensor>%s</sensor>
+</mujoco>
+""" % (rng.uniform(0.3, 0.6), rng.uniform(0.003, 0.005), rng.randint(10, 31), anchors, "".join(fingers), rng.uniform(0.3, 0.5),
+       "<freejoint/>" if free else "", ctype, rng.randint(3, 5), rng.randint(3, 5), rng.randint(3, 5), rng.uniform(0.13, 0.18), rng.uniform(30, 90),
+       "".join(tendons), "".join(acts), "".join(sens))
+
+
+@pytest.mark.parametrize("free,neighbors", [(False, False), (False, True), (True, False), (True, True)])
+def test_random_grippers_step_by_step(tmp_path, free, neighbors):
+    """16 seeded random grippers of the tree class per variant (object fixed / on a free joint, fix rows only / with the composite's
+    neighbour equalities), 40 env steps of the squeeze schedule each, along the oracle's trajectory, re-seated after every SUBSTEP: a
+    random scene need not be a stable one (seed 20's third gripper multiplies a perturbation by 5 every substep until it is flagged:
+    1e-15 in a position is 1e-6 in an accelerometer seven substeps later, on both sides alike), so the comparison is of one substep's
+    arithmetic at a time -- sensors, positions, velocities, contact / row / sweep counts.  A scene whose random geometry leaves the
+    class (too many contacts at once) or blows up may be flagged -- by BOTH sides, in the same substep, or not at all."""
+    rng = np.random.RandomState(20 + 2 * int(free) + int(neighbors))
+    touched = ran = 0
+    for i in range(16):
+        path = tmp_path / ("g%d.xml" % i)
+        path.write_text(random_gripper_xml(rng, free))
+        m = sg.compile_mjcf(str(path), composite_neighbors=neighbors)
+        nchain = int(np.flatnonzero(m.jnt_type != 3)[0])          # joints before the first non-hinge one: the fingers'
+        jids = [j for j in range(nchain, m.njnt) if m.jnt_type[j] == 2]
+        s = oracle_sim(m)
+        k = rng.uniform(300, 1400)
+        s.jnt_stiffness[jids] = k
+        s.tendon_stiffness[0] = k
+        s.reset(); s.forward(); s.step()
+        e = TreeEmu(m)
+        e.set_stiffness(k, jids, [0])
+        assert e.reset(1) == 0, i
+        np.testing.assert_allclose(e.qvel, s.qvel, atol=1e-9, err_msg=str(i))
+        most, flagged, errs = 0, False, [0.0]
+        for t, c in enumerate(episode_schedule()[:40]):
+            if c is not None:
+                e.ctrl[:] = c
+                s.ctrl[:] = c
+            for j in range(7):
+                e.qpos[:] = s.qpos; e.qvel[:] = s.qvel; e.warm[:] = s.qacc_warmstart; e.act[:] = s.act
+                w, f = s.step(), e.step(1)
+                if w or f:
+                    # both flag the scene, or neither -- but for the kernel's own capacity (SGT_MAXCON = 128 contacts an env;
+                    # the oracle holds the model's nconmax = 300), which it reports as CONTACTFULL
+                    assert (w and f) or (f == 8 and s.ncon > 128), (i, t, j, w, f, s.ncon)
+                    flagged = True
+                    break
+                assert (e.ncon, e.nefc, e.iters) == (s.ncon, s.nefc, s.solver_iter), (i, t, j)
+                scale = 1.0 + np.abs(s.sensordata).max()
+                err = max(np.abs(e.sensordata - s.sensordata).max(), np.abs(e.qvel - s.qvel).max(), 100 * np.abs(e.qpos - s.qpos).max()) / scale
+                assert err < 1e-7, (i, t, j, err)     # (a sweep that stops at the iteration cap next to a cone boundary: 2e-9 seen once)
+                errs.append(err)
+                most = max(most, s.ncon)
+            if flagged:
+                break
+        else:
+            ran += 1
+        assert np.percentile(errs, 95) < 1e-10, (i, np.percentile(errs, 95))   # the rule: one substep's arithmetic agrees to 1e-10 of the signal
+        touched += most > 0
+    assert ran >= 12 and touched >= 8, (ran, touched)
+
+
+def test_oracle_same_chain_contact_block_against_numpy(tmp_path):
+    """A contact between two boxes of ONE finger (links 2 and 5 of a curled chain) names the dofs they share twice in the oracle's
+    sparse row; the fuzz above found the oracle's A = J M^-1 J' + R using only one of the two entries (the kernel source had it
+    right).  The oracle's block is checked against dense numpy algebra on the host compiler's mass matrix and Jacobians."""
+    rng = np.random.RandomState(20)
+    for _ in range(7):
+        xml = random_gripper_xml(rng, False)
+        k = rng.uniform(300, 1400)
+    path = tmp_path / "g.xml"
+    path.write_text(xml)
+    m = sg.compile_mjcf(str(path), composite_neighbors=False)
+    nchain = int(np.flatnonzero(m.jnt_type != 3)[0])
+    jids = [j for j in range(nchain, m.njnt) if m.jnt_type[j] == 2]
+    s = oracle_sim(m)
+    s.jnt_stiffness[jids] = k
+    s.tendon_stiffness[0] = k
+    s.reset(); s.forward(); s.step()
+    sched = episode_schedule()
+    seen = 0
+    for t in range(3):
+        if sched[t] is not None:
+            s.ctrl[:] = sched[t]
+        for _ in range(7):
+            q = s.qpos.copy()
+            assert s.step() == 0
+            AR, b, ty, ids, mu = s.constraint_problem()
+            for ci, cd in enumerate(s.contacts()):
+                b1, b2 = int(m.geom_bodyid[cd["geom1"]]), int(m.geom_bodyid[cd["geom2"]])
+                if not (0 < b1 < b2 and b2 < nchain):
+                    continue
+                anc = b2
+                while anc > b1:
+                    anc = int(m.body_parentid[anc])
+                if anc != b1:
+                    continue                 # not on one chain
+                rows = np.flatnonzero((ids == ci) & (ty == ty.max()))
+                M, _ = m.mass_matrix(q)
+                kin = m.kinematics(q)
+                F = cd["frame"].reshape(3, 3)
+                J = F @ (m._jac_point(kin, b2, cd["pos"])[0] - m._jac_point(kin, b1, cd["pos"])[0])
+                A = J @ np.linalg.solve(M, J.T)
+                got = AR[np.ix_(rows, rows)]
+                assert np.abs(got - np.diag(np.diag(got)) - (A - np.diag(np.diag(A)))).max() < 1e-9 * np.abs(A).max()
+                R = np.diag(got) - np.diag(A)
+                assert (R > 0).all() and np.ptp(R) < 1e-9 * R[0]     # what is left on the diagonal is the regulariser (impratio 1, equal friction)
+                seen += 1
+    assert seen >= 4
