@@ -287,3 +287,62 @@ def test_datasets_from_the_four_finger_and_the_free_ball_scenes(tmp_path):
             for _ in range(7):
                 assert s.step() == 0
             assert np.abs(X[0, t] - s.sensordata).max() < 1e-6, (scene, t)
+
+
+@pytest.mark.parametrize("free,neighbors", [(False, False), (False, True), (True, False), (True, True)])
+def test_random_grippers_on_the_gpu(tmp_path, free, neighbors):
+    """the CPU fuzz of tests/test_tree_emu.py on the device: 10 seeded random grippers per variant (1 - 4 fingers, 1 - 5 links, other chain
+    strides, LDS layouts and workgroup counts per CU than the committed scenes), 3 envs over the stiffness range each, 40 env steps
+    re-seated on the oracles after every substep; counts exact, sensors / velocities to 1e-7 of the signal (95 % of the substeps to
+    1e-10); a scene that leaves the class or blows up is flagged by both sides in the same substep (or by the kernel alone for its own
+    capacity of 128 contacts)"""
+    from helpers import random_gripper_xml
+    torch = _torch()
+    rng = np.random.RandomState(40 + 2 * int(free) + int(neighbors))
+    ran = 0
+    for i in range(10):
+        path = tmp_path / ("g%d.xml" % i)
+        path.write_text(random_gripper_xml(rng, free))
+        m = sg.compile_mjcf(str(path), composite_neighbors=neighbors)
+        nchain = int(np.flatnonzero(m.jnt_type != 3)[0])
+        jids = [j for j in range(nchain, m.njnt) if m.jnt_type[j] == 2]
+        ks = list(rng.uniform(300, 1400, 3))
+        nm, b, sens, flags = _batch(m, ks, jids, [0])
+        sims = _oracles(m, ks, jids, [0])
+        b.reset(1, sens=sens, flags=flags)
+        assert int(flags.abs().sum()) == 0, i
+        dev = dict(device=b.device, dtype=torch.float64)
+        errs, stop = [0.0], False
+        for t, c in enumerate(episode_schedule()[:40]):
+            if c is not None:
+                b.set_ctrl_broadcast(np.full(m.nu, c))
+                for s in sims:
+                    s.ctrl[:] = c
+            for j in range(7):
+                b.set_state(qpos=torch.tensor(np.stack([s.qpos for s in sims]), **dev), qvel=torch.tensor(np.stack([s.qvel for s in sims]), **dev),
+                            act=torch.tensor(np.stack([s.act for s in sims]), **dev),
+                            qacc_warmstart=torch.tensor(np.stack([s.qacc_warmstart for s in sims]), **dev))
+                w = [s.step() for s in sims]
+                b.step(1, sens=sens, flags=flags)
+                f = flags.cpu().numpy()
+                if any(w) or f.any():
+                    for e in range(3):
+                        assert (bool(w[e]) == bool(f[e])) or (f[e] == 8 and not w[e] and sims[e].ncon > 128), (i, t, j, e, w, f)
+                    stop = True
+                    break
+                got, st = sens.cpu().numpy(), b.get_state()
+                stats = {k: v.cpu().numpy() for k, v in b.solver_stats().items()}
+                qv = st["qvel"].cpu().numpy()
+                for e, s in enumerate(sims):
+                    assert (stats["ncon"][e], stats["nefc"][e], stats["iters"][e]) == (s.ncon, s.nefc, s.solver_iter), (i, t, j, e)
+                    scale = 1.0 + np.abs(s.sensordata).max()
+                    err = max(np.abs(got[e] - s.sensordata).max(), np.abs(qv[e] - s.qvel).max()) / scale
+                    assert err < 1e-7, (i, t, j, e, err)
+                    errs.append(err)
+            if stop:
+                break
+        else:
+            ran += 1
+        assert np.percentile(errs, 95) < 1e-10, (i, np.percentile(errs, 95))
+        del b, nm
+    assert ran >= 6, ran

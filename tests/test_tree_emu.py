@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import softgrip_amd as sg
-from helpers import JOINT_IDS, TENDON_IDS, TreeEmu, model_path, oracle_sim
+from helpers import JOINT_IDS, TENDON_IDS, TreeEmu, model_path, oracle_sim, random_gripper_xml
 from softgrip_amd.create_dataset import episode_schedule
 
 FF_JOINTS = list(range(65, 283))      # reference environment/manenv.py:11 (commented four-finger ids): the ball's sliders
@@ -307,73 +307,6 @@ def test_reference_free_ball_scene_free_running():
 
 
 # ---- fuzzing the tree class: random grippers against the oracle ----
-def random_gripper_xml(rng, free=False):
-    """a random member of the tree pipeline's model class: 1 - 4 fingers around the object, 1 - 5 links each with 1 - 3 hinges and 1 - 2
-    boxes per link, a tendon through a random subset of the links' sites (>= 2 sites, the base's first), an actuator on it, an
-    accelerometer + gyro pair on a random link; a box / ellipsoid / cylinder shell, optionally on a free joint; random time step, sweep
-    count, masses, ranges"""
-    nf = rng.randint(1, 5)
-    angles = rng.permutation(4)[:nf] * (np.pi / 2) + rng.uniform(-0.2, 0.2, nf)
-    fingers, tendons, acts, sens = [], [], [], []
-    for f in range(nf):
-        nl = rng.randint(1, 6)
-        ca, sa = np.cos(angles[f]), np.sin(angles[f])
-        # a finger starts on a ring around the object and points down along -z with its flexion axis tangent to the ring
-        body = '<body pos="%.4g %.4g 0.9" quat="%.6g 0 0 %.6g">\n' % (1.2 + 0.75 * ca, 0.75 * sa, np.cos(angles[f] / 2), np.sin(angles[f] / 2))
-        sites = []
-        depth = 0
-        for l in range(nl):
-            length = rng.uniform(0.25, 0.45)
-            body += '  ' * l + '<body pos="0 0 %.4g">\n' % (-0.1 if l == 0 else -lengths_prev)
-            nj = rng.randint(1, 4)
-            axes = ["0 1 0", "1 0 0", "0 0 1"]
-            for j in range(nj):
-                lo, hi = (-0.6, 0.15) if j == 0 else (-0.03, 0.03)
-                body += '  ' * l + '  <joint type="hinge" axis="%s" limited="true" range="%.4g %.4g" stiffness="%.3g" damping="%.3g"/>\n' % (
-                    axes[j], lo * rng.uniform(.7, 1.2), hi * rng.uniform(.7, 1.2), rng.choice([0, 4, 9]), rng.choice([0, 5, 20]))
-            for g in range(rng.randint(1, 3)):
-                body += '  ' * l + '  <geom class="link" name="f%dl%dg%d" pos="%.4g 0 %.4g" size="%.4g %.4g %.4g" mass="%.4g"/>\n' % (
-                    f, l, g, -0.07 * g, -length / 2, rng.uniform(0.04, 0.08), rng.uniform(0.12, 0.2), length / 2, rng.uniform(0.03, 0.1))
-            body += '  ' * l + '  <site name="s%d_%d" pos="-0.12 0 %.4g"/>\n' % (f, l, -length / 2)
-            sites.append("s%d_%d" % (f, l))
-            lengths_prev = length
-            depth += 1
-        body += ''.join('  ' * (depth - 1 - l) + '</body>\n' for l in range(depth)) + '</body>\n'
-        fingers.append(body)
-        keep = [s for s in sites if rng.rand() < 0.7] or sites[-1:]
-        tendons.append('<spatial name="t%d"><site site="anchor%d"/>%s</spatial>' % (f, f, "".join('<site site="%s"/>' % s for s in keep)))
-        acts.append('<cylinder tendon="t%d" area="%.4g"/>' % (f, rng.uniform(150, 350)))
-        imu = sites[rng.randint(len(sites))]
-        sens.append('<accelerometer name="acc%d" site="%s"/>' % (f, imu))
-        sens.append('<gyro name="gyr%d" site="%s"/>' % (f, imu))
-    anchors = "".join('<site name="anchor%d" pos="%.4g %.4g 1.35"/>' % (f, 1.2 + 0.5 * np.cos(angles[f]), 0.5 * np.sin(angles[f])) for f in range(nf))
-    ctype = ["box", "ellipsoid", "cylinder"][rng.randint(3)]
-    return """<mujoco model="random gripper (tests/test_tree_emu.py)">
-  <compiler angle="radian" inertiafromgeom="auto" settotalmass="%.4g"/>
-  <option timestep="%.4g" solver="PGS" iterations="%d" tolerance="1e-7" cone="elliptic"/>
-  <size nconmax="300" njmax="3000"/>
-  <default><geom density="1"/><site size="0.01"/><default class="link"><geom type="box" contype="1" conaffinity="1"/></default></default>
-  <worldbody>
-    <geom name="ground" type="plane" size="0 0 1" condim="1"/>
-    <body pos="0 0 0">%s<geom class="link" name="roof" pos="1.2 0 1.5" size="0.9 0.9 0.04" mass="0.2"/>
-%s    </body>
-    <body pos="1.2 0 %.4g">%s
-      <composite prefix="OBJ" type="%s" count="%d %d %d" spacing="%.4g">
-        <geom type="capsule" size=".07 0.05" mass="0.001" contype="0" conaffinity="1"/>
-        <joint kind="main" stiffness="500" damping="%.4g" solreffix="-100 -10" solimpfix="0.9 0.97 0.000001 0.9 2"/>
-        <tendon kind="main" stiffness="500" damping="2" solreffix="-100 -10" solimpfix="0.9 0.97 0.000001 0.9 2"/>
-      </composite>
-    </body>
-  </worldbody>
-  <tendon>%s</tendon>
-  <actuator>%s</actuator>
-  <sensor>%s</sensor>
-</mujoco>
-""" % (rng.uniform(0.3, 0.6), rng.uniform(0.003, 0.005), rng.randint(10, 31), anchors, "".join(fingers), rng.uniform(0.3, 0.5),
-       "<freejoint/>" if free else "", ctype, rng.randint(3, 5), rng.randint(3, 5), rng.randint(3, 5), rng.uniform(0.13, 0.18), rng.uniform(30, 90),
-       "".join(tendons), "".join(acts), "".join(sens))
-
-
 @pytest.mark.parametrize("free,neighbors", [(False, False), (False, True), (True, False), (True, True)])
 def test_random_grippers_step_by_step(tmp_path, free, neighbors):
     """16 seeded random grippers of the tree class per variant (object fixed / on a free joint, fix rows only / with the composite's
