@@ -18,8 +18,8 @@ from softgrip_amd import native  # noqa: E402
 from softgrip_amd.create_dataset import episode_schedule  # noqa: E402
 
 NAMES = ["0 checks", "1 kinematics, box / site poses", "2 tendons, actuators", "3 mass matrix", "4 L'DL + M^-1 columns", "5 RNE, bias, smooth acc",
-         "6 sliders smooth", "7 pair walk (bounding tests)", "8 rank + narrowphase", "9 eq / limit rows", "10 contact rows (J, W, A)",
-         "11 warmstart", "12 sweep: slider limit rows", "13 sweep: contacts", "14 sweep end", "15 qacc, sensors", "16 Euler (M + hB)", "17 sweep: joint-fix rows", "18 sweep: tendon row", "19 sweep: chain limit rows"]
+         "6 sliders smooth", "7 pairs: other blocks", "8 rank + narrowphase", "9 eq / limit rows", "10 contact rows (J, W, A)",
+         "11 warmstart", "12 sweep: slider limit rows", "13 sweep: contacts", "14 sweep end", "15 qacc, sensors", "16 Euler (M + hB)", "17 sweep: joint-fix rows", "18 sweep: tendon row", "19 sweep: chain limit rows", "20 pairs: object box, box flags, block lists", "21 pairs: (capsule | sphere) x box blocks"]
 
 
 def main():

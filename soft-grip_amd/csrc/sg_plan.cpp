@@ -885,6 +885,38 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
           }
     if (P.gpairs.size() > 60000) FAIL("too many candidate collision pairs");
     H.ngpair = (int)P.gpairs.size();
+    if (tree) {
+      // block descriptors of the tree pipeline's pair walk, appended to the table at [ngpair + 1 + block]: a block is 64 consecutive
+      // pairs (one trip of the wavefront).  kind != 0: every pair of the block is (element capsule | centre sphere | finger box) x
+      // finger box -- both geoms' poses are in LDS, the walk runs them in its short loop; kind = 1 - 4: no box - box pair among them
+      // and that many distinct finger boxes, g1 = their flat indices a byte each -- such a block is skipped while all its boxes are
+      // out of reach of the object's bounding box; kind = -1: not skippable.  kind = 0: the general loop (plane, static-box pairs)
+      SgGenPair z;
+      z.kind = 0; z.g1 = z.g2 = z.pad = 0;
+      P.gpairs.push_back(z);
+      for (int p0 = 0; p0 < H.ngpair; p0 += 64) {
+        SgGenPair d = z;
+        int boxes[4], nb = 0;
+        bool pure = true, skippable = true, any = false;
+        for (int p = p0; p < H.ngpair && p < p0 + 64 && pure; p++) {
+          const SgGenPair& gp = P.gpairs[p];
+          if (gp.kind == 5) continue;   // never generated
+          const int k1 = gp.g1 >> 16, k2 = gp.g2 >> 16;
+          if (!((gp.kind == 2 || gp.kind == 3 || gp.kind == 4) && k2 == 4 && (k1 == 3 || k1 == 5 || k1 == 4))) { pure = false; break; }
+          any = true;
+          if (k1 == 4) skippable = false;
+          const int b = gp.g2 & 0xFFFF;
+          int j = 0;
+          while (j < nb && boxes[j] != b) j++;
+          if (j == nb) { if (nb == 4 || b > 255) skippable = false; else boxes[nb++] = b; }
+        }
+        if (pure && any) {
+          d.kind = skippable ? nb : -1;
+          for (int j = 0; j < nb && skippable; j++) d.g1 |= boxes[j] << (8 * j);
+        }
+        P.gpairs.push_back(d);
+      }
+    }
   }
   // mixed contact parameters of the reference pair
   {

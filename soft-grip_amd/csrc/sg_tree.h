@@ -83,7 +83,7 @@ enum { OF_P = 0, OF_Q = 3, OF_R = 7, OF_VW = 16 /* world */, OF_VL = 19, OF_WL =
 struct Lds {
   double *q, *v, *warm, *asm_, *aF, *fs, *fc, *bias, *tenJ, *kd, *qacc;
   double *xpos, *xmat, *xipos, *ximat, *bw, *bal, *ba, *bf, *bn;
-  double *anchor, *axis, *gpos, *gmat, *spos;
+  double *anchor, *axis, *gpos, *gmat, *gsz, *spos;
   double *L, *Minv, *tmpP;
   double *qe, *ve, *we, *asme, *ae, *fse, *ffix, *bfix, *Rfix, *flim, *blim, *Rlim, *ke;
   double *einvm, *ecoef, *ecen, *Ifix, *Ilim;   // 1 / (m + armature), tendon coefficient, capsule centres [3][N], 1 / (A + R) of the fix / limit rows
@@ -95,7 +95,7 @@ struct Lds {
   double* csc;   // LDS copies of the first `ncache` contacts' scalar records (the sweeps read them 30 times; the rest stay in the work space)
   int ncache;
 };
-enum { IC_NHIT = 0, IC_NCON, IC_SERIAL, IC_NLIM0 /* + chain */, IC_N = IC_NLIM0 + SGT_MAXCH };
+enum { IC_NHIT = 0, IC_NCON, IC_SERIAL, IC_NLIVE, IC_NPURE, IC_NLIM0 /* + chain */, IC_N = IC_NLIM0 + SGT_MAXCH };
 // per-chain scalars in LDS (chs[c * CHS_N + ..])
 enum { CHS_TLEN = 0, CHS_TVEL, CHS_TFRC, CHS_AFRC, CHS_ACTDOT, CHS_ACT, CHS_CTRL, CHS_KT, CHS_N };
 
@@ -112,7 +112,7 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
   L.bias = take(ND); L.tenJ = take(ND); L.kd = take(ND); L.qacc = take(ND);
   L.xpos = take(3 * NB); L.xmat = take(9 * NB); L.xipos = take(3 * NB); L.ximat = take(9 * NB); L.bw = take(3 * NB);
   L.bal = take(3 * NB); L.ba = take(3 * NB); L.bf = take(3 * NB); L.bn = take(3 * NB);
-  L.anchor = take(3 * ND); L.axis = take(3 * ND); L.gpos = take(3 * T.NG); L.gmat = take(9 * T.NG); L.spos = take(3 * T.NS);
+  L.anchor = take(3 * ND); L.axis = take(3 * ND); L.gpos = take(3 * T.NG); L.gmat = take(9 * T.NG); L.gsz = take(3 * T.NG); L.spos = take(3 * T.NS);
   L.L = takeg(T.NMAT); L.Minv = take(T.NMAT); L.tmpP = take(T.K * T.CS);
   L.qe = takeg(N); L.ve = take(N); L.we = take(N); L.asme = take(N); L.ae = take(N); L.fse = takeg(N); L.ffix = take(N);
   L.bfix = takeg(N); L.Rfix = takeg(N); L.flim = take(2 * N); L.blim = takeg(2 * N); L.Rlim = takeg(2 * N); L.ke = takeg(N);
@@ -184,6 +184,11 @@ __device__ __forceinline__ double wsum(double x) {
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
   return x;
 }
+__device__ __forceinline__ double wmax(double x) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) x = fmax(x, __shfl_xor(x, m, 64));
+  return x;
+}
 __device__ __forceinline__ int lds_inc(int* p) { return atomicAdd(p, 1); }
 #else
 #define SGT_FIRST 0
@@ -192,6 +197,7 @@ __device__ __forceinline__ int lds_inc(int* p) { return atomicAdd(p, 1); }
 #define SGT_ONE if (true)
 #define SGT_SYNC() ((void)0)
 inline double wsum(double x) { return x; }
+inline double wmax(double x) { return x; }
 inline int lds_inc(int* p) { return (*p)++; }
 #endif
 
@@ -281,8 +287,10 @@ SG_HD void mat6vec(double* r, const double* M, const double* v) {
 // completion the compiler can only wait for all at once -- which turns a prefetch into a stall
 #if SGT_DEVICE
 #define SGT_LDSP __attribute__((address_space(3)))
+#define SGT_CONST __attribute__((address_space(4)))
 #else
 #define SGT_LDSP
+#define SGT_CONST
 #endif
 // The free object's joint-fix rows, one after the other (one lane).  A function of its own ON PURPOSE: inlined into the step kernel --
 // 256 + 256 registers and spilling -- the loop's 40 live values went to scratch memory and a row cost 600 cycles; called, it gets a
@@ -366,13 +374,19 @@ SG_HD void chain_factor(double* Lc, int nd) {
 
 // the whole call for one env.  lane: threadIdx.x on the device, 0 on the host
 SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
-  const SgPlanHeader& H = *A.H;
-  const SgTreeDev& T = *A.T;
+  // The plan tables are read-only for the kernel's lifetime: read through the constant address space, a uniform index is a scalar load
+  // (K$) that the compiler may hoist and keep, not a vector load behind a full vmcnt wait after every store
+  const SGT_CONST SgPlanHeader& H = *(const SGT_CONST SgPlanHeader*)A.H;
+  const SGT_CONST SgTreeDev& T = *(const SGT_CONST SgTreeDev*)A.T;
   const int N = H.nelem, ND = T.ND, NB = T.NB, K = T.K, nv = H.nv, nu = H.nu, CS = T.CS;
   const double h = H.timestep;
   Lds S;
   lds_carve(S, lds_base, T, N, H.has_free, A.cws + (size_t)env * A.cws_stride + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (size_t)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT, nullptr, H.nnb);
-  auto E = [&](int f, int e) { return A.elem[(size_t)f * N + e]; };
+  const SGT_CONST double* const elemc = (const SGT_CONST double*)A.elem;
+  const SGT_CONST SgGenPair* const gpairs = (const SGT_CONST SgGenPair*)A.gpairs;
+  const SGT_CONST int* const nbtab = (const SGT_CONST int*)A.nbtab;
+  const SGT_CONST SgEqSlot* const sched = (const SGT_CONST SgEqSlot*)A.sched;
+  auto E = [&](int f, int e) { return elemc[(size_t)f * N + e]; };
   double* const cw = A.cws + (size_t)env * A.cws_stride;
   double* const stage = cw;
   double* const crow0 = cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW;
@@ -474,6 +488,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   int ncon = 0, nefc = 0, iters = 0, flags = 0;
   unsigned touch_lo = 0, touch_hi = 0;
   const int nfwd = A.nsub + (A.mode == 1 ? 1 : 0);
+  SGT_PAR(i, 3 * T.NG) S.gsz[i] = T.g_size[i / 3][i % 3];   // the boxes' half sizes next to their poses (the pair walk's tight test)
   for (int sub = 0; sub < nfwd; sub++) {
     const bool integrate = !(A.mode == 1 && sub == 0);
     const bool last = sub == nfwd - 1;
@@ -811,19 +826,122 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
 
     SGT_STAMP(6);
     // ---------------------------------------------------------------- stage 5: collision over the candidate-pair table
-    SGT_ONE { S.icnt[IC_NHIT] = 0; }
+    SGT_ONE { S.icnt[IC_NHIT] = 0; S.icnt[IC_NLIVE] = 0; S.icnt[IC_NPURE] = 0; }
     SGT_SYNC();
     auto elem_center = [&](int e, double* c) { c[0] = S.ecen[3 * e]; c[1] = S.ecen[3 * e + 1]; c[2] = S.ecen[3 * e + 2]; };
+    // The table is walked a BLOCK (64 consecutive pairs: one trip of the wavefront) at a time.  A block of (capsule | centre sphere) x
+    // finger-box pairs only -- most of the table: a finger body's boxes against 32 elements -- is skipped while every box in it is out
+    // of reach of the bounding box of the object (element centres and the centre sphere): no pair of it can pass its own bounding
+    // test, let alone produce a contact.  The plan lists a block's boxes behind the table (sg_plan.cpp); the live blocks are
+    // gathered in parallel (in any order: the hits are ranked by pair index afterwards), then walked.
+    const int ngpair = H.ngpair, nblk = (ngpair + 63) / 64;
+    const bool cull = nblk <= 2 * SGT_MAXHIT && T.NG <= SGT_MAXHIT;   // the list lives in hit_sorted + hit_cnt, the boxes' flags in hit_off
+    int* const live = S.hit_sorted;
+    if (cull) {
+      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+      SGT_PAR(e, N)
+        for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], S.ecen[3 * e + k]); hi[k] = fmax(hi[k], S.ecen[3 * e + k]); }
+      for (int k = 0; k < 3; k++) { lo[k] = -wmax(-lo[k]); hi[k] = wmax(hi[k]); }
+      if (H.has_center) {
+        const double* cenw = FR ? S.of + OF_CEN : H.center_pos;
+        const double ex = fmax(0.0, H.center_radius - H.cap_rbound);
+        for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], cenw[k] - ex); hi[k] = fmax(hi[k], cenw[k] + ex); }
+      }
+      SGT_PAR(g, T.NG) {
+        double d2 = 0;
+        for (int k = 0; k < 3; k++) {
+          const double x = S.gpos[3 * g + k], d = fmax(fmax(lo[k] - x, x - hi[k]), 0.0);
+          d2 += d * d;
+        }
+        const double reach = (T.g_rbound[g] + H.cap_rbound + H.con_margin) * 1.000001 + 1e-9;   // (the pairs' own bounds are floats rounded up)
+        S.hit_off[g] = d2 > reach * reach ? 1 : 0;
+      }
+      SGT_SYNC();
+      SGT_PAR(b, nblk) {
+        const SgGenPair d = gpairs[ngpair + 1 + b];
+        bool far = d.kind > 0;
+        for (int j = 0; j < d.kind; j++) far = far && S.hit_off[(d.g1 >> (8 * j)) & 0xFF] != 0;
+        if (far) continue;
+        if (d.kind != 0) live[2 * SGT_MAXHIT - 1 - lds_inc(&S.icnt[IC_NPURE])] = b;   // blocks of the common kind: their own list, from the far end
+        else live[lds_inc(&S.icnt[IC_NLIVE])] = b;
+      }
+      SGT_SYNC();
+    }
+    SGT_STAMP(20);
+    const int nlive = cull ? S.icnt[IC_NLIVE] : nblk;
+    {  // blocks of (capsule | centre sphere) x finger box pairs: no kinds to tell apart, everything in LDS -- a trip is ~40 instructions,
+       // a fraction of the latency of its table words, so the words of 8 trips are fetched together
+      const int npure = cull ? S.icnt[IC_NPURE] : 0;
+      const double* const cen0 = FR ? S.of + OF_CEN : H.center_pos;
+      const double cen[3] = {cen0[0], cen0[1], cen0[2]};
+      constexpr int G = SGT_DEVICE ? 8 : 1;
+      const double reach2 = (H.cap_rbound + H.con_margin) * (H.cap_rbound + H.con_margin) * (1.0 + 1e-12);
+      for (int b0 = 0; b0 < npure; b0 += G) {
+        SgGenPair buf[G];
+        int blks[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          buf[g].kind = SGP_UNSUPPORTED; buf[g].g1 = buf[g].g2 = buf[g].pad = 0;
+          blks[g] = b0 + g < npure ? live[2 * SGT_MAXHIT - 1 - (b0 + g)] : -1;
+          const int p = blks[g] * 64 + SGT_FIRST;
+          // (unconditional loads, all eight in flight together: a trip beyond the list or the table reads the sentinel entry at [ngpair])
+          if (SGT_DEVICE) buf[g] = gpairs[blks[g] >= 0 && p < ngpair ? p : ngpair];
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          if (blks[g] < 0) continue;
+          SGT_PAR(j, 64) {
+            const int p = blks[g] * 64 + j;
+            if (p >= ngpair) continue;
+            if (!SGT_DEVICE) buf[g] = gpairs[p];
+            const SgGenPair gp = buf[g];
+            if (gp.kind == SGP_UNSUPPORTED) continue;
+            const int i2 = sgg_index(gp.g2), i1 = sgg_index(gp.g1), k1 = sgg_kind(gp.g1);
+            const bool el = k1 == SGG_ELEM, ctr = k1 == SGG_CENTER;
+            const double* const c1 = (el ? S.ecen : S.gpos) + (ctr ? 0 : 3 * i1);   // (both in LDS)
+            float bf;
+            memcpy(&bf, &gp.pad, 4);
+            const double bound = (double)bf;
+            const double dif[3] = {S.gpos[3 * i2] - (ctr ? cen[0] : c1[0]), S.gpos[3 * i2 + 1] - (ctr ? cen[1] : c1[1]), S.gpos[3 * i2 + 2] - (ctr ? cen[2] : c1[2])};
+            if (dot3(dif, dif) > bound * bound) continue;
+            if (el) {   // tighter: the capsule's bounding sphere against the box itself
+              const double t[3] = {-dif[0], -dif[1], -dif[2]};
+              double loc[3];
+              mulmatT3(loc, S.gmat + 9 * i2, t);
+              // (box_sdist(loc, size) - cap_rbound > margin, without the root: the distance to the box squared against the reach
+              //  squared, a hair more permissive -- a filter; the narrowphase decides)
+              double q = 0;
+              for (int k = 0; k < 3; k++) { const double d = fmax(fabs(loc[k]) - S.gsz[3 * i2 + k], 0.0); q += d * d; }
+              if (q > reach2) continue;
+            }
+            const int idx = lds_inc(&S.icnt[IC_NHIT]);
+            if (idx < SGT_MAXHIT) S.hit_pair[idx] = p;
+          }
+        }
+      }
+    }
+    SGT_STAMP(21);
     {  // 64 pairs at a time; the next trip's table words are fetched before this trip's tests.  The bounding distance of a pair
        // (sum of the bounding radii + margin; plane pairs: rbound + margin) travels in the table as a float rounded up: a filter
        // that passes every pair the exact test passes -- the narrowphase decides
-      int p = SGT_FIRST;
       SgGenPair nxt;
       nxt.kind = SGP_UNSUPPORTED; nxt.g1 = nxt.g2 = nxt.pad = 0;
-      if (p < H.ngpair) nxt = A.gpairs[p];
-      for (; p < H.ngpair; p += SGT_STRIDE) {
-        const SgGenPair gp = nxt;
-        if (p + SGT_STRIDE < H.ngpair) nxt = A.gpairs[p + SGT_STRIDE];
+      if (SGT_DEVICE && nlive > 0) {
+        const int p0 = (cull ? live[0] : 0) * 64 + SGT_FIRST;
+        nxt = gpairs[p0 < ngpair ? p0 : ngpair];
+      }
+      for (int bi = 0; bi < nlive; bi++) {
+        const int blk = cull ? live[bi] : bi;
+        SgGenPair cur = nxt;
+        if (SGT_DEVICE) {
+          const int p1 = (bi + 1 < nlive ? (cull ? live[bi + 1] : bi + 1) : nblk) * 64 + SGT_FIRST;
+          nxt = gpairs[p1 < ngpair ? p1 : ngpair];
+        }
+        SGT_PAR(j, 64) {
+        const int p = blk * 64 + j;
+        if (p >= ngpair) continue;
+        if (!SGT_DEVICE) cur = gpairs[p];
+        const SgGenPair gp = cur;
         const int i1 = sgg_index(gp.g1), i2 = sgg_index(gp.g2), k2 = sgg_kind(gp.g2);
         float bf;
         memcpy(&bf, &gp.pad, 4);
@@ -854,6 +972,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           const int idx = lds_inc(&S.icnt[IC_NHIT]);
           if (idx < SGT_MAXHIT) S.hit_pair[idx] = p;
         }
+        }
       }
     }
     SGT_SYNC();
@@ -868,7 +987,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     }
     SGT_SYNC();
     SGT_PAR(i, nhit) {   // narrowphase, one lane per hit
-      const SgGenPair gp = A.gpairs[S.hit_sorted[i]];
+      const SgGenPair gp = gpairs[S.hit_sorted[i]];
       const int i1 = sgg_index(gp.g1), i2 = sgg_index(gp.g2), k1 = sgg_kind(gp.g1), k2 = sgg_kind(gp.g2);
       double* out = stage + (size_t)i * SGT_HITREC * SGT_RECW;
       int n = 0;
@@ -1009,7 +1128,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     if (NB) {
       SGT_SYNC();   // (asme / we of other lanes' elements)
       SGT_PAR(k, 3 * N) {
-        const int e = k % N, pe = A.nbtab[k];
+        const int e = k % N, pe = nbtab[k];
         double R = 0, b = 0, f = 0, I = 0;   // R = 0 marks an empty slot
         if (pe >= 0) {
           const double pos = (S.qe[e] - E(SGE_QPOS0, e)) - (S.qe[pe] - E(SGE_QPOS0, pe)), imp = impedance(H.eqj_solimp, pos, 0.0);
@@ -1058,7 +1177,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     SGT_PAR(ci, ncon) {
       const int src = S.con_src[ci], hi = src / SGT_HITREC;
       const double* rec = stage + (size_t)src * SGT_RECW;
-      const SgGenPair gp = A.gpairs[S.hit_sorted[hi]];
+      const SgGenPair gp = gpairs[S.hit_sorted[hi]];
       double* J1 = crow(ci);
       double *W1 = J1 + 3 * CS, *J2 = J1 + 6 * CS, *W2 = J1 + 9 * CS, *sc = cscal(ci);
       double fr[9];
@@ -1229,6 +1348,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     }
     SGT_SYNC();
     const bool serial_contacts = S.icnt[IC_SERIAL] != 0;
+    const double con_mu[2] = {H.con_mu[0], H.con_mu[1]};
     SGT_STAMP(10);
     // row count (nefc) and the touch bits of this contact list
     {
@@ -1253,8 +1373,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         double g = S.ffix[e] + S.ecoef[e] * ten_f + S.flim[2 * e] - S.flim[2 * e + 1];
         if (NB)
           for (int d = 0; d < 3; d++) {   // its own rows push it with +f, the rows that have it as partner (nbtab's in_slot) with -f
-            if (A.nbtab[d * N + e] >= 0) g += S.nbf[d * N + e];
-            const int in = A.nbtab[6 * N + d * N + e];
+            if (nbtab[d * N + e] >= 0) g += S.nbf[d * N + e];
+            const int in = nbtab[6 * N + d * N + e];
             if (in >= 0) g -= S.nbf[in];
           }
         S.ae[e] = S.einvm[e] * g;
@@ -1312,7 +1432,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         cost += S.flim[2 * e + 1] * (0.5 * (-ae_ + S.Rlim[2 * e + 1] * S.flim[2 * e + 1]) + S.blim[2 * e + 1]);
       }
       if (NB) SGT_PAR(k, 3 * N) {
-        const int pe = A.nbtab[k];
+        const int pe = nbtab[k];
         if (pe >= 0) cost += S.nbf[k] * (0.5 * ((slider_acc(k % N) - slider_acc(pe)) + S.nbR[k] * S.nbf[k]) + S.nbb[k]);
       }
       SGT_PAR(c, K) {
@@ -1380,7 +1500,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         // sequential sweep (sg_plan.h); 64 blocks per round, a lane each
         for (int r = 0; r < H.eq_rounds; r++) {
           SGT_PAR(sl, 64) {
-            const SgEqSlot slot = A.sched[r * 64 + sl];
+            const SgEqSlot slot = sched[r * 64 + sl];
             const int e = slot.e;
             if (e < N) {
               const double invm = S.einvm[e];
@@ -1487,12 +1607,11 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
             double p0 = 0, p1 = 0, p2 = 0;
             // whole padded rows (J is zero beyond the body's dofs), unrolled over the capacity with every load issued up front: the rows
             // sit in global memory (L2), and a loop would pay that latency once per trip.  Beyond the padded stride CS (uniform) the
-            // loads hit the record's other words and are dropped by the select.
+            // loads hit the record's other words (finite), against a zero.
 #pragma unroll
-            for (int k = 0; k < SGT_CHD; k++) {
-              const double a = aFc[k], j0 = J[k], j1 = J[CS + k], j2 = J[2 * CS + k];
-              const bool in = k < CS;
-              p0 += in ? j0 * a : 0.0; p1 += in ? j1 * a : 0.0; p2 += in ? j2 * a : 0.0;
+            for (int k = 0; k < SGT_CHD; k++) {   // (one select, not three)
+              const double a = k < CS ? aFc[k] : 0.0, j0 = J[k], j1 = J[CS + k], j2 = J[2 * CS + k];
+              p0 += j0 * a; p1 += j1 * a; p2 += j2 * a;
             }
             double w0[SGT_CHD], w1[SGT_CHD], w2[SGT_CHD];   // the W rows are on their way while the block update runs
 #pragma unroll
@@ -1501,7 +1620,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
             double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
             const double res[3] = {sc[CS_B] + sc[CS_JS] * as_ + p0 + sc[CS_R] * f[0], sc[CS_B + 1] + sc[CS_JS + 1] * as_ + p1 + sc[CS_R] * f[1],
                                    sc[CS_B + 2] + sc[CS_JS + 2] * as_ + p2 + sc[CS_R] * f[2]};
-            imp_par -= contact_block_update(sc + CS_A, res, f, H.con_mu, df);
+            imp_par -= contact_block_update(sc + CS_A, res, f, con_mu, df);
             double an[SGT_CHD];
 #pragma unroll
             for (int k = 0; k < SGT_CHD; k++) an[k] = aFc[k] + (w0[k] * df[0] + w1[k] * df[1] + w2[k] * df[2]);
