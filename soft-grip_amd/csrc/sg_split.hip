@@ -132,6 +132,8 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
 
+#define SG_CONSTAS __attribute__((address_space(4)))
+
 // section timing for scripts/section_profile.py (build_native.py --prof): every wavefront sums the cycles between stamps per
 // section in registers and adds them to W.secprof[] once, at its end.  Compiled out of the product library.
 #ifdef SG_SECTION_PROF
@@ -414,18 +416,21 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   if (env >= a.nenv) return;
   if (a.mask && !a.mask[env]) return;
   SG_T0();
-  const SgPlanHeader& H = *a.H;
+  // the plan tables are read-only for the kernel's lifetime: through the constant address space a uniform index is a scalar load the
+  // compiler may hoist and keep, not a vector load behind a full wait after every store
+  const SG_CONSTAS SgPlanHeader& H = *(const SG_CONSTAS SgPlanHeader*)a.H;
   const int N = a.nelem, nv = a.nv, nu = a.nu, e0 = a.elem_dof0, nchain = a.nchain;
   const size_t S = 2 * (size_t)a.nenv;
   const double h = a.timestep;
   __shared__ Smem2<R, CPL, NB> Sm;
-  auto EL = [&](int f, int e) { return a.elem[(size_t)f * N + e]; };
+  const SG_CONSTAS double* const elemc = (const SG_CONSTAS double*)a.elem;
+  auto EL = [&](int f, int e) { return elemc[(size_t)f * N + e]; };
   const int half = lane >> 5;
   const bool high = half != 0;
   const bool is_chain_lane = (lane & 31) == 0 && half < nchain;
   // the chains' model constants are read straight from the plan header (a few cached loads per wavefront); the chain stage itself,
   // which read them hundreds of times, runs in sg_chain_kernel
-  const SgChain& C = H.chain[half < nchain ? half : 0];
+  const SG_CONSTAS SgChain& C = H.chain[half < nchain ? half : 0];
   ChainLds2& CS = Sm.cs[half];
   SgWork& W = a.w;
 
@@ -772,7 +777,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           GL.boxp = Sm.boxp; GL.boxm = Sm.boxm; GL.K = Sm.K; GL.cs = Sm.cs;
           GL.qe = Sm.as; GL.ve = Sm.ve; GL.asme = Sm.asme; GL.we = Sm.we;
           int gfl = 0, gtouch = 0;
-          ngen = sg_gen_phase(a, H, env, GL, &gfl, &gtouch);
+          ngen = sg_gen_phase(a, *a.H, env, GL, &gfl, &gtouch);
           flags |= gfl;
           touch = gtouch;
           ns0 = ns1 = 0;                       // no contact stays on the per-finger streams
@@ -823,7 +828,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
             ve_ = Sm.ve[sl]; as_ = Sm.asme[sl]; we_ = Sm.we[sl];
             im = 1.0 / (EL(SGE_MASS, sl) + EL(SGE_ARMATURE, sl)); bw = EL(SGE_BINVW, sl);
           }
-          contact_build(c, rec, Sm.K[half], nd, CS.Minv, CS.v, CS.qacc_smooth, CS.w, C.b_invw_tran[bi], sl, ax, ve_, as_, we_, im, bw, H);
+          contact_build(c, rec, Sm.K[half], nd, CS.Minv, CS.v, CS.qacc_smooth, CS.w, C.b_invw_tran[bi], sl, ax, ve_, as_, we_, im, bw, *a.H);
           csl_[k] = sl; cinvm[k] = c.invm;
           cjsf[k] = c.Js[0] * c.f[0] + c.Js[1] * c.f[1] + c.Js[2] * c.f[2];
           Sm.cval[half][i] = c.invm * cjsf[k];
@@ -1185,7 +1190,7 @@ __global__ __launch_bounds__(64) void sg_chain_kernel(SgPhaseArgs a) {
   const int lane = threadIdx.x, c = blockIdx.x & 1, env = (int)(blockIdx.x >> 1) * 64 + lane;
   if (blockIdx.x == 0 && lane == 0) a.w.gen_count[0] = 0;   // the phase kernel of this substep refills the general pass's list
   SG_T0();
-  const SgPlanHeader& H = *a.H;
+  const SG_CONSTAS SgPlanHeader& H = *(const SG_CONSTAS SgPlanHeader*)a.H;
   const int nv = a.nv, nu = a.nu;
   const size_t S = 2 * (size_t)a.nenv;
   if (env >= a.nenv) return;
@@ -1382,7 +1387,7 @@ __global__ __launch_bounds__(64) void sg_pgs_kernel(SgPgsArgs a) {
   extern __shared__ double lds[];  // [8 envs][4 arrays][N] + invm[N] + coef[N] + limits
   const int lane = threadIdx.x, le = lane / SG_G, g = lane % SG_G;
   const int env = blockIdx.x * SG_EPW + le;
-  const SgPlanHeader& H = *a.H;
+  const SG_CONSTAS SgPlanHeader& H = *(const SG_CONSTAS SgPlanHeader*)a.H;
   const int N = H.nelem;
   const size_t S = 2 * (size_t)a.nenv;
   const int nwb = (a.nenv + SG_EPW - 1) / SG_EPW;
@@ -1642,7 +1647,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   const bool in_wave = le < EPW;             // lanes beyond the wavefront's envs stay idle (they own no LDS)
   const int lec = in_wave ? le : 0;
   const int env = blockIdx.x * EPW + le;
-  const SgPlanHeader& H = *a.H;
+  const SG_CONSTAS SgPlanHeader& H = *(const SG_CONSTAS SgPlanHeader*)a.H;
   const int N = H.nelem;
   const size_t S = 2 * (size_t)a.nenv;
   const int nwb = (a.nenv + 7) / 8;
