@@ -132,7 +132,11 @@ __device__ __forceinline__ int lanes_below2(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
 
-#define SG_CONSTAS __attribute__((address_space(4)))
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SG_CONSTAS __attribute__((address_space(4)))   // (the host pass of the same source has no address spaces to convert between)
+#else
+#define SG_CONSTAS
+#endif
 
 // section timing for scripts/section_profile.py (build_native.py --prof): every wavefront sums the cycles between stamps per
 // section in registers and adds them to W.secprof[] once, at its end.  Compiled out of the product library.
