@@ -916,6 +916,11 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
         }
         P.gpairs.push_back(d);
       }
+      if (getenv("SG_PLAN_DEBUG")) {
+        int nsk = 0, npu = 0, nb = 0;
+        for (size_t i = H.ngpair + 1; i < P.gpairs.size(); i++, nb++) { nsk += P.gpairs[i].kind > 0; npu += P.gpairs[i].kind != 0; }
+        fprintf(stderr, "pair table: %d pairs, %d blocks (%d in the short loop, %d of them skippable)\n", H.ngpair, nb, npu, nsk);
+      }
     }
   }
   // mixed contact parameters of the reference pair

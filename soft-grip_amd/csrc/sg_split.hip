@@ -428,6 +428,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   const double h = a.timestep;
   __shared__ Smem2<R, CPL, NB> Sm;
   const SG_CONSTAS double* const elemc = (const SG_CONSTAS double*)a.elem;
+  [[maybe_unused]] const SG_CONSTAS int* const nbtabc = (const SG_CONSTAS int*)a.nbtab;
   auto EL = [&](int f, int e) { return elemc[(size_t)f * N + e]; };
   const int half = lane >> 5;
   const bool high = half != 0;
@@ -965,9 +966,9 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
           if (e < N) {
 #pragma unroll
             for (int d = 0; d < 3; d++) {
-              const int e2 = a.nbtab[d * N + e];
+              const int e2 = nbtabc[d * N + e];
               if (e2 >= 0) {
-                const int id = a.nbtab[(3 + d) * N + e];
+                const int id = nbtabc[(3 + d) * N + e];
                 const double pos = (qe[r] - EL(SGE_QPOS0, e)) - (Sm.as[e2] - EL(SGE_QPOS0, e2)), imp = impedance(H.eqj_solimp, pos, 0);
                 const double Rr = fmax(SG_MINVAL, (1 - imp) / imp * (EL(SGE_INVW, e) + EL(SGE_INVW, e2)));
                 const double aref = -H.eqj_B * (ve[r] - Sm.ve[e2]) - H.eqj_K * imp * pos;
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
 #pragma unroll
               for (int d = 0; d < 3; d++) if (nbid[r][d] >= 0) fe += Sm.nbf[nbid[r][d]];
 #pragma unroll
-              for (int d = 0; d < 3; d++) { const int ii = a.nbtab[(6 + d) * N + e]; if (ii >= 0) fe -= Sm.nbf[ii]; }
+              for (int d = 0; d < 3; d++) { const int ii = nbtabc[(6 + d) * N + e]; if (ii >= 0) fe -= Sm.nbf[ii]; }
             }
             double as_ = invm[r] * fe;
 #pragma unroll
