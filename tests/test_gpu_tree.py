@@ -298,9 +298,11 @@ def test_random_grippers_on_the_gpu(tmp_path, free, neighbors):
     capacity of 128 contacts)"""
     from helpers import random_gripper_xml
     torch = _torch()
-    rng = np.random.RandomState(40 + 2 * int(free) + int(neighbors))
+    import os
+    nscene = int(os.environ.get("SG_FUZZ_SCENES", "10"))      # (a one-off sweep: SG_FUZZ_SCENES=100 SG_FUZZ_SEED=1000 pytest -k random_grippers_on_the_gpu)
+    rng = np.random.RandomState(int(os.environ.get("SG_FUZZ_SEED", "40")) + 2 * int(free) + int(neighbors))
     ran = 0
-    for i in range(10):
+    for i in range(nscene):
         path = tmp_path / ("g%d.xml" % i)
         path.write_text(random_gripper_xml(rng, free))
         m = sg.compile_mjcf(str(path), composite_neighbors=neighbors)
@@ -335,7 +337,7 @@ def test_random_grippers_on_the_gpu(tmp_path, free, neighbors):
                 qv = st["qvel"].cpu().numpy()
                 for e, s in enumerate(sims):
                     assert (stats["ncon"][e], stats["nefc"][e], stats["iters"][e]) == (s.ncon, s.nefc, s.solver_iter), (i, t, j, e)
-                    scale = 1.0 + np.abs(s.sensordata).max()
+                    scale = 1.0 + np.abs(s.sensordata).max() + np.abs(s.qacc_warmstart).max()   # (an accelerometer sample is a sum of |qacc| r terms that may cancel)
                     err = max(np.abs(got[e] - s.sensordata).max(), np.abs(qv[e] - s.qvel).max()) / scale
                     assert err < 1e-7, (i, t, j, e, err)
                     errs.append(err)
@@ -345,4 +347,5 @@ def test_random_grippers_on_the_gpu(tmp_path, free, neighbors):
             ran += 1
         assert np.percentile(errs, 95) < 1e-10, (i, np.percentile(errs, 95))
         del b, nm
-    assert ran >= 6, ran
+    assert ran >= 0.6 * nscene, ran
+    print("gpu fuzz (free %s, neighbour rows %s): %d scenes, %d ran their 40 steps unflagged" % (free, neighbors, nscene, ran))
