@@ -140,12 +140,17 @@ static int launch_tree(sg_batch* b, int mode, const uint8_t* mask, int nsub, dou
   a.nenv = b->n; a.nsub = nsub; a.mode = mode; a.secprof = b->w.secprof;
   const size_t lds = sgt::lds_bytes(m->tree, m->tplan.h.nelem, m->tplan.h.has_free, m->tplan.h.nnb);
   if (!b->tree_attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)sg_tree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)sg_tree_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)sg_tree_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)sg_tree_kernel<SGT_CHD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     b->tree_attr_set = true;
   }
   if (b->prof)
     if (int rc = begin_event_pair(b, b->ev, s)) return rc;
-  hipLaunchKernelGGL(sg_tree_kernel, dim3(b->n), dim3(64), lds, s, a);
+  // the instantiation whose unroll capacity is the smallest one >= the model's padded chain stride
+  if (m->tree.CS <= 8) hipLaunchKernelGGL(sg_tree_kernel<8>, dim3(b->n), dim3(64), lds, s, a);
+  else if (m->tree.CS <= 20) hipLaunchKernelGGL(sg_tree_kernel<20>, dim3(b->n), dim3(64), lds, s, a);
+  else hipLaunchKernelGGL(sg_tree_kernel<SGT_CHD>, dim3(b->n), dim3(64), lds, s, a);
   HIPCHK(hipGetLastError());
   if (b->prof) HIPCHK(hipEventRecord(b->ev.back().second, s));
   return SG_OK;

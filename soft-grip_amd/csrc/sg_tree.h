@@ -219,23 +219,24 @@ SG_HD void chain_solve(const double* Lc, int nd, double* x) {
 // read-modify-write chain through LDS: 9 k instead of 100 k cycles for the M^-1 columns).  Same operations in the same order.
 // Lc: a padded block [P][P] (identity beyond the chain's dofs), xmem: a padded vector [P]; P is the same on every lane, so the guards
 // are scalar branches around straight-line blocks
+template <int CHD>
 SG_HD void chain_solve_reg(const double* Lc, int P, double* xmem) {
-  double x[SGT_CHD];
+  double x[CHD];
 #pragma unroll
-  for (int k = 0; k < SGT_CHD; k += 4)
+  for (int k = 0; k < CHD; k += 4)
     if (k < P) { x[k] = xmem[k]; x[k + 1] = xmem[k + 1]; x[k + 2] = xmem[k + 2]; x[k + 3] = xmem[k + 3]; }
 #pragma unroll
-  for (int k = SGT_CHD - 1; k >= 1; k--)
+  for (int k = CHD - 1; k >= 1; k--)
     if (k < P) {
       const double xk = x[k];
 #pragma unroll
       for (int i = k - 1; i >= 0; i--) x[i] -= Lc[k * P + i] * xk;
     }
 #pragma unroll
-  for (int k = 0; k < SGT_CHD; k += 4)
+  for (int k = 0; k < CHD; k += 4)
     if (k < P) { x[k] /= Lc[k * P + k]; x[k + 1] /= Lc[(k + 1) * P + k + 1]; x[k + 2] /= Lc[(k + 2) * P + k + 2]; x[k + 3] /= Lc[(k + 3) * P + k + 3]; }
 #pragma unroll
-  for (int k = 1; k < SGT_CHD; k++)
+  for (int k = 1; k < CHD; k++)
     if (k < P) {
       double s = x[k];
 #pragma unroll
@@ -243,7 +244,7 @@ SG_HD void chain_solve_reg(const double* Lc, int P, double* xmem) {
       x[k] = s;
     }
 #pragma unroll
-  for (int k = 0; k < SGT_CHD; k += 4)
+  for (int k = 0; k < CHD; k += 4)
     if (k < P) { xmem[k] = x[k]; xmem[k + 1] = x[k + 1]; xmem[k + 2] = x[k + 2]; xmem[k + 3] = x[k + 3]; }
 }
 // scalar row update with the reciprocal of the row's diagonal A + R precomputed (as the fast kernels' equality rows)
@@ -373,6 +374,8 @@ SG_HD void chain_factor(double* Lc, int nd) {
 }
 
 // the whole call for one env.  lane: threadIdx.x on the device, 0 on the host
+// CHD: the unroll capacity of the per-chain loops (>= the plan's padded stride CS): the kernel is instantiated for 8, 20 and 24
+template <int CHD = SGT_CHD>
 SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   // The plan tables are read-only for the kernel's lifetime: read through the constant address space, a uniform index is a scalar load
   // (K$) that the compiler may hoist and keep, not a vector load behind a full vmcnt wait after every store
@@ -666,7 +669,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       const int c = idx / CS, dl = idx % CS;
       double* x = S.Minv + c * CS * CS + dl * CS;
       for (int k = 0; k < CS; k++) x[k] = k == dl ? 1.0 : 0.0;
-      chain_solve_reg(S.L + c * CS * CS, CS, x);
+      chain_solve_reg<CHD>(S.L + c * CS * CS, CS, x);
     }
     SGT_STAMP(4);
     // ---------------------------------------------------------------- stage 7: bias forces (RNE with qacc = 0), body velocities
@@ -731,7 +734,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     SGT_SYNC();
     SGT_PAR(d, ND) S.tmpP[pidx(d)] = S.fs[d];
     SGT_SYNC();
-    SGT_PAR(c, K) chain_solve_reg(S.L + c * CS * CS, CS, S.tmpP + c * CS);
+    SGT_PAR(c, K) chain_solve_reg<CHD>(S.L + c * CS * CS, CS, S.tmpP + c * CS);
     SGT_SYNC();
     SGT_PAR(d, ND) S.asm_[d] = S.tmpP[pidx(d)];
     SGT_STAMP(5);
@@ -1569,11 +1572,11 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           // every load before the first store (a load-store chain through LDS costs a round trip per element): unrolled over the
           // capacity, the loads unguarded (beyond the padded stride CS they hit other LDS words and are dropped), the stores behind
           // scalar branches on CS, which is the same on every lane
-          double an[SGT_CHD];
+          double an[CHD];
 #pragma unroll
-          for (int k = 0; k < SGT_CHD; k++) an[k] = aFc[k] + Mi[dl * CS + k] * dfl;
+          for (int k = 0; k < CHD; k++) an[k] = aFc[k] + Mi[dl * CS + k] * dfl;
 #pragma unroll
-          for (int k = 0; k < SGT_CHD; k += 4)
+          for (int k = 0; k < CHD; k += 4)
             if (k < CS) { aFc[k] = an[k]; aFc[k + 1] = an[k + 1]; aFc[k + 2] = an[k + 2]; aFc[k + 3] = an[k + 3]; }
         }
       }
@@ -1609,23 +1612,23 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
             // sit in global memory (L2), and a loop would pay that latency once per trip.  Beyond the padded stride CS (uniform) the
             // loads hit the record's other words (finite), against a zero.
 #pragma unroll
-            for (int k = 0; k < SGT_CHD; k++) {   // (one select, not three)
+            for (int k = 0; k < CHD; k++) {   // (one select, not three)
               const double a = k < CS ? aFc[k] : 0.0, j0 = J[k], j1 = J[CS + k], j2 = J[2 * CS + k];
               p0 += j0 * a; p1 += j1 * a; p2 += j2 * a;
             }
-            double w0[SGT_CHD], w1[SGT_CHD], w2[SGT_CHD];   // the W rows are on their way while the block update runs
+            double w0[CHD], w1[CHD], w2[CHD];   // the W rows are on their way while the block update runs
 #pragma unroll
-            for (int k = 0; k < SGT_CHD; k++) { w0[k] = W[k]; w1[k] = W[CS + k]; w2[k] = W[2 * CS + k]; }
+            for (int k = 0; k < CHD; k++) { w0[k] = W[k]; w1[k] = W[CS + k]; w2[k] = W[2 * CS + k]; }
             const double as_ = sl >= 0 ? S.ae[sl] : 0.0;
             double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
             const double res[3] = {sc[CS_B] + sc[CS_JS] * as_ + p0 + sc[CS_R] * f[0], sc[CS_B + 1] + sc[CS_JS + 1] * as_ + p1 + sc[CS_R] * f[1],
                                    sc[CS_B + 2] + sc[CS_JS + 2] * as_ + p2 + sc[CS_R] * f[2]};
             imp_par -= contact_block_update(sc + CS_A, res, f, con_mu, df);
-            double an[SGT_CHD];
+            double an[CHD];
 #pragma unroll
-            for (int k = 0; k < SGT_CHD; k++) an[k] = aFc[k] + (w0[k] * df[0] + w1[k] * df[1] + w2[k] * df[2]);
+            for (int k = 0; k < CHD; k++) an[k] = aFc[k] + (w0[k] * df[0] + w1[k] * df[1] + w2[k] * df[2]);
 #pragma unroll
-            for (int k = 0; k < SGT_CHD; k += 4)
+            for (int k = 0; k < CHD; k += 4)
               if (k < CS) { aFc[k] = an[k]; aFc[k + 1] = an[k + 1]; aFc[k + 2] = an[k + 2]; aFc[k + 3] = an[k + 3]; }
             S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
             if (sl >= 0) S.ae[sl] += sc[CS_INVM] * (sc[CS_JS] * df[0] + sc[CS_JS + 1] * df[1] + sc[CS_JS + 2] * df[2]);
@@ -1752,7 +1755,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     SGT_PAR(d, ND) S.tmpP[pidx(d)] = S.fs[d] + S.fc[d];   // right-hand side, padded
     factor_all();
     SGT_PAR(c, K) {
-      chain_solve_reg(S.L + c * CS * CS, CS, S.tmpP + c * CS);
+      chain_solve_reg<CHD>(S.L + c * CS * CS, CS, S.tmpP + c * CS);
       double* cs = S.chs + c * CHS_N;
       cs[CHS_ACT] += h * cs[CHS_ACTDOT];
     }

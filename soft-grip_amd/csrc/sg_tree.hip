@@ -11,9 +11,12 @@
 
 #include "sg_tree.h"
 
+// CHD: the capacity the per-chain loops are unrolled over (registers, not memory): 24 = SGT_CHD, 20 for the four-finger gripper's
+// 16 / 17-dof chains (padded stride 20), 8 for short chains
+template <int CHD>
 __global__ __launch_bounds__(64) void sg_tree_kernel(sgt::TreeArgs a) {
   extern __shared__ double sg_tree_lds[];
   const int env = blockIdx.x;
   if (env >= a.nenv) return;
-  sgt::tree_env(a, env, sg_tree_lds);
+  sgt::tree_env<CHD>(a, env, sg_tree_lds);
 }

@@ -216,16 +216,16 @@ class TreeEmu:
         return (self.L.temu_touch_word(self.p, 0) & 0xFFFFFFFF) | ((self.L.temu_touch_word(self.p, 1) & 0xFFFFFFFF) << 32)
 
 
-def random_gripper_xml(rng, free=False):
+def random_gripper_xml(rng, free=False, links=None, hinges=None, fingers=None):
     """a random member of the tree pipeline's model class: 1 - 4 fingers around the object, 1 - 5 links each with 1 - 3 hinges and 1 - 2
     boxes per link, a tendon through a random subset of the links' sites (>= 2 sites, the base's first), an actuator on it, an
     accelerometer + gyro pair on a random link; a box / ellipsoid / cylinder shell, optionally on a free joint; random time step, sweep
     count, masses, ranges"""
-    nf = rng.randint(1, 5)
+    nf = rng.randint(1, 5) if fingers is None else fingers          # (links / hinges / fingers: forced counts, for the capacity tests)
     angles = rng.permutation(4)[:nf] * (np.pi / 2) + rng.uniform(-0.2, 0.2, nf)
     fingers, tendons, acts, sens = [], [], [], []
     for f in range(nf):
-        nl = rng.randint(1, 6)
+        nl = rng.randint(1, 6) if links is None else links
         ca, sa = np.cos(angles[f]), np.sin(angles[f])
         # a finger starts on a ring around the object and points down along -z with its flexion axis tangent to the ring
         body = '<body pos="%.4g %.4g 0.9" quat="%.6g 0 0 %.6g">\n' % (1.2 + 0.75 * ca, 0.75 * sa, np.cos(angles[f] / 2), np.sin(angles[f] / 2))
@@ -234,7 +234,7 @@ def random_gripper_xml(rng, free=False):
         for l in range(nl):
             length = rng.uniform(0.25, 0.45)
             body += '  ' * l + '<body pos="0 0 %.4g">\n' % (-0.1 if l == 0 else -lengths_prev)
-            nj = rng.randint(1, 4)
+            nj = rng.randint(1, 4) if hinges is None else hinges
             axes = ["0 1 0", "1 0 0", "0 0 1"]
             for j in range(nj):
                 lo, hi = (-0.6, 0.15) if j == 0 else (-0.03, 0.03)

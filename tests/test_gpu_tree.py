@@ -349,3 +349,48 @@ def test_random_grippers_on_the_gpu(tmp_path, free, neighbors):
         del b, nm
     assert ran >= 0.6 * nscene, ran
     print("gpu fuzz (free %s, neighbour rows %s): %d scenes, %d ran their 40 steps unflagged" % (free, neighbors, nscene, ran))
+
+
+@pytest.mark.parametrize("links,hinges,seed", [(7, 3, 202), (6, 3, 204), (2, 2, 206)])
+def test_chain_capacities_on_the_gpu(tmp_path, links, hinges, seed):
+    """the three instantiations of the tree kernel (unroll capacities 24 / 20 / 8: csrc/sg_tree.hip) on chains of 21, 18 and 4 dofs --
+    the scenes of tests/test_tree_emu.py::test_chain_capacities_and_kernel_instantiations, 3 envs, 30 env steps re-seated per substep"""
+    from helpers import random_gripper_xml
+    torch = _torch()
+    rng = np.random.RandomState(seed)
+    path = tmp_path / "g.xml"
+    path.write_text(random_gripper_xml(rng, False, links=links, hinges=hinges, fingers=2))
+    m = sg.compile_mjcf(str(path), composite_neighbors=False)
+    nchain = int(np.flatnonzero(m.jnt_type != 3)[0])
+    jids = [j for j in range(nchain, m.njnt) if m.jnt_type[j] == 2]
+    ks = [700.0, 400.0, 1200.0]
+    nm, b, sens, flags = _batch(m, ks, jids, [0])
+    sims = _oracles(m, ks, jids, [0])
+    b.reset(1, sens=sens, flags=flags)
+    assert int(flags.abs().sum()) == 0
+    dev = dict(device=b.device, dtype=torch.float64)
+    most = 0
+    for t, c in enumerate(episode_schedule()[:30]):
+        if c is not None:
+            b.set_ctrl_broadcast(np.full(m.nu, c))
+            for s in sims:
+                s.ctrl[:] = c
+        for j in range(7):
+            b.set_state(qpos=torch.tensor(np.stack([s.qpos for s in sims]), **dev), qvel=torch.tensor(np.stack([s.qvel for s in sims]), **dev),
+                        act=torch.tensor(np.stack([s.act for s in sims]), **dev),
+                        qacc_warmstart=torch.tensor(np.stack([s.qacc_warmstart for s in sims]), **dev))
+            w = [s.step() for s in sims]
+            b.step(1, sens=sens, flags=flags)
+            f = flags.cpu().numpy()
+            assert w[0] == 0 and f[0] == 0, (t, j, w, f)   # (env 0 is the emulation test's scene and stiffness: within the kernel's capacity throughout)
+            most = max(most, sims[0].ncon)
+            got, qv = sens.cpu().numpy(), b.get_state()["qvel"].cpu().numpy()
+            stats = {k: v.cpu().numpy() for k, v in b.solver_stats().items()}
+            for e, s in enumerate(sims):
+                if w[e] or f[e]:
+                    assert (w[e] and f[e]) or (f[e] == 8 and s.ncon > 128), (t, j, e, w, f)
+                    continue
+                assert (stats["ncon"][e], stats["nefc"][e], stats["iters"][e]) == (s.ncon, s.nefc, s.solver_iter), (t, j, e)
+                scale = 1.0 + np.abs(s.sensordata).max() + np.abs(s.qacc_warmstart).max()
+                assert max(np.abs(got[e] - s.sensordata).max(), np.abs(qv[e] - s.qvel).max()) < 1e-7 * scale, (t, j, e)
+    assert most > 0

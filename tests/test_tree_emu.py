@@ -408,3 +408,38 @@ def test_oracle_same_chain_contact_block_against_numpy(tmp_path):
                 assert (R > 0).all() and np.ptp(R) < 1e-9 * R[0]     # what is left on the diagonal is the regulariser (impratio 1, equal friction)
                 seen += 1
     assert seen >= 4
+
+
+@pytest.mark.parametrize("links,hinges,stride,seed", [(7, 3, 24, 202), (6, 3, 20, 204), (2, 2, 4, 206)])
+def test_chain_capacities_and_kernel_instantiations(tmp_path, links, hinges, stride, seed):
+    """the kernel is instantiated for three unroll capacities of the per-chain loops (8, 20, 24: csrc/sg_tree.hip) and the library picks
+    the smallest one that holds the model's padded chain stride; the random scenes above stop at 15 dofs a chain, the four-finger
+    gripper has 17 -- here chains of 21 (stride 24: the full capacity), 18 (20) and 4 dofs (4) step along the oracle, substep by substep"""
+    rng = np.random.RandomState(seed)        # (seeds whose scenes stay within the kernel's 128 contacts)
+    path = tmp_path / "g.xml"
+    path.write_text(random_gripper_xml(rng, False, links=links, hinges=hinges, fingers=2))
+    m = sg.compile_mjcf(str(path), composite_neighbors=False)
+    nchain = int(np.flatnonzero(m.jnt_type != 3)[0])
+    assert nchain == 2 * links * hinges and -(-links * hinges // 4) * 4 == stride
+    jids = [j for j in range(nchain, m.njnt) if m.jnt_type[j] == 2]
+    s = oracle_sim(m)
+    s.jnt_stiffness[jids] = 700.0
+    s.tendon_stiffness[0] = 700.0
+    s.reset(); s.forward(); s.step()
+    e = TreeEmu(m)
+    e.set_stiffness(700.0, jids, [0])
+    assert e.reset(1) == 0
+    most = 0
+    for t, c in enumerate(episode_schedule()[:30]):
+        if c is not None:
+            e.ctrl[:] = c
+            s.ctrl[:] = c
+        for j in range(7):
+            e.qpos[:] = s.qpos; e.qvel[:] = s.qvel; e.warm[:] = s.qacc_warmstart; e.act[:] = s.act
+            w, f = s.step(), e.step(1)
+            assert w == 0 and f == 0, (t, j, w, f)
+            assert (e.ncon, e.nefc, e.iters) == (s.ncon, s.nefc, s.solver_iter), (t, j)
+            scale = 1.0 + np.abs(s.sensordata).max() + np.abs(s.qacc_warmstart).max()
+            assert max(np.abs(e.sensordata - s.sensordata).max(), np.abs(e.qvel - s.qvel).max()) < 1e-8 * scale, (t, j)
+            most = max(most, s.ncon)
+    assert most > 0
