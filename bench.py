@@ -13,14 +13,14 @@ Timed region: --steps S a multiple of 200 = S/200 whole episodes (resets include
 reset and S of its 200 steps, spread evenly over it, are timed one by one (sync + timer around each) -- an estimate of the
 episode average, not of an episode prefix (the first 40 steps have no contacts and cost a third of the average).
 
-`python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run as a child process, before this
-process touches a GPU).  Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` without a launcher starts its own N ranks (N child processes of a parent that never touches a GPU);
+started by `torch.distributed.run` it runs as a rank.  Either way the ranks share nothing but a common start and their timings, which
+go through a TCP key-value store (softgrip_amd/ranks.py): NO collective library on the default path (north_star: "no RCCL collectives
+required"; `--dist-backend nccl` puts the barriers and the MAX on RCCL instead).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
-import socket
-import subprocess
 import sys
 import time
 
@@ -97,19 +97,6 @@ def cpu_baseline(model, ks, sim_step, sched, budget_envs, threads, scene="softbo
 def stratified_steps(S, T):
     """S step indices spread evenly over an episode of T steps (the midpoints of S equal strata)"""
     return sorted({min(T - 1, int((i + 0.5) * T / S)) for i in range(S)})
-
-
-def self_launch(args, argv):
-    """--gpus N > 1 without a launcher: start N ranks with torch.distributed.run as a CHILD process (this process has not
-    touched a GPU and never does) and pass its output through."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
-    env = dict(os.environ)
-    env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(cmd, env=env)
 
 
 class Runner:
@@ -227,16 +214,16 @@ def main():
     ap.add_argument("--no-event-pass", action="store_true",
                     help="profiler runs (scripts/profile_round.sh): skip the second, HIP-event-instrumented pass over the timed region, so that the "
                          "trace holds exactly one reset + the timed steps; the line then carries no kernel durations")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL over xGMI) or gloo (for testing the multi-process path)")
+    ap.add_argument("--dist-backend", default="store", choices=["store", "nccl", "gloo"],
+                    help="what carries the barriers and the max-over-ranks time of an N > 1 run: store (default) = a TCP key-value store, no collective "
+                         "library at all; nccl = torch.distributed over RCCL / xGMI; gloo = torch.distributed on the CPU")
     ap.add_argument("--force-device", type=int, default=-1, help="testing only: put every rank on this GPU")
-    ap.add_argument("--fake-native-for-tests", action="store_true",
-                    help="testing only (tests/test_dist_gloo.py): a fake batch from tests/fake_native.py replaces the HIP library so the rank "
-                         "plumbing runs without a GPU; the JSON line is then labelled FAKE and is not a measurement")
     args = ap.parse_args()
 
+    from softgrip_amd import ranks
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if args.gpus > 1 and "RANK" not in os.environ:
-        raise SystemExit(self_launch(args, sys.argv[1:]))
+    if args.gpus > 1 and not ranks.launched_as_rank():
+        raise SystemExit(ranks.spawn_ranks(args.gpus))   # the parent: starts N copies of this command line as ranks, touches no GPU
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.with_regressor and args.steps % 200 != 0:
@@ -245,34 +232,31 @@ def main():
     import torch
 
     global device_sync
-    if args.fake_native_for_tests:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import fake_native
-        from softgrip_amd import native
-        native.NativeModel, native.NativeBatch = fake_native.FakeModel, fake_native.FakeBatch
-        device_sync = lambda: None  # noqa: E731
-    else:
-        device_sync = torch.cuda.synchronize
+    device_sync = torch.cuda.synchronize
 
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if args.force_device >= 0:
         local = args.force_device
-    dist = None
-    if not args.fake_native_for_tests and torch.cuda.device_count() <= local:
+    dist, group = None, None
+    if torch.cuda.device_count() <= local:
         # fail at once and on every rank: a rank that dies later would leave the others waiting in the first barrier
         raise SystemExit("bench.py: rank %d wants GPU %d but this node shows %d GPU(s)" % (rank, local, torch.cuda.device_count()))
     if world > 1:
-        import torch.distributed as dist
-        if not args.fake_native_for_tests:
-            torch.cuda.set_device(local)
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        torch.cuda.set_device(local)
+        if args.dist_backend == "store":
+            group = ranks.RankGroup(rank, world)
         else:
-            dist.init_process_group(args.dist_backend)
+            import torch.distributed as dist
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(args.dist_backend)
 
     def barrier():
         device_sync()
+        if group is not None:
+            group.barrier()
         if dist is not None:
             dist.barrier()
             device_sync()
@@ -309,7 +293,10 @@ def main():
     barrier()
     R.flags_or.zero_()
     dt, kernel_ms, launches, desc, nsteps, dt_prof = R.measure(args.steps, barrier, after_episode, not args.no_event_pass)
-    if dist is not None:  # the only collectives of the run: barriers and this MAX (timing, not data path)
+    if group is not None:  # every rank's time through the store; the job's time is the slowest rank's
+        per_rank_dt = group.gather("dt", dt)
+        dt = max(per_rank_dt)
+    elif dist is not None:  # --dist-backend nccl / gloo: the only collectives of the run are the barriers and this MAX (timing, not data path)
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         per_rank = [torch.zeros_like(tt) for _ in range(world)]
         dist.all_gather(per_rank, tt)      # per-rank times next to the MAX: a scaling run shows imbalance between GPUs
@@ -333,14 +320,16 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / nsteps * 1e3, "ms_per_step_with_hip_events": dt_prof / nsteps * 1e3,
             "ms_per_step_per_rank": [d / nsteps * 1e3 for d in per_rank_dt], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic" if not args.fake_native_for_tests else "FAKE native batch (plumbing test, not a measurement)",
+            "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[%d]: %d envs/GPU, %s scene (nv=%d), stiffness ~ U(300,1400)%s, reference 200-step squeeze "
                                    "schedule from reset, 7 substeps per env step; %d equality rows (composite neighbour equalities %s: DESIGN.md 2, U2)" % (
                                        4 if args.with_regressor else (3 if world > 1 else 2), n, args.scene, nm.nq,
                                        " split in per-rank bins" if world > 1 else "", model.neq, "on" if nb_on else "off") + ("; volume tendon damper integrated %sly" % damper) + (
                                        "; + ConvNet regressor: channel stats, noise augmentation, forward and one Adam step on every finished [n,200,12] block, on device, inside the timed region" if args.with_regressor else ""),
                        "envs_per_gpu": n, "substeps_per_step": R.sim_step, "physics_substeps_per_s": value * R.sim_step,
-                       "envs_flagged_bad": nbad, "launches_timed": launches, "steps_timed": nsteps, "timed_region": desc},
+                       "envs_flagged_bad": nbad, "launches_timed": launches, "steps_timed": nsteps, "timed_region": desc,
+                       "rank_sync": {"store": "TCP key-value store (barriers + per-rank times), no collective library", "nccl": "torch.distributed on RCCL",
+                                     "gloo": "torch.distributed on gloo"}[args.dist_backend] if world > 1 else None},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": None, "traffic_source": None,
                          "kernel": {"rows": "sg_chain_kernel + sg_phase_kernel + sg_pgs_rows_kernel chain of one sg_step call (rows pipeline; dominant: sg_pgs_rows_kernel)", "split": "sg_chain_kernel + sg_phase_kernel + sg_pgs_kernel chain of one sg_step call (split pipeline)",
@@ -387,7 +376,7 @@ def main():
                           "fp64 wavefront instruction; %s" % (os.path.basename(sp),
                           "the tree kernel runs one env per wavefront, two workgroups per CU (half the SIMDs), one instruction per ~7 cycles: ~0.25 is its ceiling at this occupancy" if pipe == "tree" else
                           "the PGS kernel runs one wavefront per SIMD (1024 at 4096 envs: 4 envs per wavefront) and a wavefront alone on its SIMD issues one instruction per ~7-8 cycles, so ~0.5 is this design's ceiling for it")}
-        if world == 1 and nb_on and not args.fake_native_for_tests and not args.no_fix_variant and not args.with_regressor and args.scene.endswith(("softbox", "softball", "softcylinder")):
+        if world == 1 and nb_on and not args.no_fix_variant and not args.with_regressor and args.scene.endswith(("softbox", "softball", "softcylinder")):
             # labelled secondary: the same workload on the fix-rows-only model (composite_neighbors=False)
             del R
             torch.cuda.empty_cache()
@@ -399,7 +388,7 @@ def main():
             res["config"]["fix_only_variant"] = {"value": n * ns2 / dt2, "unit": "env-steps/s", "avg_kernel_ms": km2, "equality_rows": R2.model.neq,
                                                  "note": "same workload on models/%s_fix.sgmodel (composite without its neighbour equalities) -- NOT the headline" % args.scene}
             del R2
-        if not args.no_cpu_baseline and world == 1 and not args.fake_native_for_tests:  # reported at N = 1 only
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             cores = usable_cores()
             envs = 8 * cores  # 8 full episodes per core: about 10-20 s of wall time
             ks = np.random.RandomState(0).uniform(300, 1400, n)
@@ -420,6 +409,8 @@ def main():
                                    "one_thread": {"value": v1, "sample": "2 envs x one episode on 1 thread, %.1f s" % cdt1},
                                    "mujoco_probe": "; ".join(probe)}
         print(json.dumps(res))
+    if group is not None:
+        group.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -15,7 +15,7 @@ import torch  # noqa: E402
 
 scene = sys.argv[1] if len(sys.argv) > 1 else "softbox"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-m = sg.load_model(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models", "%s.sgmodel" % scene))
+m = sg.load_model(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models", "%s.sgmodel" % scene), "explicit" if scene.startswith("softbox") else "implicit")
 b = native.NativeBatch(native.NativeModel(m), n, 0)
 b.set_stiffness(np.random.RandomState(0).uniform(300, 1400, n), list(range(11, 64)), [0])
 wins = {"idle": (10, 40), "closing": (50, 70), "peak": (95, 115), "released": (170, 200)}

@@ -15,7 +15,7 @@ cp $(ls /tmp/prof_kt/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_${SCENE}_kernel
 python3 $ROOT/scripts/trace_summary.py /tmp/prof_kt > $OUT/${TAG}_${SCENE}_phase_breakdown.txt 2>&1 || true
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_rd -- $CMD > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_wr -- $CMD > /dev/null 2>&1
-python3 $ROOT/scripts/hbm_traffic.py /tmp/prof_rd /tmp/prof_wr 201 $OUT/${TAG}_${SCENE}_hbm_traffic.json
+python3 $ROOT/scripts/hbm_traffic.py /tmp/prof_rd /tmp/prof_wr 201 $OUT/${TAG}_${SCENE}_hbm_traffic.json $OUT/${TAG}_${SCENE}_bench_line.json
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/prof_sq -- $CMD > /dev/null 2>&1
 python3 $ROOT/scripts/sq_totals.py /tmp/prof_sq 4096 200 $OUT/${TAG}_${SCENE}_sq_totals.json
 echo "profile_round done: $TAG $SCENE"

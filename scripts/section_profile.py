@@ -25,7 +25,8 @@ CHAIN_NAMES = {17: "load state", 18: "FINISH", 19: "kinematics", 20: "dynamics (
 
 
 def main():
-    m = sg.load_model("models/%s.sgmodel" % (sys.argv[1] if len(sys.argv) > 1 else "softbox"))
+    scene = sys.argv[1] if len(sys.argv) > 1 else "softbox"
+    m = sg.load_model("models/%s.sgmodel" % scene, "explicit" if scene.startswith("softbox") else "implicit")
     nm = native.NativeModel(m)
     n = 4096
     b = native.NativeBatch(nm, n, 0)

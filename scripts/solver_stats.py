@@ -3,7 +3,8 @@ sys.path.insert(0, ".")
 import softgrip_amd as sg
 from softgrip_amd import native
 from softgrip_amd.create_dataset import episode_schedule
-m = sg.load_model("models/softbox.sgmodel")
+scene = sys.argv[1] if len(sys.argv) > 1 else "softbox"
+m = sg.load_model("models/%s.sgmodel" % scene, "explicit" if scene.startswith("softbox") else "implicit")
 nm = native.NativeModel(m)
 n = 4096
 b = native.NativeBatch(nm, n, 0)
@@ -18,5 +19,5 @@ for t, c in enumerate(episode_schedule()):
     if t in (20, 45, 60, 80, 100, 119, 130, 150, 199):
         st = b.solver_stats()
         nc = st["ncon"].cpu().numpy(); it = st["iters"].cpu().numpy(); ne = st["nefc"].cpu().numpy()
-        w = nc.reshape(-1, 8)
+        w = nc.reshape(-1, 4)
         print(t, "ncon mean %.1f max %d  wave-max mean %.1f | iters mean %.1f min %d max %d | nefc mean %.0f" % (nc.mean(), nc.max(), w.max(1).mean(), it.mean(), it.min(), it.max(), ne.mean()))

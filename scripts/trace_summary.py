@@ -1,4 +1,5 @@
-"""Summarise a rocprofv3 --kernel-trace CSV of a bench.py run of the split pipeline: per-kernel time by episode phase."""
+"""Summarise a rocprofv3 --kernel-trace CSV of a bench.py run (1 reset + 200 sg_step calls): per-kernel time by episode phase -- the
+rows pipeline's kernel chain, or the tree pipeline's one kernel per call."""
 import csv
 import glob
 import sys
@@ -15,6 +16,15 @@ gp = [r for r in rows if is_gen(r)]           # the general contact pass (a smal
 ch = [r for r in rows if 'sg_chain' in r['Kernel_Name']]
 ph = [r for r in rows if 'sg_phase' in r['Kernel_Name'] and not is_gen(r)]
 pg = [r for r in rows if 'sg_pgs' in r['Kernel_Name']]
+tr = [r for r in rows if 'sg_tree_kernel' in r['Kernel_Name']]
+if tr and not pg:   # tree pipeline: one launch per sg_step call (the first one is the reset)
+    d = np.array([dur(r) for r in tr][-200:])
+    print(len(tr), "launches of", tr[0]['Kernel_Name'].split('(')[0], "VGPR", tr[0]['VGPR_Count'], tr[0].get('Accum_VGPR_Count'), "LDS", tr[0]['LDS_Block_Size'], "scratch", tr[0].get('Scratch_Size', tr[0].get('Private_Segment_Size')))
+    for a, b in [(0, 40), (40, 50), (50, 80), (80, 120), (120, 140), (140, 200)]:
+        print(a, b, "tree ms/call %.2f" % (d[a:b].mean() / 1e3))
+    print("sum kernels per episode ms %.1f" % (d.sum() / 1e3))
+    print("wall of timed region ms %.1f" % ((int(tr[-1]['End_Timestamp']) - int(tr[-200]['Start_Timestamp'])) / 1e6))
+    sys.exit(0)
 print(len(ph), len(pg), "phase VGPR", ph[0]['VGPR_Count'], ph[0].get('Accum_VGPR_Count'), "pgs VGPR", pg[0]['VGPR_Count'], pg[0].get('Accum_VGPR_Count'), "LDS", pg[0]['LDS_Block_Size'])
 php = np.array([dur(r) for r in ph][-1600:]).reshape(200, 8)
 pgp = np.array([dur(r) for r in pg][-1400:]).reshape(200, 7)

@@ -1,4 +1,8 @@
-"""Builds libsoftgrip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc."""
+"""Builds libsoftgrip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc: one translation unit per kernel family, compiled side
+by side, objects cached under soft-grip_amd/build/<variant>/ and re-made only when their source or a header is newer."""
+import concurrent.futures
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -6,46 +10,79 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libsoftgrip.so")
-SOURCES = ["sg_api.hip", "sg_plan.cpp", "sg_mjcf.cpp"]
-DEPS = SOURCES + ["sg_kernels.hip", "sg_split.hip", "sg_tree.hip", "sg_tree.h", "sg_tree_plan.h", "sg_general.h", "sg_math.h", "sg_plan.h", "sg_mjcf.h", "../../include/softgrip.h", "../../include/softgrip_model.h"]
+LEGACY_LIB = os.path.join(_HERE, "libsoftgrip_legacy.so")
+SOURCES = ["sg_api.hip", "sg_phase.hip", "sg_rows.hip", "sg_tree.hip", "sg_plan.cpp", "sg_mjcf.cpp"]   # what the product runs
+LEGACY_SOURCES = ["sg_legacy.hip"]   # r01's fused / split pipelines: test builds only (-DSG_LEGACY_PIPELINES)
+# -amdgpu-sched-strategy=iterative-ilp: LLVM's iterative ILP machine scheduler instead of the default max-occupancy one.  The
+# kernels run at one or two wavefronts per SIMD whatever their register count (the solver by design, the phase kernel by its
+# LDS), so trading registers for a shorter dependency-stalled schedule is free: solver -2.5 %, phase kernel -4.9 % per episode
+# (profiles/r02_sched_strategy.txt; max-ilp, max-memory-clause and iterative-minreg are slower, iterative-maxocc gains 2.3 %);
+# results bit-identical
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(_HERE, "..", "include", "*.h")) + [os.path.join(CSRC, "sg_kernels.hip")])
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, prof=False, count=False):
+def needs_build(lib=LIB, sources=SOURCES):
+    return _stale(lib, [os.path.join(CSRC, s) for s in sources] + _headers())
+
+
+def build(force=False, verbose=False, prof=False, count=False, legacy=False):
     """prof=True builds libsoftgrip_prof.so with the kernel section stamps (-DSG_SECTION_PROF) for scripts/section_profile.py;
     count=True builds libsoftgrip_count.so, which also counts events inside the contact update (-DSG_SECTION_COUNT: contact
-    updates, updates outside the friction cone, QCQP fallback entries and Newton evaluations) -- its cycle stamps are not timings"""
+    updates, updates outside the friction cone, QCQP fallback entries and Newton evaluations) -- its cycle stamps are not timings;
+    legacy=True builds libsoftgrip_legacy.so: the product plus r01's fused and split pipelines (-DSG_LEGACY_PIPELINES), which the
+    cross-check tests load by themselves.  force=True also removes stale variant libraries of earlier builds."""
+    if force:
+        for stale in glob.glob(os.path.join(_HERE, "libsoftgrip_*.so")):
+            os.remove(stale)
+        shutil.rmtree(os.path.join(_HERE, "build"), ignore_errors=True)
     if count:
         return _compile(os.path.join(_HERE, "libsoftgrip_count.so"), ["-DSG_SECTION_PROF", "-DSG_SECTION_COUNT"], verbose)
     if prof:
         return _compile(os.path.join(_HERE, "libsoftgrip_prof.so"), ["-DSG_SECTION_PROF"], verbose)
-    if not force and not needs_build():
+    if legacy:
+        if not force and not needs_build(LEGACY_LIB, SOURCES + LEGACY_SOURCES):
+            return LEGACY_LIB
+        return _compile(LEGACY_LIB, ["-DSG_LEGACY_PIPELINES"], verbose, SOURCES + LEGACY_SOURCES)
+    if not force and not verbose and not needs_build():
         return LIB
     return _compile(LIB, [], verbose)
 
 
-def _compile(out, extra, verbose):
+def _compile(out, extra, verbose, sources=SOURCES):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    # -amdgpu-sched-strategy=iterative-ilp: LLVM's iterative ILP machine scheduler instead of the default max-occupancy one.  The
-    # kernels run at one or two wavefronts per SIMD whatever their register count (the solver by design, the phase kernel by its
-    # LDS), so trading registers for a shorter dependency-stalled schedule is free: solver -2.5 %, phase kernel -4.9 % per episode
-    # (profiles/r02_sched_strategy.txt; max-ilp, max-memory-clause and iterative-minreg are slower, iterative-maxocc gains 2.3 %);
-    # results bit-identical
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-o", out] + extra + \
-          [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    flags = FLAGS + extra + (["-Rpass-analysis=kernel-resource-usage"] if verbose else [])
+    objdir = os.path.join(_HERE, "build", hashlib.sha1(" ".join(FLAGS + extra).encode()).hexdigest()[:12])
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = _headers()
+
+    def one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        path = os.path.join(CSRC, src)
+        if not verbose and not _stale(obj, [path] + hdrs):
+            return obj, ""
+        res = subprocess.run([hipcc] + flags + ["-c", "-o", obj, path], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, res.stderr[-4000:]))
+        return obj, res.stderr
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 1)) as ex:
+        done = list(ex.map(one, sources))
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [o for o, _ in done], capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stderr[-4000:])
+        raise RuntimeError("hipcc (link) failed:\n" + res.stderr[-4000:])
     if verbose:
-        print(res.stderr)
+        print("".join(log for _, log in done))
     return out
 
 
@@ -55,4 +92,4 @@ if __name__ == "__main__":
         i = sys.argv.index("--ko")
         print(_compile(os.path.join(_HERE, "libsoftgrip_%s.so" % sys.argv[i + 1]), sys.argv[i + 2:], False))
         sys.exit(0)
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, prof="--prof" in sys.argv, count="--count" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, prof="--prof" in sys.argv, count="--count" in sys.argv, legacy="--legacy" in sys.argv))

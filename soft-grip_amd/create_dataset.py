@@ -9,8 +9,6 @@ import hashlib
 import json
 import os
 import pickle
-import socket
-import subprocess
 import sys
 import time
 from argparse import ArgumentParser
@@ -220,30 +218,21 @@ def make_parser():
     parser.add_argument('--no-check-scene', dest="check_scene", action='store_false', default=True,
                         help="skip the load-time dry run that rejects scenes which cannot survive their own idle phase")
     parser.add_argument('--gpus', type=int, default=1,
-                        help="N > 1 without a launcher: start N ranks (torch.distributed.run as a child process), one per GPU, each with its own "
+                        help="N > 1 without a launcher: start N ranks (child processes of a parent that touches no GPU), one per GPU, each with its own "
                              "stiffness bin and shard file -- BASELINE configs[3]: --gpus 8 --n-envs 4096 --total-episodes 131072")
     parser.add_argument('--total-episodes', type=int, default=None,
                         help="fixed dataset size over all ranks and scenes: sets --num-batches to ceil(total / (ranks x n_envs x scenes))")
     parser.add_argument('--force-device', type=int, default=-1, help="testing only: put every rank on this GPU")
-    parser.add_argument('--fake-native-for-tests', action='store_true',
-                        help="testing only (tests/test_dist_gloo.py): tests/fake_native.py replaces the HIP library so the rank plumbing runs without a GPU")
     return parser
 
 
 def _self_launch(args, argv):
-    """--gpus N > 1 without a launcher: N ranks as a CHILD process tree (this process never touches a GPU), then the ranks' summary
-    files added up into one JSON line"""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    """--gpus N > 1 without a launcher: N ranks as child processes (ranks.spawn_ranks: this process never touches a GPU), then the
+    ranks' summary files added up into one JSON line.  The ranks share nothing: no collective, no store, no common file"""
+    from . import ranks
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ)
-    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-    env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "-m", "softgrip_amd.create_dataset"] + list(argv)
     t0 = time.perf_counter()
-    rc = subprocess.call(cmd, env=env)
+    rc = ranks.spawn_ranks(args.gpus, {"PYTHONPATH": root + os.pathsep + os.environ.get("PYTHONPATH", "")})
     if rc == 0:
         print(json.dumps(job_summary(args.data_folder, args.data_name, args.gpus, time.perf_counter() - t0)))
     return rc
@@ -272,11 +261,6 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", 1))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.fake_native_for_tests:
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-        import fake_native
-        from . import native
-        native.NativeModel, native.NativeBatch = fake_native.FakeModel, fake_native.FakeBatch
     if args.total_episodes is not None:
         per_round = world * args.n_envs * len(args.mujoco_model_paths)
         args.num_batches = max(1, -(-args.total_episodes // per_round))

@@ -6,10 +6,18 @@
 #include <string>
 #include <vector>
 
-#include "sg_kernels.hip"
 #include "sg_mjcf.h"
-#include "sg_split.hip"
-#include "sg_tree.hip"
+#include "sg_tree.h"
+#include "sg_work.h"
+#ifdef SG_LEGACY_PIPELINES
+#include "sg_kernels_args.h"
+#endif
+
+#ifdef SG_LEGACY_PIPELINES
+#define SG_LEGACY_ON 1
+#else
+#define SG_LEGACY_ON 0   // (the split pipeline's contact records, 126 MB at 4096 envs, are then not allocated)
+#endif
 
 namespace {
 thread_local std::string g_err;
@@ -57,7 +65,8 @@ struct sg_batch {
   SgGenPair* dgpairs;  // SgPlan::gpairs on the device (the general contact path's candidate pairs)
   int* dnbtab;       // SgPlan::nbtab on the device (neighbour-row models)
   SgEqSlot* dsched;  // SgPlan::sched + one spare round of idle slots
-  uint2* dtab;       // the same schedule as the solver's LDS table words
+  unsigned* dtab;    // the same schedule as the solver's LDS table words
+  int* dcpos;        // per element: where its equality block's step factors sit in a solver wavefront's stream (SgWork::cst)
   int *kmask_jnt, *kmask_ten, *flags, *touch, *ncon, *nefc, *iters;
   int epw_override;  // sg_set_solver_envs_per_wavefront: 0 = automatic
   int pipeline;  // 0 fused (one kernel per call), 1 split (chain / phase / pgs kernel chain), 2 split with the row-parallel PGS kernel, 3 tree
@@ -69,6 +78,7 @@ struct sg_batch {
   SgEqSlot* dtsched;  // neighbour-row models: the tree plan's block schedule and neighbour tables
   int* dtnbtab;
   int* touch_words;   // [n][2]
+  bool tree_ready;    // every table and the work space of the tree pipeline allocated and filled (tree_alloc)
   bool tree_attr_set;
   SgWork w;
   std::vector<void*> wbufs;
@@ -87,8 +97,26 @@ struct sg_batch {
 static int begin_event_pair(sg_batch* b, std::vector<std::pair<hipEvent_t, hipEvent_t>>& list, hipStream_t s);
 
 // device tables and work space of the tree pipeline (sg_tree.h), allocated when the pipeline is first selected
+static void tree_free(sg_batch* b) {
+  void** tptrs[] = {(void**)&b->dTH, (void**)&b->dT, (void**)&b->dtelem, (void**)&b->tcws, (void**)&b->dtpairs, (void**)&b->touch_words, (void**)&b->dtsched,
+                    (void**)&b->dtnbtab};
+  for (void** p : tptrs) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  b->tree_ready = false;
+}
+static int tree_alloc_all(sg_batch* b);
+// all or nothing: a failed allocation (the work space is ~0.5 MB per env for the four-finger scene) leaves no half-built pipeline behind
+// that a second sg_set_pipeline call would take for a complete one
 static int tree_alloc(sg_batch* b) {
-  if (b->dT) return SG_OK;
+  if (b->tree_ready) return SG_OK;
+  const int rc = tree_alloc_all(b);
+  if (rc != SG_OK) tree_free(b);
+  else b->tree_ready = true;
+  return rc;
+}
+static int tree_alloc_all(sg_batch* b) {
   const sg_model* m = b->m;
   if (!m->has_tree) return fail(SG_ERR_MODEL, "the tree pipeline does not run this model");
   const size_t n = b->n;
@@ -140,18 +168,12 @@ static int launch_tree(sg_batch* b, int mode, const uint8_t* mask, int nsub, dou
   a.nenv = b->n; a.nsub = nsub; a.mode = mode; a.secprof = b->w.secprof;
   const size_t lds = sgt::lds_bytes(m->tree, m->tplan.h.nelem, m->tplan.h.has_free, m->tplan.h.nnb);
   if (!b->tree_attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)sg_tree_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)sg_tree_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)sg_tree_kernel<SGT_CHD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(sg_tree_prepare());
     b->tree_attr_set = true;
   }
   if (b->prof)
     if (int rc = begin_event_pair(b, b->ev, s)) return rc;
-  // the instantiation whose unroll capacity is the smallest one >= the model's padded chain stride
-  if (m->tree.CS <= 8) hipLaunchKernelGGL(sg_tree_kernel<8>, dim3(b->n), dim3(64), lds, s, a);
-  else if (m->tree.CS <= 20) hipLaunchKernelGGL(sg_tree_kernel<20>, dim3(b->n), dim3(64), lds, s, a);
-  else hipLaunchKernelGGL(sg_tree_kernel<SGT_CHD>, dim3(b->n), dim3(64), lds, s, a);
-  HIPCHK(hipGetLastError());
+  HIPCHK(sg_launch_tree(a, m->tree.CS, lds, s));
   if (b->prof) HIPCHK(hipEventRecord(b->ev.back().second, s));
   return SG_OK;
 }
@@ -182,8 +204,7 @@ int sg_model_create(const void* blob, size_t nbytes, sg_model** out) {
     return fail(SG_ERR_MODEL, "sg_model_create: more than 256 composite elements");
   }
   if (m->has_fast && m->plan.h.nnb > 0) {  // the rows PGS kernel keeps every equality row of 8 envs in LDS (launch_split)
-    const size_t na = 8 * (size_t)((m->plan.h.nelem + 7) / 8) + 8 + 48, neqp = 4 * (size_t)m->plan.h.nelem + 1;
-    if (sizeof(double) * SG_ROWS_LDS_NB(4, na, m->plan.h.nelem, m->plan.h.eq_rounds) > 160 * 1024) {
+    if (sizeof(double) * SG_ROWS_LDS_NB(4, m->plan.h.nelem, m->plan.h.eq_rounds, 1) > 160 * 1024 || m->plan.h.nelem > 254) {  // (11-bit slider offsets in the table words)
       delete m;
       return fail(SG_ERR_MODEL, "sg_model_create: too many neighbour equality rows for the PGS kernel's LDS");
     }
@@ -226,10 +247,8 @@ int sg_model_nelem(const sg_model* m) { return m->plan.h.nelem; }
 void sg_batch_destroy(sg_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  void* tptrs[] = {b->dTH, b->dT, b->dtelem, b->tcws, b->dtpairs, b->touch_words, b->dtsched, b->dtnbtab};
-  for (void* p : tptrs)
-    if (p) (void)hipFree(p);
-  void* ptrs[] = {b->dtab, b->dgpairs, b->dnbtab, b->dsched, b->dH, b->delem, b->qpos, b->qvel, b->warm, b->act, b->ctrl, b->kenv, b->ctrl_row, b->kmask_jnt, b->kmask_ten,
+  tree_free(b);
+  void* ptrs[] = {b->dtab, b->dcpos, b->dgpairs, b->dnbtab, b->dsched, b->dH, b->delem, b->qpos, b->qvel, b->warm, b->act, b->ctrl, b->kenv, b->ctrl_row, b->kmask_jnt, b->kmask_ten,
                   b->flags, b->touch, b->ncon, b->nefc, b->iters};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -249,8 +268,8 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   HIPCHK(hipSetDevice(device));
   sg_batch* b = new sg_batch();
   b->m = m; b->n = n_envs; b->device = device; b->lds_attr_set = false; b->prof = false; b->prof_ms = 0; b->prof_n = 0; b->prof_pgs_ms = 0; b->prof_pgs_n = 0;
-  b->dnbtab = nullptr; b->dsched = nullptr; b->dgpairs = nullptr; b->dtab = nullptr; b->epw_override = 0;
-  b->dTH = nullptr; b->dT = nullptr; b->dtelem = b->tcws = nullptr; b->dtpairs = nullptr; b->touch_words = nullptr; b->tree_attr_set = false; b->dtsched = nullptr; b->dtnbtab = nullptr;
+  b->dnbtab = nullptr; b->dsched = nullptr; b->dgpairs = nullptr; b->dtab = nullptr; b->dcpos = nullptr; b->epw_override = 0;
+  b->dTH = nullptr; b->dT = nullptr; b->dtelem = b->tcws = nullptr; b->dtpairs = nullptr; b->touch_words = nullptr; b->tree_ready = false; b->tree_attr_set = false; b->dtsched = nullptr; b->dtnbtab = nullptr;
   b->dH = nullptr; b->delem = b->qpos = b->qvel = b->warm = b->act = b->ctrl = b->kenv = b->ctrl_row = nullptr;
   b->kmask_jnt = b->kmask_ten = b->flags = b->touch = b->ncon = b->nefc = b->iters = nullptr;
   const SgPlanHeader& H = m->plan.h;
@@ -280,7 +299,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
       b->wbufs.push_back(*p);
       return hipMemset(*p, 0, bytes) == hipSuccess;
     };
-    bool ok = walloc((void**)&b->w.secprof, sizeof(unsigned long long) * 48) && walloc((void**)&b->w.crec, sizeof(double) * SG_CAP * ((n + SG_EPW - 1) / SG_EPW + 1) * SG_RF * SG_SPW) && walloc((void**)&b->w.ns, sizeof(int) * S) &&
+    bool ok = walloc((void**)&b->w.secprof, sizeof(unsigned long long) * 48) && walloc((void**)&b->w.crec, sizeof(double) * (SG_LEGACY_ON ? SG_CAP * ((n + SG_EPW - 1) / SG_EPW + 1) * SG_RF * SG_SPW : 2)) && walloc((void**)&b->w.ns, sizeof(int) * S) &&
               walloc((void**)&b->w.crow, sizeof(double) * (SG_CAP + 2) * ((n + 7) / 8 + 2) * SG_RK * 64) &&
               walloc((void**)&b->w.cdummy, sizeof(double) * ((n + 3) / 4) * SG_RK * 64) &&
               walloc((void**)&b->w.envh, sizeof(double) * 4 * n) && walloc((void**)&b->w.shared, sizeof(int) * n) &&
@@ -295,11 +314,16 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
               walloc((void**)&b->w.chh, sizeof(double) * n * 2 * SG_CHW) &&
               walloc((void**)&b->w.nbf, sizeof(double) * n * (3 * N + 1)) && walloc((void**)&b->w.nbb, sizeof(double) * n * (3 * N + 1)) &&
               walloc((void**)&b->w.nbR, sizeof(double) * n * (3 * N + 1)) &&
+              walloc((void**)&b->w.cst, sizeof(double) * ((H.nnb > 0 && SG_ROWS_NB_MODE(H.nelem, H.eq_rounds) == 2) ? SG_CST_INDEX((n + 3) / 4, 0, 0, H.eq_rounds + 8) : 2)) &&
               walloc((void**)&b->w.gcon, sizeof(double) * n * SG_GEN_MAXCON * SG_GEN_W) && walloc((void**)&b->w.gen, sizeof(int) * n) &&
-              walloc((void**)&b->w.gen_count, sizeof(int) * 4) && walloc((void**)&b->w.gen_list, sizeof(int) * SG_GEN_LIST);
+              walloc((void**)&b->w.gen_count, sizeof(int) * 4) && walloc((void**)&b->w.gen_list, sizeof(int) * n);
     if (!ok) { sg_batch_destroy(b); return fail(SG_ERR_NOMEM, "hipMalloc (split-pipeline workspace)"); }
     const char* pm = getenv("SG_PIPELINE");
-    b->pipeline = (pm && strcmp(pm, "fused") == 0) ? 0 : (pm && strcmp(pm, "split") == 0) ? 1 : (pm && strcmp(pm, "tree") == 0 && m->has_tree) ? 3 : 2;
+    b->pipeline = (pm && strcmp(pm, "tree") == 0 && m->has_tree) ? 3 : 2;
+#ifdef SG_LEGACY_PIPELINES
+    if (pm && strcmp(pm, "fused") == 0) b->pipeline = 0;
+    if (pm && strcmp(pm, "split") == 0) b->pipeline = 1;
+#endif
     if (H.nnb > 0 && b->pipeline != 3) b->pipeline = 2;  // neighbour equality rows: the rows pipeline (or the tree pipeline when asked for)
   }
   if (m->has_fast && H.nnb > 0) {
@@ -312,16 +336,24 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
     HIPCHK(hipMemcpy(b->dnbtab, m->plan.nbtab.data(), sizeof(int) * m->plan.nbtab.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->dsched, sch.data(), sizeof(SgEqSlot) * sch.size(), hipMemcpyHostToDevice));
     // the solver's table words (sg_pgs_rows_kernel): lane 2 b + h of a 16-lane group holds, for the block e in slot b of the round,
-    // (x | y << 16, record offset) in LDS bytes, (x, y) = (e, p0) for h = 0 and (p1, p2) for h = 1
-    std::vector<uint2> tab(2 * sch.size());
+    // x | y << 11 | (2 e + h) << 22: the byte offsets of two slider words, (x, y) = 8 (e, p0) for h = 0 and 8 (p1, p2) for h = 1, and the
+    // lane's pair of row states in 16-byte units
+    std::vector<unsigned> tab(2 * sch.size());
     for (size_t i = 0; i < tab.size(); i++) {
       const SgEqSlot& sl = sch[i >> 1];
       const int h = (int)(i & 1);
       const unsigned x = h ? sl.p[1] : sl.e, y = h ? sl.p[2] : sl.p[0];
-      tab[i] = make_uint2((8u * x) | ((8u * y) << 16), 64u * (unsigned)sl.e + 32u * (unsigned)h);
+      tab[i] = (8u * x) | ((8u * y) << 11) | ((2u * (unsigned)sl.e + (unsigned)h) << 22);
     }
-    ALLOC(b->dtab, sizeof(uint2) * tab.size());
-    HIPCHK(hipMemcpy(b->dtab, tab.data(), sizeof(uint2) * tab.size(), hipMemcpyHostToDevice));
+    ALLOC(b->dtab, sizeof(unsigned) * tab.size());
+    HIPCHK(hipMemcpy(b->dtab, tab.data(), sizeof(unsigned) * tab.size(), hipMemcpyHostToDevice));
+    // where the phase kernel puts a block's four step factors: round r, slot g of the schedule = lanes 2 g, 2 g + 1 of the env's
+    // 16-lane group, two doubles each (SG_CST_INDEX)
+    std::vector<int> cpos(H.nelem, 0);
+    for (size_t i = 0; i < m->plan.sched.size(); i++)
+      if (m->plan.sched[i].e < H.nelem) cpos[m->plan.sched[i].e] = (int)(i / SG_EQ_SLOTS) * 128 + 4 * (int)(i % SG_EQ_SLOTS);
+    ALLOC(b->dcpos, sizeof(int) * cpos.size());
+    HIPCHK(hipMemcpy(b->dcpos, cpos.data(), sizeof(int) * cpos.size(), hipMemcpyHostToDevice));
   }
   ALLOC(b->dgpairs, sizeof(SgGenPair) * (m->plan.gpairs.size() + 1));
   HIPCHK(hipMemcpy(b->dgpairs, m->plan.gpairs.data(), sizeof(SgGenPair) * m->plan.gpairs.size(), hipMemcpyHostToDevice));
@@ -437,30 +469,26 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
   pa.kenv = b->kenv; pa.kmask_jnt = b->kmask_jnt; pa.kmask_ten = b->kmask_ten;
   pa.mask = mask; pa.sens = nullptr; pa.sens_stride = stride > 0 ? stride : H.nsensordata;
   pa.w = b->w; pa.nenv = b->n; pa.rowlayout = b->pipeline == 2;
-  pa.nbtab = b->dnbtab;
+  pa.nbtab = b->dnbtab; pa.cpos = b->dcpos; pa.cst_rounds = (H.nnb > 0 && SG_ROWS_NB_MODE(H.nelem, H.eq_rounds) == 2) ? H.eq_rounds + 8 : 0;
   pa.gpairs = b->dgpairs;
   pa.nelem = H.nelem; pa.nv = H.nv; pa.nu = H.nu; pa.elem_dof0 = H.elem_dof0; pa.nchain = H.nchain; pa.t0_id = H.t0_id; pa.timestep = H.timestep;
   SgPgsArgs ga;
   ga.sched = b->dsched; ga.nbtab = b->dnbtab; ga.tab = b->dtab;
   ga.H = b->dH; ga.elem = b->delem; ga.w = b->w; ga.nenv = b->n;
-  const size_t lds = sizeof(double) * ((size_t)(5 * 8 + 2) * H.nelem + 16 * 4 * SG_MAXLIM + 72);
+  const size_t lds = sizeof(double) * ((size_t)(5 * 8 + 2) * H.nelem + 16 * 4 * SG_MAXLIM + 72);   // (split pipeline, test builds)
+  (void)lds;
   // rows kernel: joint-fix rows per lane (template parameter, the smallest instantiated value >= ceil(nelem / 8)); its LDS
   // arrays are padded to 8 * NSL rows
-  static const int nsl_set[] = {8, 14, 20, 26, 29, 32};
-  int nsl = 32;
-  for (int v : nsl_set)
-    if (v * 8 >= H.nelem) { nsl = v; break; }
+  const int nsl = sg_rows_nsl(H.nelem);
   const bool nbm = H.nnb > 0;
-  const size_t na = 8 * (size_t)nsl + 8, neqp = 4 * (size_t)H.nelem + 1;
   const int epw = solver_epw(b);
-  const size_t lds_rows = sizeof(double) * (nbm ? SG_ROWS_LDS_NB(epw, na, H.nelem, H.eq_rounds) : SG_ROWS_LDS_FIX(epw, 8 * (size_t)nsl));
+  const int nbmode = nbm ? SG_ROWS_NB_MODE(H.nelem, H.eq_rounds) : 0;
+  const size_t lds_rows = sizeof(double) * (nbm ? SG_ROWS_LDS_NB(epw, H.nelem, H.eq_rounds, nbmode == 2) : SG_ROWS_LDS_FIX(epw, 8 * (size_t)nsl));
   if (!b->lds_attr_set) {  // per device: a batch on another GPU of the same process needs its own call
-    HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#define SG_ATTR1(v, nb, e) HIPCHK(hipFuncSetAttribute((const void*)sg_pgs_rows_kernel<v, nb, e>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-#define SG_ATTR(v) SG_ATTR1(v, false, 8); SG_ATTR1(v, false, 4); SG_ATTR1(v, true, 4)
-    SG_ATTR(8); SG_ATTR(14); SG_ATTR(20); SG_ATTR(26); SG_ATTR(29); SG_ATTR(32);
-#undef SG_ATTR
-#undef SG_ATTR1
+    HIPCHK(sg_rows_prepare());
+#ifdef SG_LEGACY_PIPELINES
+    HIPCHK(sg_legacy_prepare());
+#endif
     b->lds_attr_set = true;
   }
   // forward passes to run: (mode 1: one non-integrating forward first) + nsub integrating ones
@@ -471,25 +499,8 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     call_ev = b->ev.size() - 1;
   }
   // the main pass over all envs, then (rows pipeline, forward passes only) the general contact pass: a small fixed grid whose
-  // blocks take the envs the main pass has put on W.gen_list -- normally none, and then every block returns at once
+  // block i takes entry i of W.gen_list, the envs the main pass has put there -- normally none, and then every block returns at once
   const bool genpass = b->pipeline == 2;
-  auto phase = [&](const SgPhaseArgs& p) {
-#define SG_PHASE(r)                                                                                   \
-  if (nbm) {                                                                                          \
-    hipLaunchKernelGGL((sg_phase_kernel<r, 2, true>), dim3(b->n), dim3(64), 0, s, p);                 \
-    if (genpass && p.do_begin) hipLaunchKernelGGL((sg_phase_kernel<r, 2, true, true>), dim3(SG_GEN_LIST), dim3(64), 0, s, p); \
-  } else {                                                                                            \
-    hipLaunchKernelGGL((sg_phase_kernel<r, 2, false>), dim3(b->n), dim3(64), 0, s, p);                \
-    if (genpass && p.do_begin) hipLaunchKernelGGL((sg_phase_kernel<r, 2, false, true>), dim3(SG_GEN_LIST), dim3(64), 0, s, p); \
-  }
-    switch (b->m->rounds) {
-      case 1: SG_PHASE(1); break;
-      case 2: SG_PHASE(2); break;
-      case 3: SG_PHASE(3); break;
-      default: SG_PHASE(4); break;
-    }
-#undef SG_PHASE
-  };
   for (int k = 0; k <= nfwd; k++) {
     SgPhaseArgs p = pa;
     p.first = k == 0;
@@ -499,32 +510,16 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     p.do_begin = k < nfwd;
     p.sens = (k == nfwd) ? sens : nullptr;
     if (nfwd == 0) { p.do_begin = 0; p.do_finish = 0; }
-    hipLaunchKernelGGL(sg_chain_kernel, dim3(2 * ((b->n + 63) / 64)), dim3(64), 0, s, p);
-    HIPCHK(hipGetLastError());
+    HIPCHK(sg_launch_chain(p, b->n, s));
     p.sens = nullptr;  // the chain kernel writes the sensors (they all sit on finger sites)
-    phase(p);
-    HIPCHK(hipGetLastError());
+    HIPCHK(sg_launch_phase(p, b->m->rounds, nbm, genpass, b->n, s));
     if (k < nfwd) {
       if (b->prof)
         if (int rc = begin_event_pair(b, b->ev_pgs, s)) return rc;
-      if (b->pipeline == 2) {
-        const dim3 grid((b->n + epw - 1) / epw);
-#define SG_ROWS1(v, nb, e) hipLaunchKernelGGL((sg_pgs_rows_kernel<v, nb, e>), grid, dim3(64), lds_rows, s, ga)
-#define SG_ROWS(v)                                                                    \
-  case v:                                                                             \
-    if (nbm) SG_ROWS1(v, true, 4);                                                    \
-    else { if (epw == 8) SG_ROWS1(v, false, 8); else SG_ROWS1(v, false, 4); }         \
-    break
-        switch (nsl) {
-          SG_ROWS(8); SG_ROWS(14); SG_ROWS(20); SG_ROWS(26); SG_ROWS(29);
-          default:
-          SG_ROWS(32);
-        }
-#undef SG_ROWS
-#undef SG_ROWS1
-      }
-      else hipLaunchKernelGGL(sg_pgs_kernel, dim3((b->n + SG_EPW - 1) / SG_EPW), dim3(64), lds, s, ga);
-      HIPCHK(hipGetLastError());
+      if (b->pipeline == 2) HIPCHK(sg_launch_rows(ga, nsl, nbmode, epw, b->n, lds_rows, s));
+#ifdef SG_LEGACY_PIPELINES
+      else HIPCHK(sg_launch_pgs_split(ga, b->n, lds, s));
+#endif
       if (b->prof) HIPCHK(hipEventRecord(b->ev_pgs.back().second, s));
     }
   }
@@ -541,6 +536,7 @@ static int launch(sg_batch* b, int mode, const uint8_t* mask, int nsub, double* 
                   hipStream_t s) {
   if (b->pipeline == 3) return launch_tree(b, mode, mask, nsub, sens, stride, flags, touch, s);
   if (b->pipeline >= 1) return launch_split(b, mode, mask, nsub, sens, stride, flags, touch, s);
+#ifdef SG_LEGACY_PIPELINES
   const SgPlanHeader& H = b->m->plan.h;
   SgKArgs a;
   a.H = b->dH; a.elem = b->delem;
@@ -553,16 +549,12 @@ static int launch(sg_batch* b, int mode, const uint8_t* mask, int nsub, double* 
   a.nenv = b->n; a.nsub = nsub; a.mode = mode;
   if (b->prof)
     if (int rc = begin_event_pair(b, b->ev, s)) return rc;
-  dim3 grid(b->n), block(64);
-  switch (b->m->rounds) {
-    case 1: hipLaunchKernelGGL((sg_step_kernel<1, 2>), grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((sg_step_kernel<2, 2>), grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((sg_step_kernel<3, 2>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((sg_step_kernel<4, 2>), grid, block, 0, s, a); break;
-  }
-  HIPCHK(hipGetLastError());
+  HIPCHK(sg_launch_fused(a, b->m->rounds, b->n, s));
   if (b->prof) HIPCHK(hipEventRecord(b->ev.back().second, s));
   return SG_OK;
+#else
+  return fail(SG_ERR_MODEL, "the fused pipeline is not part of this build (test builds only: build_native.py --legacy)");
+#endif
 }
 
 int sg_reset(sg_batch* b, const uint8_t* mask, int sim_start, double* sens_out, int32_t* flags_out, int32_t* touch_out, void* stream) {
@@ -624,6 +616,9 @@ int sg_set_pipeline(sg_batch* b, int pipeline) {
     return SG_OK;
   }
   if (!b->m->has_fast) return fail(SG_ERR_MODEL, "sg_set_pipeline: the model is outside the two-finger class, only the tree pipeline runs it");
+#ifndef SG_LEGACY_PIPELINES
+  if (pipeline < 2) return fail(SG_ERR_MODEL, "sg_set_pipeline: the fused and split pipelines are not part of this build (test builds only: build_native.py --legacy)");
+#endif
   if (b->m->plan.h.nnb > 0 && pipeline != 2)
     return fail(SG_ERR_MODEL, "sg_set_pipeline: the model has neighbour equality rows, which only the rows pipeline supports");
   b->pipeline = pipeline;

@@ -27,6 +27,15 @@ SG_HD int sgg_index(int ref) { return ref & 0xFFFF; }
 // narrowphase routine of a candidate pair (geom1 / geom2 in mj_collideGeoms' order: by type, plane < sphere < capsule < box)
 enum { SGP_PLANE_CAP = 0, SGP_PLANE_BOX = 1, SGP_SPH_BOX = 2, SGP_CAP_BOX = 3, SGP_BOX_BOX = 4, SGP_UNSUPPORTED = 5,
        SGP_PLANE_SPH = 6 /* tree plans with a free object only */ };
+// the narrowphase routine a pair's two geometry references call for (a pair marked SGP_UNSUPPORTED -- other contact parameters than the
+// plan's one set -- keeps its geometry: the tree pipeline walks it like any other pair and flags the env where it would touch)
+SG_HD int sgp_geometry(int g1, int g2) {
+  const int k1 = sgg_kind(g1), k2 = sgg_kind(g2);
+  if (k1 == SGG_PLANE) return k2 == SGG_ELEM ? SGP_PLANE_CAP : (k2 == SGG_CENTER ? SGP_PLANE_SPH : SGP_PLANE_BOX);
+  if (k1 == SGG_CENTER) return SGP_SPH_BOX;
+  if (k1 == SGG_ELEM) return SGP_CAP_BOX;
+  return SGP_BOX_BOX;
+}
 #define SG_GEN_MAXCON 112   // contacts of an env on the general path (the fast path: 64 per finger); with the box - box work space
                             // the list fills the phase kernel's 8 KB contact staging area
 #define SG_GEN_ROUNDS ((SG_GEN_MAXCON + 63) / 64)

@@ -352,6 +352,9 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
   // the kernels are compiled for one chain topology: SG_CB bodies with SG_CJ hinges each
   for (int c = 0; c < nchain; c++) {
     if (H.chain[c].nbody != SG_CB) FAIL("finger chains must have exactly 2 moving bodies");
+    // (the contact read-out numbers the finger boxes 2 * chain + box: with another count per chain that is not the geom-id order the
+    //  C ABI documents for touch_out / sg_get_touch_words -- such a gripper runs in the tree pipeline, which numbers the boxes flat)
+    if (H.chain[c].ngeom != SG_CG) FAIL("finger chains must carry exactly 2 box geoms");
     for (int bi = 0; bi < SG_CB; bi++)
       if (H.chain[c].b_njnt[bi] != SG_CJ) FAIL("finger chain bodies must have exactly 2 hinge joints");
   }
@@ -900,7 +903,7 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
         bool pure = true, skippable = true, any = false;
         for (int p = p0; p < H.ngpair && p < p0 + 64 && pure; p++) {
           const SgGenPair& gp = P.gpairs[p];
-          if (gp.kind == 5) continue;   // never generated
+          if (gp.kind == 5) { pure = false; break; }   // SGP_UNSUPPORTED: the general loop tests its bounding distance and flags the env (never skipped)
           const int k1 = gp.g1 >> 16, k2 = gp.g2 >> 16;
           if (!((gp.kind == 2 || gp.kind == 3 || gp.kind == 4) && k2 == 4 && (k1 == 3 || k1 == 5 || k1 == 4))) { pure = false; break; }
           any = true;

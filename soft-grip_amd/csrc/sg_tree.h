@@ -928,7 +928,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
        // (sum of the bounding radii + margin; plane pairs: rbound + margin) travels in the table as a float rounded up: a filter
        // that passes every pair the exact test passes -- the narrowphase decides
       SgGenPair nxt;
-      nxt.kind = SGP_UNSUPPORTED; nxt.g1 = nxt.g2 = nxt.pad = 0;
+      nxt.kind = SGP_PLANE_CAP; nxt.g1 = nxt.g2 = 0; nxt.pad = (int)0xff800000u;   // (a pair that never hits: bound = -inf)
       if (SGT_DEVICE && nlive > 0) {
         const int p0 = (cull ? live[0] : 0) * 64 + SGT_FIRST;
         nxt = gpairs[p0 < ngpair ? p0 : ngpair];
@@ -946,16 +946,19 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         if (!SGT_DEVICE) cur = gpairs[p];
         const SgGenPair gp = cur;
         const int i1 = sgg_index(gp.g1), i2 = sgg_index(gp.g2), k2 = sgg_kind(gp.g2);
+        // (a pair with other contact parameters than the plan's one set, SGP_UNSUPPORTED, is walked like any pair of its geometry:
+        //  the narrowphase below turns what would be its contact into the unsupported-pair flag)
+        const int gk = gp.kind == SGP_UNSUPPORTED ? sgp_geometry(gp.g1, gp.g2) : gp.kind;
         float bf;
         memcpy(&bf, &gp.pad, 4);
         const double bound = (double)bf;
         bool hit = false;
         const double* cenw = FR ? S.of + OF_CEN : H.center_pos;   // the centre sphere (on the free body when there is one)
-        if (gp.kind == SGP_PLANE_CAP || gp.kind == SGP_PLANE_BOX || gp.kind == SGP_PLANE_SPH) {
-          const double* c = gp.kind == SGP_PLANE_SPH ? cenw : gp.kind == SGP_PLANE_CAP ? S.ecen + 3 * i2 : (k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[i2]);
+        if (gk == SGP_PLANE_CAP || gk == SGP_PLANE_BOX || gk == SGP_PLANE_SPH) {
+          const double* c = gk == SGP_PLANE_SPH ? cenw : gk == SGP_PLANE_CAP ? S.ecen + 3 * i2 : (k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[i2]);
           const double dif[3] = {c[0] - H.plane_pos[0], c[1] - H.plane_pos[1], c[2] - H.plane_pos[2]};
           hit = !(dot3(dif, H.plane_normal) > bound);
-        } else if (gp.kind != SGP_UNSUPPORTED) {
+        } else {
           // geom2 is a box (finger or static); geom1 the centre sphere, an element capsule or a box
           const double* bp = k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[i2];
           const int k1 = sgg_kind(gp.g1);
@@ -970,7 +973,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
             mulmatT3(loc, bm, t);
             hit = !(box_sdist(loc, sz) - H.cap_rbound > H.con_margin);
           }
-        }   // (a pair with other contact parameters, SGP_UNSUPPORTED, keeps its place in the table only: never generated)
+        }
         if (hit) {
           const int idx = lds_inc(&S.icnt[IC_NHIT]);
           if (idx < SGT_MAXHIT) S.hit_pair[idx] = p;
@@ -989,8 +992,11 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       S.hit_sorted[r] = p;
     }
     SGT_SYNC();
+    int unsup = 0;
     SGT_PAR(i, nhit) {   // narrowphase, one lane per hit
-      const SgGenPair gp = gpairs[S.hit_sorted[i]];
+      SgGenPair gp = gpairs[S.hit_sorted[i]];
+      const bool unsupported = gp.kind == SGP_UNSUPPORTED;
+      if (unsupported) gp.kind = sgp_geometry(gp.g1, gp.g2);
       const int i1 = sgg_index(gp.g1), i2 = sgg_index(gp.g2), k1 = sgg_kind(gp.g1), k2 = sgg_kind(gp.g2);
       double* out = stage + (size_t)i * SGT_HITREC * SGT_RECW;
       int n = 0;
@@ -1050,8 +1056,17 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         const int m = gen_box_box(p1, R1, s1, bp, bm, sz, H.con_margin, r, poly, tmp);
         for (int k = 0; k < m; k++) put(r[k], nullptr);
       }
+      if (unsupported) {
+        // A pair whose mixed contact parameters differ from the finger / object pairs' (the plan keeps ONE set) cannot become rows.
+        // It must not vanish either: what would be its contact raises the unsupported-pair flag -- data, as on the rows pipeline's
+        // general path (sg_phase.hip sg_gen_phase) -- and the host resets the env, instead of a finger passing through the geom.
+        for (int k = 0; k < n; k++)
+          if (out[k * SGT_RECW] < H.con_margin) unsup = 1;
+        n = 0;
+      }
       S.hit_cnt[i] = n;
     }
+    if (wmax((double)unsup) > 0) flags |= SG_FLAG_UNSUPPORTED_PAIR;
     SGT_SYNC();
     SGT_ONE {
       int off = 0;
@@ -1861,3 +1876,9 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
 }
 
 }  // namespace sgt
+
+#if defined(__HIPCC__)
+// launchers (sg_tree.hip): the kernel is a translation unit of its own
+hipError_t sg_tree_prepare();
+hipError_t sg_launch_tree(const sgt::TreeArgs& a, int CS, size_t lds_bytes, hipStream_t s);
+#endif

@@ -6,7 +6,6 @@
 // boxes and 17 016 candidate pairs per env the lanes have work: the pair walk, the mass-matrix entries, the M^-1 columns, the slider
 // rows and a contact's chain block are all lane-parallel.  Bounds: fp64 VALU issue and LDS latency; HBM traffic is
 // the contact rows' J / W blocks (<= 128 x 1.9 KB per env, L2-resident) and the 272 KB pair table shared by all envs.
-#pragma once
 #include <hip/hip_runtime.h>
 
 #include "sg_tree.h"
@@ -19,4 +18,19 @@ __global__ __launch_bounds__(64) void sg_tree_kernel(sgt::TreeArgs a) {
   const int env = blockIdx.x;
   if (env >= a.nenv) return;
   sgt::tree_env<CHD>(a, env, sg_tree_lds);
+}
+
+// ---- launchers (declared in sg_tree.h) ----
+hipError_t sg_tree_prepare() {
+  hipError_t e = hipFuncSetAttribute((const void*)sg_tree_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sg_tree_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sg_tree_kernel<SGT_CHD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return e;
+}
+// the instantiation whose unroll capacity is the smallest one >= the model's padded chain stride CS
+hipError_t sg_launch_tree(const sgt::TreeArgs& a, int CS, size_t lds_bytes, hipStream_t s) {
+  if (CS <= 8) hipLaunchKernelGGL(sg_tree_kernel<8>, dim3(a.nenv), dim3(64), lds_bytes, s, a);
+  else if (CS <= 20) hipLaunchKernelGGL(sg_tree_kernel<20>, dim3(a.nenv), dim3(64), lds_bytes, s, a);
+  else hipLaunchKernelGGL(sg_tree_kernel<SGT_CHD>, dim3(a.nenv), dim3(64), lds_bytes, s, a);
+  return hipGetLastError();
 }

@@ -68,12 +68,29 @@ class ManEnv(Env):
         self.contact_flag_mode = contact_flag_mode
         self.rng = np.random  # the reference draws from the global NumPy RNG (manenv.py:104)
         self.n_resets = 0     # envs reset after a simulation warning (what `except MujocoException: self.reset()` did, manenv.py:50-51)
+        self._scenes = {}     # path -> the loaded scene (model, batch, buffers, the damper it runs with): load_env() of a scene seen before
+                              # neither compiles, allocates nor dry-runs again (the reference's loop switches scene after EVERY episode)
         self._load(env_paths[0])
         self.is_closing = True
 
     # ---- model / batch management (reference manenv.py:27-41) ----
+    _SCENE_STATE = ("model", "tendon_damper", "nmodel", "env", "_sens", "_flags", "_touch", "_ctrl", "_finger_bits", "_finger_bits_names", "_fingers_left")
+
     def _load(self, path, _damper=None):
         import torch
+        if _damper is None and path in self._scenes:
+            # A scene this instance has loaded before: its batch is kept alive, the load-time verdict (which damper it needs) with it.
+            # What the reference's load_env leaves behind is a fresh MjSim -- the state after mj_resetData, the XML's own stiffness --
+            # so: that state, no per-env stiffness, the reference-mode finger list refilled.
+            for k, v in self._scenes[path].items():
+                setattr(self, k, v)
+            self._ctrl[:] = 0
+            self.stiffness = np.full(self.n_envs, np.nan)
+            self._k_range = (300, 1400)
+            self.env.set_stiffness(np.zeros(self.n_envs), [], [])
+            self.env.reset(0, flags=self._flags)
+            self._fingers_left.fill_((1 << len(self._finger_bits_names)) - 1)
+            return
         want = _damper or self._tendon_damper_arg
         self.model = load_model(path, None if want == "auto" else want)
         self.tendon_damper = "implicit" if self.model.opt_implicit_tendon_damping else "explicit"
@@ -108,6 +125,8 @@ class ManEnv(Env):
                     raise
                 print("NOTICE: %s\n        reloading it with tendon_damper=\"implicit\" (DESIGN.md D5)" % err)
                 self._load(path, "implicit")
+                return
+        self._scenes[path] = {k: getattr(self, k) for k in self._SCENE_STATE}
 
     def _check_scene(self, path, n_steps=40):
         """Fail loudly at load time for a scene that cannot produce data: the idle phase of an episode (reset + 40 env steps at

@@ -31,16 +31,23 @@ class SoftgripError(RuntimeError):
 
 
 def lib():
+    """the product library (soft-grip_amd/libsoftgrip.so; SOFTGRIP_LIB: a profiling / experiment build of it)"""
     global _LIB
-    if _LIB is not None:
-        return _LIB
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            "libsoftgrip.so is missing (%s).  Build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
-            "there is no CPU fallback for the simulator." % LIB_PATH)
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libsoftgrip.so is missing (%s).  Build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+                "there is no CPU fallback for the simulator." % LIB_PATH)
+        _LIB = load_library(os.environ.get("SOFTGRIP_LIB", LIB_PATH))
+    return _LIB
+
+
+def load_library(path):
+    """a build of the library as a configured ctypes handle.  `NativeModel(model, library=...)` binds a model -- and the batches made
+    from it -- to another build than the product's (the cross-check tests load the test build with r01's pipelines this way)."""
     import torch  # noqa: F401  -- first: PyTorch-ROCm ships its own HIP runtime, and the process must end up with ONE (loading
     # libsoftgrip.so first would pull in /opt/rocm's copy and torch would then find no devices)
-    L = C.CDLL(os.environ.get("SOFTGRIP_LIB", LIB_PATH))  # SOFTGRIP_LIB: the profiling build of scripts/section_profile.py
+    L = C.CDLL(path)
     vp, dp, ip, i64 = C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong
     L.sg_last_error.restype = C.c_char_p
     L.sg_version.restype = C.c_char_p
@@ -72,13 +79,12 @@ def lib():
     L.sg_profile_enable.argtypes = [vp, C.c_int]
     L.sg_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.sg_profile_read_solver.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
-    _LIB = L
     return L
 
 
-def check(code):
+def check(code, L=None):
     if code != SG_OK:
-        raise SoftgripError(code, lib().sg_last_error().decode())
+        raise SoftgripError(code, (L or lib()).sg_last_error().decode())
 
 
 def compile_mjcf_native(xml_path, composite_neighbors=True, implicit_tendon_damping=False):
@@ -96,12 +102,12 @@ def compile_mjcf_native(xml_path, composite_neighbors=True, implicit_tendon_damp
 class NativeModel:
     """sg_model handle built from a compiled ``mjcf.Model``."""
 
-    def __init__(self, model):
+    def __init__(self, model, library=None):
         self.model = model
+        self.L = L = library or lib()
         blob = model.to_blob()
         self.ptr = C.c_void_p()
-        check(lib().sg_model_create(blob, len(blob), C.byref(self.ptr)))
-        L = lib()
+        check(L.sg_model_create(blob, len(blob), C.byref(self.ptr)), L)
         self.nq = L.sg_model_nq(self.ptr)
         self.nv = L.sg_model_nv(self.ptr)        # == nq unless the model has a free joint (7 positions, 6 dofs)
         self.nu = L.sg_model_nu(self.ptr)
@@ -111,8 +117,8 @@ class NativeModel:
         self.nboxes = L.sg_model_nboxes(self.ptr)     # moving finger boxes = bits of the contact read-out
 
     def __del__(self):
-        if getattr(self, "ptr", None) and _LIB is not None:
-            _LIB.sg_model_destroy(self.ptr)
+        if getattr(self, "ptr", None) and getattr(self, "L", None) is not None:
+            self.L.sg_model_destroy(self.ptr)
             self.ptr = None
 
 
@@ -127,13 +133,17 @@ class NativeBatch:
         import torch
         self.torch = torch
         self.nmodel, self.n, self.device_index = nmodel, n_envs, device
+        self.L = nmodel.L
         self.ptr = C.c_void_p()
-        check(lib().sg_batch_create(nmodel.ptr, n_envs, device, C.byref(self.ptr)))
+        self._check(self.L.sg_batch_create(nmodel.ptr, n_envs, device, C.byref(self.ptr)))
         self.device = torch.device("cuda", device)
 
+    def _check(self, code):
+        check(code, self.L)
+
     def __del__(self):
-        if getattr(self, "ptr", None) and _LIB is not None:
-            _LIB.sg_batch_destroy(self.ptr)
+        if getattr(self, "ptr", None) and getattr(self, "L", None) is not None:
+            self.L.sg_batch_destroy(self.ptr)
             self.ptr = None
 
     def _stream(self):
@@ -144,68 +154,68 @@ class NativeBatch:
         assert k.shape == (self.n,)
         ja = (C.c_int * len(jnt_ids))(*jnt_ids)
         ta = (C.c_int * len(ten_ids))(*ten_ids)
-        check(lib().sg_set_stiffness(self.ptr, k.ctypes.data_as(C.c_void_p), 1, ja, len(jnt_ids), ta, len(ten_ids), self._stream()))
+        self._check(self.L.sg_set_stiffness(self.ptr, k.ctypes.data_as(C.c_void_p), 1, ja, len(jnt_ids), ta, len(ten_ids), self._stream()))
 
     def set_ctrl_broadcast(self, ctrl):
         c = np.ascontiguousarray(ctrl, dtype=np.float64)
         assert c.shape == (self.nmodel.nu,)
-        check(lib().sg_set_ctrl(self.ptr, c.ctypes.data_as(C.c_void_p), 1, self._stream()))
+        self._check(self.L.sg_set_ctrl(self.ptr, c.ctypes.data_as(C.c_void_p), 1, self._stream()))
 
     def set_ctrl(self, ctrl_t):
         assert ctrl_t.is_cuda and ctrl_t.dtype == self.torch.float64 and ctrl_t.shape == (self.n, self.nmodel.nu) and ctrl_t.is_contiguous()
-        check(lib().sg_set_ctrl(self.ptr, _ptr(ctrl_t), 0, self._stream()))
+        self._check(self.L.sg_set_ctrl(self.ptr, _ptr(ctrl_t), 0, self._stream()))
 
     def reset(self, sim_start, sens=None, flags=None, touch=None, mask=None):
-        check(lib().sg_reset(self.ptr, _ptr(mask), sim_start, _ptr(sens), _ptr(flags), _ptr(touch), self._stream()))
+        self._check(self.L.sg_reset(self.ptr, _ptr(mask), sim_start, _ptr(sens), _ptr(flags), _ptr(touch), self._stream()))
 
     def step(self, n_substeps, sens=None, sens_stride=0, flags=None, touch=None):
-        check(lib().sg_step(self.ptr, n_substeps, _ptr(sens), sens_stride, _ptr(flags), _ptr(touch), self._stream()))
+        self._check(self.L.sg_step(self.ptr, n_substeps, _ptr(sens), sens_stride, _ptr(flags), _ptr(touch), self._stream()))
 
     def get_state(self):
         t, m = self.torch, self.nmodel
         kw = dict(dtype=t.float64, device=self.device)
         out = dict(qpos=t.empty(self.n, m.nq, **kw), qvel=t.empty(self.n, m.nv, **kw), act=t.empty(self.n, m.nu, **kw),
                    qacc_warmstart=t.empty(self.n, m.nv, **kw), ctrl=t.empty(self.n, m.nu, **kw))
-        check(lib().sg_get_state(self.ptr, _ptr(out["qpos"]), _ptr(out["qvel"]), _ptr(out["act"]), _ptr(out["qacc_warmstart"]),
+        self._check(self.L.sg_get_state(self.ptr, _ptr(out["qpos"]), _ptr(out["qvel"]), _ptr(out["act"]), _ptr(out["qacc_warmstart"]),
                                  _ptr(out["ctrl"]), self._stream()))
         return out
 
     def set_state(self, qpos=None, qvel=None, act=None, qacc_warmstart=None, ctrl=None):
         for x in (qpos, qvel, act, qacc_warmstart, ctrl):
             assert x is None or (x.is_cuda and x.dtype == self.torch.float64 and x.is_contiguous())
-        check(lib().sg_set_state(self.ptr, _ptr(qpos), _ptr(qvel), _ptr(act), _ptr(qacc_warmstart), _ptr(ctrl), self._stream()))
+        self._check(self.L.sg_set_state(self.ptr, _ptr(qpos), _ptr(qvel), _ptr(act), _ptr(qacc_warmstart), _ptr(ctrl), self._stream()))
 
     def solver_stats(self):
         t = self.torch
         out = [t.empty(self.n, dtype=t.int32, device=self.device) for _ in range(3)]
-        check(lib().sg_get_solver_stats(self.ptr, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), self._stream()))
+        self._check(self.L.sg_get_solver_stats(self.ptr, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), self._stream()))
         return dict(ncon=out[0], nefc=out[1], iters=out[2])
 
     def set_pipeline(self, name):
-        check(lib().sg_set_pipeline(self.ptr, {"fused": 0, "split": 1, "rows": 2, "tree": 3}[name]))
+        self._check(self.L.sg_set_pipeline(self.ptr, {"fused": 0, "split": 1, "rows": 2, "tree": 3}[name]))
 
     def touch_words(self, nwords=2):
         """[n, nwords] int32: bit g of an env's words = moving finger box g touches an object geom (sg_get_touch_words)"""
         t = self.torch
         out = t.empty(self.n, nwords, dtype=t.int32, device=self.device)
-        check(lib().sg_get_touch_words(self.ptr, _ptr(out), nwords, self._stream()))
+        self._check(self.L.sg_get_touch_words(self.ptr, _ptr(out), nwords, self._stream()))
         return out
 
     def set_solver_envs_per_wavefront(self, epw):
-        check(lib().sg_set_solver_envs_per_wavefront(self.ptr, int(epw)))
+        self._check(self.L.sg_set_solver_envs_per_wavefront(self.ptr, int(epw)))
 
     def solver_envs_per_wavefront(self):
-        return lib().sg_solver_envs_per_wavefront(self.ptr)
+        return self.L.sg_solver_envs_per_wavefront(self.ptr)
 
     def profile_enable(self, on=True):
-        check(lib().sg_profile_enable(self.ptr, int(on)))
+        self._check(self.L.sg_profile_enable(self.ptr, int(on)))
 
     def profile_read(self, reset=True):
         ms, n = C.c_double(), C.c_longlong()
-        check(lib().sg_profile_read(self.ptr, int(reset), C.byref(ms), C.byref(n)))
+        self._check(self.L.sg_profile_read(self.ptr, int(reset), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
     def profile_read_solver(self, reset=True):
         ms, n = C.c_double(), C.c_longlong()
-        check(lib().sg_profile_read_solver(self.ptr, int(reset), C.byref(ms), C.byref(n)))
+        self._check(self.L.sg_profile_read_solver(self.ptr, int(reset), C.byref(ms), C.byref(n)))
         return ms.value, n.value

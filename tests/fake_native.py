@@ -1,5 +1,5 @@
 """A fake native batch for host-logic tests (no GPU): records every physics call; sensordata = running substep count (like the
-stub simulator of the harness fixture).  Test infrastructure only -- bench.py loads it solely under --fake-native-for-tests."""
+stub simulator of the harness fixture).  Test infrastructure only: tests/run_with_fake_native.py puts it in the library's place; no product file knows it."""
 import numpy as np
 import torch
 

@@ -13,6 +13,23 @@ def model_path(scene):
     return os.path.join(ROOT, "models", scene + ".sgmodel")
 
 
+_LEGACY = None
+
+
+def library_for(pipeline):
+    """the build of the library that has `pipeline`: the product (None: rows, tree) -- or, for r01's fused / split pipelines, the TEST
+    build with them (soft-grip_amd/libsoftgrip_legacy.so, -DSG_LEGACY_PIPELINES), which this helper builds when it is missing or
+    older than its sources (hipcc, ~1.5 minutes once) and loads beside the product: the cross-checks against those pipelines do not
+    ship in libsoftgrip.so"""
+    global _LEGACY
+    if pipeline not in ("fused", "split"):
+        return None
+    if _LEGACY is None:
+        from softgrip_amd import build_native, native
+        _LEGACY = native.load_library(build_native.build(legacy=True))
+    return _LEGACY
+
+
 class Emu:
     """ctypes wrapper of tests/emu/libsgemu.so (lane-serial run of the kernels' math)."""
 

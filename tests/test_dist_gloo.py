@@ -1,5 +1,6 @@
-"""Multi-GPU path on CPU: world_size-2 gloo processes check the shard partition (no data-path collective) and the
-max-over-ranks timing reduction bench.py uses."""
+"""Multi-GPU path on CPU, world_size 2: the shard partition (no data-path collective), bench.py's default rank synchronisation -- a TCP
+store, no collective library (softgrip_amd/ranks.py) -- self-launched and under torch.distributed.run, its optional torch.distributed
+backend on gloo, and create_dataset's ranks.  The product scripts run over tests/fake_native.py through tests/run_with_fake_native.py."""
 import os
 import socket
 import subprocess
@@ -59,13 +60,35 @@ def _free_port():
     return port
 
 
-def test_bench_launches_its_own_ranks_gloo():
-    """the REAL bench.py, `--gpus 2` with no launcher: it starts two ranks itself (torch.distributed.run as a child process), both
-    run the stratified episode loop on the fake native batch, rank 0 prints the one JSON line with the whole-job aggregate"""
+FAKE = os.path.join(ROOT, "tests", "run_with_fake_native.py")
+
+
+def test_rank_group_store_barrier_and_gather(tmp_path):
+    """ranks.RankGroup on its own: three ranks started by ranks.spawn_ranks, two barriers and a gather through the store; a rank that
+    fails ends the job with its exit code"""
+    w = tmp_path / "w.py"
+    w.write_text("import sys, os, time\nsys.path.insert(0, %r)\nfrom softgrip_amd import ranks\n"
+                 "if not ranks.launched_as_rank():\n    raise SystemExit(ranks.spawn_ranks(3))\n"
+                 "g = ranks.RankGroup()\ng.barrier()\ntime.sleep(0.05 * g.rank)\ng.barrier()\n"
+                 "v = g.gather('t', 0.5 * (g.rank + 1))\nassert v == [0.5, 1.0, 1.5], v\n"
+                 "if len(sys.argv) > 1 and g.rank == 1:\n    raise SystemExit(7)\n"
+                 "g.close()\nprint('rank', g.rank, 'ok', flush=True)\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(w)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and sorted(out.stdout.split("\n")[:3]) == ["rank 0 ok", "rank 1 ok", "rank 2 ok"], (out.stdout, out.stderr[-2000:])
+    out = subprocess.run([sys.executable, str(w), "fail"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 7, (out.returncode, out.stderr[-2000:])
+
+
+def test_bench_launches_its_own_ranks():
+    """the REAL bench.py, `--gpus 2` with no launcher, on its DEFAULT rank synchronisation: the parent starts two ranks itself (child
+    processes, no torch.distributed.run), they meet on a TCP store -- no process group, no collective -- run the stratified episode
+    loop on the fake native batch, and rank 0 prints the one JSON line with the whole-job aggregate.  Then the same file launched the
+    way the driver does it (torch.distributed.run: the ranks join the launcher's store), and once on the optional gloo backend."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "16",
-                          "--dist-backend", "gloo", "--fake-native-for-tests"], capture_output=True, text=True, env=env, timeout=600)
+    out = subprocess.run([sys.executable, FAKE, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "16"],
+                         capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                   # ONE line, from rank 0
@@ -73,15 +96,20 @@ def test_bench_launches_its_own_ranks_gloo():
     assert res["n_gpus"] == 2 and res["steps"] == 20 and res["warmup"] == 5 and res["scaling"] == "weak"
     assert res["config"]["steps_timed"] == 20 and "stratified over the episode" in res["config"]["timed_region"]
     assert abs(res["value"] - 2 * 16 * 20 / (res["ms_per_step"] * 20e-3)) < 1e-6 * res["value"]    # whole-job aggregate over max-rank time
-    assert "split in per-rank bins" in res["config"]["workload"] and res["data"].startswith("FAKE")
-    # launched the way the driver does it, the same file runs as a rank
-    port = _free_port()
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "3",
-                          "--envs", "8", "--dist-backend", "gloo", "--fake-native-for-tests"], capture_output=True, text=True, env=env, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert res["config"]["steps_timed"] == 200 and "1 whole episode" in res["config"]["timed_region"]
+    assert "split in per-rank bins" in res["config"]["workload"] and "no collective library" in res["config"]["rank_sync"]
+    assert len(res["ms_per_step_per_rank"]) == 2 and abs(max(res["ms_per_step_per_rank"]) - res["ms_per_step"]) < 1e-9
+    assert "FAKE native batch" in out.stderr
+    # launched the way the driver does it, the same file runs as a rank: default (store) and the optional torch.distributed backend
+    for extra, sync in ([], "no collective library"), (["--dist-backend", "gloo"], "gloo"):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(_free_port()), FAKE, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "3",
+                              "--envs", "8"] + extra, capture_output=True, text=True, env=env, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        res = json.loads(lines[0])
+        assert res["n_gpus"] == 2 and res["config"]["steps_timed"] == 200 and "1 whole episode" in res["config"]["timed_region"]
+        assert sync in res["config"]["rank_sync"] and len(res["ms_per_step_per_rank"]) == 2
 
 
 CD_WORKER = r"""
@@ -116,17 +144,17 @@ def test_create_dataset_main_two_ranks(tmp_path):
 
 
 def test_create_dataset_launches_its_own_ranks(tmp_path):
-    """`python -m softgrip_amd.create_dataset --gpus 2` with no launcher starts its own two ranks (a child
-    torch.distributed.run, before anything touches a GPU), each with its own stiffness bin and shard; the parent adds the ranks'
-    summary files up into one JSON line.  --total-episodes fixes the dataset size (BASELINE configs[3]: 8 x 4096 x 4)."""
+    """`python -m softgrip_amd.create_dataset --gpus 2` with no launcher starts its own two ranks (child processes of a parent that
+    touches no GPU), each with its own stiffness bin and shard; the ranks share nothing; the parent adds their summary files up into
+    one JSON line.  --total-episodes fixes the dataset size (BASELINE configs[3]: 8 x 4096 x 4)."""
     import json
     import pickle
     from helpers import model_path
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
-    out = subprocess.run([sys.executable, "-m", "softgrip_amd.create_dataset", "--gpus", "2", "--mujoco-model-paths", model_path("softbox"),
-                          "--n-envs", "5", "--total-episodes", "30", "--seed", "3", "--data-folder", str(tmp_path / "ds"), "--data-name", "cfg4",
-                          "--fake-native-for-tests"], capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+    out = subprocess.run([sys.executable, FAKE, "-m", "softgrip_amd.create_dataset", "--gpus", "2", "--mujoco-model-paths", model_path("softbox"),
+                          "--n-envs", "5", "--total-episodes", "30", "--seed", "3", "--data-folder", str(tmp_path / "ds"), "--data-name", "cfg4"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["n_gpus"] == 2 and res["episodes"] == 30 and res["env_steps"] == 30 * 200 and len(res["per_rank_env_steps_per_s"]) == 2

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import softgrip_amd as sg
-from helpers import JOINT_IDS, TENDON_IDS, model_path, oracle_sim
+from helpers import JOINT_IDS, TENDON_IDS, library_for, model_path, oracle_sim
 from softgrip_amd.create_dataset import episode_schedule
 
 pytestmark = pytest.mark.gpu
@@ -16,7 +16,7 @@ def _gpu_batch(scene, ks, pipeline=None, damper=None):
     from softgrip_amd import native
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     m = sg.load_model(model_path(scene), damper)
-    nm = native.NativeModel(m)
+    nm = native.NativeModel(m, library_for(pipeline))
     b = native.NativeBatch(nm, len(ks), 0)
     if pipeline is not None:
         b.set_pipeline(pipeline)
@@ -268,10 +268,15 @@ def test_pipelines_agree_at_full_size():
 
 
 def test_neighbour_row_model_refuses_other_pipelines():
+    """in the test build, which has them; the product build has no fused / split pipeline at all and says so"""
     from softgrip_amd import native
-    m, nm, b = _gpu_batch("softbox", [700.0])
+    m = sg.load_model(model_path("softbox"))
+    b = native.NativeBatch(native.NativeModel(m, library_for("fused")), 1, 0)
     with pytest.raises(native.SoftgripError):
         b.set_pipeline("fused")
+    m, nm, b = _gpu_batch("softbox_fix", [700.0])
+    with pytest.raises(native.SoftgripError, match="not part of this build"):
+        b.set_pipeline("split")
 
 
 @pytest.mark.parametrize("scene", ["softbox", "softbox_fix"])
@@ -828,7 +833,7 @@ def test_own_scene_through_the_native_compiler(neighbors, pipeline):
     assert m.nv == 42 and m.neq == (99 if neighbors else 35)
     jids, tids = list(range(8, 42)), [0]
     ks = [640.0, 300.0, 1400.0, 905.5, 512.25]
-    nm = native.NativeModel(m)
+    nm = native.NativeModel(m, library_for(pipeline))
     b = native.NativeBatch(nm, len(ks), 0)
     b.set_pipeline(pipeline)
     b.set_stiffness(np.asarray(ks), jids, tids)
@@ -999,7 +1004,7 @@ def test_one_slider_under_both_fingers_on_the_gpu(tmp_path, neighbors, pipeline)
     m = sg.Model.from_blob(native.compile_mjcf_native(thin_shell_scene(tmp_path / "thin.xml"), composite_neighbors=neighbors))
     jids, tids = list(range(8, m.nv)), [0]
     ks = [600.0, 300.0, 1400.0, 950.0]
-    b = native.NativeBatch(native.NativeModel(m), len(ks), 0)
+    b = native.NativeBatch(native.NativeModel(m, library_for(pipeline)), len(ks), 0)
     b.set_pipeline(pipeline)
     b.set_stiffness(np.asarray(ks), jids, tids)
     sens, flags, touch = _bufs(b, len(ks))
@@ -1090,7 +1095,7 @@ def test_general_contact_path_on_the_gpu(tmp_path, kind, neighbors):
     assert special > 300, special
     # the other pipelines have no general path: there the pair is reported as data, never silently dropped
     if not neighbors and kind == "stop":
-        b2 = native.NativeBatch(native.NativeModel(m), 2, 0)
+        b2 = native.NativeBatch(native.NativeModel(m, library_for("split")), 2, 0)
         b2.set_pipeline("split")
         b2.set_stiffness(np.asarray(ks[:2]), jids, tids)
         s2, f2, t2 = _bufs(b2, 2)
@@ -1103,22 +1108,78 @@ def test_general_contact_path_on_the_gpu(tmp_path, kind, neighbors):
         assert seen == 32
 
 
+@pytest.mark.parametrize("neighbors", [False, True])
+def test_general_contact_path_takes_the_whole_batch(tmp_path, neighbors):
+    """VERDICT r03 3(d) / ADVICE r03: the general contact path used to take 256 envs per substep and flag the rest (which 256: the order
+    of arrival).  The "rest" scene -- the object resting on the ground plane, so EVERY env is on that path in EVERY substep -- at 1 500
+    envs of one stiffness: no env flagged, all envs bit-identical whatever block of the general pass served them, env 0 equal to the
+    oracle step by step, twice from reset with the same bits."""
+    import torch
+    from oracle import oracle as O
+    from softgrip_amd import native
+    from test_emu_vs_oracle import general_path_scene, special_contacts
+    m = sg.Model.from_blob(native.compile_mjcf_native(general_path_scene("rest", tmp_path / "rest.xml"), composite_neighbors=neighbors))
+    jids, tids = list(range(8, m.nv)), [0]
+    n = 1500
+    b = native.NativeBatch(native.NativeModel(m), n, 0)
+    b.set_stiffness(np.full(n, 640.0), jids, tids)
+    sens, flags, touch = _bufs(b, n)
+    runs = []
+    for rep in range(2):
+        s = O.OracleSim(O.OracleModel(m.to_blob()))
+        s._om = s.model
+        s.jnt_stiffness[jids] = 640.0
+        s.tendon_stiffness[tids] = 640.0
+        s.reset(); s.forward(); s.step()
+        b.reset(1, sens=sens, flags=flags, touch=touch)
+        ctrl = np.zeros(2)
+        rows, special = [], 0
+        for t, c in enumerate(episode_schedule()[:60]):
+            if c is not None:
+                ctrl[:] = c
+                b.set_ctrl_broadcast(ctrl)
+                s.ctrl[:] = c
+            b.step(7, sens=sens, flags=flags, touch=touch)
+            for _ in range(7):
+                assert s.step() == 0
+            assert int(flags.abs().sum()) == 0, (t, torch.nonzero(flags).flatten()[:8].tolist())
+            x = sens.cpu().numpy()
+            assert (x == x[0]).all(), t                                          # identical envs: bit-identical, wherever they were served
+            st = b.solver_stats()
+            assert (st["ncon"] == s.ncon).all() and (st["nefc"] == s.nefc).all() and (st["iters"] == s.solver_iter).all(), t
+            assert np.abs(x[0] - s.sensordata).max() < TOL_SENSOR, t
+            special += special_contacts(m, s.contacts(), "rest")
+            rows.append(x[0].copy())
+            qp = torch.tensor(np.tile(s.qpos, (n, 1)), dtype=torch.float64, device=b.device)      # (dozens of standing contacts: re-seated per step)
+            qv = torch.tensor(np.tile(s.qvel, (n, 1)), dtype=torch.float64, device=b.device)
+            qa = torch.tensor(np.tile(s.act, (n, 1)), dtype=torch.float64, device=b.device)
+            qw = torch.tensor(np.tile(s.qacc_warmstart, (n, 1)), dtype=torch.float64, device=b.device)
+            b.set_state(qpos=qp, qvel=qv, act=qa, qacc_warmstart=qw)
+        assert special > 60 * 4, special
+        runs.append(np.stack(rows))
+    assert (runs[0] == runs[1]).all()
+
+
 def test_bench_two_ranks_with_the_real_library(tmp_path):
-    """the multi-process path with the real kernels: `bench.py --gpus 2` launches its own two workers (torch.distributed.run as a child
-    process), both placed on this box's one GPU (--force-device 0) with gloo as the rendezvous backend (RCCL refuses two ranks on one
-    device); per-rank stiffness bins, barrier + max-over-ranks timing, one JSON line from rank 0 with the whole-job rate"""
+    """the multi-process path with the real kernels on its DEFAULT rank synchronisation: `bench.py --gpus 2` starts its own two ranks
+    (children of a parent that never touches the GPU), both placed on this box's one GPU (--force-device 0); they meet on a TCP store --
+    no process group, no collective library --; per-rank stiffness bins, barrier + max-over-ranks timing, one JSON line from rank 0
+    with the whole-job rate.  Then once launched the way the driver does it (torch.distributed.run)."""
     import json
     import os
     import subprocess
     import sys
     from helpers import ROOT
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs", "512", "--steps", "10", "--warmup", "2",
-                          "--dist-backend", "gloo", "--force-device", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "weak" and d["config"]["envs_per_gpu"] == 512
-    assert d["config"]["envs_flagged_bad"] == 0 and d["value"] > 1e4 and "per-rank bins" in d["config"]["workload"]
-    assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    from softgrip_amd import ranks
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = ["--gpus", "2", "--envs", "512", "--steps", "10", "--warmup", "2", "--force-device", "0", "--no-cpu-baseline"]
+    for launcher in ([], ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(ranks.free_port())]):
+        out = subprocess.run([sys.executable] + launcher + [os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "weak" and d["config"]["envs_per_gpu"] == 512
+        assert d["config"]["envs_flagged_bad"] == 0 and d["value"] > 1e4 and "per-rank bins" in d["config"]["workload"]
+        assert "no collective library" in d["config"]["rank_sync"] and len(d["ms_per_step_per_rank"]) == 2
+        assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

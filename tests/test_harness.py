@@ -281,6 +281,53 @@ def test_multi_scene_loop_matches_reference(fake_native, tmp_path, monkeypatch):
     assert [float(np.array(x)[0, 0]) for x in d["data"]] == M["first_sensor_of_each_sample"]
 
 
+def test_load_env_of_a_scene_seen_before_reuses_its_batch(fake_native, monkeypatch, capsys):
+    """the reference's loop switches scene after every episode (create_dataset.py:68-72, NUM_EPISODES = 1).  The
+    second load_env of a scene must not compile the model, create a batch or dry-run the idle phase again -- its batch and its
+    load-time verdict (here: "needs the implicit damper") are kept -- and must leave what a fresh MjSim would: the state after
+    mj_resetData, no per-env stiffness, ctrl 0."""
+    orig = fake_native._advance
+
+    def ball_fails_explicit(self, n, sens, flags, touch):
+        orig(self, n, sens, flags, touch)
+        if flags is not None and "softball" in self.nmodel.model_path and not self.nmodel.model.opt_implicit_tendon_damping:
+            flags[0] = 4
+    loads, made = [], []
+    real_load, real_init = manenv.load_model, fake_native.__init__
+
+    def logging_load(path, tendon_damper=None):
+        loads.append((os.path.basename(path), tendon_damper))
+        m = real_load(path, tendon_damper)
+        m._path = path
+        return m
+
+    def counting_init(self, nmodel, n_envs, device=0):
+        nmodel.model_path = nmodel.model._path
+        made.append(os.path.basename(nmodel.model_path))
+        real_init(self, nmodel, n_envs, device)
+    monkeypatch.setattr(manenv, "load_model", logging_load)
+    monkeypatch.setattr(fake_native, "__init__", counting_init)
+    monkeypatch.setattr(fake_native, "_advance", ball_fails_explicit)
+    paths = [model_path("softbox_fix"), model_path("softball_fix")]
+    env = manenv.ManEnv(1, 7, paths, is_vis=False, n_envs=2)
+    env.load_env(1)
+    assert env.tendon_damper == "implicit" and "reloading it" in capsys.readouterr().out
+    n_loads, n_made = len(loads), len(made)
+    assert n_loads == 3 and made == ["softbox_fix.sgmodel", "softball_fix.sgmodel", "softball_fix.sgmodel"]   # box; ball explicit, then implicit
+    for _ in range(3):                                 # the episode loop: box, ball, box, ball ...
+        env.load_env(0)
+        assert env.tendon_damper == "explicit" and env.model.opt_implicit_tendon_damping == 0
+        env.reset(); env.close_hand(); env.step()
+        n_sub = sum(1 for e in fake_native.log if e[0] == "substep")
+        env.load_env(1)
+        assert sum(1 for e in fake_native.log if e[0] == "substep") == n_sub          # no dry run: not one substep
+        assert env.tendon_damper == "implicit" and env.model.opt_implicit_tendon_damping == 1
+        assert fake_native.log[-1] == ("reset", 0) and fake_native.log[-2][0] == "stiffness" and fake_native.log[-2][1:3] == ([], [])
+        assert np.isnan(env.stiffness).all() and (env._ctrl == 0).all() and (env.env.ctrl == 0).all()
+        env.reset(); env.step()
+    assert len(loads) == n_loads and len(made) == n_made and capsys.readouterr().out == ""
+
+
 def test_stiffness_id_sets_can_be_overridden_and_are_checked(fake_native):
     """the reference hard-codes joints 11..63 and tendon 0 (manenv.py:12-13) -- the defaults; another scene layout passes its own ids,
     and ids that do not fit the loaded scene are refused at load time instead of failing inside the library"""

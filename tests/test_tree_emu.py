@@ -203,6 +203,45 @@ def test_special_scenes_pair_kinds_and_the_serial_list(tmp_path, kind):
     assert worst < 1e-7, worst
 
 
+def test_pair_with_other_contact_parameters_is_flagged_not_dropped(tmp_path):
+    """a candidate pair whose mixed contact parameters differ from the finger / object pairs' (the plan keeps one set) cannot
+    become rows in the tree pipeline -- it must then raise SG_FLAG_UNSUPPORTED_PAIR once it is within reach, not vanish: the "stop"
+    scene's static block with a friction of its own.  No flag while the finger is away; flagged no later than the substep in which the
+    oracle (which mixes parameters per pair) reports a contact on the block."""
+    from test_emu_vs_oracle import general_path_scene, special_contacts
+    path = general_path_scene("stop", tmp_path / "stop.xml")
+    x = open(path).read().replace('<geom name="stop" class="link"', '<geom name="stop" class="link" friction="2.5 0.005 0.0001"')
+    assert 'friction="2.5' in x
+    open(path, "w").write(x)
+    m = sg.compile_mjcf(path, composite_neighbors=False)
+    jids = list(range(8, m.nv))
+    s = oracle_sim(m)
+    s.jnt_stiffness[jids] = 640.0
+    s.tendon_stiffness[0] = 640.0
+    s.reset(); s.forward(); s.step()
+    e = TreeEmu(m)
+    e.set_stiffness(640.0, jids, [0])
+    assert e.reset(1) == 0
+    first_flag = first_contact = None
+    for t, c in enumerate(episode_schedule()[:120]):
+        if c is not None:
+            e.ctrl[:] = c
+            s.ctrl[:] = c
+        for _ in range(7):
+            assert s.step() == 0
+        fl = e.step(7)
+        assert fl in (0, 32), (t, fl)                       # SG_FLAG_UNSUPPORTED_PAIR and nothing else
+        if fl and first_flag is None:
+            first_flag = t
+        if special_contacts(m, s.contacts(), "stop") and first_contact is None:
+            first_contact = t
+        if first_flag is not None and first_contact is not None:
+            break
+        e.qpos[:] = s.qpos; e.qvel[:] = s.qvel; e.warm[:] = s.qacc_warmstart; e.act[:] = s.act   # (the flagged env follows the oracle)
+    assert first_contact is not None and first_flag is not None, (first_flag, first_contact)
+    assert 40 < first_flag <= first_contact, (first_flag, first_contact)   # not during the idle phase, not after the contact
+
+
 # ---- the free object (soft_experiments_softball.xml:8): the composite's elements on a body with a free joint ----
 def _free_mini(tmp_path, far):
     """the own scene with a <freejoint/> on the object's body; far: lifted out of the gripper's reach and tilted (no contacts ever)"""
