@@ -12,6 +12,14 @@ usage: capture_mujoco_golden.py --xml <reference>/data/gripper/soft_experiments_
        (once per scene: softbox, softball, softcylinder -- the ball / cylinder captures answer DESIGN.md D5: meta["d5"] holds neq,
        the contacts at reset, the env step of the first simulation warning and the volume tendon's equality force in the idle phase)
 
+Since r04 the capture also holds the STAGE INTERMEDIATES of one forward pass -- the first substep of the first stiffness in which a
+contact exists -- as `stage_*` arrays: the state entering that substep (so that the oracle can be seated on exactly it), the contact
+list in MuJoCo's order (geoms, dist, pos, frame, friction, solref, solimp, dim), and per constraint row its type / id, position,
+margin, R, D, aref, force and its DENSE Jacobian row, plus qM, qacc_smooth, qfrc_bias, qacc.  tests/test_mujoco_golden.py
+(check_stages) then compares stage by stage: contact order and geometry, the row order and count, R (the
+impedance / diagApprox resolutions U1, U3 - U6), aref, J and A = J M^-1 J' + R, qacc_smooth and the solver's forces -- one
+capture resolves the open items one by one instead of as one sensor mismatch.
+
 It drives MuJoCo exactly as reference environment/manenv.py:44-109 and create_dataset.py:33-72 do: stiffness on joints 11..63 and
 tendon 0, reset + forward + sim_start(1) steps, then 200 env steps of sim_step(7) substeps under the 40 idle / close at 40 /
 toggle at 120 schedule.
@@ -39,6 +47,11 @@ class PyBackend:  # mujoco_py 2.0.x
     def step(self): self.sim.step()     # mujoco_py raises MujocoException on a simulation warning (what reference manenv.py:50 catches)
     def iters(self): return int(self.data.solver_iter)
     def warnings(self): return [int(w.number) for w in self.data.warning]
+    def is_sparse(self): return bool(self.mj.functions.mj_isSparse(self.model))
+    def full_M(self):
+        M = np.zeros(self.model.nv * self.model.nv)
+        self.mj.functions.mj_fullM(self.model, M, self.data.qM)
+        return M.reshape(self.model.nv, self.model.nv)
 
 
 class NewBackend:  # `mujoco` bindings
@@ -54,6 +67,11 @@ class NewBackend:  # `mujoco` bindings
     def step(self): self.mj.mj_step(self.model, self.data)
     def iters(self): return int(np.sum(np.atleast_1d(self.data.solver_niter)))
     def warnings(self): return [int(w.number) for w in self.data.warning]
+    def is_sparse(self): return bool(self.mj.mj_isSparse(self.model))
+    def full_M(self):
+        M = np.zeros((self.model.nv, self.model.nv))
+        self.mj.mj_fullM(self.model, M, self.data.qM)
+        return M
 
 
 def backend(xml):
@@ -61,6 +79,50 @@ def backend(xml):
         return PyBackend(xml)
     except ImportError:
         return NewBackend(xml)
+
+
+def dense_J(B):
+    """efc_J of the last forward pass as a dense [nefc, nv] array, whatever the Jacobian's storage"""
+    d, nv, n = B.data, B.model.nv, int(B.data.nefc)
+    J = np.zeros((n, nv))
+    flat = np.asarray(d.efc_J).ravel()
+    if B.is_sparse():
+        nnz, adr, col = np.asarray(d.efc_J_rownnz).ravel(), np.asarray(d.efc_J_rowadr).ravel(), np.asarray(d.efc_J_colind).ravel()
+        for r in range(n):
+            J[r, col[adr[r]:adr[r] + nnz[r]]] = flat[adr[r]:adr[r] + nnz[r]]
+    else:
+        J[:] = flat[:n * nv].reshape(n, nv)
+    return J
+
+
+def stage_snapshot(B, entering):
+    """everything one forward pass leaves behind (called right after the mj_step that ran it; `entering`: the state it started from)"""
+    d, n, nc = B.data, int(B.data.nefc), int(B.data.ncon)
+    st = {"stage_" + k: np.array(v, dtype=float) for k, v in entering.items()}
+    con = [d.contact[i] for i in range(nc)]
+    st.update({
+        "stage_con_geom": np.array([[c.geom1, c.geom2] for c in con], dtype=np.int32).reshape(nc, 2),
+        "stage_con_dist": np.array([c.dist for c in con]), "stage_con_pos": np.array([np.asarray(c.pos) for c in con]).reshape(nc, 3),
+        "stage_con_frame": np.array([np.asarray(c.frame) for c in con]).reshape(nc, 9),
+        "stage_con_friction": np.array([np.asarray(c.friction) for c in con]).reshape(nc, 5),
+        "stage_con_solref": np.array([np.asarray(c.solref) for c in con]).reshape(nc, 2),
+        "stage_con_solimp": np.array([np.asarray(c.solimp)[:5] for c in con]).reshape(nc, -1),
+        "stage_con_dim": np.array([c.dim for c in con], dtype=np.int32), "stage_con_efc_address": np.array([c.efc_address for c in con], dtype=np.int32),
+        "stage_con_includemargin": np.array([c.includemargin for c in con]),
+    })
+    for name in ("efc_type", "efc_id"):
+        st["stage_" + name] = np.asarray(getattr(d, name)).ravel()[:n].astype(np.int32)
+    for name in ("efc_pos", "efc_margin", "efc_R", "efc_D", "efc_aref", "efc_force", "efc_vel", "efc_diagApprox", "efc_frictionloss"):
+        if hasattr(d, name):
+            st["stage_" + name] = np.asarray(getattr(d, name)).ravel()[:n].astype(float)
+    J = dense_J(B)
+    st["stage_efc_J"] = J
+    st["stage_efc_J_nnz"] = (J != 0).sum(1).astype(np.int32)
+    st["stage_qM"] = B.full_M()
+    for name in ("qacc_smooth", "qfrc_bias", "qfrc_passive", "qfrc_actuator", "qacc", "qfrc_constraint", "ten_length", "sensordata"):
+        if hasattr(d, name):
+            st["stage_" + name] = np.array(getattr(d, name), dtype=float).ravel()
+    return st
 
 
 def schedule():
@@ -100,6 +162,7 @@ def main():
     nefc = np.zeros_like(ncon)
     iters = np.zeros_like(ncon)
     qpos = np.zeros((len(args.stiffness), N_STEPS + 1, m.nq))
+    stages = {}
     for i, k in enumerate(args.stiffness):
         for j in JOINT_IDS:
             m.jnt_stiffness[j] = k
@@ -115,8 +178,15 @@ def main():
             if c is not None:
                 B.data.ctrl[:] = c
             try:
-                for _ in range(SIM_STEP):
+                for sub in range(SIM_STEP):
+                    entering = None
+                    if i == 0 and not stages:
+                        entering = {"qpos": np.array(B.data.qpos), "qvel": np.array(B.data.qvel), "act": np.array(B.data.act), "ctrl": np.array(B.data.ctrl),
+                                    "qacc_warmstart": np.array(B.data.qacc_warmstart)}
                     B.step()
+                    if entering is not None and int(B.data.ncon) > 0:     # the forward pass of this mj_step ran on `entering` and found a contact
+                        stages = stage_snapshot(B, entering)
+                        stages["stage_where"] = np.array([i, t, sub], dtype=np.int32)
             except Exception as err:  # noqa: BLE001 -- mujoco_py.builder.MujocoException: the reference would reset() here
                 first_warning = first_warning if first_warning is not None else t
                 print("k = %g: %s at env step %d" % (k, type(err).__name__, t))
@@ -131,7 +201,7 @@ def main():
         d5["tendon_row_force_idle"].append(tforce)
     meta["d5"] = d5
     np.savez_compressed(args.out, stiffness=np.array(args.stiffness), sensordata=sens, ncon=ncon, nefc=nefc, iters=iters, qpos=qpos,
-                        meta=json.dumps(meta))
+                        meta=json.dumps(meta), **stages)
     print("wrote", args.out, meta["mujoco"], meta["counts"])
 
 

@@ -499,7 +499,7 @@ static int launch_split(sg_batch* b, int mode, const uint8_t* mask, int nsub, do
     call_ev = b->ev.size() - 1;
   }
   // the main pass over all envs, then (rows pipeline, forward passes only) the general contact pass: a small fixed grid whose
-  // block i takes entry i of W.gen_list, the envs the main pass has put there -- normally none, and then every block returns at once
+  // its blocks stride over W.gen_list, the envs the main pass has put there -- normally none, and then every block returns at once
   const bool genpass = b->pipeline == 2;
   for (int k = 0; k <= nfwd; k++) {
     SgPhaseArgs p = pa;

@@ -662,6 +662,9 @@ SG_HD double contact_block_update(const double* A, const double* res, double* f,
       more = more && !(delta < 1e-10);
       la = more ? delta : 0.0;
     }
+#ifdef SGT_X_NOQCQP   // (timing experiment only: build_native.py --ko noqcqp -DSGT_X_NOQCQP -DSG_SECTION_PROF)
+    more = false;
+#endif
     if (more) {  // uncommon: the unconstrained minimiser leaves the cone -- continue Newton on the multiplier
       for (int it = 1; it < 20; it++) {
         double det = (S11 + la) * (S22 + la) - S12 * S12;

@@ -254,19 +254,12 @@ __device__ __noinline__ double sg_gen_cost(const SgPhaseArgs& a, const int env, 
 // phase kernel: [finish previous substep] [begin next substep]
 // ------------------------------------------------------------------------------------------------
 // GEN = false: the kernel every env runs.  An env in which a collision pair outside the fast path's two kinds is within reach is put on
-// W.gen_list; the GEN = true instantiation -- launched after it with one block per env of the batch, block i takes entry i of that list (normally there is none and every block returns at once) -- then redoes
+// W.gen_list; the GEN = true instantiation -- launched after it with a small grid whose blocks stride over that list (normally empty: every block returns at once) -- then redoes
 // the BEGIN part of exactly those envs on the general contact path (sg_gen_phase) and overwrites their exports.  The general path
 // needs a stack (scratch memory) and every register; compiled into the main instantiation it doubled that kernel's time.
-template <int R, int CPL, bool NB, bool GEN = false>  // NB: the model has neighbour equality rows (H.nnb > 0)
-__global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
+template <int R, int CPL, bool NB, bool GEN>  // NB: the model has neighbour equality rows (H.nnb > 0)
+__device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env) {
   const int lane = threadIdx.x;
-  int env = blockIdx.x;
-  if constexpr (GEN) {
-    const int cnt = a.w.gen_count[0];            // uniform; the list holds every env of the batch if need be (grid = nenv blocks)
-    if ((int)blockIdx.x >= cnt || (int)blockIdx.x >= a.nenv) return;
-    env = a.w.gen_list[blockIdx.x];
-    a.do_finish = 0; a.do_reset = 0; a.sens = nullptr;   // BEGIN only: the main pass has finished the previous substep and stored the state
-  }
   if (env >= a.nenv) return;
   if (a.mask && !a.mask[env]) return;
   SG_T0();
@@ -287,7 +280,7 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   // which read them hundreds of times, runs in sg_chain_kernel
   const SG_CONSTAS SgChain& C = H.chain[half < nchain ? half : 0];
   ChainLds2& CS = Sm.cs[half];
-  SgWork& W = a.w;
+  const SgWork& W = a.w;
 
   // status and pending are LOADED here and TESTED below, after the state loads have been issued: an early return on them would put
   // one memory round trip in front of every other load of the kernel (a wavefront lives ~30 us, a round trip costs 1 - 2)
@@ -1046,6 +1039,23 @@ __global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
   SG_TEND();
 }
 
+template <int R, int CPL, bool NB, bool GEN = false>
+__global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
+  if constexpr (GEN) {
+    // the general pass: a SMALL grid (SG_GEN_GRID blocks; the kernel needs scratch memory and every register, and an empty block of it
+    // is not free: one block per env of the batch cost the default benchmark 5 %) whose blocks stride over the list -- normally empty --
+    // so that the pass takes however many envs the main pass has listed, the whole batch if need be
+    const int cnt = a.w.gen_count[0];            // uniform
+    a.do_finish = 0; a.do_reset = 0; a.sens = nullptr;   // BEGIN only: the main pass has finished the previous substep and stored the state
+    for (int i = blockIdx.x; i < cnt && i < a.nenv; i += gridDim.x) {
+      sg_phase_env<R, CPL, NB, true>(a, a.w.gen_list[i]);
+      __syncthreads();   // (the next env re-uses the block's LDS)
+    }
+  } else {
+    sg_phase_env<R, CPL, NB, false>(a, blockIdx.x);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // chain kernel: ONE LANE PER FINGER CHAIN (64 chains per wavefront, all with the same chain index).  The chain stage is a few thousand strictly serial
 // instructions; inside the phase kernel it ran on 2 of 64 lanes of every env's wavefront, here 64 chains share one
@@ -1248,10 +1258,10 @@ hipError_t sg_launch_phase(const SgPhaseArgs& p, int rounds, bool nb, bool genpa
 #define SG_PHASE(r)                                                                                   \
   if (nb) {                                                                                           \
     hipLaunchKernelGGL((sg_phase_kernel<r, 2, true>), dim3(nenv), dim3(64), 0, s, p);                 \
-    if (genpass && p.do_begin) hipLaunchKernelGGL((sg_phase_kernel<r, 2, true, true>), dim3(nenv), dim3(64), 0, s, p); \
+    if (genpass && p.do_begin) hipLaunchKernelGGL((sg_phase_kernel<r, 2, true, true>), dim3(nenv < SG_GEN_GRID ? nenv : SG_GEN_GRID), dim3(64), 0, s, p); \
   } else {                                                                                            \
     hipLaunchKernelGGL((sg_phase_kernel<r, 2, false>), dim3(nenv), dim3(64), 0, s, p);                \
-    if (genpass && p.do_begin) hipLaunchKernelGGL((sg_phase_kernel<r, 2, false, true>), dim3(nenv), dim3(64), 0, s, p); \
+    if (genpass && p.do_begin) hipLaunchKernelGGL((sg_phase_kernel<r, 2, false, true>), dim3(nenv < SG_GEN_GRID ? nenv : SG_GEN_GRID), dim3(64), 0, s, p); \
   }
   switch (rounds) {
     case 1: SG_PHASE(1); break;

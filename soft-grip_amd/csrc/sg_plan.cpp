@@ -283,7 +283,10 @@ static bool plan_build(const void* blob, size_t nbytes, SgPlan* out, SgTreeDev* 
     if (T.NG > 64) FAIL("more than 64 finger boxes (the contact read-out has 64 bits)");
     T.CS = 0;
     for (int c = 0; c < T.K; c++) T.CS = std::max(T.CS, T.c_ndof[c]);
-    T.CS = (T.CS + 3) & ~3;   // every chain's vectors and matrix blocks are padded to this stride: uniform loop counts on the device
+    // every chain's vectors and matrix blocks are padded to ONE stride, and the stride is one of the kernel's three instantiations
+    // (sg_tree.hip: 8, 20, SGT_CHD = 24): the kernel's CS is then a compile-time constant -- index arithmetic folds into immediates,
+    // the per-chain loops unroll without guards (r04; until then a multiple of four, the kernel carrying it as a run-time value)
+    T.CS = T.CS <= 8 ? 8 : (T.CS <= 20 ? 20 : SGT_CHD);
     for (int c = 0; c < T.K; c++) T.c_mat0[c] = c * T.CS * T.CS;
     T.NMAT = T.K * T.CS * T.CS;
     if (T.ND + nelem + (free_jnt >= 0 ? 1 : 0) != nv) FAIL("the model has dofs that belong neither to a finger chain nor to a composite element");

@@ -332,8 +332,9 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         ld_rec(qA, gA, c0); ld_rec(qB, gB, c1);   // (NB = 1: the LDS path keeps a set's factors in c0 / c1)
         double XA = *qA.px, YA = *qA.py, XB, YB;
         Off oA, oB;
-        const int P = (nrounds + 3) & ~3;
-        for (int k = 0; k < P; k += 4) {
+        constexpr int TRIP = CST ? 4 : 2;   // rounds per trip (LDS path: two, as ever -- an odd count runs one idle round)
+        const int P = (nrounds + TRIP - 1) & ~(TRIP - 1);
+        for (int k = 0; k < P; k += TRIP) {
           [[maybe_unused]] const double2* const cpn = k + 4 < P ? cp + 256 : cp0;   // (uniform)
 #define SG_EQ_ROUND_PAIR(CA, CB, IA, IB, LA, LB)        \
           tp += 32;                                     \
@@ -356,7 +357,6 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
             SG_EQ_ROUND_PAIR(c0, c1, 0, 64, c0, c1)
             SG_EQ_ROUND_PAIR(c2, c3, 128, 192, c2, c3)
           } else {               // LDS path: a set's next record brings its factors along (c0: set A, c1: set B)
-            SG_EQ_ROUND_PAIR(c0, c1, 0, 64, c0, c1)
             SG_EQ_ROUND_PAIR(c0, c1, 0, 64, c0, c1)
           }
 #undef SG_EQ_ROUND_PAIR

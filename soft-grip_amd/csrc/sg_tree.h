@@ -41,6 +41,9 @@
 namespace sgt {
 using namespace sgm;
 
+#ifndef SGT_DIET
+#define SGT_DIET 0x3f    // which groups of build-only arrays live in the env's work space instead of LDS (lds_carve); all six by default
+#endif
 #define SGT_MAXCON 128   // contacts of an env
 #define SGT_MAXHIT 256   // candidate pairs that pass the bounding tests
 #define SGT_HITREC 8     // contacts one pair can produce (box - box)
@@ -87,7 +90,7 @@ struct Lds {
   double *L, *Minv, *tmpP;
   double *qe, *ve, *we, *asme, *ae, *fse, *ffix, *bfix, *Rfix, *flim, *blim, *Rlim, *ke;
   double *einvm, *ecoef, *ecen, *Ifix, *Ilim;   // 1 / (m + armature), tendon coefficient, capsule centres [3][N], 1 / (A + R) of the fix / limit rows
-  double *lrow, *seg, *chs, *cf, *red;
+  double *lrow, *seg, *chs, *cf, *red, *swc;   // swc: the step's scalars for the sweep function (SWC_*)
   double *nbf, *nbb, *nbR, *nbI, *nbA;   // neighbour equality rows by slot d * N + e (the d-th row registered for element e): force, b, R, 1 / (A + R); free object: A + R
   double *frow;   // free object: the joint-fix rows' constants for the serial sweep, [N][5]: b, R, A + R, 1 / (A + R), 1 / D
   double *of, *Be, *Ce, *Afix;   // free object (plans with has_free): scalars (OF_*), B_e [N][6], C_e = -S^-1 B_e / D_e [N][6], the fix rows' diagonals A + R
@@ -108,17 +111,22 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
   auto take = [&](size_t n) { double* r = p; p += (n + 1) & ~(size_t)1; return r; };
   auto takeg = [&](size_t n) { double* r = g; g += (n + 1) & ~(size_t)1; return r; };
   const int ND = T.ND, NB = T.NB;
-  L.q = take(ND); L.v = take(ND); L.warm = take(ND); L.asm_ = take(ND); L.aF = take(T.K * T.CS); L.fs = take(ND); L.fc = take(ND);
-  L.bias = take(ND); L.tenJ = take(ND); L.kd = take(ND); L.qacc = take(ND);
-  L.xpos = take(3 * NB); L.xmat = take(9 * NB); L.xipos = take(3 * NB); L.ximat = take(9 * NB); L.bw = take(3 * NB);
-  L.bal = take(3 * NB); L.ba = take(3 * NB); L.bf = take(3 * NB); L.bn = take(3 * NB);
-  L.anchor = take(3 * ND); L.axis = take(3 * ND); L.gpos = take(3 * T.NG); L.gmat = take(9 * T.NG); L.gsz = take(3 * T.NG); L.spos = take(3 * T.NS);
-  L.L = takeg(T.NMAT); L.Minv = take(T.NMAT); L.tmpP = take(T.K * T.CS);
-  L.qe = takeg(N); L.ve = take(N); L.we = take(N); L.asme = take(N); L.ae = take(N); L.fse = takeg(N); L.ffix = take(N);
+  // r04: LDS holds what the SWEEP touches (accelerations, forces, limit rows), what the PAIR WALK touches (capsule centres, box poses) and
+  // M^-1; everything only the once-per-substep build stages read or write -- chain state and kinematics, body poses and RNE
+  // temporaries, the sliders' state, tendon segments -- sits in the env's work space (coalesced, L2 / Infinity-Cache resident):
+  // 49 KB instead of 76 for the four-finger scene, i.e. THREE workgroups per CU instead of two
+  auto tk = [&](int bit, size_t n) { return (SGT_DIET >> bit) & 1 ? takeg(n) : take(n); };   // (SGT_DIET: which groups live in the work space)
+  L.q = take(ND); L.v = take(ND); L.warm = take(ND); L.asm_ = take(ND); L.aF = take(T.K * T.CS);   // (read joint by joint by the one-lane-per-chain stages: LDS)
+  L.fs = tk(0, ND); L.fc = tk(0, ND); L.bias = tk(0, ND); L.tenJ = tk(0, ND); L.kd = tk(0, ND); L.qacc = tk(0, ND);
+  L.xpos = tk(1, 3 * NB); L.xmat = tk(1, 9 * NB); L.xipos = tk(1, 3 * NB); L.ximat = tk(1, 9 * NB); L.bw = tk(1, 3 * NB);
+  L.bal = tk(1, 3 * NB); L.ba = tk(1, 3 * NB); L.bf = tk(1, 3 * NB); L.bn = tk(1, 3 * NB);
+  L.anchor = tk(2, 3 * ND); L.axis = tk(2, 3 * ND); L.gpos = take(3 * T.NG); L.gmat = take(9 * T.NG); L.gsz = take(3 * T.NG); L.spos = tk(2, 3 * T.NS);
+  L.L = takeg(T.NMAT); L.Minv = take(T.NMAT); L.tmpP = tk(3, T.K * T.CS);
+  L.qe = takeg(N); L.ve = tk(4, N); L.we = tk(4, N); L.asme = tk(4, N); L.ae = take(N); L.fse = takeg(N); L.ffix = take(N);
   L.bfix = takeg(N); L.Rfix = takeg(N); L.flim = take(2 * N); L.blim = takeg(2 * N); L.Rlim = takeg(2 * N); L.ke = takeg(N);
   L.einvm = take(N); L.ecoef = takeg(N); L.ecen = take(3 * N); L.Ifix = takeg(N); L.Ilim = takeg(2 * N);
-  L.lrow = take(SGT_LROW * 2 * ND); L.seg = take(4 * T.K * SGT_MAXTS); L.chs = take(CHS_N * SGT_MAXCH); L.cf = take(3 * SGT_MAXCON);
-  L.red = take(16);
+  L.lrow = take(SGT_LROW * 2 * ND); L.seg = tk(5, 4 * T.K * SGT_MAXTS); L.chs = tk(5, CHS_N * SGT_MAXCH); L.cf = take(3 * SGT_MAXCON);
+  L.red = take(16); L.swc = take(16);
   L.of = take(has_free ? OF_N : 0); L.Be = take(has_free ? 6 * N : 0); L.Ce = take(has_free ? 6 * N : 0); L.Afix = takeg(has_free ? N : 0);
   L.frow = take(has_free ? 5 * N : 0);
   L.nbf = takeg(nnb ? 3 * N : 0); L.nbb = takeg(nnb ? 3 * N : 0); L.nbR = takeg(nnb ? 3 * N : 0); L.nbI = takeg(nnb ? 3 * N : 0);
@@ -133,8 +141,11 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
   L.con_chain = ip; ip += SGT_MAXCON;
   L.icnt = ip; ip += 32;
   // what is left of the LDS up to the next occupancy step (160 KB / k workgroups per CU) caches contact scalars
-  const size_t used = (size_t)((char*)ip - (char*)base), total = 160 * 1024 - 2048;
-  const size_t kper = used < total ? total / used : 1, room = total / (kper ? kper : 1) - used;
+  // (the hardware hands LDS out in granules -- a workgroup's request is rounded up -- so a share is taken a granule short of 160 KB / k:
+  //  r04 measured 53 920 B per workgroup, 3 x which is under 160 KB, still running TWO per CU)
+  const size_t used = (size_t)((char*)ip - (char*)base), total = 160 * 1024;
+  const size_t kper = used + 2560 < total ? total / (used + 2560) : 1, share = (total / (kper ? kper : 1)) / 2560 * 2560 - 2560;
+  const size_t room = share > used ? share - used : 0;
   size_t nc = room / (SGT_CSC * sizeof(double));
   if (nc > SGT_MAXCON) nc = SGT_MAXCON;
   L.ncache = (int)nc;
@@ -168,21 +179,50 @@ SG_HD size_t gws_doubles(const SgTreeDev& T, int N, int has_free, int nnb) {   /
     }                                                                                 \
   } while (0)
 #define SGT_STAMP_INIT() long long sgt_t_last = clock64()
+#define SGT_STAMP_RESET() sgt_t_last = clock64()   /* after a called stage that kept its own stamps */
 #else
+#define SGT_STAMP_RESET() ((void)0)
 #define SGT_STAMP(k) ((void)0)
 #define SGT_STAMP_INIT() ((void)0)
 #endif
 
+// a parallel loop over the composite's elements whose per-item constants live in a small per-lane array across loops (the sweep's row
+// constants: read from the work space ONCE, not once per sweep): e the element, t its slot in the lane's array (N <= 256: four a lane)
+#define SGT_NSLOT (SGT_DEVICE ? 4 : 256)
+#if SGT_DEVICE
+#define SGT_PAR_SLOT(e, t, n) _Pragma("unroll") for (int t = 0, e = (int)threadIdx.x; t < 4; t++, e += 64) if (e < (n))
+#else
+#define SGT_PAR_SLOT(e, t, n) for (int e = 0, t = 0; e < (n); e++, t = e)
+#endif
 #if SGT_DEVICE
 #define SGT_FIRST ((int)threadIdx.x)
 #define SGT_STRIDE 64
 #define SGT_PAR(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
 #define SGT_ONE if (threadIdx.x == 0)
 #define SGT_SYNC() __syncthreads()
-__device__ __forceinline__ double wsum(double x) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+// cross-lane moves without LDS: DPP on the two halves of a double (row_ror:n = 0x120 + n, rotation inside a row of 16 lanes)
+template <int CTRL>
+__device__ __forceinline__ double dpp64(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a row (a LANE GROUP: one finger chain's lanes in the sweep), result in all 16: a butterfly of rotations
+__device__ __forceinline__ double rowsum16(double x) {
+  x += dpp64<0x128>(x);
+  x += dpp64<0x124>(x);
+  x += dpp64<0x122>(x);
+  x += dpp64<0x121>(x);
   return x;
+}
+__device__ __forceinline__ double readlane64(double x, int l) {   // l uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+// sum over the wavefront, result in all lanes: the rows by rotations, the four rows by scalar reads (was six ds_bpermute round trips)
+__device__ __forceinline__ double wsum(double x) {
+  x = rowsum16(x);
+  return ((readlane64(x, 0) + readlane64(x, 16)) + readlane64(x, 32)) + readlane64(x, 48);
 }
 __device__ __forceinline__ double wmax(double x) {
 #pragma unroll
@@ -289,9 +329,11 @@ SG_HD void mat6vec(double* r, const double* M, const double* v) {
 #if SGT_DEVICE
 #define SGT_LDSP __attribute__((address_space(3)))
 #define SGT_CONST __attribute__((address_space(4)))
+#define SGT_GLOBP __attribute__((address_space(1)))
 #else
 #define SGT_LDSP
 #define SGT_CONST
+#define SGT_GLOBP
 #endif
 // The free object's joint-fix rows, one after the other (one lane).  A function of its own ON PURPOSE: inlined into the step kernel --
 // 256 + 256 registers and spilling -- the loop's 40 live values went to scratch memory and a row cost 600 cycles; called, it gets a
@@ -373,6 +415,483 @@ SG_HD void chain_factor(double* Lc, int nd) {
   }
 }
 
+// scalars the sweep takes from / hands back to the step (S.swc, in LDS: uniform reads)
+enum { SWC_TEN_R = 0, SWC_TEN_B, SWC_TEN_F, SWC_TJ_A, SWC_TEN_I, SWC_CTEN, SWC_NCON = SWC_CTEN + 6, SWC_SERIAL, SWC_ITERS, SWC_N = 16 };
+
+// ---------------------------------------------------------------- stage 10b: the PGS sweeps (mj_solPGS) of one forward pass, one env
+// Everything the rows need was laid out by tree_env: the sliders' rows (S.ffix, S.flim, constants in the work space), the chains' limit
+// rows (S.lrow), the contacts' J / W rows and scalars (work space), the accelerations a = M^-1 J' f of the current forces (S.aF, S.ae).
+// A function of its own ON PURPOSE (see the call site).  Pointers come typed by address space, uniform values are made scalar again.
+template <int CHD>
+static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_CONST SgTreeDev* Tp, const SGT_CONST int* nbtab, const SGT_CONST SgEqSlot* sched,
+                                    const int* nbtab_generic, SGT_GLOBP double* cw_, SGT_LDSP double* lds_, unsigned long long* secprof) {
+#if SGT_DEVICE
+  // (arguments of a called function arrive in vector registers: back to scalar ones, so that the plan tables are scalar loads again)
+  auto uni = [](auto* q) { return (decltype(q))(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)q >> 32)) << 32) |
+                                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)q)); };
+  Hp = uni(Hp); Tp = uni(Tp); nbtab = uni(nbtab); sched = uni(sched); nbtab_generic = uni(nbtab_generic); secprof = uni(secprof);
+  cw_ = (SGT_GLOBP double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)cw_ >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)cw_));
+  lds_ = (SGT_LDSP double*)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)lds_);
+#endif
+  const SGT_CONST SgPlanHeader& H = *Hp;
+  const SGT_CONST SgTreeDev& T = *Tp;
+  double* const cw = (double*)cw_;
+  const int N = H.nelem, K = T.K;
+  constexpr int CS = CHD;   // (= T.CS: the plan pads the chains' stride to the instantiation's capacity)
+  const bool FR = H.has_free != 0, NB = H.nnb > 0;
+  Lds S;
+  lds_carve(S, (double*)lds_, T, N, H.has_free, cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (size_t)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT, nullptr, H.nnb);
+  double* const crow0 = cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW;
+  const long long CW = cws_row_doubles(CS);
+  auto crow = [&](int c) { return crow0 + (size_t)c * CW; };
+  auto cscr = [&](int c) -> const double* { return c < S.ncache ? S.csc + (size_t)c * SGT_CSC : crow0 + (size_t)c * CW + 12 * CS; };
+  struct { unsigned long long* secprof; const int* nbtab; } A = {secprof, nbtab_generic};   // (what SGT_STAMP and the free object's row functions name)
+  (void)A;
+  SGT_STAMP_INIT();
+  const double con_mu[2] = {H.con_mu[0], H.con_mu[1]};
+  const int ncon = (int)S.swc[SWC_NCON];
+  const bool serial_contacts = S.swc[SWC_SERIAL] != 0.0;
+  const double ten_R = S.swc[SWC_TEN_R], ten_b = S.swc[SWC_TEN_B], tj_A = S.swc[SWC_TJ_A], ten_I = S.swc[SWC_TEN_I];
+  double ten_f = S.swc[SWC_TEN_F];
+  const double cten[6] = {S.swc[SWC_CTEN], S.swc[SWC_CTEN + 1], S.swc[SWC_CTEN + 2], S.swc[SWC_CTEN + 3], S.swc[SWC_CTEN + 4], S.swc[SWC_CTEN + 5]};
+  auto slider_acc = [&](int e) {   // a slider's constraint acceleration: with a free object its local part minus the body's share
+    return FR ? S.ae[e] - dot6(S.Be + 6 * e, S.of + OF_AF) * S.einvm[e] : S.ae[e];
+  };
+  int iters = 0;
+  // the sliders' row constants, per lane for the whole solve (r04): b, R, 1 / (A + R) of the joint-fix row, R, b, 1 / (A + R) of the two
+  // limit rows, 1 / m and the tendon coefficient.  They sit in the work space (not in LDS); every sweep used to fetch
+  // them again -- four dependent trips of the wavefront to L2 per pass, 6 % + 3 % of a substep at the squeeze
+  double kfb[SGT_NSLOT], kfR[SGT_NSLOT], kfI[SGT_NSLOT], kim[SGT_NSLOT], kco[SGT_NSLOT], klR[SGT_NSLOT][2], klb[SGT_NSLOT][2], klI[SGT_NSLOT][2];
+  SGT_PAR_SLOT(e, t, N) {
+    kfb[t] = S.bfix[e]; kfR[t] = S.Rfix[e]; kfI[t] = S.Ifix[e]; kim[t] = S.einvm[e]; kco[t] = S.ecoef[e];
+    for (int sd = 0; sd < 2; sd++) { klR[t][sd] = S.Rlim[2 * e + sd]; klb[t][sd] = S.blim[2 * e + sd]; klI[t][sd] = S.Ilim[2 * e + sd]; }
+  }
+  for (int it = 0; it < H.iterations; it++) {
+    double imp_par = 0, imp_uni = 0;
+    // joint-fix rows: each on its own slider
+    double S_ae = 0;
+    if (FR) {
+      // with a free object a joint-fix row moves the body and through it every slider: the rows run one after the other (mj_solPGS's
+      // order), the body's acceleration a_f in registers, a row's own slider from its local part and a_f
+      if (NB) SGT_ONE {
+        S.red[0] = free_eq_blocks((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.Ce, (SGT_LDSP double*)S.ffix,
+                                  (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N, A.nbtab, S.nbf, S.nbb, S.nbR, S.nbA, S.nbI);
+      }
+      if (!NB) SGT_ONE {
+        S.red[0] = free_fix_rows((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.Ce, (SGT_LDSP double*)S.ffix,
+                                 (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N);
+      }
+      SGT_SYNC();
+      imp_uni += S.red[0];
+      SGT_PAR(e, N) S_ae += S.ecoef[e] * S.ae[e];
+      S_ae = wsum(S_ae) - dot6(H.obj_tenB, S.of + OF_AF);   // sum coef_e a_e, a_e = local part - B_e . a_f / D_e
+    } else if (NB) {
+      // equality BLOCKS [fix_e, e's neighbour rows] in the plan's list schedule: the blocks of a round share no slider (they
+      // commute exactly), every block sits in a later round than the blocks it depends on -- the rounds in order ARE mj_solPGS's
+      // sequential sweep (sg_plan.h); 64 blocks per round, a lane each
+      for (int r = 0; r < H.eq_rounds; r++) {
+        SGT_PAR(sl, 64) {
+          const SgEqSlot slot = sched[r * 64 + sl];
+          const int e = slot.e;
+          if (e < N) {
+            const double invm = S.einvm[e];
+            double ae_ = S.ae[e], f = S.ffix[e];
+            double old = f;
+            imp_par -= scalar_update_rcp(f, S.bfix[e], ae_, S.Rfix[e], invm + S.Rfix[e], S.Ifix[e], false);
+            S.ffix[e] = f;
+            ae_ += invm * (f - old);
+            for (int d = 0; d < 3; d++) {
+              const int pe = slot.p[d];
+              if (pe >= N) continue;
+              const int k = d * N + e;
+              const double ap = S.ae[pe], ipm = S.einvm[pe], R = S.nbR[k];
+              f = S.nbf[k]; old = f;
+              imp_par -= scalar_update_rcp(f, S.nbb[k], ae_ - ap, R, invm + ipm + R, S.nbI[k], false);
+              S.nbf[k] = f;
+              ae_ += invm * (f - old);
+              S.ae[pe] = ap - ipm * (f - old);
+            }
+            S.ae[e] = ae_;
+          }
+        }
+        SGT_SYNC();
+      }
+      SGT_PAR(e, N) S_ae += S.ecoef[e] * S.ae[e];
+      S_ae = wsum(S_ae);
+    } else {
+      SGT_PAR_SLOT(e, t, N) {
+        const double invm = kim[t];
+        double f = S.ffix[e];
+        const double old = f, ael = S.ae[e];
+        imp_par -= scalar_update_rcp(f, kfb[t], ael, kfR[t], invm + kfR[t], kfI[t], false);
+        S.ffix[e] = f;
+        const double an = ael + invm * (f - old);
+        S.ae[e] = an;
+        S_ae += kco[t] * an;
+      }
+      S_ae = wsum(S_ae);
+    }
+    SGT_STAMP(17);
+    {  // the tendon-fix row over all sliders
+      const double old = ten_f;
+      imp_uni -= scalar_update_rcp(ten_f, ten_b, S_ae, ten_R, tj_A + ten_R, ten_I, false);
+      const double dfl = ten_f - old;
+      SGT_PAR_SLOT(e, t, N) S.ae[e] += kco[t] * dfl * kim[t];
+      if (FR) {
+        SGT_SYNC();
+        SGT_ONE { for (int q = 0; q < 6; q++) S.of[OF_AF + q] += cten[q] * dfl; }
+        SGT_SYNC();
+      }
+    }
+    SGT_STAMP(18);
+    // chain limit rows: serial within a chain, the chains side by side
+#if SGT_DEVICE
+    // A LANE GROUP per chain (r04): the 16 lanes of a DPP row hold the chain's accelerations -- lane l dofs l and l + 16 -- in registers
+    // for the whole pass; a row's J a = +-a[dof] is a masked row sum (rotations, no LDS), its scalar update runs on all 16 lanes
+    // alike, its push a += M^-1[dof][.] df is one multiply-add per lane and word.  (One lane per chain -- 4 of 64 -- read and wrote
+    // all CS words through LDS per row: 1 900 cycles a row, 13 % of a substep at the squeeze.)  Four chains per pass.
+    {
+      const int grp = (int)threadIdx.x >> 4, l = (int)threadIdx.x & 15;
+      const bool lo_w = l < CS, hi_w = l + 16 < CS;   // (short chains: CS < 16 -- the lanes beyond the stride hold no word)
+      const int ll = lo_w ? l : 0;
+      for (int c0 = 0; c0 < K; c0 += 4) {
+        const int c = c0 + grp, cc = c < K ? c : 0;
+        double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[cc];
+        const double* Mi = S.Minv + cc * CS * CS;
+        double a0 = lo_w ? S.aF[cc * CS + l] : 0.0, a1 = hi_w ? S.aF[cc * CS + l + 16] : 0.0;
+        const int nrow = c < K ? S.icnt[IC_NLIM0 + cc] : 0;
+        int nmax = __builtin_amdgcn_readlane(nrow, 0);
+        for (int g2 = 16; g2 < 64; g2 += 16) { const int o = __builtin_amdgcn_readlane(nrow, g2); nmax = o > nmax ? o : nmax; }
+        // (two register sets: the next row's record and its row of M^-1 -- two dependent LDS round trips -- are on their way during a row's update)
+        struct LRec { double sg, R, b, f, Ainv, mdd, m0, m1; int dl; };
+        auto load_row = [&](LRec& q, int i) {
+          const double* r = rows + SGT_LROW * (i < nrow ? i : 0);
+          const int dl = (int)r[0];
+          q.dl = dl; q.sg = r[1]; q.R = r[2]; q.b = r[3]; q.f = r[4]; q.Ainv = r[5];
+          q.mdd = Mi[dl * CS + dl]; q.m0 = Mi[dl * CS + ll]; q.m1 = Mi[dl * CS + (hi_w ? l + 16 : ll)];
+        };
+        auto update_row = [&](const LRec& q, int i) {
+          const bool act = i < nrow;
+          double f = q.f;
+          const double adl = rowsum16(l == (q.dl & 15) ? (q.dl < 16 ? a0 : a1) : 0.0);
+          const double ch = scalar_update_rcp(f, q.b, q.sg * adl, q.R, q.mdd + q.R, q.Ainv, true);
+          const double dfl = act ? q.sg * (f - q.f) : 0.0;
+          if (lo_w) a0 += q.m0 * dfl;
+          if (hi_w) a1 += q.m1 * dfl;
+          if (act && l == 0) { imp_par -= ch; rows[SGT_LROW * i + 4] = f; }
+        };
+        LRec qa, qb;
+        if (nmax > 0) load_row(qa, 0);
+        for (int i = 0; i < nmax; i += 2) {
+          load_row(qb, i + 1);
+          update_row(qa, i);
+          load_row(qa, i + 2);
+          update_row(qb, i + 1);
+        }
+        if (c < K) {
+          if (lo_w) S.aF[cc * CS + l] = a0;
+          if (hi_w) S.aF[cc * CS + l + 16] = a1;
+        }
+      }
+    }
+#else
+    SGT_PAR(c, K) {
+      double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
+      const double* Mi = S.Minv + c * CS * CS;
+      double* aFc = S.aF + c * CS;
+      const int nrow = S.icnt[IC_NLIM0 + c];
+      for (int i = 0; i < nrow; i++) {
+        double* r = rows + SGT_LROW * i;
+        const int dl = (int)r[0];
+        double f = r[4];
+        const double old = f;
+        imp_par -= scalar_update_rcp(f, r[3], r[1] * aFc[dl], r[2], Mi[dl * CS + dl] + r[2], r[5], true);
+        r[4] = f;
+        const double dfl = r[1] * (f - old);
+        // every load before the first store (a load-store chain through LDS costs a round trip per element): unrolled over the
+        // capacity, the loads unguarded (beyond the padded stride CS they hit other LDS words and are dropped), the stores behind
+        // scalar branches on CS, which is the same on every lane
+        double an[CHD];
+#pragma unroll
+        for (int k = 0; k < CHD; k++) an[k] = aFc[k] + Mi[dl * CS + k] * dfl;
+#pragma unroll
+        for (int k = 0; k < CHD; k += 4)
+          if (k < CS) { aFc[k] = an[k]; aFc[k + 1] = an[k + 1]; aFc[k + 2] = an[k + 2]; aFc[k + 3] = an[k + 3]; }
+      }
+    }
+#endif
+    SGT_STAMP(19);
+    // slider limit rows
+    SGT_PAR_SLOT(e, t, N) {
+      const double invm = kim[t];
+#pragma unroll
+      for (int sd = 0; sd < 2; sd++) {
+        const double R = klR[t][sd];
+        if (R == 0.0) continue;
+        const double sg = sd ? -1.0 : 1.0;
+        double f = S.flim[2 * e + sd];
+        const double old = f;
+        imp_par -= scalar_update_rcp(f, klb[t][sd], sg * S.ae[e], R, invm + R, klI[t][sd], true);
+        S.flim[2 * e + sd] = f;
+        S.ae[e] += invm * sg * (f - old);
+      }
+    }
+    SGT_SYNC();
+    SGT_STAMP(12);
+    // contacts: one stream per chain ...
+    if (!serial_contacts) {
+#if SGT_DEVICE
+      // One STREAM PER CHAIN on a lane group (r04): the chain's accelerations in registers as in the limit-row pass (lane l: dofs l,
+      // l + 16), a contact's J and W rows read one word per lane and row (coalesced 128-byte pieces from the work space, the NEXT
+      // contact's on their way during this one's update), J a as three row sums, the 3 x 3 block update on all 16 lanes alike, the
+      // push a += W' df as three multiply-adds per lane and word.  The streams' contact lists (S.hit_pair: contact ids by chain,
+      // offsets behind them) are built with the rows.  One lane per chain cost ~14 k cycles an update: 120 loads and the whole
+      // chain vector through LDS per contact, 47 % of a substep at the squeeze.
+      {
+        const int grp = (int)threadIdx.x >> 4, l = (int)threadIdx.x & 15;
+        const bool lo_w = l < CS, hi_w = l + 16 < CS;   // (short chains: CS < 16 -- the lanes beyond the stride hold no word)
+        const int ll = lo_w ? l : 0;
+        const int* const order = S.hit_pair;
+        const int* const soff = S.hit_pair + SGT_MAXCON;   // [K + 1]
+        // a contact as the sweep needs it: J and W rows, word l (j, w) and word l + 16 (k, x), and the scalars of its record -- all from the
+        // work space (one address space: the loads of the NEXT contact, requested before this one's update, stay in flight across it;
+        // through a pointer that may be LDS or global every use waited for every load issued before it)
+        struct CRec { double j0, j1, j2, k0, k1, k2, w0, w1, w2, x0, x1, x2, A[6], B[3], R, invm, Js[3], slf; int ci; };
+        auto load_rec = [&](CRec& q, int ci) {
+          const double* J = crow(ci);
+          const double* W = J + 3 * CS;
+          const double* sc = J + 12 * CS;
+          const int lh = hi_w ? l + 16 : ll;   // (a lane without a word reads word 0 / word ll again: its product is zeroed below)
+          q.ci = ci;
+          q.j0 = J[ll]; q.j1 = J[CS + ll]; q.j2 = J[2 * CS + ll]; q.k0 = J[lh]; q.k1 = J[CS + lh]; q.k2 = J[2 * CS + lh];
+          q.w0 = W[ll]; q.w1 = W[CS + ll]; q.w2 = W[2 * CS + ll]; q.x0 = W[lh]; q.x1 = W[CS + lh]; q.x2 = W[2 * CS + lh];
+#pragma unroll
+          for (int k = 0; k < 6; k++) q.A[k] = sc[CS_A + k];
+#pragma unroll
+          for (int k = 0; k < 3; k++) { q.B[k] = sc[CS_B + k]; q.Js[k] = sc[CS_JS + k]; }
+          q.R = sc[CS_R]; q.invm = sc[CS_INVM]; q.slf = sc[CS_SL];
+        };
+        for (int c0 = 0; c0 < K; c0 += 4) {
+          const int c = c0 + grp, cc = c < K ? c : 0;
+          double a0 = lo_w ? S.aF[cc * CS + l] : 0.0, a1 = hi_w ? S.aF[cc * CS + l + 16] : 0.0;   // (0 on a lane without a word: its J a terms vanish)
+          const int base = soff[cc], nmine = c < K ? soff[cc + 1] - base : 0;
+          int nmax = __builtin_amdgcn_readlane(nmine, 0);
+          for (int g2 = 16; g2 < 64; g2 += 16) { const int o = __builtin_amdgcn_readlane(nmine, g2); nmax = o > nmax ? o : nmax; }
+          if (nmax == 0) continue;
+          const int ci_safe = order[0];   // (some stream has a contact, so entry 0 exists: what a group past its own list reads)
+          auto idx = [&](int j) { return j < nmine ? order[base + j] : ci_safe; };
+          auto update = [&](const CRec& q, const bool act) {
+            const int ci = q.ci, sl = (int)q.slf;
+            const double p0 = rowsum16(q.j0 * a0 + q.k0 * a1), p1 = rowsum16(q.j1 * a0 + q.k1 * a1), p2 = rowsum16(q.j2 * a0 + q.k2 * a1);
+            const double as_ = sl >= 0 ? S.ae[sl] : 0.0;
+            double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
+            const double res[3] = {q.B[0] + q.Js[0] * as_ + p0 + q.R * f[0], q.B[1] + q.Js[1] * as_ + p1 + q.R * f[1], q.B[2] + q.Js[2] * as_ + p2 + q.R * f[2]};
+            const double ch = contact_block_update(q.A, res, f, con_mu, df);
+            if (act) {
+              if (lo_w) a0 += q.w0 * df[0] + q.w1 * df[1] + q.w2 * df[2];
+              if (hi_w) a1 += q.x0 * df[0] + q.x1 * df[1] + q.x2 * df[2];
+              if (l == 0) {
+                imp_par -= ch;
+                S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
+                if (sl >= 0) S.ae[sl] += q.invm * (q.Js[0] * df[0] + q.Js[1] * df[1] + q.Js[2] * df[2]);
+              }
+            }
+          };
+          CRec ra, rb;   // two register sets: no copies, the other set's loads in flight during an update
+          load_rec(ra, idx(0));
+          for (int j = 0; j < nmax; j += 2) {
+            load_rec(rb, idx(j + 1));
+            update(ra, j < nmine);
+            load_rec(ra, idx(j + 2));
+            update(rb, j + 1 < nmine);
+          }
+          if (c < K) {
+            if (lo_w) S.aF[cc * CS + l] = a0;
+            if (hi_w) S.aF[cc * CS + l + 16] = a1;
+          }
+        }
+      }
+#else
+      SGT_PAR(c, K) {
+        double* aFc = S.aF + c * CS;
+        for (int ci = 0; ci < ncon; ci++) {
+          if (S.con_chain[ci] != c) continue;
+          const double* sc = cscr(ci);
+          const double* J = crow(ci);
+          const double* W = J + 3 * CS;
+          const int sl = (int)sc[CS_SL];
+          double p0 = 0, p1 = 0, p2 = 0;
+          // whole padded rows (J is zero beyond the body's dofs), unrolled over the capacity with every load issued up front: the rows
+          // sit in global memory (L2), and a loop would pay that latency once per trip.  Beyond the padded stride CS (uniform) the
+          // loads hit the record's other words (finite), against a zero.
+#pragma unroll
+          for (int k = 0; k < CHD; k++) {   // (one select, not three)
+            const double a = k < CS ? aFc[k] : 0.0, j0 = J[k], j1 = J[CS + k], j2 = J[2 * CS + k];
+            p0 += j0 * a; p1 += j1 * a; p2 += j2 * a;
+          }
+          double w0[CHD], w1[CHD], w2[CHD];   // the W rows are on their way while the block update runs
+#pragma unroll
+          for (int k = 0; k < CHD; k++) { w0[k] = W[k]; w1[k] = W[CS + k]; w2[k] = W[2 * CS + k]; }
+          const double as_ = sl >= 0 ? S.ae[sl] : 0.0;
+          double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
+          const double res[3] = {sc[CS_B] + sc[CS_JS] * as_ + p0 + sc[CS_R] * f[0], sc[CS_B + 1] + sc[CS_JS + 1] * as_ + p1 + sc[CS_R] * f[1],
+                                 sc[CS_B + 2] + sc[CS_JS + 2] * as_ + p2 + sc[CS_R] * f[2]};
+          imp_par -= contact_block_update(sc + CS_A, res, f, con_mu, df);
+          double an[CHD];
+#pragma unroll
+          for (int k = 0; k < CHD; k++) an[k] = aFc[k] + (w0[k] * df[0] + w1[k] * df[1] + w2[k] * df[2]);
+#pragma unroll
+          for (int k = 0; k < CHD; k += 4)
+            if (k < CS) { aFc[k] = an[k]; aFc[k + 1] = an[k + 1]; aFc[k + 2] = an[k + 2]; aFc[k + 3] = an[k + 3]; }
+          S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
+          if (sl >= 0) S.ae[sl] += sc[CS_INVM] * (sc[CS_JS] * df[0] + sc[CS_JS + 1] * df[1] + sc[CS_JS + 2] * df[2]);
+        }
+      }
+#endif
+      SGT_SYNC();
+    }
+    // ... or one serial list, the lanes spread over the dofs of a contact's chain block(s)
+#if SGT_DEVICE
+    // (r04) WAVE-SYNCHRONOUS when all chain words fit the wavefront (K CS <= 64: the free ball's two-finger gripper): lane c CS + d
+    // keeps chain word d of chain c in a register for the whole pass, the free body's acceleration and S^-1 sit in registers on every
+    // lane alike, a contact's J / W words, scalars and object columns come from the work space one contact AHEAD (two register
+    // sets), J a is three wavefront sums (DPP), and nothing in the loop waits at a barrier.  Per contact the bulk-synchronous
+    // version below pays two barriers -- each draining every outstanding load -- and two exposed round trips to the work space:
+    // 7.6 k cycles an update, 70 % of a free-ball substep.
+    const bool serial_fast = serial_contacts && K * CS <= 64;
+    if (serial_fast) {
+      const int lane = (int)threadIdx.x;
+      const bool dofl = lane < K * CS;
+      const int mc = dofl ? lane / CS : -1, mdl = dofl ? lane % CS : 0;
+      double a = dofl ? S.aF[lane] : 0.0;
+      double af[6] = {0, 0, 0, 0, 0, 0}, gf[6] = {0, 0, 0, 0, 0, 0}, Si[36];
+      if (FR) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) { af[q] = S.of[OF_AF + q]; gf[q] = S.of[OF_GF + q]; }
+#pragma unroll
+        for (int q = 0; q < 36; q++) Si[q] = S.of[OF_SINV + q];
+      }
+      struct SRec { double j0, j1, j2, w0, w1, w2, A[6], B[3], R, invm, Js[3], slf, rowsf, objf, Jo[18]; int ci; };
+      auto load_srec = [&](SRec& q, int ci) {
+        const double* J = crow(ci);
+        const double* sc = J + 12 * CS;
+        const int cc12 = S.hit_cnt[ci];   // (c1 + 1) | (c2 + 1) << 8, packed with the rows
+        const int c1 = (cc12 & 0xff) - 1, c2 = ((cc12 >> 8) & 0xff) - 1;
+        const int blk = (dofl && mc == c1) ? 0 : ((dofl && mc == c2) ? 1 : -1);
+        const double* Jb = J + (blk == 1 ? 6 * CS : 0) + (blk >= 0 ? mdl : 0);
+        const double z = blk >= 0 ? 1.0 : 0.0;
+        q.ci = ci;
+        q.j0 = z * Jb[0]; q.j1 = z * Jb[CS]; q.j2 = z * Jb[2 * CS];
+        q.w0 = z * Jb[3 * CS]; q.w1 = z * Jb[4 * CS]; q.w2 = z * Jb[5 * CS];
+#pragma unroll
+        for (int k = 0; k < 6; k++) q.A[k] = sc[CS_A + k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { q.B[k] = sc[CS_B + k]; q.Js[k] = sc[CS_JS + k]; }
+        q.R = sc[CS_R]; q.invm = sc[CS_INVM]; q.slf = sc[CS_SL]; q.rowsf = sc[CS_ROWS]; q.objf = sc[CS_OBJ];
+        if (FR) {
+#pragma unroll
+          for (int k = 0; k < 18; k++) q.Jo[k] = sc[CS_JO + k];
+        }
+      };
+      auto update = [&](const SRec& q, const bool have) {
+        const int ci = q.ci, sl = (int)q.slf;
+        const bool act = have && q.rowsf != 0.0, ob = FR && q.objf != 0.0;
+        double p0 = wsum(q.j0 * a), p1 = wsum(q.j1 * a), p2 = wsum(q.j2 * a);
+        if (ob) { p0 += dot6(q.Jo, af); p1 += dot6(q.Jo + 6, af); p2 += dot6(q.Jo + 12, af); }
+        double as_ = 0.0;
+        if (sl >= 0) as_ = FR ? S.ae[sl] - dot6(S.Be + 6 * sl, af) * S.einvm[sl] : S.ae[sl];
+        double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
+        const double res[3] = {q.B[0] + q.Js[0] * as_ + p0 + q.R * f[0], q.B[1] + q.Js[1] * as_ + p1 + q.R * f[1], q.B[2] + q.Js[2] * as_ + p2 + q.R * f[2]};
+        const double ch = contact_block_update(q.A, res, f, con_mu, df);
+        if (act) {
+          imp_uni -= ch;
+          a += q.w0 * df[0] + q.w1 * df[1] + q.w2 * df[2];
+          const double dge = sl >= 0 ? q.Js[0] * df[0] + q.Js[1] * df[1] + q.Js[2] * df[2] : 0.0;
+          if (lane == 0) {
+            S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
+            if (sl >= 0) S.ae[sl] += q.invm * dge;
+          }
+          if (ob) {   // the push on the body: g_f += J_o' df; a_f += S^-1 J_o' df + C_sl dg_e
+            double dg[6], da[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) dg[k] = q.Jo[k] * df[0] + q.Jo[6 + k] * df[1] + q.Jo[12 + k] * df[2];
+            mat6vec(da, Si, dg);
+#pragma unroll
+            for (int k = 0; k < 6; k++) { gf[k] += dg[k]; af[k] += da[k] + (sl >= 0 ? S.Ce[6 * sl + k] * dge : 0.0); }
+          }
+        }
+      };
+      if (ncon > 0) {
+        SRec ra, rb;
+        load_srec(ra, 0);
+        for (int j = 0; j < ncon; j += 2) {
+          load_srec(rb, j + 1 < ncon ? j + 1 : 0);
+          update(ra, true);
+          load_srec(ra, j + 2 < ncon ? j + 2 : 0);
+          update(rb, j + 1 < ncon);
+        }
+      }
+      if (dofl) S.aF[lane] = a;
+      if (FR && lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) { S.of[OF_AF + q] = af[q]; S.of[OF_GF + q] = gf[q]; }
+      }
+      SGT_SYNC();
+    }
+    for (int ci = 0; serial_contacts && !serial_fast && ci < ncon; ci++) {
+#else
+    for (int ci = 0; serial_contacts && ci < ncon; ci++) {
+#endif
+      const double* sc = cscr(ci);
+      if (sc[CS_ROWS] == 0.0) continue;
+      const int c1 = (int)sc[CS_C1], c2 = (int)sc[CS_C2], n1 = (int)sc[CS_N1], n2 = (int)sc[CS_N2], sl = (int)sc[CS_SL];
+      double p0 = 0, p1 = 0, p2 = 0;
+      SGT_PAR(i, n1 + n2) {
+        const bool second = i >= n1;
+        const int dl = second ? i - n1 : i;
+        const double* J = crow(ci) + (second ? 6 * CS : 0);
+        const double a = S.aF[(second ? c2 : c1) * CS + dl];
+        p0 += J[dl] * a; p1 += J[CS + dl] * a; p2 += J[2 * CS + dl] * a;
+      }
+      p0 = wsum(p0); p1 = wsum(p1); p2 = wsum(p2);
+      const bool ob = FR && sc[CS_OBJ] != 0.0;
+      if (ob) { p0 += dot6(sc + CS_JO, S.of + OF_AF); p1 += dot6(sc + CS_JO + 6, S.of + OF_AF); p2 += dot6(sc + CS_JO + 12, S.of + OF_AF); }
+      const double as_ = sl >= 0 ? slider_acc(sl) : 0.0;
+      double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
+      const double res[3] = {sc[CS_B] + sc[CS_JS] * as_ + p0 + sc[CS_R] * f[0], sc[CS_B + 1] + sc[CS_JS + 1] * as_ + p1 + sc[CS_R] * f[1],
+                             sc[CS_B + 2] + sc[CS_JS + 2] * as_ + p2 + sc[CS_R] * f[2]};
+      imp_uni -= contact_block_update(sc + CS_A, res, f, H.con_mu, df);
+      SGT_SYNC();   // every lane has read the old forces and accelerations
+      const int n1c = c1 >= 0 ? CS : 0, n2c = c2 >= 0 ? CS : 0;
+      SGT_PAR(i, n1c + n2c) {
+        const bool second = i >= n1c;
+        const int dl = second ? i - n1c : i;
+        const double* W = crow(ci) + (second ? 9 * CS : 3 * CS);
+        S.aF[(second ? c2 : c1) * CS + dl] += W[dl] * df[0] + W[CS + dl] * df[1] + W[2 * CS + dl] * df[2];
+      }
+      SGT_ONE {
+        S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
+        const double dge = sl >= 0 ? sc[CS_JS] * df[0] + sc[CS_JS + 1] * df[1] + sc[CS_JS + 2] * df[2] : 0.0;
+        if (sl >= 0) S.ae[sl] += sc[CS_INVM] * dge;
+        if (ob) {   // the push on the body: g_f += J_o' df; a_f += S^-1 J_o' df + C_sl dg_e
+          double dg[6], da[6];
+          for (int q = 0; q < 6; q++) dg[q] = sc[CS_JO + q] * df[0] + sc[CS_JO + 6 + q] * df[1] + sc[CS_JO + 12 + q] * df[2];
+          mat6vec(da, S.of + OF_SINV, dg);
+          for (int q = 0; q < 6; q++) { S.of[OF_GF + q] += dg[q]; S.of[OF_AF + q] += da[q] + (sl >= 0 ? S.Ce[6 * sl + q] * dge : 0.0); }
+        }
+      }
+      SGT_SYNC();
+    }
+    SGT_STAMP(13);
+    const double improvement = (wsum(imp_par) + imp_uni) * H.pgs_scale;
+    iters = it + 1;
+    if (improvement < H.tolerance) break;
+  }
+
+  SGT_ONE { S.swc[SWC_ITERS] = iters; S.swc[SWC_TEN_F] = ten_f; }
+}
+
 // the whole call for one env.  lane: threadIdx.x on the device, 0 on the host
 // CHD: the unroll capacity of the per-chain loops (>= the plan's padded stride CS): the kernel is instantiated for 8, 20 and 24
 template <int CHD = SGT_CHD>
@@ -381,7 +900,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   // (K$) that the compiler may hoist and keep, not a vector load behind a full vmcnt wait after every store
   const SGT_CONST SgPlanHeader& H = *(const SGT_CONST SgPlanHeader*)A.H;
   const SGT_CONST SgTreeDev& T = *(const SGT_CONST SgTreeDev*)A.T;
-  const int N = H.nelem, ND = T.ND, NB = T.NB, K = T.K, nv = H.nv, nu = H.nu, CS = T.CS;
+  const int N = H.nelem, ND = T.ND, NB = T.NB, K = T.K, nv = H.nv, nu = H.nu;
+  constexpr int CS = CHD;   // (= T.CS: the plan pads the chains' stride to the instantiation's capacity, sg_plan.cpp)
   const double h = H.timestep;
   Lds S;
   lds_carve(S, lds_base, T, N, H.has_free, A.cws + (size_t)env * A.cws_stride + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (size_t)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT, nullptr, H.nnb);
@@ -463,7 +983,64 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   // per row i < k: L[i][j] -= (L[k][i] / L[k][k]) L[k][j] for j <= i, then row k is scaled.  Same operations as chain_factor.
   // The blocks are padded to [CS][CS]; a row's update runs over the whole row (the entries right of the diagonal are never read), so
   // that every lane's loop has the same count.
+  int maxnd = 0;
+  for (int c = 0; c < K; c++) maxnd = T.c_ndof[c] > maxnd ? T.c_ndof[c] : maxnd;
   auto factor_all = [&]() {
+#if SGT_DEVICE
+    // L'DL IN REGISTERS (r04), chains of up to 17 dofs: a lane group per chain, lane i holds row i of the (symmetric) block.  Pivot k
+    // (from the last dof down, mj_factorM's order): every lane i < k needs a = M[i][k] / D_k -- its own word and one broadcast -- and
+    // row k's words M[k][j] = M[j][k], j < k: the SAME register of the lanes j, k shuffles; then M[i][j] -= a M[k][j] in registers
+    // (both triangles are kept, so that the words a lane needs of row k are the column words of the other lanes) and U[i][k] = a is
+    // L[k][i].  Row 16 -- the 17th dof of the four-finger gripper's long chains, one more than a group has lanes -- is eliminated
+    // first and is never updated: its words are read by every lane of the group.  ~400 shuffles + 140 multiply-adds for all chains
+    // at once; step by step through the work space with two barriers a pivot it took 100 k cycles, and it runs twice a substep
+    // (M and M + h B: 40 % of a contact-free substep).
+    constexpr int NC = CHD < 17 ? CHD : 17;
+    if (maxnd <= NC && CS <= 20) {
+      const int grp = (int)threadIdx.x >> 4, l = (int)threadIdx.x & 15, gb = (int)threadIdx.x & 48;
+      for (int c0 = 0; c0 < K; c0 += 4) {
+        const int c = c0 + grp, cc = c < K ? c : 0;
+        double* Lc = S.L + cc * CS * CS;
+        const bool row = c < K && l < CS;   // the lane holds a row of a chain (else a virtual identity row: every step a no-op)
+        double m[NC];
+#pragma unroll
+        for (int j = 0; j < NC; j++) m[j] = (row && j < CS) ? Lc[l * CS + j] : (j == l ? 1.0 : 0.0);
+        if constexpr (NC == 17) {
+          if (CS > 16) {   // (uniform)
+            const double a = m[16] / Lc[16 * CS + 16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) m[j] -= a * Lc[16 * CS + j];
+            m[16] = a;
+          }
+        }
+#pragma unroll
+        for (int k = (NC == 17 ? 15 : NC - 1); k >= 1; k--) {
+          const double Dk = __shfl(m[k], gb + k, 64);
+          double v[16];
+#pragma unroll
+          for (int j = 0; j < k; j++) v[j] = __shfl(m[k], gb + j, 64);
+          if (l < k) {
+            const double a = m[k] / Dk;
+#pragma unroll
+            for (int j = 0; j < k; j++) m[j] -= a * v[j];
+            m[k] = a;
+          }
+        }
+        // back to the work space in chain_solve's layout: D on the diagonal, L[k][i] (i < k) below it -- lane i writes column i
+        if (row) {
+          double dd = m[0];
+#pragma unroll
+          for (int j = 1; j < NC; j++) dd = j == l ? m[j] : dd;
+          Lc[l * CS + l] = dd;
+#pragma unroll
+          for (int k = 1; k < NC; k++)
+            if (l < k && k < CS) Lc[k * CS + l] = m[k];
+        }
+      }
+      SGT_SYNC();
+      return;
+    }
+#endif
     for (int st = 0; st + 1 < CS; st++) {
       SGT_PAR(idx, K * CS) {
         const int c = idx / CS, i = idx % CS, k = T.c_ndof[c] - 1 - st;
@@ -639,11 +1216,21 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     }
     SGT_STAMP(2);
     // ---------------------------------------------------------------- stage 4: mass matrix, one lane per entry of the lower triangles
-    SGT_PAR(i, T.NMAT) {
+    // (the identity padding of the blocks never changes: written by the first forward pass of a call)
+    if (sub == 0) SGT_PAR(i, T.NMAT) {
       const int c = i / (CS * CS), a = (i % (CS * CS)) / CS, b = i % CS, nd = T.c_ndof[c];
-      if (a >= nd || b >= nd) {
-        Mg[i] = a == b ? 1.0 : 0.0;   // identity padding
-      } else if (b <= a) {
+      if (a >= nd || b >= nd) Mg[i] = a == b ? 1.0 : 0.0;
+    }
+    // one lane per entry of the LOWER TRIANGLES only (r04: 840 items for the four-finger gripper's four 20 x 20 blocks instead of 1 600,
+    // of which the upper ones idled through the trips of their wavefront): item = (chain, triangular index)
+    const int TRI = CS * (CS + 1) / 2;
+    SGT_PAR(i, K * TRI) {
+      const int c = i / TRI, tt = i % TRI, nd = T.c_ndof[c];
+      int a = (int)((sqrt(8.0 * tt + 1.0) - 1.0) * 0.5);
+      while (a * (a + 1) / 2 > tt) a--;
+      while ((a + 1) * (a + 2) / 2 <= tt) a++;
+      const int b = tt - a * (a + 1) / 2;
+      if (a < nd) {
         const int da = T.c_dof0[c] + a, db = T.c_dof0[c] + b;
         double s = a == b ? T.d_armature[da] : 0.0;
         for (int tb = T.d_body[da]; tb < T.c_body0[c] + T.c_nbody[c]; tb++) {
@@ -1366,6 +1953,26 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     }
     SGT_SYNC();
     const bool serial_contacts = S.icnt[IC_SERIAL] != 0;
+#if SGT_DEVICE
+    // the serial list's wave-synchronous pass reads a contact's chains from LDS (S.hit_cnt: the narrowphase counts are done with)
+    if (serial_contacts) {
+      SGT_PAR(ci, ncon) S.hit_cnt[ci] = (((int)cscal(ci)[CS_C1] + 1) & 0xff) | ((((int)cscal(ci)[CS_C2] + 1) & 0xff) << 8);
+      SGT_SYNC();
+    }
+    // the streams' contact lists for the sweep's lane groups: the contact ids ordered by chain (mj_solPGS's order within a chain) in
+    // S.hit_pair[0 .. ), the chains' offsets behind them (the pair walk's hit list is done with: rank + narrowphase read it last)
+    if (!serial_contacts) {
+      SGT_PAR(c, K + 1) {
+        int off = 0;
+        for (int ci = 0; ci < ncon; ci++) off += (S.con_chain[ci] >= 0 && S.con_chain[ci] < c) ? 1 : 0;
+        S.hit_pair[SGT_MAXCON + c] = off;
+        if (c < K)
+          for (int ci = 0; ci < ncon; ci++)
+            if (S.con_chain[ci] == c) S.hit_pair[off++] = ci;
+      }
+      SGT_SYNC();
+    }
+#endif
     const double con_mu[2] = {H.con_mu[0], H.con_mu[1]};
     SGT_STAMP(10);
     // row count (nefc) and the touch bits of this contact list
@@ -1493,211 +2100,20 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     }
     iters = 0;
     SGT_STAMP(11);
-    for (int it = 0; it < H.iterations; it++) {
-      double imp_par = 0, imp_uni = 0;
-      // joint-fix rows: each on its own slider
-      double S_ae = 0;
-      if (FR) {
-        // with a free object a joint-fix row moves the body and through it every slider: the rows run one after the other (mj_solPGS's
-        // order), the body's acceleration a_f in registers, a row's own slider from its local part and a_f
-        if (NB) SGT_ONE {
-          S.red[0] = free_eq_blocks((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.Ce, (SGT_LDSP double*)S.ffix,
-                                    (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N, A.nbtab, S.nbf, S.nbb, S.nbR, S.nbA, S.nbI);
-        }
-        if (!NB) SGT_ONE {
-          S.red[0] = free_fix_rows((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.Ce, (SGT_LDSP double*)S.ffix,
-                                   (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N);
-        }
-        SGT_SYNC();
-        imp_uni += S.red[0];
-        SGT_PAR(e, N) S_ae += S.ecoef[e] * S.ae[e];
-        S_ae = wsum(S_ae) - dot6(H.obj_tenB, S.of + OF_AF);   // sum coef_e a_e, a_e = local part - B_e . a_f / D_e
-      } else if (NB) {
-        // equality BLOCKS [fix_e, e's neighbour rows] in the plan's list schedule: the blocks of a round share no slider (they
-        // commute exactly), every block sits in a later round than the blocks it depends on -- the rounds in order ARE mj_solPGS's
-        // sequential sweep (sg_plan.h); 64 blocks per round, a lane each
-        for (int r = 0; r < H.eq_rounds; r++) {
-          SGT_PAR(sl, 64) {
-            const SgEqSlot slot = sched[r * 64 + sl];
-            const int e = slot.e;
-            if (e < N) {
-              const double invm = S.einvm[e];
-              double ae_ = S.ae[e], f = S.ffix[e];
-              double old = f;
-              imp_par -= scalar_update_rcp(f, S.bfix[e], ae_, S.Rfix[e], invm + S.Rfix[e], S.Ifix[e], false);
-              S.ffix[e] = f;
-              ae_ += invm * (f - old);
-              for (int d = 0; d < 3; d++) {
-                const int pe = slot.p[d];
-                if (pe >= N) continue;
-                const int k = d * N + e;
-                const double ap = S.ae[pe], ipm = S.einvm[pe], R = S.nbR[k];
-                f = S.nbf[k]; old = f;
-                imp_par -= scalar_update_rcp(f, S.nbb[k], ae_ - ap, R, invm + ipm + R, S.nbI[k], false);
-                S.nbf[k] = f;
-                ae_ += invm * (f - old);
-                S.ae[pe] = ap - ipm * (f - old);
-              }
-              S.ae[e] = ae_;
-            }
-          }
-          SGT_SYNC();
-        }
-        SGT_PAR(e, N) S_ae += S.ecoef[e] * S.ae[e];
-        S_ae = wsum(S_ae);
-      } else {
-        SGT_PAR(e, N) {
-          const double invm = S.einvm[e];
-          double f = S.ffix[e];
-          const double old = f;
-          imp_par -= scalar_update_rcp(f, S.bfix[e], S.ae[e], S.Rfix[e], invm + S.Rfix[e], S.Ifix[e], false);
-          S.ffix[e] = f;
-          S.ae[e] += invm * (f - old);
-          S_ae += S.ecoef[e] * S.ae[e];
-        }
-        S_ae = wsum(S_ae);
-      }
-      SGT_STAMP(17);
-      {  // the tendon-fix row over all sliders
-        const double old = ten_f;
-        imp_uni -= scalar_update_rcp(ten_f, ten_b, S_ae, ten_R, tj_A + ten_R, ten_I, false);
-        const double dfl = ten_f - old;
-        SGT_PAR(e, N) S.ae[e] += S.ecoef[e] * dfl * S.einvm[e];
-        if (FR) {
-          SGT_SYNC();
-          SGT_ONE { for (int q = 0; q < 6; q++) S.of[OF_AF + q] += cten[q] * dfl; }
-          SGT_SYNC();
-        }
-      }
-      SGT_STAMP(18);
-      // chain limit rows: serial within a chain, the chains side by side
-      SGT_PAR(c, K) {
-        double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
-        const double* Mi = S.Minv + c * CS * CS;
-        double* aFc = S.aF + c * CS;
-        const int nrow = S.icnt[IC_NLIM0 + c];
-        for (int i = 0; i < nrow; i++) {
-          double* r = rows + SGT_LROW * i;
-          const int dl = (int)r[0];
-          double f = r[4];
-          const double old = f;
-          imp_par -= scalar_update_rcp(f, r[3], r[1] * aFc[dl], r[2], Mi[dl * CS + dl] + r[2], r[5], true);
-          r[4] = f;
-          const double dfl = r[1] * (f - old);
-          // every load before the first store (a load-store chain through LDS costs a round trip per element): unrolled over the
-          // capacity, the loads unguarded (beyond the padded stride CS they hit other LDS words and are dropped), the stores behind
-          // scalar branches on CS, which is the same on every lane
-          double an[CHD];
-#pragma unroll
-          for (int k = 0; k < CHD; k++) an[k] = aFc[k] + Mi[dl * CS + k] * dfl;
-#pragma unroll
-          for (int k = 0; k < CHD; k += 4)
-            if (k < CS) { aFc[k] = an[k]; aFc[k + 1] = an[k + 1]; aFc[k + 2] = an[k + 2]; aFc[k + 3] = an[k + 3]; }
-        }
-      }
-      SGT_STAMP(19);
-      // slider limit rows
-      SGT_PAR(e, N) {
-        const double invm = S.einvm[e];
-        for (int sd = 0; sd < 2; sd++) {
-          const double R = S.Rlim[2 * e + sd];
-          if (R == 0.0) continue;
-          const double sg = sd ? -1.0 : 1.0;
-          double f = S.flim[2 * e + sd];
-          const double old = f;
-          imp_par -= scalar_update_rcp(f, S.blim[2 * e + sd], sg * S.ae[e], R, invm + R, S.Ilim[2 * e + sd], true);
-          S.flim[2 * e + sd] = f;
-          S.ae[e] += invm * sg * (f - old);
-        }
-      }
-      SGT_SYNC();
-      SGT_STAMP(12);
-      // contacts: one stream per chain ...
-      if (!serial_contacts) {
-        SGT_PAR(c, K) {
-          double* aFc = S.aF + c * CS;
-          for (int ci = 0; ci < ncon; ci++) {
-            if (S.con_chain[ci] != c) continue;
-            const double* sc = cscr(ci);
-            const double* J = crow(ci);
-            const double* W = J + 3 * CS;
-            const int sl = (int)sc[CS_SL];
-            double p0 = 0, p1 = 0, p2 = 0;
-            // whole padded rows (J is zero beyond the body's dofs), unrolled over the capacity with every load issued up front: the rows
-            // sit in global memory (L2), and a loop would pay that latency once per trip.  Beyond the padded stride CS (uniform) the
-            // loads hit the record's other words (finite), against a zero.
-#pragma unroll
-            for (int k = 0; k < CHD; k++) {   // (one select, not three)
-              const double a = k < CS ? aFc[k] : 0.0, j0 = J[k], j1 = J[CS + k], j2 = J[2 * CS + k];
-              p0 += j0 * a; p1 += j1 * a; p2 += j2 * a;
-            }
-            double w0[CHD], w1[CHD], w2[CHD];   // the W rows are on their way while the block update runs
-#pragma unroll
-            for (int k = 0; k < CHD; k++) { w0[k] = W[k]; w1[k] = W[CS + k]; w2[k] = W[2 * CS + k]; }
-            const double as_ = sl >= 0 ? S.ae[sl] : 0.0;
-            double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
-            const double res[3] = {sc[CS_B] + sc[CS_JS] * as_ + p0 + sc[CS_R] * f[0], sc[CS_B + 1] + sc[CS_JS + 1] * as_ + p1 + sc[CS_R] * f[1],
-                                   sc[CS_B + 2] + sc[CS_JS + 2] * as_ + p2 + sc[CS_R] * f[2]};
-            imp_par -= contact_block_update(sc + CS_A, res, f, con_mu, df);
-            double an[CHD];
-#pragma unroll
-            for (int k = 0; k < CHD; k++) an[k] = aFc[k] + (w0[k] * df[0] + w1[k] * df[1] + w2[k] * df[2]);
-#pragma unroll
-            for (int k = 0; k < CHD; k += 4)
-              if (k < CS) { aFc[k] = an[k]; aFc[k + 1] = an[k + 1]; aFc[k + 2] = an[k + 2]; aFc[k + 3] = an[k + 3]; }
-            S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
-            if (sl >= 0) S.ae[sl] += sc[CS_INVM] * (sc[CS_JS] * df[0] + sc[CS_JS + 1] * df[1] + sc[CS_JS + 2] * df[2]);
-          }
-        }
-        SGT_SYNC();
-      }
-      // ... or one serial list, the lanes spread over the dofs of a contact's chain block(s)
-      for (int ci = 0; serial_contacts && ci < ncon; ci++) {
-        const double* sc = cscr(ci);
-        if (sc[CS_ROWS] == 0.0) continue;
-        const int c1 = (int)sc[CS_C1], c2 = (int)sc[CS_C2], n1 = (int)sc[CS_N1], n2 = (int)sc[CS_N2], sl = (int)sc[CS_SL];
-        double p0 = 0, p1 = 0, p2 = 0;
-        SGT_PAR(i, n1 + n2) {
-          const bool second = i >= n1;
-          const int dl = second ? i - n1 : i;
-          const double* J = crow(ci) + (second ? 6 * CS : 0);
-          const double a = S.aF[(second ? c2 : c1) * CS + dl];
-          p0 += J[dl] * a; p1 += J[CS + dl] * a; p2 += J[2 * CS + dl] * a;
-        }
-        p0 = wsum(p0); p1 = wsum(p1); p2 = wsum(p2);
-        const bool ob = FR && sc[CS_OBJ] != 0.0;
-        if (ob) { p0 += dot6(sc + CS_JO, S.of + OF_AF); p1 += dot6(sc + CS_JO + 6, S.of + OF_AF); p2 += dot6(sc + CS_JO + 12, S.of + OF_AF); }
-        const double as_ = sl >= 0 ? slider_acc(sl) : 0.0;
-        double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
-        const double res[3] = {sc[CS_B] + sc[CS_JS] * as_ + p0 + sc[CS_R] * f[0], sc[CS_B + 1] + sc[CS_JS + 1] * as_ + p1 + sc[CS_R] * f[1],
-                               sc[CS_B + 2] + sc[CS_JS + 2] * as_ + p2 + sc[CS_R] * f[2]};
-        imp_uni -= contact_block_update(sc + CS_A, res, f, H.con_mu, df);
-        SGT_SYNC();   // every lane has read the old forces and accelerations
-        const int n1c = c1 >= 0 ? CS : 0, n2c = c2 >= 0 ? CS : 0;
-        SGT_PAR(i, n1c + n2c) {
-          const bool second = i >= n1c;
-          const int dl = second ? i - n1c : i;
-          const double* W = crow(ci) + (second ? 9 * CS : 3 * CS);
-          S.aF[(second ? c2 : c1) * CS + dl] += W[dl] * df[0] + W[CS + dl] * df[1] + W[2 * CS + dl] * df[2];
-        }
-        SGT_ONE {
-          S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
-          const double dge = sl >= 0 ? sc[CS_JS] * df[0] + sc[CS_JS + 1] * df[1] + sc[CS_JS + 2] * df[2] : 0.0;
-          if (sl >= 0) S.ae[sl] += sc[CS_INVM] * dge;
-          if (ob) {   // the push on the body: g_f += J_o' df; a_f += S^-1 J_o' df + C_sl dg_e
-            double dg[6], da[6];
-            for (int q = 0; q < 6; q++) dg[q] = sc[CS_JO + q] * df[0] + sc[CS_JO + 6 + q] * df[1] + sc[CS_JO + 12 + q] * df[2];
-            mat6vec(da, S.of + OF_SINV, dg);
-            for (int q = 0; q < 6; q++) { S.of[OF_GF + q] += dg[q]; S.of[OF_AF + q] += da[q] + (sl >= 0 ? S.Ce[6 * sl + q] * dge : 0.0); }
-          }
-        }
-        SGT_SYNC();
-      }
-      SGT_STAMP(13);
-      const double improvement = (wsum(imp_par) + imp_uni) * H.pgs_scale;
-      iters = it + 1;
-      if (improvement < H.tolerance) break;
+    // the PGS sweeps run in a function of their own (tree_sweep, above tree_env): its register allocation is not the monolith's --
+    // the step's ~40 stages in one function left the sweep's loops 249 spilled registers and 2.3 KB of scratch memory per lane
+    SGT_ONE {
+      double* w = S.swc;
+      w[SWC_TEN_R] = ten_R; w[SWC_TEN_B] = ten_b; w[SWC_TEN_F] = ten_f; w[SWC_TJ_A] = tj_A; w[SWC_TEN_I] = ten_I;
+      for (int q = 0; q < 6; q++) w[SWC_CTEN + q] = cten[q];
+      w[SWC_NCON] = ncon; w[SWC_SERIAL] = serial_contacts ? 1.0 : 0.0;
     }
+    SGT_SYNC();
+    tree_sweep<CHD>((const SGT_CONST SgPlanHeader*)A.H, (const SGT_CONST SgTreeDev*)A.T, (const SGT_CONST int*)A.nbtab, (const SGT_CONST SgEqSlot*)A.sched, A.nbtab,
+                    (SGT_GLOBP double*)(A.cws + (size_t)env * A.cws_stride), (SGT_LDSP double*)lds_base, A.secprof);
+    SGT_SYNC();
+    SGT_STAMP_RESET();
+    iters = (int)S.swc[SWC_ITERS];
 
     SGT_STAMP(14);
     // ---------------------------------------------------------------- qacc, qfrc_constraint, warmstart, sensors

@@ -27,10 +27,10 @@ hipError_t sg_tree_prepare() {
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sg_tree_kernel<SGT_CHD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return e;
 }
-// the instantiation whose unroll capacity is the smallest one >= the model's padded chain stride CS
+// the instantiation whose capacity IS the model's padded chain stride CS (sg_plan.cpp pads to 8, 20 or SGT_CHD)
 hipError_t sg_launch_tree(const sgt::TreeArgs& a, int CS, size_t lds_bytes, hipStream_t s) {
-  if (CS <= 8) hipLaunchKernelGGL(sg_tree_kernel<8>, dim3(a.nenv), dim3(64), lds_bytes, s, a);
-  else if (CS <= 20) hipLaunchKernelGGL(sg_tree_kernel<20>, dim3(a.nenv), dim3(64), lds_bytes, s, a);
+  if (CS == 8) hipLaunchKernelGGL(sg_tree_kernel<8>, dim3(a.nenv), dim3(64), lds_bytes, s, a);
+  else if (CS == 20) hipLaunchKernelGGL(sg_tree_kernel<20>, dim3(a.nenv), dim3(64), lds_bytes, s, a);
   else hipLaunchKernelGGL(sg_tree_kernel<SGT_CHD>, dim3(a.nenv), dim3(64), lds_bytes, s, a);
   return hipGetLastError();
 }

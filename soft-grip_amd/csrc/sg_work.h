@@ -25,6 +25,7 @@ using namespace sgm;
 #define SG_G 8           // lanes per env in the PGS kernel (8 measured best: 16 -> 1.35x slower PGS, 4 -> 1.07x slower)
 #define SG_EPW (64 / SG_G)   // envs per PGS wavefront
 #define SG_SPW (2 * SG_EPW)  // finger streams per PGS wavefront
+#define SG_GEN_GRID 256  // blocks of the general contact pass (they stride over the listed envs: no limit on how many there are)
 #define SG_CHW 160       // doubles of chain hand-off per stream (layout: see sg_chain_kernel)
 
 struct SgWork {          // device workspace of one batch (all pointers device memory)
@@ -180,7 +181,7 @@ struct SgPgsArgs {
 #define SG_ROWS_NB_MODE(N, ROUNDS) (sizeof(double) * SG_ROWS_LDS_NB(4, N, ROUNDS, 0) <= 40 * 1024 ? 1 : 2)
 // ---- launchers (defined next to their kernels) ----
 hipError_t sg_launch_chain(const SgPhaseArgs& p, int nenv, hipStream_t s);
-// the main pass over all envs and, when genpass, the general contact pass behind it (one block per env, all but the listed ones return at once; sg_general.h)
+// the main pass over all envs and, when genpass, the general contact pass behind it (SG_GEN_GRID blocks striding over the listed envs; sg_general.h)
 hipError_t sg_launch_phase(const SgPhaseArgs& p, int rounds, bool nb, bool genpass, int nenv, hipStream_t s);
 hipError_t sg_rows_prepare();                 // once per device: dynamic-LDS limits of every solver instantiation
 int sg_rows_nsl(int nelem);                   // the instantiated joint-fix rows per lane (template parameter NSL) that holds nelem

@@ -84,8 +84,8 @@ void temu_run(TreeEmu* E, int mode, int nsub) {
   A.cws = E->cws.data(); A.cws_stride = (long long)E->cws.size();
   A.nenv = 1; A.nsub = nsub; A.mode = mode; A.secprof = nullptr;
   // the same choice of instantiation as the library's launch (sg_api.hip launch_tree)
-  if (E->T.CS <= 8) sgt::tree_env<8>(A, 0, E->lds.data());
-  else if (E->T.CS <= 20) sgt::tree_env<20>(A, 0, E->lds.data());
+  if (E->T.CS == 8) sgt::tree_env<8>(A, 0, E->lds.data());
+  else if (E->T.CS == 20) sgt::tree_env<20>(A, 0, E->lds.data());
   else sgt::tree_env<SGT_CHD>(A, 0, E->lds.data());
 }
 

@@ -120,6 +120,15 @@ def oracle_sim(model, k=None):
 # few envs that have already diverged dominate a step's standard deviation -- so what is bounded is the 99th percentile over (step,
 # channel) and, more loosely, the worst case.
 ENS_TOL = {"mean_p99": 0.25, "mean_max": 1.0, "std_p99": 0.5, "std_max": 2.0, "quantile_p99": 0.5, "quantile_max": 3.0, "feat": 0.25, "spearman": 0.2}
+# The ball and the cylinder (default models, implicit tendon damper) at 48 envs -- their oracle is 6 x slower and they are MORE chaotic
+# than the box (the cylinder: a 1e-13 perturbation at step 5 is 3e-5 at step 40 and O(100) from step 100; 19 % of its rows still agree
+# point-wise at the end against 72 % for the box).  Calibrated like ENS_TOL on "the oracle vs the oracle + 1e-13"
+# (scripts/calibrate_ensemble.py -> profiles/r04_ensemble_calibration.txt): that pair gives mean_p99 0.21 / 0.35, quantile_p99 0.43 / 0.62,
+# feat 0.11 / 0.41 (ball / cylinder); the same data one env step late 8.1 / 0.59 and 8.4 / 1.03, accelerometers 15 % off 14 / 0.9 and
+# feat 12.9 / 2.9.  So for the ball the statistic rejects both wrong systems by a factor of 15; for the cylinder it rejects a scale error
+# (feat) and little else -- that scene's ensemble is noise on top of a mean, and the bound below says no more than that.  The spread
+# statistic (std_*) is dominated by the few envs that have blown up and is kept loose.
+ENS_TOL_48 = {"mean_p99": 0.6, "mean_max": 1.2, "std_p99": 1.5, "std_max": 2.5, "quantile_p99": 1.0, "quantile_max": 3.0, "feat": 0.7, "spearman": 0.45}
 
 
 def oracle_episodes(model, ks, threads, perturb=0.0, perturb_step=47, joint_ids=JOINT_IDS, tendon_ids=TENDON_IDS):
