@@ -1,5 +1,5 @@
 """mju_QCQP2's Newton iteration as the oracle writes it (inverse of the 2 x 2 block S + la per evaluation) against the form the solver
-kernel runs since r03 (eigen-coordinates of S, csrc/sg_split.hip): same evaluation counts, same results?  NumPy only.
+kernel runs since r03 (eigen-coordinates of S, csrc/sg_rows.hip): same evaluation counts, same results?  NumPy only.
 usage: python scripts/qcqp_eigen_check.py > profiles/r03_qcqp_eigen_check.txt"""
 import numpy as np
 

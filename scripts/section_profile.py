@@ -1,5 +1,5 @@
 """Per-section cycle profile of the phase kernel (profiling build: `python soft-grip_amd/build_native.py --prof`, which
-compiles the SG_T stamps of csrc/sg_split.hip in).  Prints, for windows of the 200-step squeeze episode, the average cycles
+compiles the SG_T stamps of csrc/sg_phase.hip and csrc/sg_rows.hip in).  Prints, for windows of the 200-step squeeze episode, the average cycles
 one wavefront spends in each section of sg_phase_kernel.
 
 usage (GPU box): SOFTGRIP_LIB=soft-grip_amd/libsoftgrip_prof.so python scripts/section_profile.py

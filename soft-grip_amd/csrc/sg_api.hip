@@ -667,6 +667,22 @@ int sg_debug_sections(sg_batch* b, unsigned long long* out32) {
 }
 #endif
 
+#ifdef SG_DEBUG_WORK
+// debugging build only (build_native.py --ko NAME -DSG_DEBUG_WORK, scripts/dev/work_diff.py): one env's tree-pipeline work space
+// (sg_tree.h: staged narrowphase records | contact rows | mass-matrix blocks | the arrays lds_carve backs with global memory), to be
+// held word by word against the host emulation's after the same launch.  -> the number of doubles copied (<= cap), or a negative error
+long long sg_debug_tree_work(sg_batch* b, int env, double* out, long long cap) {
+  if (!b || !out || env < 0 || env >= b->n || !b->tcws) return fail(SG_ERR_INVALID, "sg_debug_tree_work: bad argument");
+  const sg_model* m = b->m;
+  long long n = sgt::cws_doubles(m->tree, m->tplan.h.nelem, m->tplan.h.has_free, m->tplan.h.nnb);
+  if (n > cap) n = cap;
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, b->tcws + (size_t)env * sgt::cws_doubles(m->tree, m->tplan.h.nelem, m->tplan.h.has_free, m->tplan.h.nnb), sizeof(double) * n, hipMemcpyDeviceToHost));
+  return n;
+}
+#endif
+
 int sg_profile_enable(sg_batch* b, int enable) {
   if (!b) return fail(SG_ERR_INVALID, "sg_profile_enable: bad argument");
   b->prof = enable != 0;

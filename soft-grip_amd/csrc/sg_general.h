@@ -1,7 +1,7 @@
 // sg_general.h -- the GENERAL contact path: every collision pair the model class allows, in MuJoCo's order.
 //
 // The kernels' fast path knows one kind of contact: a moving finger box against an element capsule or the object's centre sphere,
-// kept as two independent per-finger streams (sg_split.hip).  mj_collision for this model class also produces (SURVEY.md 8(a) a11,
+// kept as two independent per-finger streams (sg_phase.hip, sg_rows.hip).  mj_collision for this model class also produces (SURVEY.md 8(a) a11,
 // reference data/gripper/soft_grip_two_fingers.xml:55-94, soft_scene.xml:46)
 //   plane - capsule, static box - capsule      (an element reaching the ground or the gripper's base: one slider, no finger),
 //   plane - box, static box - finger box       (a finger reaching the ground or the base: one finger chain, up to 4 / 8 contacts),
@@ -66,7 +66,7 @@ SG_HD void pick3(const double (*M)[3], int k, double* out) {
 
 // plane (point pp, unit normal pn) against a capsule: one sphere test per end cap (oracle collision(), plane - capsule branch)
 template <class Rec>
-SG_HD int gen_plane_capsule(const double* pp, const double* pn, const double* cp, const double* cax, double r, double hl, double margin,
+SG_HD_HEAVY int gen_plane_capsule(const double* pp, const double* pn, const double* cp, const double* cax, double r, double hl, double margin,
                             Rec& o0, Rec& o1) {
   int n = 0;
   for (int s = -1; s <= 1; s += 2) {
@@ -83,7 +83,7 @@ SG_HD int gen_plane_capsule(const double* pp, const double* pn, const double* cp
 
 // plane against a box: the corners within the margin, in corner order (x fastest), at most 4 (oracle plane_box)
 template <class Rec>
-SG_HD int gen_plane_box(const double* pp, const double* pn, const double* bp, const double* bm, const double* sz, double margin, Rec* out) {
+SG_HD_HEAVY int gen_plane_box(const double* pp, const double* pn, const double* bp, const double* bm, const double* sz, double margin, Rec* out) {
   int n = 0;
   for (int q = 0; q < 8 && n < 4; q++) {
     double loc[3] = {(q & 1 ? 1 : -1) * sz[0], (q & 2 ? 1 : -1) * sz[1], (q & 4 ? 1 : -1) * sz[2]}, w[3];
@@ -102,7 +102,7 @@ SG_HD int gen_plane_box(const double* pp, const double* pn, const double* bp, co
 // Normal from box 1 towards box 2, dist < 0 = penetration.  poly / tmp: work space for the clipped polygon, 16 points each.
 #define SG_BB_FUDGE 1.05
 template <class Rec>
-SG_HD int gen_box_box(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2, double margin,
+SG_HD_HEAVY int gen_box_box(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2, double margin,
                       Rec* out, double (*poly)[3], double (*tmp)[3]) {
   double T[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, A[3][3], B[3][3];
   for (int k = 0; k < 3; k++) { A[k][0] = R1[k]; A[k][1] = R1[3 + k]; A[k][2] = R1[6 + k]; B[k][0] = R2[k]; B[k][1] = R2[3 + k]; B[k][2] = R2[6 + k]; }

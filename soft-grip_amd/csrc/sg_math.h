@@ -2,7 +2,7 @@
 //
 // Everything here is a pure function of its arguments (no cross-lane traffic, no memory
 // side effects besides its out-parameters), compiled both for gfx950 device code
-// (sg_kernels.hip) and for the host, where tests/emu drives the very same functions lane
+// (sg_phase.hip; the test build's sg_kernels.hip) and for the host, where tests/emu drives the very same functions lane
 // by lane to validate the matrix-free restructuring against the CPU oracle.
 //
 // Stage numbers refer to SURVEY.md App. B (the mj_step pipeline behind
@@ -16,6 +16,12 @@
 #define SG_HD __host__ __device__ __forceinline__
 #else
 #define SG_HD inline
+#endif
+// the narrowphase routines: forced inline everywhere but in the tree pipeline's translation unit (sg_tree.hip defines SG_HD_HEAVY as a
+// called function: one env's whole step is ONE kernel there, and with every geometry routine pasted into it the register allocator
+// spilled 800 scalar + 500 vector registers)
+#ifndef SG_HD_HEAVY
+#define SG_HD_HEAVY SG_HD
 #endif
 
 #define SG_MINVAL 1e-15
@@ -358,7 +364,7 @@ struct ConRec {
   double dist, pos[3], n[3];
 };
 
-SG_HD int sphere_box(const double* c, double r, const double* bp, const double* bm, const double* sz, double margin, ConRec& out) {
+SG_HD_HEAVY int sphere_box(const double* c, double r, const double* bp, const double* bm, const double* sz, double margin, ConRec& out) {
   double t[3] = {c[0] - bp[0], c[1] - bp[1], c[2] - bp[2]}, cen[3], dif[3];
   mulmatT3(cen, bm, t);
   for (int k = 0; k < 3; k++) {
@@ -463,7 +469,7 @@ SG_HD double seg_box_param(const double* p, const double* h, const double* sz) {
 
 // capsule (centre cp, unit axis cax, radius r, half length hl) against a box; up to two contacts.
 // Returns a bit mask: bit 0 -> o0 valid (closest / deepest point), bit 1 -> o1 valid (far end cap).
-SG_HD int capsule_box(const double* cp, const double* cax, double r, double hl, const double* bp, const double* bm, const double* sz,
+SG_HD_HEAVY int capsule_box(const double* cp, const double* cax, double r, double hl, const double* bp, const double* bm, const double* sz,
                       double margin, ConRec& o0, ConRec& o1) {
   double t[3] = {cp[0] - bp[0], cp[1] - bp[1], cp[2] - bp[2]}, p[3], h[3];
   mulmatT3(p, bm, t);

@@ -31,6 +31,12 @@
 #include "../../include/softgrip_model.h"
 #include "sg_general.h"
 #include "sg_plan.h"
+#if defined(SGT_EMU_SEPARATE)
+#include <stdlib.h>
+
+#include <utility>
+#include <vector>
+#endif
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 #define SGT_DEVICE 1
@@ -42,12 +48,16 @@ namespace sgt {
 using namespace sgm;
 
 #ifndef SGT_DIET
-#define SGT_DIET 0x3f    // which groups of build-only arrays live in the env's work space instead of LDS (lds_carve); all six by default
+#define SGT_DIET 0x13f   // which groups of arrays live in the env's work space instead of LDS (lds_carve): bits 0 - 5 the build-only groups,
+                         // 8 the capsule centres of a free object's scene.  Bits 6 (M^-1) and 7 (1 / m) stay in LDS: with them out, four
+                         // workgroups share a CU instead of three -- measured +3 % only (122 against 119 k env-steps/s, four-finger scene),
+                         // and one fuzz scene with 70+ contacts went wrong in a way not yet understood (r04 notes in DESIGN 4.7)
 #endif
 #define SGT_MAXCON 128   // contacts of an env
 #define SGT_MAXHIT 256   // candidate pairs that pass the bounding tests
 #define SGT_HITREC 8     // contacts one pair can produce (box - box)
 #define SGT_RECW 10      // doubles of a staged narrowphase record: dist, pos[3], n[3], tangent hint[3]
+#define SGT_LDS_HEADER 2   // doubles at the head of the env's LDS block (lds_carve)
 #define SGT_CSC 56       // scalar doubles of a contact record in the work space
 #define SGT_LROW 6       // doubles of a chain limit row: dof, sign, R, b, f, 1 / (A + R)
 
@@ -77,7 +87,8 @@ SG_HD long long cws_row_doubles(int CS) { return 12LL * CS + SGT_CSC; }   // 2 b
 
 // scalar part of a contact record
 enum { CS_A = 0, CS_B = 6, CS_F0 = 9, CS_R = 12, CS_INVM = 13, CS_JS = 14, CS_SL = 17, CS_C1 = 18, CS_N1 = 19, CS_C2 = 20, CS_N2 = 21,
-       CS_ROWS = 22, CS_TOUCH = 23, CS_OBJ = 24 /* the contact touches the free object */, CS_JO = 25 /* [3][6]: its rows on the object's free dofs, body frame */ };
+       CS_ROWS = 22, CS_TOUCH = 23, CS_OBJ = 24 /* the contact touches the free object */, CS_JO = 25 /* [3][6]: its rows on the object's free dofs, body frame */,
+       CS_TMP = 43 /* [12]: between the phases of the rows' build: J v, J a_smooth, J a_warm, body invweights, blocks, distance */ };
 // the free object's block in LDS (S.of[..]); body frame unless said otherwise
 enum { OF_P = 0, OF_Q = 3, OF_R = 7, OF_VW = 16 /* world */, OF_VL = 19, OF_WL = 22 /* (v, w) contiguous */, OF_WARM = 25, OF_ASM = 31, OF_AF = 37, OF_GF = 43, OF_SINV = 49,
        OF_CEN = 85 /* world */, OF_GL = 88, OF_CTEN = 91, OF_BIAS = 97, OF_X = 103, OF_Y = 109, OF_WB = 115 /* OF_WARM: dof coordinates (world translations), kept
@@ -90,7 +101,7 @@ struct Lds {
   double *L, *Minv, *tmpP;
   double *qe, *ve, *we, *asme, *ae, *fse, *ffix, *bfix, *Rfix, *flim, *blim, *Rlim, *ke;
   double *einvm, *ecoef, *ecen, *Ifix, *Ilim;   // 1 / (m + armature), tendon coefficient, capsule centres [3][N], 1 / (A + R) of the fix / limit rows
-  double *lrow, *seg, *chs, *cf, *red, *swc;   // swc: the step's scalars for the sweep function (SWC_*)
+  double *lrow, *seg, *chs, *cf, *red, *swc, *ctx;   // swc: the step's scalars for the sweep function (SWC_*); ctx: those the stage functions hand on (CTX_*)
   double *nbf, *nbb, *nbR, *nbI, *nbA;   // neighbour equality rows by slot d * N + e (the d-th row registered for element e): force, b, R, 1 / (A + R); free object: A + R
   double *frow;   // free object: the joint-fix rows' constants for the serial sweep, [N][5]: b, R, A + R, 1 / (A + R), 1 / D
   double *of, *Be, *Ce, *Afix;   // free object (plans with has_free): scalars (OF_*), B_e [N][6], C_e = -S^-1 B_e / D_e [N][6], the fix rows' diagonals A + R
@@ -106,27 +117,53 @@ enum { CHS_TLEN = 0, CHS_TVEL, CHS_TFRC, CHS_AFRC, CHS_ACTDOT, CHS_ACT, CHS_CTRL
 // phase behind a barrier) touches -- the L'DL blocks, the sliders' sweep constants and build-only state: 35 KB of the four-finger
 // scene's 113 KB, which is what lets two workgroups share a CU's LDS (the loads are coalesced and L2-resident).  Returns the LDS
 // bytes; *gdoubles the doubles taken from gbase.
-SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_free, double* gbase, size_t* gdoubles, int nnb = 0) {
-  double *p = base, *g = gbase;
+#if !SGT_DEVICE && defined(SGT_EMU_SEPARATE)
+// Host emulation, checking build (tests/emu, `make sep`): every array of the carve is a heap block of its own, EXACT in size, so that
+// AddressSanitizer sees an access one element past ANY array -- inside the env's one LDS block / work space such an access lands in the
+// neighbouring array and shows, if at all, as a wrong number on some other layout.  The driver owns the pool (blocks are handed out in
+// the carve's order, the same on every call) and poisons the LDS-class blocks before a launch.
+struct SepPool { std::vector<std::pair<void*, size_t>> lds, glob; size_t il = 0, ig = 0; double* part[3] = {nullptr, nullptr, nullptr}; };   // part: staged records, contact rows, mass-matrix blocks
+inline SepPool*& sep_pool() { static SepPool* p = nullptr; return p; }
+inline double* sep_part(int k, size_t n) { SepPool* sp = sep_pool(); if (!sp->part[k]) sp->part[k] = (double*)calloc(n ? n : 1, sizeof(double)); return sp->part[k]; }
+inline void* sep_take(std::vector<std::pair<void*, size_t>>& v, size_t& i, size_t bytes) {
+  if (i == v.size()) v.push_back({calloc(bytes ? bytes : 1, 1), bytes});
+  if (v[i].second != bytes) abort();   // (the carve's order and sizes are a function of the model alone)
+  return v[i++].first;
+}
+#endif
+SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_free, double* gbase, size_t* gdoubles, int nnb = 0, size_t* used_out = nullptr) {
+  L = Lds();   // (every pointer null until assigned: an array the carve forgets faults on the host emulation instead of reading the stack's leftovers)
+  double *p = base + SGT_LDS_HEADER, *g = gbase;   // (the block's first words: the launch's argument segment for the called stages, tree_stage)
+#if !SGT_DEVICE && defined(SGT_EMU_SEPARATE)
+  SepPool* const sp = (base != reinterpret_cast<double*>((uintptr_t)4096)) ? sep_pool() : nullptr;   // (the sizing calls carve from address 4096)
+  if (sp) sp->il = sp->ig = 0;
+  auto take = [&](size_t n) { double* r = p; p += (n + 1) & ~(size_t)1; return sp ? (double*)sep_take(sp->lds, sp->il, n * sizeof(double)) : r; };
+  auto takeg = [&](size_t n) { double* r = g; g += (n + 1) & ~(size_t)1; return sp ? (double*)sep_take(sp->glob, sp->ig, n * sizeof(double)) : r; };
+#else
   auto take = [&](size_t n) { double* r = p; p += (n + 1) & ~(size_t)1; return r; };
   auto takeg = [&](size_t n) { double* r = g; g += (n + 1) & ~(size_t)1; return r; };
+#endif
   const int ND = T.ND, NB = T.NB;
-  // r04: LDS holds what the SWEEP touches (accelerations, forces, limit rows), what the PAIR WALK touches (capsule centres, box poses) and
-  // M^-1; everything only the once-per-substep build stages read or write -- chain state and kinematics, body poses and RNE
-  // temporaries, the sliders' state, tendon segments -- sits in the env's work space (coalesced, L2 / Infinity-Cache resident):
-  // 49 KB instead of 76 for the four-finger scene, i.e. THREE workgroups per CU instead of two
+  // r04: LDS holds what the SWEEP touches (accelerations, forces, limit rows) and what the PAIR WALK touches (capsule centres, box poses);
+  // everything only the once-per-substep build stages read or write -- kinematics, body poses and RNE temporaries, the sliders' state,
+  // tendon segments -- sits in the env's work space (coalesced, L2 / Infinity-Cache resident): 52 KB instead of 76 for the four-finger
+  // scene, i.e. THREE workgroups per CU instead of two (M^-1 too would make it four: see SGT_DIET)
   auto tk = [&](int bit, size_t n) { return (SGT_DIET >> bit) & 1 ? takeg(n) : take(n); };   // (SGT_DIET: which groups live in the work space)
   L.q = take(ND); L.v = take(ND); L.warm = take(ND); L.asm_ = take(ND); L.aF = take(T.K * T.CS);   // (read joint by joint by the one-lane-per-chain stages: LDS)
   L.fs = tk(0, ND); L.fc = tk(0, ND); L.bias = tk(0, ND); L.tenJ = tk(0, ND); L.kd = tk(0, ND); L.qacc = tk(0, ND);
   L.xpos = tk(1, 3 * NB); L.xmat = tk(1, 9 * NB); L.xipos = tk(1, 3 * NB); L.ximat = tk(1, 9 * NB); L.bw = tk(1, 3 * NB);
   L.bal = tk(1, 3 * NB); L.ba = tk(1, 3 * NB); L.bf = tk(1, 3 * NB); L.bn = tk(1, 3 * NB);
   L.anchor = tk(2, 3 * ND); L.axis = tk(2, 3 * ND); L.gpos = take(3 * T.NG); L.gmat = take(9 * T.NG); L.gsz = take(3 * T.NG); L.spos = tk(2, 3 * T.NS);
-  L.L = takeg(T.NMAT); L.Minv = take(T.NMAT); L.tmpP = tk(3, T.K * T.CS);
+  L.L = takeg(T.NMAT); L.Minv = tk(6, T.NMAT); L.tmpP = tk(3, T.K * T.CS);   // (M^-1: the sweep's limit rows prefetch its rows, W = J M^-1 reads it lane = word)
   L.qe = takeg(N); L.ve = tk(4, N); L.we = tk(4, N); L.asme = tk(4, N); L.ae = take(N); L.fse = takeg(N); L.ffix = take(N);
   L.bfix = takeg(N); L.Rfix = takeg(N); L.flim = take(2 * N); L.blim = takeg(2 * N); L.Rlim = takeg(2 * N); L.ke = takeg(N);
-  L.einvm = take(N); L.ecoef = takeg(N); L.ecen = take(3 * N); L.Ifix = takeg(N); L.Ilim = takeg(2 * N);
+  // 1 / m: in registers for the sweeps (the free object's serial rows read it per contact: LDS there).  The capsule centres: LDS for the pair
+  // walk -- but a free object's scene has few candidate pairs and its own LDS arrays (B_e, C_e, the rows' constants): work space there
+  L.einvm = has_free ? take(N) : tk(7, N); L.ecoef = takeg(N);
+  L.ecen = (has_free && ((SGT_DIET >> 8) & 1)) ? takeg(3 * N) : take(3 * N);
+  L.Ifix = takeg(N); L.Ilim = takeg(2 * N);
   L.lrow = take(SGT_LROW * 2 * ND); L.seg = tk(5, 4 * T.K * SGT_MAXTS); L.chs = tk(5, CHS_N * SGT_MAXCH); L.cf = take(3 * SGT_MAXCON);
-  L.red = take(16); L.swc = take(16);
+  L.red = take(16); L.swc = take(16); L.ctx = take(16);
   L.of = take(has_free ? OF_N : 0); L.Be = take(has_free ? 6 * N : 0); L.Ce = take(has_free ? 6 * N : 0); L.Afix = takeg(has_free ? N : 0);
   L.frow = take(has_free ? 5 * N : 0);
   L.nbf = takeg(nnb ? 3 * N : 0); L.nbb = takeg(nnb ? 3 * N : 0); L.nbR = takeg(nnb ? 3 * N : 0); L.nbI = takeg(nnb ? 3 * N : 0);
@@ -140,25 +177,46 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
   L.con_src = ip; ip += SGT_MAXCON;
   L.con_chain = ip; ip += SGT_MAXCON;
   L.icnt = ip; ip += 32;
+#if !SGT_DEVICE && defined(SGT_EMU_SEPARATE)
+  if (sp) {
+    auto takei = [&](size_t n) { return (int*)sep_take(sp->lds, sp->il, n * sizeof(int)); };
+    L.hit_pair = takei(SGT_MAXHIT); L.hit_sorted = takei(SGT_MAXHIT); L.hit_cnt = takei(SGT_MAXHIT); L.hit_off = takei(SGT_MAXHIT);
+    L.con_src = takei(SGT_MAXCON); L.con_chain = takei(SGT_MAXCON); L.icnt = takei(32);
+  }
+#endif
   // what is left of the LDS up to the next occupancy step (160 KB / k workgroups per CU) caches contact scalars
   // (the hardware hands LDS out in granules -- a workgroup's request is rounded up -- so a share is taken a granule short of 160 KB / k:
   //  r04 measured 53 920 B per workgroup, 3 x which is under 160 KB, still running TWO per CU)
   const size_t used = (size_t)((char*)ip - (char*)base), total = 160 * 1024;
+  if (used_out) *used_out = used;
   const size_t kper = used + 2560 < total ? total / (used + 2560) : 1, share = (total / (kper ? kper : 1)) / 2560 * 2560 - 2560;
   const size_t room = share > used ? share - used : 0;
   size_t nc = room / (SGT_CSC * sizeof(double));
   if (nc > SGT_MAXCON) nc = SGT_MAXCON;
   L.ncache = (int)nc;
   L.csc = (double*)ip;
+#if !SGT_DEVICE && defined(SGT_EMU_SEPARATE)
+  if (sp) L.csc = (double*)sep_take(sp->lds, sp->il, nc * SGT_CSC * sizeof(double));
+#endif
   return used + nc * SGT_CSC * sizeof(double);
 }
 SG_HD size_t lds_bytes(const SgTreeDev& T, int N, int has_free = 0, int nnb = 0) {
   Lds L;
   return lds_carve(L, reinterpret_cast<double*>((uintptr_t)4096), T, N, has_free, reinterpret_cast<double*>((uintptr_t)4096), nullptr, nnb);
 }
+SG_HD size_t lds_used_bytes(const SgTreeDev& T, int N, int has_free = 0, int nnb = 0) {   // without the contact-scalar cache that fills the share
+  Lds L;
+  size_t u = 0;
+  lds_carve(L, reinterpret_cast<double*>((uintptr_t)4096), T, N, has_free, reinterpret_cast<double*>((uintptr_t)4096), nullptr, nnb, &u);
+  return u;
+}
 SG_HD size_t gws_doubles(const SgTreeDev& T, int N, int has_free, int nnb);
 SG_HD long long cws_doubles(const SgTreeDev& T, int N, int has_free, int nnb = 0) {
-  return (long long)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (long long)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT + (long long)gws_doubles(T, N, has_free, nnb);
+  long long n = (long long)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (long long)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT + (long long)gws_doubles(T, N, has_free, nnb);
+#ifdef SG_DEBUG_WORK   // (debugging build: the env's LDS block is copied behind its work space when a launch ends, scripts/dev/work_diff.py)
+  n += (long long)(lds_bytes(T, N, has_free, nnb) / sizeof(double));
+#endif
+  return n;
 }
 SG_HD size_t gws_doubles(const SgTreeDev& T, int N, int has_free, int nnb) {   // the work-space doubles behind the global-backed arrays
   Lds L;
@@ -197,9 +255,18 @@ SG_HD size_t gws_doubles(const SgTreeDev& T, int N, int has_free, int nnb) {   /
 #if SGT_DEVICE
 #define SGT_FIRST ((int)threadIdx.x)
 #define SGT_STRIDE 64
+#ifdef SGT_X_PARANOID   // (experiment: a fence + barrier in front of every parallel loop and single-lane section)
+#define SGT_PAR(i, n) for (int i = (__syncthreads(), (int)threadIdx.x); i < (n); i += 64)
+#define SGT_ONE if ((__syncthreads(), threadIdx.x == 0))
+#else
 #define SGT_PAR(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
 #define SGT_ONE if (threadIdx.x == 0)
+#endif
+#ifdef SGT_X_INVL1   // (experiment: a barrier that also invalidates the CU's vector L1 -- agent-scope acquire)
+#define SGT_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
+#else
 #define SGT_SYNC() __syncthreads()
+#endif
 // cross-lane moves without LDS: DPP on the two halves of a double (row_ror:n = 0x120 + n, rotation inside a row of 16 lanes)
 template <int CTRL>
 __device__ __forceinline__ double dpp64(double x) {
@@ -299,7 +366,7 @@ SG_HD double scalar_update_rcp(double& f, double b, double Ja, double R, double 
   return change;
 }
 // inverse of a symmetric positive definite 6 x 6 matrix (Gauss-Jordan without pivoting: the free object's Schur complement)
-SG_HD void spd_inverse6(const double* Sm, double* Si) {
+SG_HD_HEAVY void spd_inverse6(const double* Sm, double* Si) {
   double a[6][12];
   for (int i = 0; i < 6; i++)
     for (int j = 0; j < 6; j++) { a[i][j] = Sm[6 * i + j]; a[i][6 + j] = i == j ? 1.0 : 0.0; }
@@ -442,8 +509,12 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
   const bool FR = H.has_free != 0, NB = H.nnb > 0;
   Lds S;
   lds_carve(S, (double*)lds_, T, N, H.has_free, cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (size_t)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT, nullptr, H.nnb);
-  double* const crow0 = cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW;
   const long long CW = cws_row_doubles(CS);
+#if !SGT_DEVICE && defined(SGT_EMU_SEPARATE)
+  double* const crow0 = sep_pool() ? sep_part(1, (size_t)SGT_MAXCON * CW) : cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW;
+#else
+  double* const crow0 = cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW;
+#endif
   auto crow = [&](int c) { return crow0 + (size_t)c * CW; };
   auto cscr = [&](int c) -> const double* { return c < S.ncache ? S.csc + (size_t)c * SGT_CSC : crow0 + (size_t)c * CW + 12 * CS; };
   struct { unsigned long long* secprof; const int* nbtab; } A = {secprof, nbtab_generic};   // (what SGT_STAMP and the free object's row functions name)
@@ -546,7 +617,7 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
     }
     SGT_STAMP(18);
     // chain limit rows: serial within a chain, the chains side by side
-#if SGT_DEVICE
+#if SGT_DEVICE && !defined(SGT_X_NOLG)
     // A LANE GROUP per chain (r04): the 16 lanes of a DPP row hold the chain's accelerations -- lane l dofs l and l + 16 -- in registers
     // for the whole pass; a row's J a = +-a[dof] is a masked row sum (rotations, no LDS), its scalar update runs on all 16 lanes
     // alike, its push a += M^-1[dof][.] df is one multiply-add per lane and word.  (One lane per chain -- 4 of 64 -- read and wrote
@@ -566,8 +637,12 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
         // (two register sets: the next row's record and its row of M^-1 -- two dependent LDS round trips -- are on their way during a row's update)
         struct LRec { double sg, R, b, f, Ainv, mdd, m0, m1; int dl; };
         auto load_row = [&](LRec& q, int i) {
-          const double* r = rows + SGT_LROW * (i < nrow ? i : 0);
-          const int dl = (int)r[0];
+          // (a group past its own list -- or without one -- reads row 0's words and dof 0's row of M^-1: both exist, nothing is applied.
+          //  The dof index MUST be a valid one: M^-1 sits in the work space, and a stale LDS word as an index into it is a memory fault)
+          const bool have = i < nrow;
+          const double* r = rows + SGT_LROW * (have ? i : 0);
+          int dl = have ? (int)r[0] : 0;
+          dl = dl < 0 ? 0 : (dl >= CS ? CS - 1 : dl);
           q.dl = dl; q.sg = r[1]; q.R = r[2]; q.b = r[3]; q.f = r[4]; q.Ainv = r[5];
           q.mdd = Mi[dl * CS + dl]; q.m0 = Mi[dl * CS + ll]; q.m1 = Mi[dl * CS + (hi_w ? l + 16 : ll)];
         };
@@ -581,13 +656,17 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
           if (hi_w) a1 += q.m1 * dfl;
           if (act && l == 0) { imp_par -= ch; rows[SGT_LROW * i + 4] = f; }
         };
-        LRec qa, qb;
-        if (nmax > 0) load_row(qa, 0);
-        for (int i = 0; i < nmax; i += 2) {
-          load_row(qb, i + 1);
+        LRec qa, qb, qc, qd;   // four register sets: a row's words are requested three rows ahead (M^-1 sits in the work space: ~1 us away)
+        if (nmax > 0) { load_row(qa, 0); load_row(qb, 1); load_row(qc, 2); }
+        for (int i = 0; i < nmax; i += 4) {
+          load_row(qd, i + 3);
           update_row(qa, i);
-          load_row(qa, i + 2);
+          load_row(qa, i + 4);
           update_row(qb, i + 1);
+          load_row(qb, i + 5);
+          update_row(qc, i + 2);
+          load_row(qc, i + 6);
+          update_row(qd, i + 3);
         }
         if (c < K) {
           if (lo_w) S.aF[cc * CS + l] = a0;
@@ -641,7 +720,7 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
     SGT_STAMP(12);
     // contacts: one stream per chain ...
     if (!serial_contacts) {
-#if SGT_DEVICE
+#if SGT_DEVICE && !defined(SGT_X_NOSTREAM)
       // One STREAM PER CHAIN on a lane group (r04): the chain's accelerations in registers as in the limit-row pass (lane l: dofs l,
       // l + 16), a contact's J and W rows read one word per lane and row (coalesced 128-byte pieces from the work space, the NEXT
       // contact's on their way during this one's update), J a as three row sums, the 3 x 3 block update on all 16 lanes alike, the
@@ -759,7 +838,11 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
     // sets), J a is three wavefront sums (DPP), and nothing in the loop waits at a barrier.  Per contact the bulk-synchronous
     // version below pays two barriers -- each draining every outstanding load -- and two exposed round trips to the work space:
     // 7.6 k cycles an update, 70 % of a free-ball substep.
+#ifdef SGT_X_NOSF
+    const bool serial_fast = false;
+#else
     const bool serial_fast = serial_contacts && K * CS <= 64;
+#endif
     if (serial_fast) {
       const int lane = (int)threadIdx.x;
       const bool dofl = lane < K * CS;
@@ -892,10 +975,40 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
   SGT_ONE { S.swc[SWC_ITERS] = iters; S.swc[SWC_TEN_F] = ten_f; }
 }
 
-// the whole call for one env.  lane: threadIdx.x on the device, 0 on the host
-// CHD: the unroll capacity of the per-chain loops (>= the plan's padded stride CS): the kernel is instantiated for 8, 20 and 24
-template <int CHD = SGT_CHD>
-SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
+// ---------------------------------------------------------------- the step's stages, each a function of its own
+// One env's whole step used to be ONE function: every stage below pasted into the kernel, ~60 array pointers, the plan's tables and
+// every stage's temporaries competing for one register allocation -- 850 scalar and 550 - 1 650 vector registers spilled (r04
+// profile), the scalar ones into lanes of vector registers that were themselves parked in accumulation registers.  Builds of that
+// function that differed only in unrelated places (a profiling stamp, a debugging copy at the end) then disagreed about single
+// stores of the contact rows' build -- a word of a contact's record keeping its old value -- which is how a fuzz scene went
+// to NaN on one build and not on the next.  Now: the step is a sequence of CALLED functions, one per group of
+// stages (PH), each with its own registers; what they hand each other lives in the env's LDS block and work space anyway, and the
+// step's few scalars (flags, counts, the touch bits) travel in S.ctx.  On the device a stage finds the launch arguments in the
+// kernel-argument segment (uniform: scalar loads) and its env in the workgroup id; on the host they are passed.
+enum { CTX_FLAGS = 0, CTX_NCON, CTX_NEFC, CTX_ITERS, CTX_TLO, CTX_THI, CTX_STOP, CTX_LAST, CTX_INTEGRATE, CTX_SUB, CTX_N = 16 };
+#if SGT_DEVICE
+#define SGT_STAGE_PARAMS SGT_LDSP double* lds_
+#define SGT_STAGE_CALL(PH) tree_stage<CHD, PH>((SGT_LDSP double*)lds_base)
+#else
+#define SGT_STAGE_PARAMS const TreeArgs& A, const int env, double* lds_base
+#define SGT_STAGE_CALL(PH) tree_stage<CHD, PH>(A, env, lds_base)
+#endif
+// PH 1: checks, kinematics, tendons, mass matrix, L'DL + M^-1, bias and smooth accelerations (chains, sliders, free object)
+// PH 2: collision -- block culling, the pair walks, rank, narrowphase
+// PH 3: constraint rows (equality, limits, contacts), warmstart, the PGS sweeps (tree_sweep)
+// PH 4: qacc, sensors, Euler with implicit damping
+template <int CHD, int PH>
+static SGT_NOINLINE void tree_stage(SGT_STAGE_PARAMS) {
+#if SGT_DEVICE
+  // (the launch arguments: the kernel left the address of its argument segment in the first word of the LDS block -- a called function
+  //  has no register for it -- and the segment is read through the constant address space: uniform, scalar loads)
+  lds_ = (SGT_LDSP double*)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)lds_);
+  const unsigned long long ka_ = *(const SGT_LDSP unsigned long long*)lds_;
+  const SGT_CONST TreeArgs& A = *(const SGT_CONST TreeArgs*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ka_ >> 32)) << 32) |
+                                                               (unsigned)__builtin_amdgcn_readfirstlane((int)ka_));
+  const int env = (int)blockIdx.x;
+  double* const lds_base = (double*)lds_;
+#endif
   // The plan tables are read-only for the kernel's lifetime: read through the constant address space, a uniform index is a scalar load
   // (K$) that the compiler may hoist and keep, not a vector load behind a full vmcnt wait after every store
   const SGT_CONST SgPlanHeader& H = *(const SGT_CONST SgPlanHeader*)A.H;
@@ -911,16 +1024,24 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   const SGT_CONST SgEqSlot* const sched = (const SGT_CONST SgEqSlot*)A.sched;
   auto E = [&](int f, int e) { return elemc[(size_t)f * N + e]; };
   double* const cw = A.cws + (size_t)env * A.cws_stride;
+  const long long CW = cws_row_doubles(CS);
+#if !SGT_DEVICE && defined(SGT_EMU_SEPARATE)
+  double* const stage = sep_pool() ? sep_part(0, (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW) : cw;
+  double* const crow0 = sep_pool() ? sep_part(1, (size_t)SGT_MAXCON * CW) : cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW;
+#else
   double* const stage = cw;
   double* const crow0 = cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW;
-  const long long CW = cws_row_doubles(CS);
+#endif
   auto crow = [&](int c) { return crow0 + (size_t)c * CW; };                 // J1[3][CS] | W1[3][CS] | J2[3][CS] | W2[3][CS] | scalars
   auto cscal = [&](int c) { return crow0 + (size_t)c * CW + 12 * CS; };
   auto cscr = [&](int c) -> const double* { return c < S.ncache ? S.csc + (size_t)c * SGT_CSC : crow0 + (size_t)c * CW + 12 * CS; };   // for the sweeps: the LDS copy when there is one
+#if !SGT_DEVICE && defined(SGT_EMU_SEPARATE)
+  double* const Mg = sep_pool() ? sep_part(2, (size_t)T.NMAT) : crow0 + (size_t)SGT_MAXCON * CW;
+#else
   double* const Mg = crow0 + (size_t)SGT_MAXCON * CW;    // the chains' mass-matrix blocks [K][CS][CS], identity-padded
+#endif
   auto pidx = [&](int d) { const int c = T.d_chain[d]; return c * CS + d - T.c_dof0[c]; };   // flat chain dof -> index in a padded [K][CS] vector
 
-  if (A.mode == 1 && A.mask && !A.mask[env]) return;   // masked reset: the other envs keep everything
   const bool FR = H.has_free != 0;   // the composite's elements hang off a free body (6 dofs): the "object block" below
   double* const gq = A.qpos + (size_t)env * H.nq;
   double* const gv = A.qvel + (size_t)env * nv;
@@ -928,57 +1049,9 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   double* const gact = A.act + (size_t)env * (nu > 0 ? nu : 1);
   double* const gctrl = A.ctrl + (size_t)env * (nu > 0 ? nu : 1);
 
-  // ---------------------------------------------------------------- state in
   const double kenv = A.kenv[env];
-  SGT_PAR(d, ND) {
-    const int j = T.d_gid[d];
-    const bool rs = A.mode == 1;
-    S.q[d] = rs ? T.d_qpos0[d] : gq[j];
-    S.v[d] = rs ? 0.0 : gv[j];
-    S.warm[d] = rs ? 0.0 : gw[j];
-    S.kd[d] = A.kmask_jnt[j] ? kenv : T.d_stiffness[d];
-    S.qacc[d] = 0;
-  }
-  SGT_PAR(e, N) {
-    const int jd = H.elem_dof0 + e, jq = H.elem_qpos0 + e;
-    const bool rs = A.mode == 1;
-    S.qe[e] = rs ? E(SGE_QPOS0, e) : gq[jq];
-    S.ve[e] = rs ? 0.0 : gv[jd];
-    S.we[e] = rs ? 0.0 : gw[jd];
-    S.ke[e] = A.kmask_jnt[H.elem_jnt0 + e] ? kenv : E(SGE_K0, e);
-    S.einvm[e] = 1.0 / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
-    S.ecoef[e] = E(SGE_COEF, e);
-    if (FR) {   // B_e = m_e (a_e ; k_e x a_e): the slider's column of the object's mass matrix, body frame (constant)
-      const double m = E(SGE_MASS, e), a[3] = {E(SGE_AX, e), E(SGE_AY, e), E(SGE_AZ, e)}, k0[3] = {E(SGE_KX, e), E(SGE_KY, e), E(SGE_KZ, e)};
-      double kxa[3];
-      cross3(kxa, k0, a);
-      for (int c = 0; c < 3; c++) { S.Be[6 * e + c] = m * a[c]; S.Be[6 * e + 3 + c] = m * kxa[c]; }
-    }
-  }
-  if (FR) {
-    SGT_ONE {
-      const bool rs = A.mode == 1;
-      for (int c = 0; c < 7; c++) S.of[OF_P + c] = rs ? H.free_q0[c] : gq[H.free_qadr + c];
-      for (int c = 0; c < 3; c++) { S.of[OF_VW + c] = rs ? 0.0 : gv[H.free_dadr + c]; S.of[OF_WL + c] = rs ? 0.0 : gv[H.free_dadr + 3 + c]; }
-      for (int c = 0; c < 6; c++) S.of[OF_WARM + c] = rs ? 0.0 : gw[H.free_dadr + c];   // warmstart in dof coordinates (world translations)
-    }
-  }
-  SGT_PAR(c, K) {
-    double* cs = S.chs + c * CHS_N;
-    const bool rs = A.mode == 1;
-    cs[CHS_ACT] = (T.a_has[c] && !rs) ? gact[T.a_id[c]] : 0.0;
-    cs[CHS_CTRL] = (T.a_has[c] && !rs) ? gctrl[T.a_id[c]] : 0.0;
-    cs[CHS_KT] = T.t_has[c] ? (A.kmask_ten[T.t_id[c]] ? kenv : T.t_k0[c]) : 0.0;
-  }
-  SGT_ONE {
-    for (int i = 0; i < 32; i++) S.icnt[i] = 0;
-    if (A.mode == 1)
-      for (int u = 0; u < nu; u++) gctrl[u] = 0.0;   // mj_resetData clears ctrl
-  }
   const double kt0 = A.kmask_ten[H.t0_id] ? kenv : H.t0_k0;
-  SGT_SYNC();
-
-  SGT_STAMP_INIT();
+  (void)kenv; (void)gq; (void)gv; (void)gw; (void)gact; (void)gctrl; (void)kt0; (void)stage; (void)Mg; (void)nu; (void)sched; (void)nbtab; (void)gpairs;
   // L'DL of every chain block in S.L at once (mj_factorM on serial chains): step s eliminates dof k = nd - 1 - s of each chain, one lane
   // per row i < k: L[i][j] -= (L[k][i] / L[k][k]) L[k][j] for j <= i, then row k is scaled.  Same operations as chain_factor.
   // The blocks are padded to [CS][CS]; a row's update runs over the whole row (the entries right of the diagonal are never read), so
@@ -986,7 +1059,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   int maxnd = 0;
   for (int c = 0; c < K; c++) maxnd = T.c_ndof[c] > maxnd ? T.c_ndof[c] : maxnd;
   auto factor_all = [&]() {
-#if SGT_DEVICE
+#if SGT_DEVICE && !defined(SGT_X_NOREGLDL)
     // L'DL IN REGISTERS (r04), chains of up to 17 dofs: a lane group per chain, lane i holds row i of the (symmetric) block.  Pivot k
     // (from the last dof down, mj_factorM's order): every lane i < k needs a = M[i][k] / D_k -- its own word and one broadcast -- and
     // row k's words M[k][j] = M[j][k], j < k: the SAME register of the lanes j, k shuffles; then M[i][j] -= a M[k][j] in registers
@@ -1037,6 +1110,9 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
             if (l < k && k < CS) Lc[k * CS + l] = m[k];
         }
       }
+#ifdef SGT_X_LDLFENCE
+      __threadfence();
+#endif
       SGT_SYNC();
       return;
     }
@@ -1065,13 +1141,44 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       SGT_SYNC();
     }
   };
-  int ncon = 0, nefc = 0, iters = 0, flags = 0;
-  unsigned touch_lo = 0, touch_hi = 0;
-  const int nfwd = A.nsub + (A.mode == 1 ? 1 : 0);
-  SGT_PAR(i, 3 * T.NG) S.gsz[i] = T.g_size[i / 3][i % 3];   // the boxes' half sizes next to their poses (the pair walk's tight test)
-  for (int sub = 0; sub < nfwd; sub++) {
-    const bool integrate = !(A.mode == 1 && sub == 0);
-    const bool last = sub == nfwd - 1;
+  auto tree_motion = [&](const double* qacc) {
+    SGT_PAR(c, K) {
+      double w[3] = {0, 0, 0}, al[3] = {0, 0, 0}, a[3] = {-H.gravity[0], -H.gravity[1], -H.gravity[2]}, P[3], r[3], t[3], t2[3];
+      for (int k = 0; k < 3; k++) P[k] = T.c_root_pos[c][k];
+      for (int bi = 0; bi < T.c_nbody[c]; bi++) {
+        const int tb = T.c_body0[c] + bi;
+        for (int kj = 0; kj <= T.b_njnt[tb]; kj++) {
+          const bool lastj = kj == T.b_njnt[tb];
+          const int d = T.b_dof0[tb] + kj;
+          const double* Q = lastj ? S.xpos + 3 * tb : S.anchor + 3 * d;
+          for (int k = 0; k < 3; k++) r[k] = Q[k] - P[k];
+          cross3(t, w, r);
+          cross3(t2, al, r); addscl3(a, t2, 1);
+          cross3(t2, w, t); addscl3(a, t2, 1);
+          for (int k = 0; k < 3; k++) P[k] = Q[k];
+          if (lastj) break;
+          const double* u = S.axis + 3 * d;
+          const double qd = S.v[d], qdd = qacc ? qacc[d] : 0.0;
+          cross3(t, w, u);
+          addscl3(al, u, qdd); addscl3(al, t, qd);
+          addscl3(w, u, qd);
+        }
+        for (int k = 0; k < 3; k++) { S.bw[3 * tb + k] = w[k]; S.bal[3 * tb + k] = al[k]; S.ba[3 * tb + k] = a[k]; }
+      }
+    }
+  };
+  auto slider_acc = [&](int e) {   // a slider's constraint acceleration: with a free object its local part minus the body's share
+    return FR ? S.ae[e] - dot6(S.Be + 6 * e, S.of + OF_AF) * S.einvm[e] : S.ae[e];
+  };
+  int flags = (int)S.ctx[CTX_FLAGS], ncon = (int)S.ctx[CTX_NCON], nefc = (int)S.ctx[CTX_NEFC], iters = (int)S.ctx[CTX_ITERS], stop = 0;
+  unsigned touch_lo = (unsigned)S.ctx[CTX_TLO], touch_hi = (unsigned)S.ctx[CTX_THI];
+  const bool last = S.ctx[CTX_LAST] != 0.0, integrate = S.ctx[CTX_INTEGRATE] != 0.0;
+  const int sub = (int)S.ctx[CTX_SUB];
+  (void)last; (void)integrate; (void)sub; (void)nefc; (void)iters; (void)touch_lo; (void)touch_hi; (void)ncon;
+  SGT_SYNC();   // (every lane has the step's scalars before lane 0 writes them back)
+  SGT_STAMP_INIT();
+  {
+    if constexpr (PH == 1) {
     // ---------------------------------------------------------------- mj_checkPos / mj_checkVel
     {
       double bad = 0;
@@ -1083,7 +1190,7 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         const int nb = (int)bad;
         if (nb % 1024) flags |= SG_FLAG_BADQPOS;
         if (nb / 1024) flags |= SG_FLAG_BADQVEL;
-        break;   // uniform: the env stops integrating for the rest of the call
+        { stop = 1; goto stage_done; }   // uniform: the env stops integrating for the rest of the call
       }
     }
     SGT_STAMP(0);
@@ -1258,34 +1365,11 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       for (int k = 0; k < CS; k++) x[k] = k == dl ? 1.0 : 0.0;
       chain_solve_reg<CHD>(S.L + c * CS * CS, CS, x);
     }
+#ifdef SGT_X_S1
+    SGT_SYNC();
+#endif
     SGT_STAMP(4);
     // ---------------------------------------------------------------- stage 7: bias forces (RNE with qacc = 0), body velocities
-    auto tree_motion = [&](const double* qacc) {
-      SGT_PAR(c, K) {
-        double w[3] = {0, 0, 0}, al[3] = {0, 0, 0}, a[3] = {-H.gravity[0], -H.gravity[1], -H.gravity[2]}, P[3], r[3], t[3], t2[3];
-        for (int k = 0; k < 3; k++) P[k] = T.c_root_pos[c][k];
-        for (int bi = 0; bi < T.c_nbody[c]; bi++) {
-          const int tb = T.c_body0[c] + bi;
-          for (int kj = 0; kj <= T.b_njnt[tb]; kj++) {
-            const bool lastj = kj == T.b_njnt[tb];
-            const int d = T.b_dof0[tb] + kj;
-            const double* Q = lastj ? S.xpos + 3 * tb : S.anchor + 3 * d;
-            for (int k = 0; k < 3; k++) r[k] = Q[k] - P[k];
-            cross3(t, w, r);
-            cross3(t2, al, r); addscl3(a, t2, 1);
-            cross3(t2, w, t); addscl3(a, t2, 1);
-            for (int k = 0; k < 3; k++) P[k] = Q[k];
-            if (lastj) break;
-            const double* u = S.axis + 3 * d;
-            const double qd = S.v[d], qdd = qacc ? qacc[d] : 0.0;
-            cross3(t, w, u);
-            addscl3(al, u, qdd); addscl3(al, t, qd);
-            addscl3(w, u, qd);
-          }
-          for (int k = 0; k < 3; k++) { S.bw[3 * tb + k] = w[k]; S.bal[3 * tb + k] = al[k]; S.ba[3 * tb + k] = a[k]; }
-        }
-      }
-    };
     tree_motion(nullptr);
     SGT_SYNC();
     SGT_PAR(tb, NB) {
@@ -1415,6 +1499,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     SGT_SYNC();
 
     SGT_STAMP(6);
+    }
+    if constexpr (PH == 2) {
     // ---------------------------------------------------------------- stage 5: collision over the candidate-pair table
     SGT_ONE { S.icnt[IC_NHIT] = 0; S.icnt[IC_NLIVE] = 0; S.icnt[IC_NPURE] = 0; }
     SGT_SYNC();
@@ -1669,6 +1755,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     SGT_SYNC();
 
     SGT_STAMP(8);
+    }
+    if constexpr (PH == 3) {
     // ---------------------------------------------------------------- stage 6: constraint rows
     // (a) equality rows: one joint-fix row per element, the tendon-fix row over all sliders
     double tj_pos = 0, tj_vel = 0, tj_asm = 0, tj_warm = 0, tj_A = 0;
@@ -1848,8 +1936,9 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
           if (FR) { object_side(sg); binvw += H.free_binvw; }
         }
       }
-      // W = J M^-1 over the whole chain, A = J M^-1 J' + R
-      double Am[6] = {0, 0, 0, 0, 0, 0}, vel[3], js[3], jw[3];
+      // J v, J a_smooth, J a_warmstart (the rows' reference accelerations need them); W = J M^-1 and A = J M^-1 J' + R follow in the next two
+      // phases.  What this lane knows about the contact travels in its scalar record (the final A, b, f overwrite the temporaries).
+      double vel[3], js[3], jw[3];
       for (int rr = 0; rr < 3; rr++) {
         vel[rr] = sl >= 0 ? Js[rr] * S.ve[sl] : 0.0;
         js[rr] = sl >= 0 ? Js[rr] * S.asme[sl] : 0.0;
@@ -1858,21 +1947,60 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       }
       for (int b = 0; b < nblk; b++) {
         const int c = ch[b], d0 = T.c_dof0[c], n = nd[b];
-        const double* Mi = S.Minv + c * CS * CS;
-        double* J = b ? J2 : J1;
-        double* W = b ? W2 : W1;
-        for (int rr = 0; rr < 3; rr++) {
-          for (int dl = 0; dl < CS; dl++) {   // (M^-1's padding columns are zero in the rows of real dofs)
-            double s = 0;
-            for (int e2 = 0; e2 < n; e2++) s += J[rr * CS + e2] * Mi[e2 * CS + dl];
-            W[rr * CS + dl] = s;
-          }
+        const double* J = b ? J2 : J1;
+        for (int rr = 0; rr < 3; rr++)
           for (int dl = 0; dl < n; dl++) {
             vel[rr] += J[rr * CS + dl] * S.v[d0 + dl];
             js[rr] += J[rr * CS + dl] * S.asm_[d0 + dl];
             jw[rr] += J[rr * CS + dl] * S.warm[d0 + dl];
           }
-        }
+      }
+      for (int k = 0; k < 3; k++) { sc[CS_TMP + k] = vel[k]; sc[CS_TMP + 3 + k] = js[k]; sc[CS_TMP + 6 + k] = jw[k]; sc[CS_JS + k] = Js[k]; }
+      sc[CS_TMP + 9] = binvw; sc[CS_TMP + 10] = nblk; sc[CS_TMP + 11] = rec[0];
+      sc[CS_INVM] = invm; sc[CS_SL] = sl;
+      sc[CS_C1] = ch[0]; sc[CS_N1] = nd[0]; sc[CS_C2] = ch[1]; sc[CS_N2] = nd[1];
+      sc[CS_TOUCH] = (obj && touchbit >= 0) ? touchbit : -1;
+      sc[CS_OBJ] = onfree ? 1.0 : 0.0;
+      for (int rr = 0; rr < 3; rr++)
+        for (int q = 0; q < 6; q++) sc[CS_JO + 6 * rr + q] = Jo[rr][q];
+    }
+    SGT_SYNC();
+    // (e2) W = J M^-1, one lane per WORD of a W row (r04: contact, chain block, row, dof -- 780 items for 13 contacts; a contact's own lane
+    //      used to run the 3 x CS x n products alone, out of an LDS copy of M^-1: with M^-1 in the work space the lanes of a row read
+    //      consecutive words of its rows)
+    SGT_PAR(i, ncon * 6 * CS) {
+      const int ci = i / (6 * CS), rem = i % (6 * CS), b = rem / (3 * CS), rr = (rem / CS) % 3, dl = rem % CS;
+      const double* sc = cscal(ci);
+      const int c = (int)sc[b ? CS_C2 : CS_C1];
+      if (c >= 0) {
+        const double* J = crow(ci) + (b ? 6 * CS : 0) + rr * CS;
+        const double* Mi = S.Minv + c * CS * CS;
+        double s = 0;
+#pragma unroll
+        for (int e2 = 0; e2 < CS; e2++) s += J[e2] * Mi[e2 * CS + dl];   // (J is zero beyond the body's dofs: the same sum as over them)
+        crow(ci)[(b ? 9 * CS : 3 * CS) + rr * CS + dl] = s;
+      }
+    }
+    SGT_SYNC();
+    // (e3) A, the reference accelerations, the warmstart force: the contact's lane again
+    SGT_PAR(ci, ncon) {
+      double* J1 = crow(ci);
+      double *W1 = J1 + 3 * CS, *J2 = J1 + 6 * CS, *W2 = J1 + 9 * CS, *sc = cscal(ci);
+      int ch[2] = {(int)sc[CS_C1], (int)sc[CS_C2]}, nd[2] = {(int)sc[CS_N1], (int)sc[CS_N2]};
+      const int sl = (int)sc[CS_SL], nblk = (int)sc[CS_TMP + 10];
+      const bool onfree = sc[CS_OBJ] != 0.0;
+      const double invm = sc[CS_INVM], binvw = sc[CS_TMP + 9];
+      double Js[3], vel[3], js[3], jw[3], Jo[3][6];
+      for (int k = 0; k < 3; k++) { Js[k] = sc[CS_JS + k]; vel[k] = sc[CS_TMP + k]; js[k] = sc[CS_TMP + 3 + k]; jw[k] = sc[CS_TMP + 6 + k]; }
+      for (int rr = 0; rr < 3; rr++)
+        for (int q = 0; q < 6; q++) Jo[rr][q] = sc[CS_JO + 6 * rr + q];
+      const double rec0 = sc[CS_TMP + 11];
+      const double* rec = &rec0;
+      double Am[6] = {0, 0, 0, 0, 0, 0};
+      for (int b = 0; b < nblk; b++) {
+        const int n = nd[b];
+        const double* J = b ? J2 : J1;
+        const double* W = b ? W2 : W1;
         int k = 0;
         for (int rr = 0; rr < 3; rr++)
           for (int s2 = rr; s2 < 3; s2++) {
@@ -1920,14 +2048,9 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       }
       const bool rows = dist < H.con_margin;   // mj_makeConstraint: a contact at dist >= margin - gap is listed but gets no rows
       for (int k = 0; k < 6; k++) sc[CS_A + k] = Am[k];
-      for (int k = 0; k < 3; k++) { sc[CS_B + k] = bb[k]; sc[CS_F0 + k] = rows ? f[k] : 0.0; sc[CS_JS + k] = Js[k]; S.cf[3 * ci + k] = rows ? f[k] : 0.0; }
-      sc[CS_R] = R; sc[CS_INVM] = invm; sc[CS_SL] = sl;
-      sc[CS_C1] = ch[0]; sc[CS_N1] = nd[0]; sc[CS_C2] = ch[1]; sc[CS_N2] = nd[1];
+      for (int k = 0; k < 3; k++) { sc[CS_B + k] = bb[k]; sc[CS_F0 + k] = rows ? f[k] : 0.0; S.cf[3 * ci + k] = rows ? f[k] : 0.0; }
+      sc[CS_R] = R;
       sc[CS_ROWS] = rows ? 1.0 : 0.0;
-      sc[CS_TOUCH] = (obj && touchbit >= 0) ? touchbit : -1;
-      sc[CS_OBJ] = onfree ? 1.0 : 0.0;
-      for (int rr = 0; rr < 3; rr++)
-        for (int q = 0; q < 6; q++) sc[CS_JO + 6 * rr + q] = Jo[rr][q];
       // the contact's stream in the sweep: its one chain; -1 = no rows; -2 = not exactly one chain block (both fingers, or a slider
       // against a static geom): such a list is swept serially
       S.con_chain[ci] = !rows ? -1 : ((nblk == 1 && !onfree) ? ch[0] : -2);   // (a free object couples every contact on it: serial list)
@@ -2043,9 +2166,6 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
       }
     };
     if (FR) { SGT_ONE { for (int q = 0; q < 6; q++) S.of[OF_GF + q] = 0; } }
-    auto slider_acc = [&](int e) {   // a slider's constraint acceleration: with a free object its local part minus the body's share
-      return FR ? S.ae[e] - dot6(S.Be + 6 * e, S.of + OF_AF) * S.einvm[e] : S.ae[e];
-    };
     apply_all();
     {
       double cost = 0, S_ae = 0;
@@ -2116,6 +2236,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     iters = (int)S.swc[SWC_ITERS];
 
     SGT_STAMP(14);
+    }
+    if constexpr (PH == 4) {
     // ---------------------------------------------------------------- qacc, qfrc_constraint, warmstart, sensors
     SGT_PAR(d, ND) {
       const int c = T.d_chain[d], dl = d - T.c_dof0[c];
@@ -2173,8 +2295,8 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
         so[0] = out[0]; so[1] = out[1]; so[2] = out[2];
       }
     }
-    if (badacc > 0) { flags |= SG_FLAG_BADQACC; break; }
-    if (!integrate) continue;
+    if (badacc > 0) { flags |= SG_FLAG_BADQACC; stop = 1; goto stage_done; }
+    if (!integrate) goto stage_done;
     SGT_STAMP(15);
     // ---------------------------------------------------------------- stage 12: Euler with implicit joint damping
     SGT_PAR(i, T.NMAT) {
@@ -2265,7 +2387,126 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
     }
     SGT_SYNC();
     SGT_STAMP(16);
+    }
   }
+stage_done: __attribute__((unused));
+  SGT_SYNC();
+  SGT_ONE {
+    S.ctx[CTX_FLAGS] = flags; S.ctx[CTX_NCON] = ncon; S.ctx[CTX_NEFC] = nefc; S.ctx[CTX_ITERS] = iters;
+    S.ctx[CTX_TLO] = touch_lo; S.ctx[CTX_THI] = touch_hi; S.ctx[CTX_STOP] = stop;
+  }
+  SGT_SYNC();
+}
+
+// the whole call for one env.  lane: threadIdx.x on the device, 0 on the host
+// CHD: the unroll capacity of the per-chain loops (>= the plan's padded stride CS): the kernel is instantiated for 8, 20 and 24
+template <int CHD = SGT_CHD>
+SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
+  // The plan tables are read-only for the kernel's lifetime: read through the constant address space, a uniform index is a scalar load
+  // (K$) that the compiler may hoist and keep, not a vector load behind a full vmcnt wait after every store
+  const SGT_CONST SgPlanHeader& H = *(const SGT_CONST SgPlanHeader*)A.H;
+  const SGT_CONST SgTreeDev& T = *(const SGT_CONST SgTreeDev*)A.T;
+  const int N = H.nelem, ND = T.ND, NB = T.NB, K = T.K, nv = H.nv, nu = H.nu;
+  constexpr int CS = CHD;   // (= T.CS: the plan pads the chains' stride to the instantiation's capacity, sg_plan.cpp)
+  const double h = H.timestep;
+  Lds S;
+  lds_carve(S, lds_base, T, N, H.has_free, A.cws + (size_t)env * A.cws_stride + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (size_t)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT, nullptr, H.nnb);
+  const SGT_CONST double* const elemc = (const SGT_CONST double*)A.elem;
+  const SGT_CONST SgGenPair* const gpairs = (const SGT_CONST SgGenPair*)A.gpairs;
+  const SGT_CONST int* const nbtab = (const SGT_CONST int*)A.nbtab;
+  const SGT_CONST SgEqSlot* const sched = (const SGT_CONST SgEqSlot*)A.sched;
+  auto E = [&](int f, int e) { return elemc[(size_t)f * N + e]; };
+  double* const cw = A.cws + (size_t)env * A.cws_stride;
+  const long long CW = cws_row_doubles(CS);
+#if !SGT_DEVICE && defined(SGT_EMU_SEPARATE)
+  double* const stage = sep_pool() ? sep_part(0, (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW) : cw;
+  double* const crow0 = sep_pool() ? sep_part(1, (size_t)SGT_MAXCON * CW) : cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW;
+#else
+  double* const stage = cw;
+  double* const crow0 = cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW;
+#endif
+  auto crow = [&](int c) { return crow0 + (size_t)c * CW; };                 // J1[3][CS] | W1[3][CS] | J2[3][CS] | W2[3][CS] | scalars
+  auto cscal = [&](int c) { return crow0 + (size_t)c * CW + 12 * CS; };
+  auto cscr = [&](int c) -> const double* { return c < S.ncache ? S.csc + (size_t)c * SGT_CSC : crow0 + (size_t)c * CW + 12 * CS; };   // for the sweeps: the LDS copy when there is one
+#if !SGT_DEVICE && defined(SGT_EMU_SEPARATE)
+  double* const Mg = sep_pool() ? sep_part(2, (size_t)T.NMAT) : crow0 + (size_t)SGT_MAXCON * CW;
+#else
+  double* const Mg = crow0 + (size_t)SGT_MAXCON * CW;    // the chains' mass-matrix blocks [K][CS][CS], identity-padded
+#endif
+  auto pidx = [&](int d) { const int c = T.d_chain[d]; return c * CS + d - T.c_dof0[c]; };   // flat chain dof -> index in a padded [K][CS] vector
+
+  if (A.mode == 1 && A.mask && !A.mask[env]) return;   // masked reset: the other envs keep everything
+  const bool FR = H.has_free != 0;   // the composite's elements hang off a free body (6 dofs): the "object block" below
+  double* const gq = A.qpos + (size_t)env * H.nq;
+  double* const gv = A.qvel + (size_t)env * nv;
+  double* const gw = A.warm + (size_t)env * nv;
+  double* const gact = A.act + (size_t)env * (nu > 0 ? nu : 1);
+  double* const gctrl = A.ctrl + (size_t)env * (nu > 0 ? nu : 1);
+
+  // ---------------------------------------------------------------- state in
+  const double kenv = A.kenv[env];
+  SGT_PAR(d, ND) {
+    const int j = T.d_gid[d];
+    const bool rs = A.mode == 1;
+    S.q[d] = rs ? T.d_qpos0[d] : gq[j];
+    S.v[d] = rs ? 0.0 : gv[j];
+    S.warm[d] = rs ? 0.0 : gw[j];
+    S.kd[d] = A.kmask_jnt[j] ? kenv : T.d_stiffness[d];
+    S.qacc[d] = 0;
+  }
+  SGT_PAR(e, N) {
+    const int jd = H.elem_dof0 + e, jq = H.elem_qpos0 + e;
+    const bool rs = A.mode == 1;
+    S.qe[e] = rs ? E(SGE_QPOS0, e) : gq[jq];
+    S.ve[e] = rs ? 0.0 : gv[jd];
+    S.we[e] = rs ? 0.0 : gw[jd];
+    S.ke[e] = A.kmask_jnt[H.elem_jnt0 + e] ? kenv : E(SGE_K0, e);
+    S.einvm[e] = 1.0 / (E(SGE_MASS, e) + E(SGE_ARMATURE, e));
+    S.ecoef[e] = E(SGE_COEF, e);
+    if (FR) {   // B_e = m_e (a_e ; k_e x a_e): the slider's column of the object's mass matrix, body frame (constant)
+      const double m = E(SGE_MASS, e), a[3] = {E(SGE_AX, e), E(SGE_AY, e), E(SGE_AZ, e)}, k0[3] = {E(SGE_KX, e), E(SGE_KY, e), E(SGE_KZ, e)};
+      double kxa[3];
+      cross3(kxa, k0, a);
+      for (int c = 0; c < 3; c++) { S.Be[6 * e + c] = m * a[c]; S.Be[6 * e + 3 + c] = m * kxa[c]; }
+    }
+  }
+  if (FR) {
+    SGT_ONE {
+      const bool rs = A.mode == 1;
+      for (int c = 0; c < 7; c++) S.of[OF_P + c] = rs ? H.free_q0[c] : gq[H.free_qadr + c];
+      for (int c = 0; c < 3; c++) { S.of[OF_VW + c] = rs ? 0.0 : gv[H.free_dadr + c]; S.of[OF_WL + c] = rs ? 0.0 : gv[H.free_dadr + 3 + c]; }
+      for (int c = 0; c < 6; c++) S.of[OF_WARM + c] = rs ? 0.0 : gw[H.free_dadr + c];   // warmstart in dof coordinates (world translations)
+    }
+  }
+  SGT_PAR(c, K) {
+    double* cs = S.chs + c * CHS_N;
+    const bool rs = A.mode == 1;
+    cs[CHS_ACT] = (T.a_has[c] && !rs) ? gact[T.a_id[c]] : 0.0;
+    cs[CHS_CTRL] = (T.a_has[c] && !rs) ? gctrl[T.a_id[c]] : 0.0;
+    cs[CHS_KT] = T.t_has[c] ? (A.kmask_ten[T.t_id[c]] ? kenv : T.t_k0[c]) : 0.0;
+  }
+  SGT_ONE {
+    for (int i = 0; i < 32; i++) S.icnt[i] = 0;
+    if (A.mode == 1)
+      for (int u = 0; u < nu; u++) gctrl[u] = 0.0;   // mj_resetData clears ctrl
+  }
+  SGT_ONE { for (int i = 0; i < CTX_N; i++) S.ctx[i] = 0; }
+  SGT_SYNC();
+
+  const int nfwd = A.nsub + (A.mode == 1 ? 1 : 0);
+  SGT_PAR(i, 3 * T.NG) S.gsz[i] = T.g_size[i / 3][i % 3];   // the boxes' half sizes next to their poses (the pair walk's tight test)
+  for (int sub = 0; sub < nfwd; sub++) {
+    SGT_ONE { S.ctx[CTX_SUB] = sub; S.ctx[CTX_LAST] = sub == nfwd - 1 ? 1.0 : 0.0; S.ctx[CTX_INTEGRATE] = (A.mode == 1 && sub == 0) ? 0.0 : 1.0; }
+    SGT_SYNC();
+    SGT_STAGE_CALL(1);
+    if (S.ctx[CTX_STOP] != 0.0) break;   // (uniform: bad positions / velocities -- the env stops integrating for the rest of the call)
+    SGT_STAGE_CALL(2);
+    SGT_STAGE_CALL(3);
+    SGT_STAGE_CALL(4);
+    if (S.ctx[CTX_STOP] != 0.0) break;   // (bad accelerations)
+  }
+  const int flags = (int)S.ctx[CTX_FLAGS], ncon = (int)S.ctx[CTX_NCON], nefc = (int)S.ctx[CTX_NEFC], iters = (int)S.ctx[CTX_ITERS];
+  const unsigned touch_lo = (unsigned)S.ctx[CTX_TLO], touch_hi = (unsigned)S.ctx[CTX_THI];
 
   // ---------------------------------------------------------------- state and outputs back
   SGT_SYNC();
@@ -2284,6 +2525,13 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
   }
   SGT_PAR(c, K)
     if (T.a_has[c]) gact[T.a_id[c]] = S.chs[c * CHS_N + CHS_ACT];
+#ifdef SG_DEBUG_WORK
+  {
+    SGT_SYNC();
+    const long long nl = (long long)(lds_bytes(T, N, H.has_free, H.nnb) / sizeof(double)), at = cws_doubles(T, N, H.has_free, H.nnb) - nl;
+    SGT_PAR(i, nl) cw[at + i] = lds_base[i];
+  }
+#endif
   SGT_ONE {
     A.flags[env] = flags; A.ncon[env] = ncon; A.nefc[env] = nefc; A.iters[env] = iters;
     A.touch[env] = (int)touch_lo;

@@ -2,7 +2,7 @@
 //
 // the reference's four-finger gripper (data/gripper/soft_grip_four_fingers.xml:50-363; its ids are the
 // comments in environment/manenv.py:11,16) has 4 finger chains of 8 links / 16 - 17 hinge dofs, 2 boxes per link, one spatial tendon
-// through 8 sites per finger.  The fast kernels (sg_split.hip) are compiled for 2 chains x 2 bodies x 2 hinges with closed-form 4 x 4
+// through 8 sites per finger.  The fast kernels (sg_phase.hip, sg_rows.hip) are compiled for 2 chains x 2 bodies x 2 hinges with closed-form 4 x 4
 // algebra; this plan describes the general member of the same family:
 //   * K <= 8 serial hinge CHAINS hanging off static bodies, <= 24 dofs each (dense mass-matrix block per chain, L'DL in LDS),
 //     any number of hinges per body, box geoms, sites;

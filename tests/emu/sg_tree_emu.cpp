@@ -19,6 +19,14 @@ struct TreeEmu {
   std::vector<int> kmask_jnt, kmask_ten;
   double kenv;
   int flags, touch, touchw[2], ncon, nefc, iters;
+#ifdef SGT_EMU_SEPARATE
+  sgt::SepPool pool;   // the checking build: one heap block per array (sg_tree.h lds_carve)
+  ~TreeEmu() {
+    for (auto& b : pool.lds) free(b.first);
+    for (auto& b : pool.glob) free(b.first);
+    for (double* q : pool.part) free(q);
+  }
+#endif
 };
 
 extern "C" {
@@ -53,6 +61,37 @@ int temu_nq(TreeEmu* E) { return E->P.h.nq; }
 int temu_nu(TreeEmu* E) { return E->P.h.nu; }
 int temu_nsens(TreeEmu* E) { return E->P.h.nsensordata; }
 size_t temu_lds_bytes(TreeEmu* E) { return sgt::lds_bytes(E->T, E->P.h.nelem, E->P.h.has_free, E->P.h.nnb); }
+// (debugging: the env's work space and where its arrays sit in it -- scripts/dev/work_diff.py holds the GPU's against it)
+double* temu_cws(TreeEmu* E) { return E->cws.data(); }
+long long temu_cws_doubles(TreeEmu* E) { return (long long)E->cws.size(); }
+int temu_layout(TreeEmu* E, char* buf, int cap) {
+  const SgPlanHeader& H = E->P.h;
+  sgt::Lds S;
+  double* const cw = E->cws.data();
+  const long long CW = sgt::cws_row_doubles(E->T.CS);
+  double* const g0 = cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (size_t)SGT_MAXCON * CW + E->T.NMAT;
+  sgt::lds_carve(S, E->lds.data(), E->T, H.nelem, H.has_free, g0, nullptr, H.nnb);
+  int n = snprintf(buf, cap, "stage 0\ncrow %lld\nMg %lld\n", (long long)SGT_MAXHIT * SGT_HITREC * SGT_RECW, (long long)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (long long)SGT_MAXCON * CW);
+#define LAY(f) do { const long long o = (long long)(S.f - cw); if (o >= 0 && o < (long long)E->cws.size()) n += snprintf(buf + n, cap - n, #f " %lld\n", o); } while (0)
+  LAY(fs); LAY(fc); LAY(bias); LAY(tenJ); LAY(kd); LAY(qacc); LAY(xpos); LAY(xmat); LAY(xipos); LAY(ximat); LAY(bw); LAY(bal); LAY(ba); LAY(bf); LAY(bn);
+  LAY(anchor); LAY(axis); LAY(spos); LAY(L); LAY(Minv); LAY(tmpP); LAY(qe); LAY(ve); LAY(we); LAY(asme); LAY(fse); LAY(bfix); LAY(Rfix); LAY(blim); LAY(Rlim);
+  LAY(ke); LAY(einvm); LAY(ecoef); LAY(ecen); LAY(Ifix); LAY(Ilim); LAY(seg); LAY(chs); LAY(Afix); LAY(nbf); LAY(nbb); LAY(nbR); LAY(nbI); LAY(nbA);
+#undef LAY
+#ifdef SG_DEBUG_WORK
+  {
+    const long long nl = (long long)(sgt::lds_bytes(E->T, H.nelem, H.has_free, H.nnb) / sizeof(double)), at = (long long)E->cws.size() - nl;
+#define LAYL(f) n += snprintf(buf + n, cap - n, "lds." #f " %lld\n", at + (long long)((double*)S.f - E->lds.data()))
+    n += snprintf(buf + n, cap - n, "lds.hdr %lld\n", at);
+    LAYL(q); LAYL(v); LAYL(warm); LAYL(asm_); LAYL(aF); LAYL(gpos); LAYL(gmat); LAYL(gsz); LAYL(ae); LAYL(ffix); LAYL(flim); LAYL(lrow); LAYL(cf); LAYL(red); LAYL(swc);
+    LAYL(of); LAYL(Be); LAYL(Ce); LAYL(frow); LAYL(hit_pair); LAYL(hit_sorted); LAYL(hit_cnt); LAYL(hit_off); LAYL(con_src); LAYL(con_chain); LAYL(icnt); LAYL(csc);
+    if (H.has_free) LAYL(einvm);
+#undef LAYL
+  }
+#endif
+  n += snprintf(buf + n, cap - n, "end %lld\nCS %d\nCW %lld\n", (long long)E->cws.size(), E->T.CS, CW);
+  return n;
+}
+size_t temu_lds_used(TreeEmu* E) { return sgt::lds_used_bytes(E->T, E->P.h.nelem, E->P.h.has_free, E->P.h.nnb); }
 double* temu_qpos(TreeEmu* E) { return E->qpos.data(); }
 double* temu_qvel(TreeEmu* E) { return E->qvel.data(); }
 double* temu_warm(TreeEmu* E) { return E->warm.data(); }
@@ -83,6 +122,17 @@ void temu_run(TreeEmu* E, int mode, int nsub) {
   A.flags = &E->flags; A.touch = &E->touch; A.touch_words = E->touchw; A.ncon = &E->ncon; A.nefc = &E->nefc; A.iters = &E->iters;
   A.cws = E->cws.data(); A.cws_stride = (long long)E->cws.size();
   A.nenv = 1; A.nsub = nsub; A.mode = mode; A.secprof = nullptr;
+  // a workgroup's LDS block holds whatever the previous workgroup on that CU left there: every launch starts from poison here
+  // (SGT_EMU_POISON = the byte, default 0xff: NaN as a double, -1 as an int), so a word read before it is written shows
+  static const int poison = getenv("SGT_EMU_POISON") ? (int)strtol(getenv("SGT_EMU_POISON"), nullptr, 0) : 0xff;
+  memset(E->lds.data(), poison, E->lds.size() * sizeof(double));
+#ifdef SGT_EMU_SEPARATE
+  sgt::sep_pool() = &E->pool;
+  for (auto& b : E->pool.lds) memset(b.first, poison, b.second);
+#ifdef SGT_EMU_MSAN   // (scripts/sanitize/tree_msan_main.cpp: the LDS block is UNINITIALISED at a launch, and MSan knows it)
+  for (auto& b : E->pool.lds) __msan_poison(b.first, b.second);
+#endif
+#endif
   // the same choice of instantiation as the library's launch (sg_api.hip launch_tree)
   if (E->T.CS == 8) sgt::tree_env<8>(A, 0, E->lds.data());
   else if (E->T.CS == 20) sgt::tree_env<20>(A, 0, E->lds.data());

@@ -59,3 +59,32 @@ def test_no_cpu_fallback():
     with pytest.raises(native.SoftgripError) as ei:
         native.NativeBatch(nm, 4, 0)
     assert ei.value.code == native.SG_ERR_NO_DEVICE
+
+
+def test_asymmetric_box_counts_leave_the_two_finger_class(tmp_path):
+    """the two-finger kernels number the finger boxes 2 * chain + box; with another count per chain that is not the geom-id
+    order the C ABI documents for touch_out / sg_get_touch_words (and ManEnv._chain_geom_bits enumerates).  The two-finger plan
+    therefore takes chains with exactly two boxes only; a gripper with three boxes on one finger -- or one -- runs in the tree
+    pipeline, which numbers the boxes flat in geom-id order: the model is accepted, sg_model_nboxes counts all of them, and the
+    two-finger plan's reason says why it is not the fast kernels' model."""
+    import subprocess
+    x = open(os.path.join(ROOT, "tests", "data", "mini_gripper.xml")).read()
+    extra = '<geom class="link" name="fL2" size="0.25 0.08 0.2" mass="0.06"/>'
+    assert extra in x
+    three = x.replace(extra, extra + '\n            <geom class="link" name="fL3" pos="0.3 0 0" size="0.05 0.08 0.2" mass="0.01"/>')
+    p = tmp_path / "three.xml"
+    p.write_text(three)
+    m = sg.compile_mjcf(str(p), composite_neighbors=False)
+    nm = native.NativeModel(m)                                   # accepted: the tree pipeline's model
+    assert nm.nboxes == 5
+    moving = [g for g in range(m.ngeom) if m.body_weldid[m.geom_bodyid[g]] != 0 and m.geom_type[g] == 6]
+    assert [m.geom_names[g] for g in moving] == ["fL1", "fL2", "fL3", "fR1", "fR2"]     # bit g of the touch words = box g in this order
+    # the two-finger plan on the same blob: refused, with the reason
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu")], stdout=subprocess.DEVNULL)
+    E = C.CDLL(os.path.join(ROOT, "tests", "emu", "libsgemu.so"))
+    blob = m.to_blob()
+    out = (C.c_int * (4 * 8 * 4096))()
+    nelem, nnb, err = C.c_int(), C.c_int(), C.create_string_buffer(256)
+    E.emu_plan_schedule.restype = C.c_int
+    assert E.emu_plan_schedule(blob, C.c_size_t(len(blob)), out, 8 * 4096, C.byref(nelem), C.byref(nnb), err, C.c_size_t(256)) <= 0
+    assert b"box geoms" in err.value, err.value
