@@ -17,4 +17,4 @@ g++ -O1 -g -DSGT_EMU_SEPARATE -fsanitize=address,undefined -fno-omit-frame-point
     tests/emu/sg_tree_emu.cpp soft-grip_amd/csrc/sg_plan.cpp
 gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -shared -fopenmp -o oracle/liboracle.so oracle/sg_oracle.c -lm
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
-    python -m pytest tests/test_emu_vs_oracle.py tests/test_oracle_kat.py tests/test_tree_emu.py -x -q
+    python -m pytest tests/test_emu_vs_oracle.py tests/test_oracle_kat.py tests/test_tree_emu.py -x -q ${SG_SANITIZE_PYTEST_ARGS:-}

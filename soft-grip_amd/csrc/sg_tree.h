@@ -48,10 +48,10 @@ namespace sgt {
 using namespace sgm;
 
 #ifndef SGT_DIET
-#define SGT_DIET 0x13f   // which groups of arrays live in the env's work space instead of LDS (lds_carve): bits 0 - 5 the build-only groups,
-                         // 8 the capsule centres of a free object's scene.  Bits 6 (M^-1) and 7 (1 / m) stay in LDS: with them out, four
-                         // workgroups share a CU instead of three -- measured +3 % only (122 against 119 k env-steps/s, four-finger scene),
-                         // and one fuzz scene with 70+ contacts went wrong in a way not yet understood (r04 notes in DESIGN 4.7)
+#define SGT_DIET 0x1ff   // which groups of arrays live in the env's work space instead of LDS (lds_carve): bits 0 - 5 the build-only groups,
+                         // 6 M^-1, 7 the sliders' 1 / m (scenes without a free object), 8 the capsule centres of a free object's scene.
+                         // All set: 37 KB of LDS for the four-finger scene, FOUR workgroups per CU (129 against 94 k env-steps/s with
+                         // M^-1 and 1 / m in LDS, r04v profile)
 #endif
 #define SGT_MAXCON 128   // contacts of an env
 #define SGT_MAXHIT 256   // candidate pairs that pass the bounding tests
@@ -146,8 +146,8 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
   const int ND = T.ND, NB = T.NB;
   // r04: LDS holds what the SWEEP touches (accelerations, forces, limit rows) and what the PAIR WALK touches (capsule centres, box poses);
   // everything only the once-per-substep build stages read or write -- kinematics, body poses and RNE temporaries, the sliders' state,
-  // tendon segments -- sits in the env's work space (coalesced, L2 / Infinity-Cache resident): 52 KB instead of 76 for the four-finger
-  // scene, i.e. THREE workgroups per CU instead of two (M^-1 too would make it four: see SGT_DIET)
+  // tendon segments, M^-1 (whose rows the sweep prefetches) -- sits in the env's work space (coalesced, L2 / Infinity-Cache resident):
+  // 37.5 KB instead of 76 for the four-finger scene, i.e. FOUR workgroups per CU (one per SIMD) instead of two
   auto tk = [&](int bit, size_t n) { return (SGT_DIET >> bit) & 1 ? takeg(n) : take(n); };   // (SGT_DIET: which groups live in the work space)
   L.q = take(ND); L.v = take(ND); L.warm = take(ND); L.asm_ = take(ND); L.aF = take(T.K * T.CS);   // (read joint by joint by the one-lane-per-chain stages: LDS)
   L.fs = tk(0, ND); L.fc = tk(0, ND); L.bias = tk(0, ND); L.tenJ = tk(0, ND); L.kd = tk(0, ND); L.qacc = tk(0, ND);
@@ -180,7 +180,7 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
 #if !SGT_DEVICE && defined(SGT_EMU_SEPARATE)
   if (sp) {
     auto takei = [&](size_t n) { return (int*)sep_take(sp->lds, sp->il, n * sizeof(int)); };
-    L.hit_pair = takei(SGT_MAXHIT); L.hit_sorted = takei(SGT_MAXHIT); L.hit_cnt = takei(SGT_MAXHIT); L.hit_off = takei(SGT_MAXHIT);
+    L.hit_pair = takei(SGT_MAXHIT); L.hit_sorted = takei(2 * SGT_MAXHIT); L.hit_cnt = L.hit_sorted + SGT_MAXHIT; L.hit_off = takei(SGT_MAXHIT);   // (hit_sorted + hit_cnt: ONE array to the pair walk's block lists)
     L.con_src = takei(SGT_MAXCON); L.con_chain = takei(SGT_MAXCON); L.icnt = takei(32);
   }
 #endif
@@ -255,18 +255,9 @@ SG_HD size_t gws_doubles(const SgTreeDev& T, int N, int has_free, int nnb) {   /
 #if SGT_DEVICE
 #define SGT_FIRST ((int)threadIdx.x)
 #define SGT_STRIDE 64
-#ifdef SGT_X_PARANOID   // (experiment: a fence + barrier in front of every parallel loop and single-lane section)
-#define SGT_PAR(i, n) for (int i = (__syncthreads(), (int)threadIdx.x); i < (n); i += 64)
-#define SGT_ONE if ((__syncthreads(), threadIdx.x == 0))
-#else
 #define SGT_PAR(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
 #define SGT_ONE if (threadIdx.x == 0)
-#endif
-#ifdef SGT_X_INVL1   // (experiment: a barrier that also invalidates the CU's vector L1 -- agent-scope acquire)
-#define SGT_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
-#else
 #define SGT_SYNC() __syncthreads()
-#endif
 // cross-lane moves without LDS: DPP on the two halves of a double (row_ror:n = 0x120 + n, rotation inside a row of 16 lanes)
 template <int CTRL>
 __device__ __forceinline__ double dpp64(double x) {
@@ -418,10 +409,12 @@ static SGT_NOINLINE double free_fix_rows(const SGT_LDSP double* frow, const SGT_
     const double ael = na;
     for (int q = 0; q < 5; q++) r5[q] = nr[q];
     for (int q = 0; q < 6; q++) { B6[q] = nB[q]; C6[q] = nC[q]; }
-    {  // (the row behind the last one is read too: the arrays are followed by other words of the block, and the values are dropped)
-      for (int q = 0; q < 5; q++) nr[q] = frow[5 * (e + 1) + q];
-      for (int q = 0; q < 6; q++) { nB[q] = Be[6 * (e + 1) + q]; nC[q] = Ce[6 * (e + 1) + q]; }
-      nf = ffix[e + 1]; na = ae[e + 1];
+    {  // (on the device the row behind the last one is read too: the arrays are followed by other words of the LDS block, and the values
+       //  are dropped; the host build reads the last row again -- its checking layout gives every array a heap block of its own)
+      const int en = (SGT_DEVICE || e + 1 < N) ? e + 1 : e;
+      for (int q = 0; q < 5; q++) nr[q] = frow[5 * en + q];
+      for (int q = 0; q < 6; q++) { nB[q] = Be[6 * en + q]; nC[q] = Ce[6 * en + q]; }
+      nf = ffix[en]; na = ae[en];
     }
     const double old = f;
     imp -= scalar_update_rcp(f, r5[0], ael - dot6(B6, af6) * r5[4], r5[1], r5[2], r5[3], false);
@@ -1110,9 +1103,6 @@ static SGT_NOINLINE void tree_stage(SGT_STAGE_PARAMS) {
             if (l < k && k < CS) Lc[k * CS + l] = m[k];
         }
       }
-#ifdef SGT_X_LDLFENCE
-      __threadfence();
-#endif
       SGT_SYNC();
       return;
     }
@@ -1365,9 +1355,6 @@ static SGT_NOINLINE void tree_stage(SGT_STAGE_PARAMS) {
       for (int k = 0; k < CS; k++) x[k] = k == dl ? 1.0 : 0.0;
       chain_solve_reg<CHD>(S.L + c * CS * CS, CS, x);
     }
-#ifdef SGT_X_S1
-    SGT_SYNC();
-#endif
     SGT_STAMP(4);
     // ---------------------------------------------------------------- stage 7: bias forces (RNE with qacc = 0), body velocities
     tree_motion(nullptr);
@@ -1679,9 +1666,10 @@ static SGT_NOINLINE void tree_stage(SGT_STAGE_PARAMS) {
         for (int k = 0; k < 3; k++) { o[1 + k] = r.pos[k]; o[4 + k] = r.n[k]; o[7 + k] = hint ? hint[k] : 0.0; }
         n++;
       };
-      const double* bp = k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[i2];
-      const double* bm = k2 == SGG_BOX ? S.gmat + 9 * i2 : H.st_mat[i2];
-      const double* sz = k2 == SGG_BOX ? T.g_size[i2] : H.st_size[i2];
+      const int st2 = k2 == SGG_STATIC ? i2 : 0;   // (a plane pair's geom2 is an element or a box: no static geom is named, none is read)
+      const double* bp = k2 == SGG_BOX ? S.gpos + 3 * i2 : H.st_pos[st2];
+      const double* bm = k2 == SGG_BOX ? S.gmat + 9 * i2 : H.st_mat[st2];
+      const double* sz = k2 == SGG_BOX ? T.g_size[i2] : H.st_size[st2];
       const double* cenw = FR ? S.of + OF_CEN : H.center_pos;
       auto elem_axis = [&](int e, double* cax) {   // the capsule's axis in the world (it turns with a free body)
         const double cl[3] = {E(SGE_CX, e), E(SGE_CY, e), E(SGE_CZ, e)};
