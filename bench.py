@@ -328,6 +328,7 @@ def main():
                                        "; + ConvNet regressor: channel stats, noise augmentation, forward and one Adam step on every finished [n,200,12] block, on device, inside the timed region" if args.with_regressor else ""),
                        "envs_per_gpu": n, "substeps_per_step": R.sim_step, "physics_substeps_per_s": value * R.sim_step,
                        "envs_flagged_bad": nbad, "launches_timed": launches, "steps_timed": nsteps, "timed_region": desc,
+                       "tree_workgroups_per_cu": (R.batch.tree_workgroups_per_cu() if hasattr(R.batch, "tree_workgroups_per_cu") else 0) or None,
                        "rank_sync": {"store": "TCP key-value store (barriers + per-rank times), no collective library", "nccl": "torch.distributed on RCCL",
                                      "gloo": "torch.distributed on gloo"}[args.dist_backend] if world > 1 else None},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

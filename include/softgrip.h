@@ -145,6 +145,11 @@ int sg_model_nboxes(const sg_model* m);
 int sg_set_solver_envs_per_wavefront(sg_batch* b, int epw);
 int sg_solver_envs_per_wavefront(const sg_batch* b);
 
+/* tree pipeline: how many workgroups (= envs, one wavefront each) of this batch's kernel the runtime places on one CU with the LDS the
+ * launch asks for (hipOccupancyMaxActiveBlocksPerMultiprocessor) -- what bench.py reports as config.tree_workgroups_per_cu.
+ * 0 for a batch that does not run the tree pipeline; negative: an error code. */
+int sg_tree_workgroups_per_cu(const sg_batch* b);
+
 /* kernel timing hook for bench.py: average device time (ms) of one sg_step/sg_reset call's kernels over the
  * calls since the last call with reset != 0, measured with HIP events on the launch
  * stream.  Synchronises the host. */

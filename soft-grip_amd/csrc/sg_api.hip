@@ -654,6 +654,14 @@ int sg_set_solver_envs_per_wavefront(sg_batch* b, int epw) {
   return SG_OK;
 }
 int sg_solver_envs_per_wavefront(const sg_batch* b) { return b ? solver_epw(b) : 0; }
+int sg_tree_workgroups_per_cu(const sg_batch* b) {
+  if (!b) return fail(SG_ERR_INVALID, "sg_tree_workgroups_per_cu: bad argument");
+  if (!b->tree_ready) return 0;
+  const sg_model* m = b->m;
+  if (hipSetDevice(b->device) != hipSuccess) return fail(SG_ERR_NO_DEVICE, "hipSetDevice");
+  if (sg_tree_prepare() != hipSuccess) return fail(SG_ERR_HIP, "sg_tree_prepare");
+  return sg_tree_occupancy(m->tree.CS, sgt::lds_bytes(m->tree, m->tplan.h.nelem, m->tplan.h.has_free, m->tplan.h.nnb));
+}
 
 #ifdef SG_SECTION_PROF
 // profiling build only (build_native.py --prof, scripts/section_profile.py): read and clear the per-section cycle sums

@@ -164,8 +164,8 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
   L.Ifix = takeg(N); L.Ilim = takeg(2 * N);
   L.lrow = take(SGT_LROW * 2 * ND); L.seg = tk(5, 4 * T.K * SGT_MAXTS); L.chs = tk(5, CHS_N * SGT_MAXCH); L.cf = take(3 * SGT_MAXCON);
   L.red = take(16); L.swc = take(16); L.ctx = take(16);
-  L.of = take(has_free ? OF_N : 0); L.Be = take(has_free ? 6 * N : 0); L.Ce = take(has_free ? 6 * N : 0); L.Afix = takeg(has_free ? N : 0);
-  L.frow = take(has_free ? 5 * N : 0);
+  L.of = take(has_free ? OF_N : 0); L.Be = take(has_free ? 6 * N : 0); L.Ce = take((has_free && nnb) ? 6 * N : 0); L.Afix = takeg(has_free ? N : 0);   // (C_e: kept for the neighbour-row blocks only -- the plain rows recompute it, free_fix_rows)
+  L.frow = take(has_free ? 4 * N : 0);
   L.nbf = takeg(nnb ? 3 * N : 0); L.nbb = takeg(nnb ? 3 * N : 0); L.nbR = takeg(nnb ? 3 * N : 0); L.nbI = takeg(nnb ? 3 * N : 0);
   L.nbA = takeg((nnb && has_free) ? 3 * N : 0);
   if (gdoubles) *gdoubles = (size_t)(g - gbase);
@@ -396,31 +396,43 @@ SG_HD void mat6vec(double* r, const double* M, const double* v) {
 // The free object's joint-fix rows, one after the other (one lane).  A function of its own ON PURPOSE: inlined into the step kernel --
 // 256 + 256 registers and spilling -- the loop's 40 live values went to scratch memory and a row cost 600 cycles; called, it gets a
 // register allocation of its own.  The next row's 19 words are loaded before this row's dependent arithmetic.
-static SGT_NOINLINE double free_fix_rows(const SGT_LDSP double* frow, const SGT_LDSP double* Be, const SGT_LDSP double* Ce, SGT_LDSP double* ffix, SGT_LDSP double* ae,
-                                         SGT_LDSP double* af, int N) {
-  double af6[6], imp = 0;
+static SGT_NOINLINE double free_fix_rows(const SGT_LDSP double* frow, const SGT_LDSP double* Be, const SGT_LDSP double* einvm, const SGT_LDSP double* Sinv,
+                                         SGT_LDSP double* ffix, SGT_LDSP double* ae, SGT_LDSP double* af, int N) {
+  // C_e = -S^-1 B_e / D_e is RECOMPUTED per row (r04: 36 multiply-adds that do not depend on the previous row -- they run in the shadow
+  // of its dependent chain) instead of read from a [N][6] array: without that array and the rows' copy of 1 / D the free ball's
+  // LDS block is 37.8 KB instead of 50 -- four workgroups per CU instead of three.  Same expressions as the rows' build (tree_stage).
+  double af6[6], imp = 0, Si[36];
   for (int q = 0; q < 6; q++) af6[q] = af[q];
-  double nr[5], nB[6], nC[6], nf = ffix[0], na = ae[0];
-  for (int q = 0; q < 5; q++) nr[q] = frow[q];
-  for (int q = 0; q < 6; q++) { nB[q] = Be[q]; nC[q] = Ce[q]; }
+  for (int q = 0; q < 36; q++) Si[q] = Sinv[q];
+  double nr[4], nB[6], nC[6], nf = ffix[0], na = ae[0], ni = einvm[0];
+  for (int q = 0; q < 4; q++) nr[q] = frow[q];
+  for (int q = 0; q < 6; q++) nB[q] = Be[q];
+  {
+    double Bs[6];
+    mat6vec(Bs, Si, nB);
+    for (int q = 0; q < 6; q++) nC[q] = -Bs[q] * ni;
+  }
 #pragma unroll 2
   for (int e = 0; e < N; e++) {
-    double r5[5], B6[6], C6[6], f = nf;
-    const double ael = na;
-    for (int q = 0; q < 5; q++) r5[q] = nr[q];
+    double r4[4], B6[6], C6[6], f = nf;
+    const double ael = na, invm = ni;
+    for (int q = 0; q < 4; q++) r4[q] = nr[q];
     for (int q = 0; q < 6; q++) { B6[q] = nB[q]; C6[q] = nC[q]; }
     {  // (on the device the row behind the last one is read too: the arrays are followed by other words of the LDS block, and the values
        //  are dropped; the host build reads the last row again -- its checking layout gives every array a heap block of its own)
       const int en = (SGT_DEVICE || e + 1 < N) ? e + 1 : e;
-      for (int q = 0; q < 5; q++) nr[q] = frow[5 * en + q];
-      for (int q = 0; q < 6; q++) { nB[q] = Be[6 * en + q]; nC[q] = Ce[6 * en + q]; }
-      nf = ffix[en]; na = ae[en];
+      for (int q = 0; q < 4; q++) nr[q] = frow[4 * en + q];
+      for (int q = 0; q < 6; q++) nB[q] = Be[6 * en + q];
+      nf = ffix[en]; na = ae[en]; ni = einvm[en];
+      double Bs[6];
+      mat6vec(Bs, Si, nB);
+      for (int q = 0; q < 6; q++) nC[q] = -Bs[q] * ni;
     }
     const double old = f;
-    imp -= scalar_update_rcp(f, r5[0], ael - dot6(B6, af6) * r5[4], r5[1], r5[2], r5[3], false);
+    imp -= scalar_update_rcp(f, r4[0], ael - dot6(B6, af6) * invm, r4[1], r4[2], r4[3], false);
     const double dfl = f - old;
     ffix[e] = f;
-    ae[e] = ael + r5[4] * dfl;
+    ae[e] = ael + invm * dfl;
     for (int q = 0; q < 6; q++) af6[q] += C6[q] * dfl;
   }
   for (int q = 0; q < 6; q++) af[q] = af6[q];
@@ -429,7 +441,7 @@ static SGT_NOINLINE double free_fix_rows(const SGT_LDSP double* frow, const SGT_
 // The same with the composite's neighbour equalities: the equality BLOCKS [fix_e, e's neighbour rows (partner p: J = +1 on e, -1 on p)] in
 // mj_solPGS's order.  A neighbour row moves two sliders and, through both, the body: a_f += (C_e - C_p) df.  (The neighbour rows' words
 // sit in the work space: generic pointers.)
-static SGT_NOINLINE double free_eq_blocks(const SGT_LDSP double* frow, const SGT_LDSP double* Be, const SGT_LDSP double* Ce, SGT_LDSP double* ffix, SGT_LDSP double* ae,
+static SGT_NOINLINE double free_eq_blocks(const SGT_LDSP double* frow, const SGT_LDSP double* Be, const SGT_LDSP double* Ce, const SGT_LDSP double* einvm, SGT_LDSP double* ffix, SGT_LDSP double* ae,
                                           SGT_LDSP double* af, int N, const int* nbtab, double* nbf, const double* nbb, const double* nbR, const double* nbA,
                                           const double* nbI) {
   double af6[6], imp = 0;
@@ -437,9 +449,9 @@ static SGT_NOINLINE double free_eq_blocks(const SGT_LDSP double* frow, const SGT
   for (int e = 0; e < N; e++) {
     double B6[6], C6[6];
     for (int q = 0; q < 6; q++) { B6[q] = Be[6 * e + q]; C6[q] = Ce[6 * e + q]; }
-    const double invm = frow[5 * e + 4];
+    const double invm = einvm[e];
     double f = ffix[e], old = f, ael = ae[e];
-    imp -= scalar_update_rcp(f, frow[5 * e], ael - dot6(B6, af6) * invm, frow[5 * e + 1], frow[5 * e + 2], frow[5 * e + 3], false);
+    imp -= scalar_update_rcp(f, frow[4 * e], ael - dot6(B6, af6) * invm, frow[4 * e + 1], frow[4 * e + 2], frow[4 * e + 3], false);
     double dfl = f - old;
     ffix[e] = f;
     ael += invm * dfl;
@@ -449,7 +461,7 @@ static SGT_NOINLINE double free_eq_blocks(const SGT_LDSP double* frow, const SGT
       if (pe < 0) continue;
       double Bp[6], Cp[6];
       for (int q = 0; q < 6; q++) { Bp[q] = Be[6 * pe + q]; Cp[q] = Ce[6 * pe + q]; }
-      const double ipm = frow[5 * pe + 4], apl = ae[pe];
+      const double ipm = einvm[pe], apl = ae[pe];
       f = nbf[k]; old = f;
       imp -= scalar_update_rcp(f, nbb[k], (ael - dot6(B6, af6) * invm) - (apl - dot6(Bp, af6) * ipm), nbR[k], nbA[k], nbI[k], false);
       dfl = f - old;
@@ -482,7 +494,7 @@ enum { SWC_TEN_R = 0, SWC_TEN_B, SWC_TEN_F, SWC_TJ_A, SWC_TEN_I, SWC_CTEN, SWC_N
 // Everything the rows need was laid out by tree_env: the sliders' rows (S.ffix, S.flim, constants in the work space), the chains' limit
 // rows (S.lrow), the contacts' J / W rows and scalars (work space), the accelerations a = M^-1 J' f of the current forces (S.aF, S.ae).
 // A function of its own ON PURPOSE (see the call site).  Pointers come typed by address space, uniform values are made scalar again.
-template <int CHD>
+template <int CHD, bool FRT, bool NBT>   // FRT: the scene has a free object, NBT: the composite's neighbour rows -- compile-time facts of the instantiation, so that a sweep carries only its own scene class's code (r04: 355 -> 190 spill instructions for the four-finger gripper's)
 static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_CONST SgTreeDev* Tp, const SGT_CONST int* nbtab, const SGT_CONST SgEqSlot* sched,
                                     const int* nbtab_generic, SGT_GLOBP double* cw_, SGT_LDSP double* lds_, unsigned long long* secprof) {
 #if SGT_DEVICE
@@ -499,7 +511,7 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
   double* const cw = (double*)cw_;
   const int N = H.nelem, K = T.K;
   constexpr int CS = CHD;   // (= T.CS: the plan pads the chains' stride to the instantiation's capacity)
-  const bool FR = H.has_free != 0, NB = H.nnb > 0;
+  constexpr bool FR = FRT, NB = NBT;
   Lds S;
   lds_carve(S, (double*)lds_, T, N, H.has_free, cw + (size_t)SGT_MAXHIT * SGT_HITREC * SGT_RECW + (size_t)SGT_MAXCON * cws_row_doubles(T.CS) + T.NMAT, nullptr, H.nnb);
   const long long CW = cws_row_doubles(CS);
@@ -539,12 +551,12 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
       // with a free object a joint-fix row moves the body and through it every slider: the rows run one after the other (mj_solPGS's
       // order), the body's acceleration a_f in registers, a row's own slider from its local part and a_f
       if (NB) SGT_ONE {
-        S.red[0] = free_eq_blocks((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.Ce, (SGT_LDSP double*)S.ffix,
+        S.red[0] = free_eq_blocks((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.Ce, (const SGT_LDSP double*)S.einvm, (SGT_LDSP double*)S.ffix,
                                   (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N, A.nbtab, S.nbf, S.nbb, S.nbR, S.nbA, S.nbI);
       }
       if (!NB) SGT_ONE {
-        S.red[0] = free_fix_rows((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.Ce, (SGT_LDSP double*)S.ffix,
-                                 (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N);
+        S.red[0] = free_fix_rows((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.einvm, (const SGT_LDSP double*)(S.of + OF_SINV),
+                                 (SGT_LDSP double*)S.ffix, (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N);
       }
       SGT_SYNC();
       imp_uni += S.red[0];
@@ -893,8 +905,18 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
 #pragma unroll
             for (int k = 0; k < 6; k++) dg[k] = q.Jo[k] * df[0] + q.Jo[6 + k] * df[1] + q.Jo[12 + k] * df[2];
             mat6vec(da, Si, dg);
+            double Cs[6] = {0, 0, 0, 0, 0, 0};   // C_sl = -S^-1 B_sl / D_sl: the neighbour-row models keep it, the others recompute it (free_fix_rows)
+            if (sl >= 0) {
+              if (NB) { for (int k = 0; k < 6; k++) Cs[k] = S.Ce[6 * sl + k]; }
+              else {
+                double Bs[6];
+                mat6vec(Bs, Si, S.Be + 6 * sl);
+                const double im = S.einvm[sl];
+                for (int k = 0; k < 6; k++) Cs[k] = -Bs[k] * im;
+              }
+            }
 #pragma unroll
-            for (int k = 0; k < 6; k++) { gf[k] += dg[k]; af[k] += da[k] + (sl >= 0 ? S.Ce[6 * sl + k] * dge : 0.0); }
+            for (int k = 0; k < 6; k++) { gf[k] += dg[k]; af[k] += da[k] + Cs[k] * dge; }
           }
         }
       };
@@ -954,7 +976,16 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
           double dg[6], da[6];
           for (int q = 0; q < 6; q++) dg[q] = sc[CS_JO + q] * df[0] + sc[CS_JO + 6 + q] * df[1] + sc[CS_JO + 12 + q] * df[2];
           mat6vec(da, S.of + OF_SINV, dg);
-          for (int q = 0; q < 6; q++) { S.of[OF_GF + q] += dg[q]; S.of[OF_AF + q] += da[q] + (sl >= 0 ? S.Ce[6 * sl + q] * dge : 0.0); }
+          double Cs[6] = {0, 0, 0, 0, 0, 0};
+          if (sl >= 0) {
+            if (NB) { for (int q = 0; q < 6; q++) Cs[q] = S.Ce[6 * sl + q]; }
+            else {
+              double Bs[6];
+              mat6vec(Bs, S.of + OF_SINV, S.Be + 6 * sl);
+              for (int q = 0; q < 6; q++) Cs[q] = -Bs[q] * S.einvm[sl];
+            }
+          }
+          for (int q = 0; q < 6; q++) { S.of[OF_GF + q] += dg[q]; S.of[OF_AF + q] += da[q] + Cs[q] * dge; }
         }
       }
       SGT_SYNC();
@@ -1760,10 +1791,10 @@ static SGT_NOINLINE void tree_stage(SGT_STAGE_PARAMS) {
         double Bs[6];
         mat6vec(Bs, S.of + OF_SINV, S.Be + 6 * e);
         Aee = invm + dot6(S.Be + 6 * e, Bs) * invm * invm;
-        for (int q = 0; q < 6; q++) S.Ce[6 * e + q] = -Bs[q] * invm;
+        if (H.nnb > 0) for (int q = 0; q < 6; q++) S.Ce[6 * e + q] = -Bs[q] * invm;   // (kept for the neighbour-row blocks only: lds_carve)
         S.Afix[e] = Aee + R;
-        double* fr5 = S.frow + 5 * e;
-        fr5[0] = S.bfix[e]; fr5[1] = R; fr5[2] = Aee + R; fr5[3] = 1.0 / (Aee + R); fr5[4] = invm;
+        double* fr4 = S.frow + 4 * e;
+        fr4[0] = S.bfix[e]; fr4[1] = R; fr4[2] = Aee + R; fr4[3] = 1.0 / (Aee + R);
       }
       S.Ifix[e] = 1.0 / (Aee + R);
       tj_pos += co * S.qe[e]; tj_vel += co * S.ve[e]; tj_asm += co * S.asme[e]; tj_warm += co * S.we[e]; tj_A += co * co * invm;
@@ -2217,8 +2248,18 @@ static SGT_NOINLINE void tree_stage(SGT_STAGE_PARAMS) {
       w[SWC_NCON] = ncon; w[SWC_SERIAL] = serial_contacts ? 1.0 : 0.0;
     }
     SGT_SYNC();
-    tree_sweep<CHD>((const SGT_CONST SgPlanHeader*)A.H, (const SGT_CONST SgTreeDev*)A.T, (const SGT_CONST int*)A.nbtab, (const SGT_CONST SgEqSlot*)A.sched, A.nbtab,
-                    (SGT_GLOBP double*)(A.cws + (size_t)env * A.cws_stride), (SGT_LDSP double*)lds_base, A.secprof);
+    {   // (uniform branches: one instantiation of the sweep per scene class)
+      const SGT_CONST SgPlanHeader* const hp = (const SGT_CONST SgPlanHeader*)A.H;
+      const SGT_CONST SgTreeDev* const tp = (const SGT_CONST SgTreeDev*)A.T;
+      const SGT_CONST int* const nbc = (const SGT_CONST int*)A.nbtab;
+      const SGT_CONST SgEqSlot* const sc = (const SGT_CONST SgEqSlot*)A.sched;
+      SGT_GLOBP double* const cwp = (SGT_GLOBP double*)(A.cws + (size_t)env * A.cws_stride);
+      SGT_LDSP double* const lp = (SGT_LDSP double*)lds_base;
+      if (FR && NB) tree_sweep<CHD, true, true>(hp, tp, nbc, sc, A.nbtab, cwp, lp, A.secprof);
+      else if (FR) tree_sweep<CHD, true, false>(hp, tp, nbc, sc, A.nbtab, cwp, lp, A.secprof);
+      else if (NB) tree_sweep<CHD, false, true>(hp, tp, nbc, sc, A.nbtab, cwp, lp, A.secprof);
+      else tree_sweep<CHD, false, false>(hp, tp, nbc, sc, A.nbtab, cwp, lp, A.secprof);
+    }
     SGT_SYNC();
     SGT_STAMP_RESET();
     iters = (int)S.swc[SWC_ITERS];
@@ -2532,5 +2573,6 @@ SG_HD void tree_env(const TreeArgs& A, const int env, double* lds_base) {
 #if defined(__HIPCC__)
 // launchers (sg_tree.hip): the kernel is a translation unit of its own
 hipError_t sg_tree_prepare();
+int sg_tree_occupancy(int CS, size_t lds_bytes);   // workgroups per CU the runtime grants the instantiation (sg_tree.hip)
 hipError_t sg_launch_tree(const sgt::TreeArgs& a, int CS, size_t lds_bytes, hipStream_t s);
 #endif

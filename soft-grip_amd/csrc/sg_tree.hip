@@ -31,6 +31,13 @@ hipError_t sg_tree_prepare() {
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sg_tree_kernel<SGT_CHD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return e;
 }
+int sg_tree_occupancy(int CS, size_t lds_bytes) {
+  int n = 0;
+  hipError_t e = CS == 8    ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sg_tree_kernel<8>, 64, lds_bytes)
+                 : CS == 20 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sg_tree_kernel<20>, 64, lds_bytes)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sg_tree_kernel<SGT_CHD>, 64, lds_bytes);
+  return e == hipSuccess ? n : -1;
+}
 // the instantiation whose capacity IS the model's padded chain stride CS (sg_plan.cpp pads to 8, 20 or SGT_CHD)
 hipError_t sg_launch_tree(const sgt::TreeArgs& a, int CS, size_t lds_bytes, hipStream_t s) {
   if (CS == 8) hipLaunchKernelGGL(sg_tree_kernel<8>, dim3(a.nenv), dim3(64), lds_bytes, s, a);

@@ -19,7 +19,7 @@ SYMBOLS = [
     "sg_batch_nenvs", "sg_batch_device", "sg_set_stiffness", "sg_set_ctrl", "sg_reset", "sg_step", "sg_get_state",
     "sg_set_state", "sg_get_solver_stats", "sg_set_pipeline", "sg_profile_enable", "sg_profile_read", "sg_profile_read_solver",
     "sg_model_compile", "sg_mjcf_compile", "sg_blob_free", "sg_set_solver_envs_per_wavefront", "sg_solver_envs_per_wavefront",
-    "sg_get_touch_words", "sg_model_nboxes", "sg_model_nv", "sg_model_njnt",
+    "sg_get_touch_words", "sg_model_nboxes", "sg_model_nv", "sg_model_njnt", "sg_tree_workgroups_per_cu",
 ]
 SG_COMPILE_NO_NEIGHBORS, SG_COMPILE_IMPLICIT_TENDON_DAMPER = 1, 2
 
@@ -76,6 +76,7 @@ def load_library(path):
     L.sg_set_pipeline.argtypes = [vp, C.c_int]
     L.sg_set_solver_envs_per_wavefront.argtypes = [vp, C.c_int]
     L.sg_solver_envs_per_wavefront.argtypes = [vp]
+    L.sg_tree_workgroups_per_cu.argtypes = [vp]
     L.sg_profile_enable.argtypes = [vp, C.c_int]
     L.sg_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.sg_profile_read_solver.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
@@ -206,6 +207,10 @@ class NativeBatch:
 
     def solver_envs_per_wavefront(self):
         return self.L.sg_solver_envs_per_wavefront(self.ptr)
+
+    def tree_workgroups_per_cu(self):
+        """tree pipeline: workgroups (= envs) per CU the runtime grants the kernel with this model's LDS block; 0 on the rows pipeline"""
+        return self.L.sg_tree_workgroups_per_cu(self.ptr)
 
     def profile_enable(self, on=True):
         self._check(self.L.sg_profile_enable(self.ptr, int(on)))
