@@ -466,3 +466,19 @@ def test_chain_capacities_on_the_gpu(tmp_path, links, hinges, seed):
                 scale = 1.0 + np.abs(s.sensordata).max() + np.abs(s.qacc_warmstart).max()
                 assert max(np.abs(got[e] - s.sensordata).max(), np.abs(qv[e] - s.qvel).max()) < 1e-7 * scale, (t, j, e)
     assert most > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,jids,want", [("fourfinger_softball_fix", FF_JOINTS, 4), ("freeball_fix", list(range(9, 227)), 4), ("freeball", list(range(9, 227)), 3)])
+def test_tree_kernel_workgroups_per_cu(scene, jids, want):
+    """the occupancy the r04 numbers rest on: the env's LDS block is small enough for four workgroups per CU -- one
+    wavefront per SIMD -- on the four-finger gripper (37.6 KB) and on the free ball (37.8 KB); the free ball's neighbour-row model
+    keeps C_e in LDS for its blocks (48 KB: three).  sg_tree_workgroups_per_cu asks the runtime
+    (hipOccupancyMaxActiveBlocksPerMultiprocessor with the launch's LDS bytes); a two-finger batch on the rows pipeline answers 0."""
+    from softgrip_amd import native
+    m = sg.load_model(model_path(scene), "implicit")
+    nm, b, sens, flags = _batch(m, [700.0, 900.0], jids, [0])
+    assert b.tree_workgroups_per_cu() == want
+    m2 = sg.load_model(model_path("softbox_fix"))
+    b2 = native.NativeBatch(native.NativeModel(m2), 2, 0)
+    assert b2.tree_workgroups_per_cu() == 0

@@ -1,12 +1,16 @@
 """The TREE pipeline's source (csrc/sg_tree.h: grippers outside the two-finger class) compiled for the host
 (tests/emu/sg_tree_emu.cpp: a parallel loop becomes a serial loop) against the oracle: the reference's four-finger gripper
 (soft_grip_four_fingers.xml) and, as a cross-check of the general code on models the fast kernels also run, the two-finger scenes."""
+import os
+
 import numpy as np
 import pytest
 
 import softgrip_amd as sg
 from helpers import JOINT_IDS, TENDON_IDS, TreeEmu, model_path, oracle_sim, random_gripper_xml
 from softgrip_amd.create_dataset import episode_schedule
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 FF_JOINTS = list(range(65, 283))      # reference environment/manenv.py:11 (commented four-finger ids): the ball's sliders
 
@@ -482,3 +486,32 @@ def test_chain_capacities_and_kernel_instantiations(tmp_path, links, hinges, str
             assert max(np.abs(e.sensordata - s.sensordata).max(), np.abs(e.qvel - s.qvel).max()) < 1e-8 * scale, (t, j)
             most = max(most, s.ncon)
     assert most > 0
+
+
+def test_checking_layout_gives_the_same_numbers(tmp_path):
+    """scripts/sanitize/run_emu_oracle.sh runs the emulation in its checking layout (SGT_EMU_SEPARATE: every array of the env's LDS block
+    and work space a heap block of its own, so that ASan sees one-past-the-end of ANY array).  This keeps that layout compiling and
+    equal to the plain one: the free ball's first env steps, bit for bit."""
+    import ctypes as C
+    import subprocess
+    so = str(tmp_path / "libsgtreeemu_sep.so")
+    subprocess.check_call(["g++", "-O1", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-DSGT_EMU_SEPARATE", "-o", so,
+                           os.path.join(ROOT, "tests", "emu", "sg_tree_emu.cpp"), os.path.join(ROOT, "soft-grip_amd", "csrc", "sg_plan.cpp")])
+    m = sg.load_model(model_path("freeball_fix"), "implicit")
+    plain = TreeEmu(m)
+    real = C.CDLL
+    try:
+        C.CDLL = lambda p, *a, **k: real(so if str(p).endswith("libsgtreeemu.so") else p, *a, **k)
+        sep = TreeEmu(m)
+    finally:
+        C.CDLL = real
+    for e in (plain, sep):
+        e.set_stiffness(700.0, list(range(9, 227)), [0])
+        e.reset(1)
+    for t_ in range(3):
+        for e in (plain, sep):
+            e.ctrl[:] = 0.0 if t_ < 1 else 1.0
+            e.step(7)
+        assert (plain.ncon, plain.nefc, plain.iters, plain.flags) == (sep.ncon, sep.nefc, sep.iters, sep.flags)
+        np.testing.assert_array_equal(plain.sensordata, sep.sensordata)
+        np.testing.assert_array_equal(plain.qpos, sep.qpos)
