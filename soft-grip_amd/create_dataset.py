@@ -226,13 +226,21 @@ def make_parser():
     return parser
 
 
-def _self_launch(args, argv):
+def _self_launch(args, argv, explicit_argv):
     """--gpus N > 1 without a launcher: N ranks as child processes (ranks.spawn_ranks: this process never touches a GPU), then the
-    ranks' summary files added up into one JSON line.  The ranks share nothing: no collective, no store, no common file"""
+    ranks' summary files added up into one JSON line.  The ranks share nothing: no collective, no store, no common file.
+    A rank runs `python -m softgrip_amd.create_dataset <argv>` when main() was CALLED with an argv (a script, a notebook, a test: its
+    own command line is not a create_dataset command), and this process's own command line when main() is the CLI entry (which keeps
+    whatever wrapper the user started it under, e.g. tests/run_with_fake_native.py)."""
     from . import ranks
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     t0 = time.perf_counter()
-    rc = ranks.spawn_ranks(args.gpus, {"PYTHONPATH": root + os.pathsep + os.environ.get("PYTHONPATH", "")})
+    cmd = [sys.executable, "-m", "softgrip_amd.create_dataset"] + list(argv) if explicit_argv else None
+    for r in range(args.gpus):   # summaries of an earlier job under the same name must not be added up as this one's
+        stale = os.path.join(args.data_folder, "%s.rank%d.summary.json" % (args.data_name, r))
+        if os.path.exists(stale):
+            os.remove(stale)
+    rc = ranks.spawn_ranks(args.gpus, {"PYTHONPATH": root + os.pathsep + os.environ.get("PYTHONPATH", "")}, cmd=cmd)
     if rc == 0:
         print(json.dumps(job_summary(args.data_folder, args.data_name, args.gpus, time.perf_counter() - t0)))
     return rc
@@ -254,10 +262,11 @@ def job_summary(folder, name, world, wall_seconds=None):
 
 
 def main(argv=None):
+    explicit_argv = argv is not None
     argv = sys.argv[1:] if argv is None else list(argv)
     args, _ = make_parser().parse_known_args(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
-        raise SystemExit(_self_launch(args, argv))
+        raise SystemExit(_self_launch(args, argv, explicit_argv))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))

@@ -40,7 +40,7 @@ class ManEnv(Env):
     n_actuated = 2    # close_hand / loose_hand drive ctrl[0 .. n_actuated - 1] (`for i in range(2)`, reference manenv.py:93-101); 4 for the four-finger gripper
 
     def __init__(self, sim_start, sim_step, env_paths, is_vis=True, n_envs=1, device=0, contact_flag_mode="intent", check_scene=True,
-                 tendon_damper="auto", joint_ids=None, tendon_ids=None, finger_names=None, n_actuated=None):
+                 tendon_damper="auto", joint_ids=None, tendon_ids=None, finger_names=None, n_actuated=None, max_cached_scenes=4):
         """``joint_ids`` / ``tendon_ids``: which model entries ``set_new_stiffness`` writes; default = the reference's class attributes
         (joints 11..63 and tendon 0: manenv.py:12-13), to be overridden for a scene with another layout (e.g. a smaller shell).
         ``tendon_damper``: how the damper of the composite's volume tendon is integrated (mjcf.load_model).
@@ -61,6 +61,7 @@ class ManEnv(Env):
         if n_actuated is not None:
             self.n_actuated = int(n_actuated)
         self.check_scene = check_scene
+        self.max_cached_scenes = int(max_cached_scenes)   # scenes whose native batch stays allocated across load_env() calls (LRU; close() drops them)
         self.is_vis = is_vis  # no viewer exists; kept for signature parity (render() is a no-op)
         self.env_paths = env_paths
         self.n_envs = int(n_envs)
@@ -82,9 +83,12 @@ class ManEnv(Env):
             # A scene this instance has loaded before: its batch is kept alive, the load-time verdict (which damper it needs) with it.
             # What the reference's load_env leaves behind is a fresh MjSim -- the state after mj_resetData, the XML's own stiffness --
             # so: that state, no per-env stiffness, the reference-mode finger list refilled.
+            self._scenes[path] = self._scenes.pop(path)      # most recently used last
             for k, v in self._scenes[path].items():
                 setattr(self, k, v)
             self._ctrl[:] = 0
+            self._sens.zero_()      # a fresh MjSim's sensordata and contact list are empty: get_sensor_sensordata() right after
+            self._touch.zero_()     # load_env() must not show the previous episode's last sample
             self.stiffness = np.full(self.n_envs, np.nan)
             self._k_range = (300, 1400)
             self.env.set_stiffness(np.zeros(self.n_envs), [], [])
@@ -127,6 +131,14 @@ class ManEnv(Env):
                 self._load(path, "implicit")
                 return
         self._scenes[path] = {k: getattr(self, k) for k in self._SCENE_STATE}
+        while len(self._scenes) > max(1, self.max_cached_scenes):      # least recently used first; never the scene just loaded
+            self._scenes.pop(next(iter(self._scenes)))
+
+    def close(self):
+        """drops every cached scene but the current one (a cached scene pins its native batch: state + work space, ~0.1 MB per env on
+        the rows pipeline, ~0.5 MB per env on the tree pipeline -- hundreds of MB at 4096 envs)"""
+        cur = [p for p, sc in self._scenes.items() if sc.get("env") is self.env]
+        self._scenes = {p: self._scenes[p] for p in cur}
 
     def _check_scene(self, path, n_steps=40):
         """Fail loudly at load time for a scene that cannot produce data: the idle phase of an episode (reset + 40 env steps at

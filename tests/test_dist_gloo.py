@@ -162,3 +162,104 @@ def test_create_dataset_launches_its_own_ranks(tmp_path):
     k0 = pickle.load(open(tmp_path / "ds" / "cfg4.rank0.pickle", "rb"))["stiffness"]
     k1 = pickle.load(open(tmp_path / "ds" / "cfg4.rank1.pickle", "rb"))["stiffness"]
     assert len(k0) == 15 and len(k1) == 15 and all(300 <= k < 850 for k in k0) and all(850 <= k < 1400 for k in k1)
+
+
+# ---- BASELINE configs[3] at its real rank count: 8 ranks, on the CPU over the fake native batch -------------------
+# What this pins is everything around the kernels that an 8-GPU run needs and a 2-rank run does not prove: eight processes meeting on one
+# store and port, eight disjoint stiffness bins of width 137.5, eight shards, ONE JSON line, and a dead rank ending the job with its code.
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def test_bench_eight_ranks():
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    args = ["--gpus", "8", "--steps", "10", "--warmup", "2", "--envs", "8", "--no-cpu-baseline", "--no-fix-variant"]
+    for launcher in ([], ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]):
+        out = subprocess.run([sys.executable] + launcher + [FAKE, bench] + args, capture_output=True, text=True, env=_clean_env(), timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1                                   # ONE line, from rank 0
+        res = json.loads(lines[0])
+        assert res["n_gpus"] == 8 and res["steps"] == 10 and res["warmup"] == 2 and res["scaling"] == "weak"
+        assert len(res["ms_per_step_per_rank"]) == 8 and abs(max(res["ms_per_step_per_rank"]) - res["ms_per_step"]) < 1e-9
+        assert abs(res["value"] - 8 * 8 * 10 / (res["ms_per_step"] * 10e-3)) < 1e-6 * res["value"]
+        assert "configs[3]" in res["config"]["workload"] and "no collective library" in res["config"]["rank_sync"]
+
+
+def test_create_dataset_eight_ranks(tmp_path):
+    import json
+    import pickle
+    from helpers import model_path
+    out = subprocess.run([sys.executable, FAKE, "-m", "softgrip_amd.create_dataset", "--gpus", "8", "--mujoco-model-paths", model_path("softbox"),
+                          "--n-envs", "4", "--total-episodes", "64", "--seed", "11", "--data-folder", str(tmp_path / "ds"), "--data-name", "cfg3"],
+                         capture_output=True, text=True, env=_clean_env(), timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["episodes"] == 64 and res["env_steps"] == 64 * 200 and len(res["shard_bytes"]) == 8
+    assert len(res["per_rank_env_steps_per_s"]) == 8
+    seen = []
+    for r in range(8):
+        d = pickle.load(open(tmp_path / "ds" / ("cfg3.rank%d.pickle" % r), "rb"))
+        k = np.array(d["stiffness"])
+        assert len(k) == 8 and len(d["data"]) == 8 and np.array(d["data"][0]).shape == (200, 12)
+        assert (k >= 300 + 137.5 * r).all() and (k < 300 + 137.5 * (r + 1)).all(), (r, k)   # 8 disjoint bins of width 137.5 (SURVEY 8(d) cfg 4)
+        seen.extend(k.tolist())
+    assert len(set(seen)) == 64       # the ranks' RNG streams differ (seed + 1000 rank)
+
+
+def test_a_killed_rank_of_eight_ends_the_job_with_its_code(tmp_path):
+    """rank 5 of 8 is killed (SIGKILL, as the OOM killer or a GPU fault would) while the others wait at a barrier: the parent ends the
+    seven survivors and returns 128 + 9; nobody is left behind"""
+    import time
+    w = tmp_path / "w.py"
+    w.write_text("import sys, os, signal, time\nsys.path.insert(0, %r)\nfrom softgrip_amd import ranks\n"
+                 "if not ranks.launched_as_rank():\n    raise SystemExit(ranks.spawn_ranks(8, grace_s=3.0))\n"
+                 "open(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                 "g = ranks.RankGroup(timeout_s=120)\ng.barrier()\n"
+                 "if g.rank == 5:\n    os.kill(os.getpid(), signal.SIGKILL)\n"
+                 "g.barrier()\ng.close()\n" % (ROOT, str(tmp_path)))
+    t0 = time.time()
+    out = subprocess.run([sys.executable, str(w)], capture_output=True, text=True, env=_clean_env(), timeout=300)
+    assert out.returncode == 128 + 9, (out.returncode, out.stderr[-2000:])
+    assert time.time() - t0 < 100                      # ended by the parent, not by the store's timeout
+    for r in range(8):
+        pid = int(open(tmp_path / ("pid%d" % r)).read())
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except OSError:
+            alive = False
+        assert not alive, "rank %d (pid %d) outlived the job" % (r, pid)
+
+
+def test_programmatic_main_with_gpus_launches_create_dataset_ranks(monkeypatch, tmp_path):
+    """create_dataset.main(argv) called from someone else's process (a script, a notebook, pytest) with --gpus N must
+    start N `python -m softgrip_amd.create_dataset <argv>` ranks -- not N copies of the caller's own command line"""
+    import pytest
+    from softgrip_amd import create_dataset, ranks
+    calls = []
+
+    def fake_spawn(n, extra_env=None, poll=0.05, cmd=None, **kw):
+        calls.append((n, cmd, extra_env))
+        return 3
+
+    monkeypatch.setattr(ranks, "spawn_ranks", fake_spawn)
+    monkeypatch.delenv("RANK", raising=False)
+    argv = ["--gpus", "4", "--mujoco-model-paths", "a.xml", "--data-folder", str(tmp_path), "--data-name", "x"]
+    with pytest.raises(SystemExit) as e:
+        create_dataset.main(argv)
+    assert e.value.code == 3
+    (n, cmd, extra), = calls
+    assert n == 4 and cmd == [sys.executable, "-m", "softgrip_amd.create_dataset"] + argv and ROOT in extra["PYTHONPATH"]
+    calls.clear()
+    monkeypatch.setattr(sys, "argv", ["create_dataset"] + argv)      # the CLI entry: the ranks re-run the process's own command line
+    with pytest.raises(SystemExit):
+        create_dataset.main()
+    assert calls[0][1] is None

@@ -71,6 +71,9 @@ def _reference_flag(m, contacts, fingers_left, obj_name="OBJ"):
     return flag
 
 
+# (env step, env) samples of the 9-env cylinder episode that sit on a knife edge of the ORACLE (test_episode_matches_oracle): measured r04 / r05
+CYL_KNIFE_EDGE_SAMPLES = {(129, 6), (130, 6), (132, 7)}
+CYL_DRAWS = 64
 FREE_RUN_STEPS = 47  # env steps over which the neighbour-row scene is also compared free-running (contact starts at ~45; the error grows 10x every 5 steps from there: 1e-10 at 47, 7e-10 at 50, 3e-8 at 60)
 
 
@@ -135,24 +138,42 @@ def test_episode_matches_oracle(scene, pipeline, damper):
         err_e = np.abs(got - want_s).max(axis=1)
         if scene == "softcylinder" and reseat:
             # The cylinder's squeeze is the most violent of the scenes (sensor spikes of 1e2 .. 1e3): a few times an episode a
-            # contact sits at its threshold so closely that the round-off of the kernels' arithmetic -- the same numbers summed in another
-            # order than mj_step's -- decides it the other way within the seven substeps, and that env step differs by an impact (1e0 ..
-            # 1e2).  Such a sample is held against the KERNELS' OWN ARITHMETIC instead: the host emulation (tests/emu, the kernels' source
-            # compiled for the CPU) started from the oracle's state before the step must give what the GPU gave.  Counted: a handful in
-            # 9 x 200 samples (measured: 3, env steps 129 / 130 / 132); every other sample holds the tolerance against the oracle.
-            for e in np.flatnonzero(~(err_e < TOL_SENSOR)):
-                from helpers import Emu
-                emu = Emu(m.to_blob(), m.nv)
-                emu.set_stiffness(ks[e], JOINT_IDS, TENDON_IDS)
-                emu.reset()
-                emu.set_ctrl(ctrl[0])
-                emu.set_state(*pre[e])
-                for _ in range(7):
-                    emu.substep()
-                assert np.abs(got[e] - emu.sensordata).max() < 1e-6 * (1 + np.abs(got[e]).max()), (t, e, got[e], emu.sensordata)
+            # contact sits at its threshold so closely that round-off -- the same numbers summed in another order than the oracle sums
+            # them -- decides it the other way within the seven substeps, and that env step differs by an impact (1e0 .. 1e2).  Such a
+            # sample is NOT excused and NOT held against the kernels' own arithmetic (r04 did that: a self-comparison): it is held against
+            # THE ORACLE'S OWN OUTCOME SET.  The oracle is restarted from its pre-step state with +-1e-13 added to every position and
+            # velocity (CYL_DRAWS seeded draws: the round-off two correct implementations differ by), and the GPU's row must be one of
+            # the outcomes the oracle itself produces -- sensors to 1e-6 relative, (ncon, nefc, sweeps) and the touch bits exactly.
+            # Measured (r05, CPU prototype + GPU): the step is a several-way knife edge -- env 6 at step 129 has four distinct outcomes
+            # among 48 draws (one is the GPU's), at steps 130 / 132 nearly every perturbed draw gives the GPU's row and the UNPERTURBED
+            # oracle is the odd one out.  Only these three samples of the 9 x 200 may take this path.
+            for e in np.flatnonzero(~((err_e < TOL_SENSOR) & same)):
+                assert (t, int(e)) in CYL_KNIFE_EDGE_SAMPLES, ("a new sample off the oracle", t, e, err_e[e], counts[e])
+                ok, seen = False, []
+                rng = np.random.RandomState(1000 * t + int(e))
+                for _ in range(CYL_DRAWS):
+                    s2 = O.OracleSim(om)
+                    s2._om = om
+                    s2.jnt_stiffness[JOINT_IDS] = ks[e]
+                    s2.tendon_stiffness[TENDON_IDS] = ks[e]
+                    s2.reset(); s2.forward()
+                    s2.ctrl[:] = ctrl
+                    q, v, w, a = pre[e]
+                    s2.qpos[:] = q + 1e-13 * rng.uniform(-1, 1, q.shape)
+                    s2.qvel[:] = v + 1e-13 * rng.uniform(-1, 1, v.shape)
+                    s2.qacc_warmstart[:] = w
+                    s2.act[:] = a
+                    assert O.step_many(om, [s2], 7, 1) == 0
+                    d = np.abs(s2.sensordata - got[e]).max() / (1 + np.abs(got[e]).max())
+                    seen.append(float(d))
+                    if d < 1e-6 and counts[e] == (s2.ncon, s2.nefc, s2.solver_iter) and \
+                            int(touch[e].item()) == _expected_touch(m, s2.contacts(), bit_of):
+                        ok = True
+                        break
+                assert ok, ("the GPU's row is none of the oracle's outcomes under 1e-13 perturbations", t, e, got[e], sorted(seen)[:4])
                 events += 1
-                same[e] = False
-            assert events <= 8, (t, events)
+                same[e] = False     # (its state is not compared below: the batch is re-seated on the unperturbed oracle's state anyway)
+            assert events <= len(CYL_KNIFE_EDGE_SAMPLES), (t, events)
         else:
             assert same.all(), (t, counts)
         worst = max(worst, np.abs(got[same] - want_s[same]).max()) if same.any() else worst
@@ -1275,3 +1296,137 @@ def test_bench_two_ranks_with_the_real_library(tmp_path):
         assert d["config"]["envs_flagged_bad"] == 0 and d["value"] > 1e4 and "per-rank bins" in d["config"]["workload"]
         assert "no collective library" in d["config"]["rank_sync"] and len(d["ms_per_step_per_rank"]) == 2
         assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+# BASELINE configs[3] is 8 ranks.  This pool kills a job that has more than 6 processes on its GPU at once ("process guard"), and the
+# pytest process itself holds the device -- so the rehearsal with the REAL library runs 5 ranks on the one GPU; the same files run at
+# world_size 8 on the CPU (tests/test_dist_gloo.py: the store, the port, the bins and the exit-code path at the real rank count).
+RANKS_ON_ONE_GPU = 5
+
+
+def test_bench_many_ranks_with_the_real_library():
+    """configs[3] rehearsal: `bench.py --gpus N` self-launched and under torch.distributed.run, N ranks with the
+    real library sharing this box's one GPU; one JSON line, N per-rank times, the whole-job aggregate over the slowest rank"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    from softgrip_amd import ranks
+    N = RANKS_ON_ONE_GPU
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = ["--gpus", str(N), "--envs", "512", "--steps", "10", "--warmup", "2", "--force-device", "0", "--no-cpu-baseline", "--no-fix-variant"]
+    for launcher in ([], ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(N), "--master-addr", "127.0.0.1", "--master-port", str(ranks.free_port())]):
+        out = subprocess.run([sys.executable] + launcher + [os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == N and d["steps"] == 10 and d["scaling"] == "weak" and d["config"]["envs_per_gpu"] == 512
+        assert d["config"]["envs_flagged_bad"] == 0 and d["value"] > 1e4 and "per-rank bins" in d["config"]["workload"]
+        assert "no collective library" in d["config"]["rank_sync"] and len(d["ms_per_step_per_rank"]) == N
+        assert abs(max(d["ms_per_step_per_rank"]) - d["ms_per_step"]) < 1e-9
+        assert abs(d["value"] - N * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_create_dataset_many_ranks_with_the_real_library(tmp_path):
+    """configs[3] rehearsal, the dataset job: `python -m softgrip_amd.create_dataset --gpus N` starts its own N ranks on the one GPU, each
+    with its own stiffness bin and shard; N shards whose labels fall in N disjoint bins, episode rows finite, and shard r's first
+    episode equal to the oracle's for its label (first 40 steps: the idle phase, before the default model amplifies round-off)"""
+    import json
+    import os
+    import pickle
+    import subprocess
+    import sys
+    from helpers import ROOT
+    N = RANKS_ON_ONE_GPU
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    out = subprocess.run([sys.executable, "-m", "softgrip_amd.create_dataset", "--gpus", str(N), "--mujoco-model-paths", model_path("softbox"),
+                          "--n-envs", "64", "--total-episodes", str(N * 64 * 2), "--seed", "5", "--force-device", "0", "--data-folder", str(tmp_path / "ds"),
+                          "--data-name", "cfg3"], capture_output=True, text=True, env=env, timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == N and res["episodes"] == N * 64 * 2 and res["env_steps"] == N * 64 * 2 * 200 and len(res["shard_bytes"]) == N
+    assert res["envs_reset_after_a_warning"] == 0
+    w = 1100.0 / N
+    m = sg.load_model(model_path("softbox"))
+    for r in range(N):
+        d = pickle.load(open(tmp_path / "ds" / ("cfg3.rank%d.pickle" % r), "rb"))
+        k = np.array(d["stiffness"])
+        assert len(k) == 128 and (k >= 300 + w * r).all() and (k < 300 + w * (r + 1)).all() and len(set(k.tolist())) == 128
+        rows = np.array(d["data"])
+        assert rows.shape == (128, 200, 12) and np.isfinite(rows).all()
+        s = oracle_sim(m, float(k[0]))
+        s.reset(); s.forward(); s.step()
+        for t in range(40):
+            for _ in range(7):
+                s.step()
+            assert np.abs(rows[0, t] - s.sensordata).max() < TOL_SENSOR, (r, t)
+
+
+def test_config0_one_env_one_episode_on_the_device(tmp_path):
+    """BASELINE configs[0] with the HIP path in MuJoCo's place: ManEnv(n_envs=1) through create_dataset.log_into_file,
+    the reference's own shape (reference create_dataset.py:33-65, manenv.py:44-53,65-85): step() -> (ndarray(12,) float64, bool),
+    reset() -> a Python float, the pickle one (200, 12) array and one float label; all 200 rows against the oracle at 1e-7 (softbox_fix: the
+    variant that can be compared free-running), and the contact flag of every step against the oracle's contact list"""
+    import pickle
+    import types
+    from softgrip_amd import ManEnv
+    from softgrip_amd import create_dataset as cd
+    np.random.seed(0)
+    args = types.SimpleNamespace(mujoco_model_paths=[model_path("softbox_fix")], sim_start=1, sim_step=7, vis=False, mask_contact=False,
+                                 data_folder=str(tmp_path), data_name="one")
+    path = cd.log_into_file(args)                      # no n_envs attribute at all: the reference's argparse has none
+    d = pickle.load(open(path, "rb"))
+    assert set(d) == {"data", "stiffness"} and len(d["data"]) == 1 and len(d["stiffness"]) == 1
+    assert type(d["stiffness"][0]) is float and d["stiffness"][0] == 903.6948543200572        # seed 0's first U(300, 1400) draw (SURVEY 8(d) cfg 1)
+    rows = d["data"][0]
+    assert isinstance(rows, np.ndarray) and rows.shape == (200, 12) and rows.dtype == np.float64
+    m = sg.load_model(model_path("softbox_fix"))
+    s = oracle_sim(m, d["stiffness"][0])
+    s.reset(); s.forward(); s.step()
+    # the same episode once more by hand, call by call, for the per-call return types and the contact flag
+    np.random.seed(0)
+    env = ManEnv(1, 7, [model_path("softbox_fix")], is_vis=False)
+    k = env.reset()
+    assert isinstance(k, float) and k == d["stiffness"][0]
+    nflag = 0
+    for t, c in enumerate(episode_schedule()):
+        if c is not None:
+            s.ctrl[:] = c
+            (env.close_hand if c < 0 else env.loose_hand)()
+        for _ in range(7):
+            s.step()
+        readings, contact = env.step()
+        assert isinstance(readings, np.ndarray) and readings.shape == (12,) and readings.dtype == np.float64 and type(contact) is bool
+        assert np.abs(rows[t] - s.sensordata).max() < TOL_SENSOR, t
+        assert np.abs(readings - s.sensordata).max() < TOL_SENSOR, t
+        assert contact == _reference_flag(m, s.contacts(), list(ManEnv.finger_names)), t   # the reference's loop (manenv.py:65-85) on the oracle's contact list
+        nflag += contact
+        r2, c2 = env.get_sensor_sensordata()
+        assert np.array_equal(r2, readings) and c2 == contact
+    assert 0 < nflag < 200
+
+
+def test_cached_scene_reload_starts_like_a_fresh_sim():
+    """load_env() of a scene seen before reuses its batch -- and must still look like the reference's fresh MjSim:
+    sensordata and the contact read-out empty until the first reset / step"""
+    from softgrip_amd import ManEnv
+    np.random.seed(1)
+    env = ManEnv(1, 7, [model_path("softbox_fix"), model_path("softbox")], is_vis=False, n_envs=3)
+    env.reset()
+    env.close_hand()
+    for _ in range(60):
+        env.step()
+    r, c = env.get_sensor_sensordata()
+    assert float(r.abs().max()) > 0 and bool(c.any())
+    first = env.env
+    env.load_env(1)
+    env.load_env(0)
+    assert env.env is first                                  # the cached batch
+    r, c = env.get_sensor_sensordata()
+    assert float(r.abs().max()) == 0.0 and not bool(c.any())
+    env.max_cached_scenes = 1
+    env.close()
+    assert list(env._scenes) == [model_path("softbox_fix")]
