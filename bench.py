@@ -199,6 +199,11 @@ class Runner:
         return dt, kernel_ms, launches, desc, nsteps, dtp
 
 
+def _positive_or_none(v):
+    """an occupancy query that failed returns a negative error code: not an occupancy"""
+    return int(v) if v is not None and v > 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -328,11 +333,11 @@ def main():
                                        "; + ConvNet regressor: channel stats, noise augmentation, forward and one Adam step on every finished [n,200,12] block, on device, inside the timed region" if args.with_regressor else ""),
                        "envs_per_gpu": n, "substeps_per_step": R.sim_step, "physics_substeps_per_s": value * R.sim_step,
                        "envs_flagged_bad": nbad, "launches_timed": launches, "steps_timed": nsteps, "timed_region": desc,
-                       "tree_workgroups_per_cu": (R.batch.tree_workgroups_per_cu() if hasattr(R.batch, "tree_workgroups_per_cu") else 0) or None,
+                       "tree_workgroups_per_cu": _positive_or_none(R.batch.tree_workgroups_per_cu() if hasattr(R.batch, "tree_workgroups_per_cu") else 0),
                        "rank_sync": {"store": "TCP key-value store (barriers + per-rank times), no collective library", "nccl": "torch.distributed on RCCL",
                                      "gloo": "torch.distributed on gloo"}[args.dist_backend] if world > 1 else None},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "traffic_source": None,
+                         "traffic": None, "traffic_source": None, "traffic_measured_in_this_run": False,
                          "kernel": {"rows": "sg_chain_kernel + sg_phase_kernel + sg_pgs_rows_kernel chain of one sg_step call (rows pipeline; dominant: sg_pgs_rows_kernel)", "split": "sg_chain_kernel + sg_phase_kernel + sg_pgs_kernel chain of one sg_step call (split pipeline)",
                                     "tree": "sg_tree_kernel: one launch per sg_step call, one env per wavefront (tree pipeline)"}.get(pipe, "sg_step_kernel"),
                          "avg_kernel_ms": kernel_ms,
@@ -360,6 +365,7 @@ def main():
         tp = os.path.join(ROOT, "profiles", "%s_%s_hbm_traffic.json" % (PROFILE_TAG, args.scene))
         if attach and os.path.exists(tp):
             res["roofline"]["traffic"] = json.load(open(tp))["per_sg_step_call_bytes"]
+            res["roofline"]["traffic_attached_from"] = "profiles/" + os.path.basename(tp)   # NOT measured in this run: a committed PMC pass of this command
             res["roofline"]["traffic_source"] = ("profiles/%s: episode average per sg_step call (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; gfx950 x2 "
                                                  "correction on the 16-B-per-lane reads of the PGS kernel, none on the tree kernel's 8-B reads; fabric-side: Infinity-Cache hits included)" % os.path.basename(tp))
         sp = os.path.join(ROOT, "profiles", "%s_%s_sq_totals.json" % (PROFILE_TAG, args.scene))
@@ -369,13 +375,16 @@ def main():
             sq = json.load(open(sp))["per_env_step"]
             peak = 1024 * 2.4e9 / 4.0
             a2 = sq["SQ_INSTS_VALU"] * value / world   # per GPU
+            wg = res["config"]["tree_workgroups_per_cu"]
             res["roofline"]["secondary"] = {
+                "attached_from": "profiles/" + os.path.basename(sp), "counters_measured_in_this_run": False,
                 "bound": "fp64 VALU issue", "unit": "wavefront-instructions/s", "achieved": a2, "peak": peak, "frac": a2 / peak,
                 "valu_insts_per_env_step": sq["SQ_INSTS_VALU"], "salu_insts_per_env_step": sq["SQ_INSTS_SALU"],
                 "lds_insts_per_env_step": sq["SQ_INSTS_LDS"],
                 "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_*, own pass, episode average); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per "
                           "fp64 wavefront instruction; %s" % (os.path.basename(sp),
-                          "the tree kernel runs one env per wavefront, two workgroups per CU (half the SIMDs), one instruction per ~7 cycles: ~0.25 is its ceiling at this occupancy" if pipe == "tree" else
+                          ("the tree kernel runs one env per wavefront, %s workgroups per CU (one wavefront each: %s of a CU's four SIMDs busy), a wavefront alone on its SIMD "
+                           "issues one instruction per ~7 cycles: ~%.2f is its ceiling at this occupancy" % (wg, wg, 0.57 * min(wg or 4, 4) / 4.0)) if pipe == "tree" else
                           "the PGS kernel runs one wavefront per SIMD (1024 at 4096 envs: 4 envs per wavefront) and a wavefront alone on its SIMD issues one instruction per ~7-8 cycles, so ~0.5 is this design's ceiling for it")}
         if world == 1 and nb_on and not args.no_fix_variant and not args.with_regressor and args.scene.endswith(("softbox", "softball", "softcylinder")):
             # labelled secondary: the same workload on the fix-rows-only model (composite_neighbors=False)

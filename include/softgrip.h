@@ -81,7 +81,10 @@ int sg_batch_device(const sg_batch* b);
 /* replaces `model.jnt_stiffness[i] = k` / `model.tendon_stiffness[i] = k`
  * (manenv.py:105-108): env e uses k[e] on the listed joint and tendon ids and the model's
  * own stiffness everywhere else.  k: device or host pointer to n_envs doubles
- * (k_on_host selects); ids: host pointers.  The id sets replace those of earlier calls. */
+ * (k_on_host selects); ids: host pointers.  The id sets replace those of earlier calls.
+ * SYNCHRONISES THE HOST with `stream` when k is a host pointer or when the id sets differ
+ * from the previous call's (once per scene; the step path never calls it): with a device k
+ * and unchanged id sets it enqueues one copy on `stream` and returns. */
 int sg_set_stiffness(sg_batch* b, const double* k, int k_on_host, const int* jnt_ids, int nj, const int* ten_ids, int nt,
                      void* stream);
 

@@ -1,11 +1,14 @@
 """Builds libsoftgrip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc: one translation unit per kernel family, compiled side
 by side, objects cached under soft-grip_amd/build/<variant>/ and re-made only when their source or a header is newer."""
 import concurrent.futures
+import contextlib
+import fcntl
 import glob
 import hashlib
 import os
 import shutil
 import subprocess
+import tempfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
@@ -41,11 +44,15 @@ def build(force=False, verbose=False, prof=False, count=False, legacy=False):
     count=True builds libsoftgrip_count.so, which also counts events inside the contact update (-DSG_SECTION_COUNT: contact
     updates, updates outside the friction cone, QCQP fallback entries and Newton evaluations) -- its cycle stamps are not timings;
     legacy=True builds libsoftgrip_legacy.so: the product plus r01's fused and split pipelines (-DSG_LEGACY_PIPELINES), which the
-    cross-check tests load by themselves.  force=True also removes stale variant libraries of earlier builds."""
+    cross-check tests load by themselves.  force=True also removes the variant libraries THIS function makes (prof, count, legacy) and
+    the object cache -- not the hand-made `--ko NAME` experiment libraries (scripts/dev/ab_*.sh keep an A/B library of an earlier round
+    there)."""
     if force:
-        for stale in glob.glob(os.path.join(_HERE, "libsoftgrip_*.so")):
-            os.remove(stale)
-        shutil.rmtree(os.path.join(_HERE, "build"), ignore_errors=True)
+        with _build_lock():
+            for name in OWNED_VARIANTS:
+                with contextlib.suppress(FileNotFoundError):
+                    os.remove(os.path.join(_HERE, "libsoftgrip_%s.so" % name))
+            shutil.rmtree(os.path.join(_HERE, "build"), ignore_errors=True)
     if count:
         return _compile(os.path.join(_HERE, "libsoftgrip_count.so"), ["-DSG_SECTION_PROF", "-DSG_SECTION_COUNT"], verbose)
     if prof:
@@ -59,7 +66,33 @@ def build(force=False, verbose=False, prof=False, count=False, legacy=False):
     return _compile(LIB, [], verbose)
 
 
+OWNED_VARIANTS = ("prof", "count", "legacy")
+
+
+@contextlib.contextmanager
+def _build_lock():
+    """one builder at a time per checkout (ranks, pytest-xdist workers and helpers.library_for may all ask for a build at once): an
+    exclusive flock on soft-grip_amd/build/.lock; re-entrant inside one process"""
+    if getattr(_build_lock, "depth", 0):
+        yield
+        return
+    os.makedirs(os.path.join(_HERE, "build"), exist_ok=True)
+    with open(os.path.join(_HERE, "build", ".lock"), "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        _build_lock.depth = 1
+        try:
+            yield
+        finally:
+            _build_lock.depth = 0
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
 def _compile(out, extra, verbose, sources=SOURCES):
+    with _build_lock():
+        return _compile_locked(out, extra, verbose, sources)
+
+
+def _compile_locked(out, extra, verbose, sources):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     flags = FLAGS + extra + (["-Rpass-analysis=kernel-resource-usage"] if verbose else [])
     objdir = os.path.join(_HERE, "build", hashlib.sha1(" ".join(FLAGS + extra).encode()).hexdigest()[:12])
@@ -71,16 +104,25 @@ def _compile(out, extra, verbose, sources=SOURCES):
         path = os.path.join(CSRC, src)
         if not verbose and not _stale(obj, [path] + hdrs):
             return obj, ""
-        res = subprocess.run([hipcc] + flags + ["-c", "-o", obj, path], capture_output=True, text=True)
+        fd, tmp = tempfile.mkstemp(suffix=".o", dir=objdir)      # never a half-written object under the name a linker may pick up
+        os.close(fd)
+        res = subprocess.run([hipcc] + flags + ["-c", "-o", tmp, path], capture_output=True, text=True)
         if res.returncode != 0:
+            os.remove(tmp)
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, res.stderr[-4000:]))
+        os.replace(tmp, obj)
         return obj, res.stderr
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 1)) as ex:
         done = list(ex.map(one, sources))
-    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [o for o, _ in done], capture_output=True, text=True)
+    fd, tmp = tempfile.mkstemp(suffix=".so", dir=_HERE)
+    os.close(fd)
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [o for o, _ in done], capture_output=True, text=True)
     if res.returncode != 0:
+        os.remove(tmp)
         raise RuntimeError("hipcc (link) failed:\n" + res.stderr[-4000:])
+    os.chmod(tmp, 0o755)
+    os.replace(tmp, out)      # a process that has the old library mapped keeps it; a new load sees a whole file
     if verbose:
         print("".join(log for _, log in done))
     return out

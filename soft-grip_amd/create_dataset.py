@@ -64,6 +64,12 @@ def _fingerprint(args, env, rank, world, lo, hi, num_batches):
             "joint_ids": list(env.joint_ids), "tendon_ids": list(env.tendon_ids)}
 
 
+class ContactCapacityExceeded(RuntimeError):
+    """more than --max-capacity-resets of the simulated episodes ran out of the kernels' contact capacity (64 per finger stream, 128 per
+    env in the tree pipeline; the reference's MuJoCo holds nconmax = 500, soft_grip_two_fingers.xml:8, and would have carried on): such
+    an env is reset with a re-drawn label like a MuJoCo warning, which is a SELECTION on the data that the reference does not make"""
+
+
 class PartMismatch(RuntimeError):
     """a <name>.partNNNNN.pickle found on resume was written by a run with another configuration"""
 
@@ -98,7 +104,7 @@ def log_into_file(args):
     n_skipped = 0
     writer, pending = None, None
     fingerprint = _fingerprint(args, env, rank, world, lo, hi, num_batches)
-    t_start, n_simulated, n_flagged = time.perf_counter(), 0, 0
+    t_start, n_simulated, n_flagged, n_capacity = time.perf_counter(), 0, 0, 0
 
     for ep in range(num_batches * num_envs):
         part = _part_path(args.data_folder, name, ep)
@@ -151,6 +157,13 @@ def log_into_file(args):
                 stiffness.extend(ep_k)
             n_simulated += n
             n_flagged = int(getattr(env, "n_resets", 0))
+            n_capacity = int(getattr(env, "n_capacity_resets", 0))
+            limit = float(getattr(args, "max_capacity_resets", 0.001))
+            if n_capacity > limit * n_simulated:
+                if pending is not None:
+                    pending.result()
+                raise ContactCapacityExceeded("%d of %d simulated episodes hit the kernels' contact capacity (limit: %.3g of them, "
+                                              "--max-capacity-resets); scene %s" % (n_capacity, n_simulated, limit, args.mujoco_model_paths[current_env]))
 
         if (ep + 1) % num_batches == 0 and num_envs > 1 and ep + 1 < num_batches * num_envs:
             # next scene (reference create_dataset.py:68-72; after the last one the reference asks load_env for an index past the
@@ -178,6 +191,7 @@ def log_into_file(args):
     summary = {"rank": rank, "world": world, "shard": os.path.basename(path), "shard_bytes": os.path.getsize(path), "episodes": len(data),
                "episodes_simulated": n_simulated, "episodes_resumed": len(data) - n_simulated, "env_steps": n_simulated * n_steps,
                "seconds": dt, "env_steps_per_s": n_simulated * n_steps / dt if dt > 0 else 0.0, "envs_reset_after_a_warning": n_flagged,
+               "envs_reset_at_contact_capacity": n_capacity,
                "stiffness_bin": [float(lo), float(hi)]}
     with open(os.path.join(args.data_folder, "{}.summary.json".format(name)), "w") as file:
         json.dump(summary, file)
@@ -222,6 +236,9 @@ def make_parser():
                              "stiffness bin and shard file -- BASELINE configs[3]: --gpus 8 --n-envs 4096 --total-episodes 131072")
     parser.add_argument('--total-episodes', type=int, default=None,
                         help="fixed dataset size over all ranks and scenes: sets --num-batches to ceil(total / (ranks x n_envs x scenes))")
+    parser.add_argument('--max-capacity-resets', type=float, default=0.001,
+                        help="fail when more than this share of the simulated episodes hit the kernels' contact capacity (an env MuJoCo, with the "
+                             "reference's nconmax = 500, would have kept: resetting it is a selection the reference does not make)")
     parser.add_argument('--force-device', type=int, default=-1, help="testing only: put every rank on this GPU")
     return parser
 
@@ -257,6 +274,7 @@ def job_summary(folder, name, world, wall_seconds=None):
     return {"job": "create_dataset", "n_gpus": world, "episodes": sum(r["episodes"] for r in ranks), "env_steps": steps,
             "env_steps_per_s": steps / slowest if slowest > 0 else 0.0, "slowest_rank_seconds": slowest, "wall_seconds_with_launch": wall_seconds,
             "envs_reset_after_a_warning": sum(r["envs_reset_after_a_warning"] for r in ranks),
+            "envs_reset_at_contact_capacity": sum(r.get("envs_reset_at_contact_capacity", 0) for r in ranks),
             "shard_bytes": [r["shard_bytes"] for r in ranks], "per_rank_env_steps_per_s": [r["env_steps_per_s"] for r in ranks],
             "note": "end to end on the host: ManEnv.step() with its per-step flag check, device -> host copies, pickling, file writes"}
 

@@ -68,6 +68,7 @@ struct sg_batch {
   unsigned* dtab;    // the same schedule as the solver's LDS table words
   int* dcpos;        // per element: where its equality block's step factors sit in a solver wavefront's stream (SgWork::cst)
   int *kmask_jnt, *kmask_ten, *flags, *touch, *ncon, *nefc, *iters;
+  std::vector<int> kmask_jnt_host, kmask_ten_host;   // what the device masks hold (sg_set_stiffness copies them only when they change)
   int epw_override;  // sg_set_solver_envs_per_wavefront: 0 = automatic
   int pipeline;  // 0 fused (one kernel per call), 1 split (chain / phase / pgs kernel chain), 2 split with the row-parallel PGS kernel, 3 tree
   // tree pipeline (allocated when first selected)
@@ -376,6 +377,7 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
   HIPCHK(hipMemset(b->act, 0, sizeof(double) * n * nu)); HIPCHK(hipMemset(b->ctrl, 0, sizeof(double) * n * nu));
   HIPCHK(hipMemset(b->kenv, 0, sizeof(double) * n));
   HIPCHK(hipMemset(b->kmask_jnt, 0, sizeof(int) * njnt)); HIPCHK(hipMemset(b->kmask_ten, 0, sizeof(int) * nt));
+  b->kmask_jnt_host.assign(njnt, 0); b->kmask_ten_host.assign(nt, 0);
   HIPCHK(hipMemset(b->flags, 0, sizeof(int) * n)); HIPCHK(hipMemset(b->touch, 0, sizeof(int) * n));
   HIPCHK(hipMemset(b->ncon, 0, sizeof(int) * n)); HIPCHK(hipMemset(b->nefc, 0, sizeof(int) * n)); HIPCHK(hipMemset(b->iters, 0, sizeof(int) * n));
   if (b->pipeline == 3)
@@ -400,10 +402,17 @@ int sg_set_stiffness(sg_batch* b, const double* k, int k_on_host, const int* jnt
     mt[ten_ids[i]] = 1;
   }
   hipStream_t s = (hipStream_t)stream;
-  // the masks are tiny; a synchronous copy keeps the host vectors' lifetime trivial
-  HIPCHK(hipStreamSynchronize(s));
-  HIPCHK(hipMemcpy(b->kmask_jnt, mj.data(), sizeof(int) * H.njnt, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(b->kmask_ten, mt.data(), sizeof(int) * H.ntendon, hipMemcpyHostToDevice));
+  // Host synchronisation (softgrip.h says so): the id masks are tiny and change once per scene, not once per episode -- they are
+  // copied (synchronously: the host vectors' lifetime stays trivial) only when they differ from what the device holds; a HOST k is a
+  // synchronous copy by nature (pageable memory).  With unchanged id sets and a DEVICE k the call enqueues one copy and returns.
+  const bool masks_changed = mj != b->kmask_jnt_host || mt != b->kmask_ten_host;
+  if (masks_changed || k_on_host) HIPCHK(hipStreamSynchronize(s));
+  if (masks_changed) {
+    HIPCHK(hipMemcpy(b->kmask_jnt, mj.data(), sizeof(int) * H.njnt, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->kmask_ten, mt.data(), sizeof(int) * H.ntendon, hipMemcpyHostToDevice));
+    b->kmask_jnt_host = mj;
+    b->kmask_ten_host = mt;
+  }
   if (k_on_host) HIPCHK(hipMemcpy(b->kenv, k, sizeof(double) * b->n, hipMemcpyHostToDevice));
   else HIPCHK(hipMemcpyAsync(b->kenv, k, sizeof(double) * b->n, hipMemcpyDeviceToDevice, s));
   return SG_OK;

@@ -69,6 +69,9 @@ class ManEnv(Env):
         self.contact_flag_mode = contact_flag_mode
         self.rng = np.random  # the reference draws from the global NumPy RNG (manenv.py:104)
         self.n_resets = 0     # envs reset after a simulation warning (what `except MujocoException: self.reset()` did, manenv.py:50-51)
+        self.n_capacity_resets = 0   # ... of which: envs that ran out of the KERNELS' contact capacity (SG_FLAG_CONTACTFULL: 64 per finger stream /
+                                     # 128 per env) -- not a MuJoCo warning: the reference's nconmax is 500 (soft_grip_two_fingers.xml:8) and MuJoCo
+                                     # would have carried on.  Counted apart so that a dataset job can refuse to paper over it (create_dataset)
         self._scenes = {}     # path -> the loaded scene (model, batch, buffers, the damper it runs with): load_env() of a scene seen before
                               # neither compiles, allocates nor dry-runs again (the reference's loop switches scene after EVERY episode)
         self._load(env_paths[0])
@@ -193,6 +196,7 @@ class ManEnv(Env):
         self.env.step(num_steps, sens=self._sens, flags=self._flags, touch=self._touch)
         bad = (self._flags != 0)
         if bool(bad.any()):  # mujoco_py raised -> the reference resets (re-drawing the stiffness) and carries on
+            self.n_capacity_resets += int(((self._flags & native.SG_FLAG_CONTACTFULL) != 0).sum())
             self._reset_envs(bad)
         return self._result()
 
@@ -204,6 +208,7 @@ class ManEnv(Env):
         self._ctrl[:] = 0  # mj_resetData clears ctrl
         bad = (self._flags != 0)
         if bool(bad.any()):
+            self.n_capacity_resets += int(((self._flags & native.SG_FLAG_CONTACTFULL) != 0).sum())
             self._reset_envs(bad)
         return current_stiffness
 

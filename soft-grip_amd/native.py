@@ -10,6 +10,8 @@ LIB_PATH = os.path.join(_HERE, "libsoftgrip.so")
 _LIB = None
 
 SG_OK, SG_ERR_INVALID, SG_ERR_MODEL, SG_ERR_NO_DEVICE, SG_ERR_HIP, SG_ERR_NOMEM = 0, -1, -2, -3, -4, -5
+# per-env flags (include/softgrip.h: sg_flag)
+SG_FLAG_BADQPOS, SG_FLAG_BADQVEL, SG_FLAG_BADQACC, SG_FLAG_CONTACTFULL, SG_FLAG_CNSTRFULL, SG_FLAG_UNSUPPORTED_PAIR = 1, 2, 4, 8, 16, 32
 FLAG_BADQPOS, FLAG_BADQVEL, FLAG_BADQACC, FLAG_CONTACTFULL, FLAG_CNSTRFULL, FLAG_UNSUPPORTED_PAIR = 1, 2, 4, 8, 16, 32
 
 # every symbol include/softgrip.h declares (tests/test_abi.py checks the library exports them all)

@@ -540,3 +540,37 @@ def test_tree_kernel_workgroups_per_cu(scene, jids, want):
     m2 = sg.load_model(model_path("softbox_fix"))
     b2 = native.NativeBatch(native.NativeModel(m2), 2, 0)
     assert b2.tree_workgroups_per_cu() == 0
+
+
+def test_contact_capacity_overflow_is_loud(tmp_path):
+    """the reference's MuJoCo holds nconmax = 500 contacts (soft_grip_two_fingers.xml:8), the tree pipeline 128 per
+    env.  An env that runs out of them is flagged SG_FLAG_CONTACTFULL and reset with a re-drawn label like a MuJoCo warning -- but it is
+    COUNTED APART (ManEnv.n_capacity_resets), and a dataset job in which more than --max-capacity-resets (default 0.1 %) of the episodes
+    end that way fails instead of silently selecting its data.  Driven past the capacity for real: the free ball's default model at
+    k = 1200 lands with 191 contacts at env step 52 (test_free_ball_episode_matches_oracle)."""
+    import types
+    from softgrip_amd import ManEnv
+    from softgrip_amd import create_dataset as cd
+    jids = list(range(9, 227))
+    np.random.seed(0)
+    env = ManEnv(1, 7, [model_path("freeball")], is_vis=False, n_envs=3, joint_ids=jids, tendon_damper="implicit")
+    env.reset()
+    env.set_stiffness_values([450.0, 1200.0, 600.0])
+    for t, c in enumerate(episode_schedule()[:60]):
+        if c is not None:
+            (env.close_hand if c < 0 else env.loose_hand)()
+        env.step()
+        assert (env.n_capacity_resets, env.n_resets) == ((0, 0) if t < 52 else (1, 1)), t
+    assert env.stiffness[1] != 1200.0 and env.stiffness[0] == 450.0 and env.stiffness[2] == 600.0      # the label was re-drawn, the others went on
+    # the dataset job: refuses by default, obeys an explicit allowance
+    args = types.SimpleNamespace(mujoco_model_paths=[model_path("freeball")], sim_start=1, sim_step=7, vis=False, mask_contact=False,
+                                 data_folder=str(tmp_path), data_name="fb", n_envs=16, device=0, joint_ids=jids, tendon_damper="implicit")
+    np.random.seed(3)
+    with pytest.raises(cd.ContactCapacityExceeded):
+        cd.log_into_file(args)
+    args.max_capacity_resets = 1.0
+    np.random.seed(3)
+    cd.log_into_file(args)
+    import json
+    s = json.load(open(tmp_path / "fb.summary.json"))
+    assert s["envs_reset_at_contact_capacity"] >= 1 and s["envs_reset_after_a_warning"] >= s["envs_reset_at_contact_capacity"]

@@ -338,3 +338,32 @@ def test_stiffness_id_sets_can_be_overridden_and_are_checked(fake_native):
     assert manenv.ManEnv.joint_ids == list(range(11, 64))           # the class attributes stay the reference's
     with pytest.raises(ValueError, match="do not fit"):
         manenv.ManEnv(1, 7, [model_path("softbox_fix")], is_vis=False, check_scene=False, joint_ids=[5, 118])
+
+
+def test_contact_capacity_resets_are_counted_apart_and_fail_the_job(fake_native, tmp_path, monkeypatch):
+    """an env flagged SG_FLAG_CONTACTFULL is reset like a MuJoCo warning (manenv.py:50-51) but counted in n_capacity_resets; the dataset
+    job fails when more than --max-capacity-resets of its episodes end that way"""
+    import types
+    from softgrip_amd import create_dataset as cd
+    orig = fake_native._advance
+    hit = {"n": 0}
+
+    def advance(self, n, sens, flags, touch):
+        orig(self, n, sens, flags, touch)
+        if flags is not None and self.nsub == 1 + 7 * 50 and hit["n"] == 0:     # env step 50 of the first episode-batch: env 2 runs out of contacts
+            flags[2] = native.SG_FLAG_CONTACTFULL
+            hit["n"] = 1
+
+    monkeypatch.setattr(fake_native, "_advance", advance)
+    args = types.SimpleNamespace(mujoco_model_paths=[model_path("softbox_fix")], sim_start=1, sim_step=7, vis=False, mask_contact=False,
+                                 data_folder=str(tmp_path), data_name="cap", n_envs=4, device=0, check_scene=False)
+    np.random.seed(0)
+    with pytest.raises(cd.ContactCapacityExceeded):
+        cd.log_into_file(args)
+    hit["n"] = 0
+    args.max_capacity_resets = 0.5
+    np.random.seed(0)
+    cd.log_into_file(args)
+    import json
+    s = json.load(open(tmp_path / "cap.summary.json"))
+    assert s["envs_reset_at_contact_capacity"] == 1 and s["envs_reset_after_a_warning"] == 1
