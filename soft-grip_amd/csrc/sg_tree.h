@@ -249,6 +249,8 @@ SG_HD size_t gws_doubles(const SgTreeDev& T, int N, int has_free, int nnb) {   /
 #define SGT_NSLOT (SGT_DEVICE ? 4 : 256)
 #if SGT_DEVICE
 #define SGT_PAR_SLOT(e, t, n) _Pragma("unroll") for (int t = 0, e = (int)threadIdx.x; t < 4; t++, e += 64) if (e < (n))
+#elif defined(SGT_EMU_REVERSE)
+#define SGT_PAR_SLOT(e, t, n) for (int e = (n) - 1, t = e; e >= 0; e--, t = e)
 #else
 #define SGT_PAR_SLOT(e, t, n) for (int e = 0, t = 0; e < (n); e++, t = e)
 #endif
@@ -291,7 +293,14 @@ __device__ __forceinline__ int lds_inc(int* p) { return atomicAdd(p, 1); }
 #else
 #define SGT_FIRST 0
 #define SGT_STRIDE 1
+#if defined(SGT_EMU_REVERSE)
+// host emulation, order-checking build (tests/emu `make rev`): every parallel loop runs its items in DESCENDING order.  A parallel loop's
+// items must not depend on one another (on the device they run in lockstep, 64 at a time); the ascending serial loop of the normal
+// emulation satisfies any dependency of item i on an item j < i by accident.  Same results in both orders = no such dependency.
+#define SGT_PAR(i, n) for (int i = (n) - 1; i >= 0; i--)
+#else
 #define SGT_PAR(i, n) for (int i = 0; i < (n); i++)
+#endif
 #define SGT_ONE if (true)
 #define SGT_SYNC() ((void)0)
 inline double wsum(double x) { return x; }
@@ -1021,8 +1030,15 @@ enum { CTX_FLAGS = 0, CTX_NCON, CTX_NEFC, CTX_ITERS, CTX_TLO, CTX_THI, CTX_STOP,
 // PH 2: collision -- block culling, the pair walks, rank, narrowphase
 // PH 3: constraint rows (equality, limits, contacts), warmstart, the PGS sweeps (tree_sweep)
 // PH 4: qacc, sensors, Euler with implicit damping
+// (SGT_X_MONO: the r04 layout that produced the dropped stores -- every stage pasted into the kernel, one register allocation for the
+//  whole step -- kept buildable for scripts/repro/tree_mono: `build_native.py --ko mono -DSGT_X_MONO`; never the product)
+#if defined(SGT_X_MONO) && defined(__HIPCC__)
+#define SGT_STAGE_ATTR __host__ __device__ __forceinline__
+#else
+#define SGT_STAGE_ATTR SGT_NOINLINE
+#endif
 template <int CHD, int PH>
-static SGT_NOINLINE void tree_stage(SGT_STAGE_PARAMS) {
+static SGT_STAGE_ATTR void tree_stage(SGT_STAGE_PARAMS) {
 #if SGT_DEVICE
   // (the launch arguments: the kernel left the address of its argument segment in the first word of the LDS block -- a called function
   //  has no register for it -- and the segment is read through the constant address space: uniform, scalar loads)

@@ -8,7 +8,9 @@
 // the contact rows' J / W blocks (<= 128 x 1.9 KB per env, L2-resident) and the 272 KB pair table shared by all envs.
 #include <hip/hip_runtime.h>
 
+#ifndef SGT_X_MONO
 #define SG_HD_HEAVY __host__ __device__ inline __attribute__((noinline))   // (sg_math.h: the narrowphase routines are CALLED here)
+#endif
 #include "sg_tree.h"
 
 // CHD: the capacity the per-chain loops are unrolled over (registers, not memory): 24 = SGT_CHD, 20 for the four-finger gripper's

@@ -190,8 +190,9 @@ class TreeEmu:
     """ctypes wrapper of tests/emu/libsgtreeemu.so: the tree pipeline's source (csrc/sg_tree.h) compiled for the host, one env."""
 
     def __init__(self, model):
-        so = os.path.join(ROOT, "tests", "emu", "libsgtreeemu.so")
-        subprocess.check_call(["make", "-C", os.path.dirname(so)], stdout=subprocess.DEVNULL)
+        variant = os.environ.get("SGT_EMU_VARIANT", "")     # "rev": the order-checking build (parallel loops in descending order)
+        so = os.path.join(ROOT, "tests", "emu", "libsgtreeemu%s.so" % ("_" + variant if variant else ""))
+        subprocess.check_call(["make", "-C", os.path.dirname(so)] + ([variant] if variant else []), stdout=subprocess.DEVNULL)
         L = C.CDLL(so)
         L.temu_new.restype = C.c_void_p
         L.temu_new.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
