@@ -2,6 +2,7 @@
 by side, objects cached under soft-grip_amd/build/<variant>/ and re-made only when their source or a header is newer."""
 import concurrent.futures
 import contextlib
+import sys
 import fcntl
 import glob
 import hashlib
@@ -11,6 +12,8 @@ import subprocess
 import tempfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)      # isa_check.py (this directory is a package with a hyphen in its name: imported by file)
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libsoftgrip.so")
 LEGACY_LIB = os.path.join(_HERE, "libsoftgrip_legacy.so")
@@ -104,14 +107,32 @@ def _compile_locked(out, extra, verbose, sources):
         path = os.path.join(CSRC, src)
         if not verbose and not _stale(obj, [path] + hdrs):
             return obj, ""
-        fd, tmp = tempfile.mkstemp(suffix=".o", dir=objdir)      # never a half-written object under the name a linker may pick up
-        os.close(fd)
-        res = subprocess.run([hipcc] + flags + ["-c", "-o", tmp, path], capture_output=True, text=True)
-        if res.returncode != 0:
-            os.remove(tmp)
-            raise RuntimeError("hipcc failed on %s:\n%s" % (src, res.stderr[-4000:]))
-        os.replace(tmp, obj)
-        return obj, res.stderr
+        # compiled in a private directory (never a half-written object under the name a linker may pick up); a .hip source with
+        # -save-temps, whose by-product -- the device assembly -- is kept beside the object and CHECKED (isa_check.py: the
+        # miscompilation pattern behind the tree kernel's dropped stores): a build with such a site fails here
+        tmpdir = tempfile.mkdtemp(prefix=os.path.splitext(src)[0] + ".", dir=objdir)
+        try:
+            tmp = os.path.join(tmpdir, os.path.basename(obj))
+            hip = src.endswith(".hip")
+            res = subprocess.run([hipcc] + flags + (["-save-temps=obj"] if hip else []) + ["-c", "-o", tmp, path], capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError("hipcc failed on %s:\n%s" % (src, res.stderr[-4000:]))
+            log = res.stderr
+            if hip:
+                dev = glob.glob(os.path.join(tmpdir, "*-hip-amdgcn-amd-amdhsa-gfx950.s"))
+                if len(dev) != 1:
+                    raise RuntimeError("no device assembly among the by-products of %s: %s" % (src, sorted(os.listdir(tmpdir))))
+                from isa_check import check_asm, describe
+                bad = check_asm(dev[0])
+                if bad and not os.environ.get("SG_ALLOW_ISA_FINDINGS"):     # (experiment builds of the reproducer set it)
+                    raise RuntimeError("the compiler produced the exec-restore miscompilation pattern (soft-grip_amd/isa_check.py) in %s:\n%s\n"
+                                       "change the source or the scheduling flags until the site is gone; do NOT ship this object" % (src, describe(bad, src)))
+                os.replace(dev[0], os.path.splitext(obj)[0] + ".device.s")
+                log += "isa_check: %s clean\n" % src if not bad else describe(bad, src) + "\n"
+            os.replace(tmp, obj)
+        finally:
+            shutil.rmtree(tmpdir, ignore_errors=True)
+        return obj, log
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 1)) as ex:
         done = list(ex.map(one, sources))
@@ -128,8 +149,13 @@ def _compile_locked(out, extra, verbose, sources):
     return out
 
 
+def device_asm_files(extra=()):
+    """the device assembly kept by the last build of the given variant (flags beyond FLAGS), one file per .hip source"""
+    objdir = os.path.join(_HERE, "build", hashlib.sha1(" ".join(FLAGS + list(extra)).encode()).hexdigest()[:12])
+    return sorted(glob.glob(os.path.join(objdir, "*.device.s")))
+
+
 if __name__ == "__main__":
-    import sys
     if "--ko" in sys.argv:  # knock-out / experiment builds: --ko NAME -DFLAG ... -> libsoftgrip_NAME.so
         i = sys.argv.index("--ko")
         print(_compile(os.path.join(_HERE, "libsoftgrip_%s.so" % sys.argv[i + 1]), sys.argv[i + 2:], False))

@@ -1850,6 +1850,9 @@ static SGT_STAGE_ATTR void tree_stage(SGT_STAGE_PARAMS) {
       ten_f = -(tj_warm - aref) / ten_R;
     }
     const double ten_I = 1.0 / (tj_A + ten_R);
+#ifdef SGT_X_TAP   // (scripts/repro/tree_mono: the tendon row's intermediates into spare words of S.red, for a word-by-word comparison with the emulation)
+    SGT_ONE { S.red[8] = tj_pos; S.red[9] = tj_vel; S.red[10] = tj_asm; S.red[11] = tj_warm; S.red[12] = tj_A; S.red[13] = ten_R; S.red[14] = ten_b; S.red[15] = H.t0_L0; }
+#endif
     // (a') the composite's neighbour equalities q_e1 - q0_e1 = q_e2 - q0_e2 (MuJoCo's documented composite): slot
     //      d * N + e = the d-th row registered for element e (its partner: nbtab's out_e2); J = +1 on e, -1 on the partner
     const bool NB = H.nnb > 0;
