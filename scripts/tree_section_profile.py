@@ -52,6 +52,10 @@ def main():
             print("step %d, %s: %.0f cycles per env and substep (mean ncon %.1f, sweeps %.1f)" % (t, windows[t], v.sum(), float(st["ncon"].double().mean()), float(st["iters"].double().mean())))
             for k, name in enumerate(NAMES):
                 print("   %-36s %9.0f  %5.1f %%" % (name, v[k], 100 * v[k] / v.sum()))
+            x = np.array(buf[40:48], dtype=np.float64)
+            if x[1] or x[5]:
+                print("   contact streams: %.2f update slots per pass (the longest stream of the wavefront), %.0f cycles inside the 3 x 3 block update per slot; "
+                      "chain limit rows: %.2f row slots per pass" % (x[0] / max(x[1], 1), x[2] / max(x[3], 1), x[4] / max(x[5], 1)))
 
 
 if __name__ == "__main__":

@@ -109,7 +109,8 @@ struct Lds {
   double* csc;   // LDS copies of the first `ncache` contacts' scalar records (the sweeps read them 30 times; the rest stay in the work space)
   int ncache;
 };
-enum { IC_NHIT = 0, IC_NCON, IC_SERIAL, IC_NLIVE, IC_NPURE, IC_NLIM0 /* + chain */, IC_N = IC_NLIM0 + SGT_MAXCH };
+enum { IC_NHIT = 0, IC_NCON, IC_SERIAL, IC_NLIVE, IC_NPURE, IC_NLIM0 /* + chain */, IC_NLEV = IC_NLIM0 + SGT_MAXCH /* levels of the contact schedule */, IC_N };
+static_assert(IC_N <= 32, "S.icnt holds 32 counters");
 // per-chain scalars in LDS (chs[c * CHS_N + ..])
 enum { CHS_TLEN = 0, CHS_TVEL, CHS_TFRC, CHS_AFRC, CHS_ACTDOT, CHS_ACT, CHS_CTRL, CHS_KT, CHS_N };
 
@@ -402,6 +403,17 @@ SG_HD void mat6vec(double* r, const double* M, const double* v) {
 #define SGT_CONST
 #define SGT_GLOBP
 #endif
+// the address space of the arrays whose home SGT_DIET decides (lds_carve): M^-1 (bit 6), the sliders' 1 / m without a free object (bit 7)
+#if (SGT_DIET >> 6) & 1
+#define SGT_MINV_AS SGT_GLOBP
+#else
+#define SGT_MINV_AS SGT_LDSP
+#endif
+#if (SGT_DIET >> 7) & 1
+#define SGT_EINVM_AS SGT_GLOBP
+#else
+#define SGT_EINVM_AS SGT_LDSP
+#endif
 // The free object's joint-fix rows, one after the other (one lane).  A function of its own ON PURPOSE: inlined into the step kernel --
 // 256 + 256 registers and spilling -- the loop's 40 live values went to scratch memory and a row cost 600 cycles; called, it gets a
 // register allocation of its own.  The next row's 19 words are loaded before this row's dependent arithmetic.
@@ -531,6 +543,33 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
 #endif
   auto crow = [&](int c) { return crow0 + (size_t)c * CW; };
   auto cscr = [&](int c) -> const double* { return c < S.ncache ? S.csc + (size_t)c * SGT_CSC : crow0 + (size_t)c * CW + 12 * CS; };
+  // The sweeps' arrays once more, TYPED BY ADDRESS SPACE (r05).  Through the carve's generic pointers every access is a FLAT instruction,
+  // which counts on both memory counters: the wait for an LDS word (a contact's force, a slider's acceleration) then also waits for
+  // every global load in flight -- the NEXT contact's record, requested one update ahead precisely so that its latency is hidden.  The
+  // r04 ISA had `flat_load_dwordx4 (S.cf)` + `s_waitcnt vmcnt(0)` in the middle of every update: ~8 k cycles an update, two exposed
+  // round trips.  Typed, the LDS words are ds_read / ds_write (lgkmcnt only) and the prefetch stays in flight.
+  SGT_LDSP double* const aeL = (SGT_LDSP double*)S.ae;
+  SGT_LDSP double* const aFL = (SGT_LDSP double*)S.aF;
+  SGT_LDSP double* const cfL = (SGT_LDSP double*)S.cf;
+  SGT_LDSP double* const ffixL = (SGT_LDSP double*)S.ffix;
+  SGT_LDSP double* const flimL = (SGT_LDSP double*)S.flim;
+  SGT_LDSP double* const lrowL = (SGT_LDSP double*)S.lrow;
+  SGT_LDSP double* const ofL = (SGT_LDSP double*)S.of;
+  SGT_LDSP double* const BeL = (SGT_LDSP double*)S.Be;
+  const SGT_LDSP int* const icntL = (const SGT_LDSP int*)S.icnt;
+  const SGT_LDSP int* const hitpairL = (const SGT_LDSP int*)S.hit_pair;
+  const SGT_LDSP int* const hitcntL = (const SGT_LDSP int*)S.hit_cnt;
+  const SGT_MINV_AS double* const MinvT = (const SGT_MINV_AS double*)S.Minv;
+  const SGT_GLOBP double* const bfixG = (const SGT_GLOBP double*)S.bfix;
+  const SGT_GLOBP double* const RfixG = (const SGT_GLOBP double*)S.Rfix;
+  const SGT_GLOBP double* const IfixG = (const SGT_GLOBP double*)S.Ifix;
+  const SGT_GLOBP double* const nbbG = (const SGT_GLOBP double*)S.nbb;
+  const SGT_GLOBP double* const nbRG = (const SGT_GLOBP double*)S.nbR;
+  const SGT_GLOBP double* const nbIG = (const SGT_GLOBP double*)S.nbI;
+  SGT_GLOBP double* const nbfG = (SGT_GLOBP double*)S.nbf;
+  const SGT_EINVM_AS double* const einvmNF = (const SGT_EINVM_AS double*)S.einvm;   // scenes WITHOUT a free object only (with one: LDS, lds_carve)
+  (void)aeL; (void)aFL; (void)cfL; (void)ffixL; (void)flimL; (void)lrowL; (void)ofL; (void)BeL; (void)icntL; (void)hitpairL; (void)hitcntL; (void)MinvT;
+  (void)bfixG; (void)RfixG; (void)IfixG; (void)nbbG; (void)nbRG; (void)nbIG; (void)nbfG; (void)einvmNF;
   struct { unsigned long long* secprof; const int* nbtab; } A = {secprof, nbtab_generic};   // (what SGT_STAMP and the free object's row functions name)
   (void)A;
   SGT_STAMP_INIT();
@@ -580,39 +619,40 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
           const SgEqSlot slot = sched[r * 64 + sl];
           const int e = slot.e;
           if (e < N) {
-            const double invm = S.einvm[e];
-            double ae_ = S.ae[e], f = S.ffix[e];
+            const double invm = einvmNF[e];
+            double ae_ = aeL[e], f = ffixL[e];
             double old = f;
-            imp_par -= scalar_update_rcp(f, S.bfix[e], ae_, S.Rfix[e], invm + S.Rfix[e], S.Ifix[e], false);
-            S.ffix[e] = f;
+            const double Rf = RfixG[e];
+            imp_par -= scalar_update_rcp(f, bfixG[e], ae_, Rf, invm + Rf, IfixG[e], false);
+            ffixL[e] = f;
             ae_ += invm * (f - old);
             for (int d = 0; d < 3; d++) {
               const int pe = slot.p[d];
               if (pe >= N) continue;
               const int k = d * N + e;
-              const double ap = S.ae[pe], ipm = S.einvm[pe], R = S.nbR[k];
-              f = S.nbf[k]; old = f;
-              imp_par -= scalar_update_rcp(f, S.nbb[k], ae_ - ap, R, invm + ipm + R, S.nbI[k], false);
-              S.nbf[k] = f;
+              const double ap = aeL[pe], ipm = einvmNF[pe], R = nbRG[k];
+              f = nbfG[k]; old = f;
+              imp_par -= scalar_update_rcp(f, nbbG[k], ae_ - ap, R, invm + ipm + R, nbIG[k], false);
+              nbfG[k] = f;
               ae_ += invm * (f - old);
-              S.ae[pe] = ap - ipm * (f - old);
+              aeL[pe] = ap - ipm * (f - old);
             }
-            S.ae[e] = ae_;
+            aeL[e] = ae_;
           }
         }
         SGT_SYNC();
       }
-      SGT_PAR(e, N) S_ae += S.ecoef[e] * S.ae[e];
+      SGT_PAR_SLOT(e, t, N) S_ae += kco[t] * aeL[e];
       S_ae = wsum(S_ae);
     } else {
       SGT_PAR_SLOT(e, t, N) {
         const double invm = kim[t];
-        double f = S.ffix[e];
-        const double old = f, ael = S.ae[e];
+        double f = ffixL[e];
+        const double old = f, ael = aeL[e];
         imp_par -= scalar_update_rcp(f, kfb[t], ael, kfR[t], invm + kfR[t], kfI[t], false);
-        S.ffix[e] = f;
+        ffixL[e] = f;
         const double an = ael + invm * (f - old);
-        S.ae[e] = an;
+        aeL[e] = an;
         S_ae += kco[t] * an;
       }
       S_ae = wsum(S_ae);
@@ -622,7 +662,7 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
       const double old = ten_f;
       imp_uni -= scalar_update_rcp(ten_f, ten_b, S_ae, ten_R, tj_A + ten_R, ten_I, false);
       const double dfl = ten_f - old;
-      SGT_PAR_SLOT(e, t, N) S.ae[e] += kco[t] * dfl * kim[t];
+      SGT_PAR_SLOT(e, t, N) aeL[e] += kco[t] * dfl * kim[t];
       if (FR) {
         SGT_SYNC();
         SGT_ONE { for (int q = 0; q < 6; q++) S.of[OF_AF + q] += cten[q] * dfl; }
@@ -642,19 +682,22 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
       const int ll = lo_w ? l : 0;
       for (int c0 = 0; c0 < K; c0 += 4) {
         const int c = c0 + grp, cc = c < K ? c : 0;
-        double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[cc];
-        const double* Mi = S.Minv + cc * CS * CS;
-        double a0 = lo_w ? S.aF[cc * CS + l] : 0.0, a1 = hi_w ? S.aF[cc * CS + l + 16] : 0.0;
-        const int nrow = c < K ? S.icnt[IC_NLIM0 + cc] : 0;
+        SGT_LDSP double* rows = lrowL + SGT_LROW * 2 * T.c_dof0[cc];
+        const SGT_MINV_AS double* Mi = MinvT + cc * CS * CS;
+        double a0 = lo_w ? aFL[cc * CS + l] : 0.0, a1 = hi_w ? aFL[cc * CS + l + 16] : 0.0;
+        const int nrow = c < K ? icntL[IC_NLIM0 + cc] : 0;
         int nmax = __builtin_amdgcn_readlane(nrow, 0);
         for (int g2 = 16; g2 < 64; g2 += 16) { const int o = __builtin_amdgcn_readlane(nrow, g2); nmax = o > nmax ? o : nmax; }
+#if defined(SG_SECTION_PROF)
+        if (threadIdx.x == 0) { atomicAdd(&A.secprof[44], (unsigned long long)nmax); atomicAdd(&A.secprof[45], 1ull); }   // chain limit rows: row slots per pass
+#endif
         // (two register sets: the next row's record and its row of M^-1 -- two dependent LDS round trips -- are on their way during a row's update)
         struct LRec { double sg, R, b, f, Ainv, mdd, m0, m1; int dl; };
         auto load_row = [&](LRec& q, int i) {
           // (a group past its own list -- or without one -- reads row 0's words and dof 0's row of M^-1: both exist, nothing is applied.
           //  The dof index MUST be a valid one: M^-1 sits in the work space, and a stale LDS word as an index into it is a memory fault)
           const bool have = i < nrow;
-          const double* r = rows + SGT_LROW * (have ? i : 0);
+          const SGT_LDSP double* r = rows + SGT_LROW * (have ? i : 0);
           int dl = have ? (int)r[0] : 0;
           dl = dl < 0 ? 0 : (dl >= CS ? CS - 1 : dl);
           q.dl = dl; q.sg = r[1]; q.R = r[2]; q.b = r[3]; q.f = r[4]; q.Ainv = r[5];
@@ -683,8 +726,8 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
           update_row(qd, i + 3);
         }
         if (c < K) {
-          if (lo_w) S.aF[cc * CS + l] = a0;
-          if (hi_w) S.aF[cc * CS + l + 16] = a1;
+          if (lo_w) aFL[cc * CS + l] = a0;
+          if (hi_w) aFL[cc * CS + l + 16] = a1;
         }
       }
     }
@@ -723,11 +766,11 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
         const double R = klR[t][sd];
         if (R == 0.0) continue;
         const double sg = sd ? -1.0 : 1.0;
-        double f = S.flim[2 * e + sd];
+        double f = flimL[2 * e + sd];
         const double old = f;
-        imp_par -= scalar_update_rcp(f, klb[t][sd], sg * S.ae[e], R, invm + R, klI[t][sd], true);
-        S.flim[2 * e + sd] = f;
-        S.ae[e] += invm * sg * (f - old);
+        imp_par -= scalar_update_rcp(f, klb[t][sd], sg * aeL[e], R, invm + R, klI[t][sd], true);
+        flimL[2 * e + sd] = f;
+        aeL[e] += invm * sg * (f - old);
       }
     }
     SGT_SYNC();
@@ -745,8 +788,8 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
         const int grp = (int)threadIdx.x >> 4, l = (int)threadIdx.x & 15;
         const bool lo_w = l < CS, hi_w = l + 16 < CS;   // (short chains: CS < 16 -- the lanes beyond the stride hold no word)
         const int ll = lo_w ? l : 0;
-        const int* const order = S.hit_pair;
-        const int* const soff = S.hit_pair + SGT_MAXCON;   // [K + 1]
+        const SGT_LDSP int* const lvl = hitpairL;       // [nlev][K]: the contact of chain c in level L, or -1 (tree_stage 3)
+        const int nlev = icntL[IC_NLEV], nb = (K + 3) >> 2, nslot = nlev * nb;   // a slot = (level, batch of four chains): one update per lane group
         // a contact as the sweep needs it: J and W rows, word l (j, w) and word l + 16 (k, x), and the scalars of its record -- all from the
         // work space (one address space: the loads of the NEXT contact, requested before this one's update, stay in flight across it;
         // through a pointer that may be LDS or global every use waited for every load issued before it)
@@ -765,51 +808,76 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
           for (int k = 0; k < 3; k++) { q.B[k] = sc[CS_B + k]; q.Js[k] = sc[CS_JS + k]; }
           q.R = sc[CS_R]; q.invm = sc[CS_INVM]; q.slf = sc[CS_SL];
         };
-        for (int c0 = 0; c0 < K; c0 += 4) {
-          const int c = c0 + grp, cc = c < K ? c : 0;
-          double a0 = lo_w ? S.aF[cc * CS + l] : 0.0, a1 = hi_w ? S.aF[cc * CS + l + 16] : 0.0;   // (0 on a lane without a word: its J a terms vanish)
-          const int base = soff[cc], nmine = c < K ? soff[cc + 1] - base : 0;
-          int nmax = __builtin_amdgcn_readlane(nmine, 0);
-          for (int g2 = 16; g2 < 64; g2 += 16) { const int o = __builtin_amdgcn_readlane(nmine, g2); nmax = o > nmax ? o : nmax; }
-          if (nmax == 0) continue;
-          const int ci_safe = order[0];   // (some stream has a contact, so entry 0 exists: what a group past its own list reads)
-          auto idx = [&](int j) { return j < nmine ? order[base + j] : ci_safe; };
+        if (nslot > 0) {
+#if defined(SG_SECTION_PROF)
+          if (threadIdx.x == 0) { atomicAdd(&A.secprof[40], (unsigned long long)nslot); atomicAdd(&A.secprof[41], 1ull); }   // update slots per pass
+#endif
+          int ci_safe = 0;   // (level 0 holds a contact: what a group without one in a slot reads; nothing of it is applied)
+          for (int c = K - 1; c >= 0; c--) { const int x = lvl[c]; ci_safe = x >= 0 ? x : ci_safe; }
+          const bool one_batch = nb == 1;   // (K <= 4: a group keeps ITS chain's accelerations in registers over the whole pass)
+          auto chain_of = [&](int sl_) { return 4 * (sl_ % nb) + grp; };
+          auto contact_of = [&](int sl_) { const int c = chain_of(sl_); return (sl_ < nslot && c < K) ? lvl[(sl_ / nb) * K + c] : -1; };
+          int cc = grp < K ? grp : 0;
+          double a0 = lo_w ? aFL[cc * CS + l] : 0.0, a1 = hi_w ? aFL[cc * CS + l + 16] : 0.0;   // (0 on a lane without a word: its J a terms vanish)
           auto update = [&](const CRec& q, const bool act) {
             const int ci = q.ci, sl = (int)q.slf;
             const double p0 = rowsum16(q.j0 * a0 + q.k0 * a1), p1 = rowsum16(q.j1 * a0 + q.k1 * a1), p2 = rowsum16(q.j2 * a0 + q.k2 * a1);
-            const double as_ = sl >= 0 ? S.ae[sl] : 0.0;
-            double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
+            const double as_ = sl >= 0 ? aeL[sl] : 0.0;
+            double f[3] = {cfL[3 * ci], cfL[3 * ci + 1], cfL[3 * ci + 2]}, df[3];
             const double res[3] = {q.B[0] + q.Js[0] * as_ + p0 + q.R * f[0], q.B[1] + q.Js[1] * as_ + p1 + q.R * f[1], q.B[2] + q.Js[2] * as_ + p2 + q.R * f[2]};
+#if defined(SG_SECTION_PROF)
+            const long long tq0 = clock64();
+#endif
             const double ch = contact_block_update(q.A, res, f, con_mu, df);
+#if defined(SG_SECTION_PROF)
+            if (threadIdx.x == 0) { atomicAdd(&A.secprof[42], (unsigned long long)(clock64() - tq0)); atomicAdd(&A.secprof[43], 1ull); }   // cycles inside the 3 x 3 block update
+#endif
             if (act) {
               if (lo_w) a0 += q.w0 * df[0] + q.w1 * df[1] + q.w2 * df[2];
               if (hi_w) a1 += q.x0 * df[0] + q.x1 * df[1] + q.x2 * df[2];
               if (l == 0) {
                 imp_par -= ch;
-                S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
-                if (sl >= 0) S.ae[sl] += q.invm * (q.Js[0] * df[0] + q.Js[1] * df[1] + q.Js[2] * df[2]);
+                cfL[3 * ci] = f[0]; cfL[3 * ci + 1] = f[1]; cfL[3 * ci + 2] = f[2];
+                if (sl >= 0) aeL[sl] += q.invm * (q.Js[0] * df[0] + q.Js[1] * df[1] + q.Js[2] * df[2]);
               }
             }
           };
+          // one slot: more than four chains -> the group's chain changes from slot to slot, its accelerations go through LDS
+          auto slot = [&](const CRec& q, int sl_, int ci) {
+            if (!one_batch) {
+              const int c = chain_of(sl_);
+              cc = c < K ? c : 0;
+              a0 = lo_w ? aFL[cc * CS + l] : 0.0; a1 = hi_w ? aFL[cc * CS + l + 16] : 0.0;
+            }
+            update(q, ci >= 0);
+            if (!one_batch && ci >= 0) {
+              if (lo_w) aFL[cc * CS + l] = a0;
+              if (hi_w) aFL[cc * CS + l + 16] = a1;
+            }
+          };
           CRec ra, rb;   // two register sets: no copies, the other set's loads in flight during an update
-          load_rec(ra, idx(0));
-          for (int j = 0; j < nmax; j += 2) {
-            load_rec(rb, idx(j + 1));
-            update(ra, j < nmine);
-            load_rec(ra, idx(j + 2));
-            update(rb, j + 1 < nmine);
+          int cia = contact_of(0), cib;
+          load_rec(ra, cia >= 0 ? cia : ci_safe);
+          for (int j = 0; j < nslot; j += 2) {
+            cib = contact_of(j + 1);
+            load_rec(rb, cib >= 0 ? cib : ci_safe);
+            slot(ra, j, cia);
+            cia = contact_of(j + 2);
+            load_rec(ra, cia >= 0 ? cia : ci_safe);
+            slot(rb, j + 1, cib);
           }
-          if (c < K) {
-            if (lo_w) S.aF[cc * CS + l] = a0;
-            if (hi_w) S.aF[cc * CS + l + 16] = a1;
+          if (one_batch && grp < K) {
+            if (lo_w) aFL[cc * CS + l] = a0;
+            if (hi_w) aFL[cc * CS + l + 16] = a1;
           }
         }
       }
 #else
-      SGT_PAR(c, K) {
-        double* aFc = S.aF + c * CS;
-        for (int ci = 0; ci < ncon; ci++) {
-          if (S.con_chain[ci] != c) continue;
+      for (int Lv = 0; Lv < S.icnt[IC_NLEV]; Lv++) {   // the levels in sequence, a level's contacts (one per chain at most) side by side
+        SGT_PAR(c, K) {
+          double* aFc = S.aF + c * CS;
+          const int ci = S.hit_pair[Lv * K + c];
+          if (ci < 0) continue;
           const double* sc = cscr(ci);
           const double* J = crow(ci);
           const double* W = J + 3 * CS;
@@ -840,6 +908,7 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
           S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
           if (sl >= 0) S.ae[sl] += sc[CS_INVM] * (sc[CS_JS] * df[0] + sc[CS_JS + 1] * df[1] + sc[CS_JS + 2] * df[2]);
         }
+        SGT_SYNC();
       }
 #endif
       SGT_SYNC();
@@ -861,19 +930,22 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
       const int lane = (int)threadIdx.x;
       const bool dofl = lane < K * CS;
       const int mc = dofl ? lane / CS : -1, mdl = dofl ? lane % CS : 0;
-      double a = dofl ? S.aF[lane] : 0.0;
+      // (with a free object its LDS arrays -- B_e, 1 / m, C_e -- are read through typed pointers too: FR is a fact of the instantiation)
+      const SGT_LDSP double* const einvmL = (const SGT_LDSP double*)S.einvm;
+      const SGT_LDSP double* const CeL = (const SGT_LDSP double*)S.Ce;
+      double a = dofl ? aFL[lane] : 0.0;
       double af[6] = {0, 0, 0, 0, 0, 0}, gf[6] = {0, 0, 0, 0, 0, 0}, Si[36];
       if (FR) {
 #pragma unroll
-        for (int q = 0; q < 6; q++) { af[q] = S.of[OF_AF + q]; gf[q] = S.of[OF_GF + q]; }
+        for (int q = 0; q < 6; q++) { af[q] = ofL[OF_AF + q]; gf[q] = ofL[OF_GF + q]; }
 #pragma unroll
-        for (int q = 0; q < 36; q++) Si[q] = S.of[OF_SINV + q];
+        for (int q = 0; q < 36; q++) Si[q] = ofL[OF_SINV + q];
       }
       struct SRec { double j0, j1, j2, w0, w1, w2, A[6], B[3], R, invm, Js[3], slf, rowsf, objf, Jo[18]; int ci; };
       auto load_srec = [&](SRec& q, int ci) {
         const double* J = crow(ci);
         const double* sc = J + 12 * CS;
-        const int cc12 = S.hit_cnt[ci];   // (c1 + 1) | (c2 + 1) << 8, packed with the rows
+        const int cc12 = hitcntL[ci];   // (c1 + 1) | (c2 + 1) << 8, packed with the rows
         const int c1 = (cc12 & 0xff) - 1, c2 = ((cc12 >> 8) & 0xff) - 1;
         const int blk = (dofl && mc == c1) ? 0 : ((dofl && mc == c2) ? 1 : -1);
         const double* Jb = J + (blk == 1 ? 6 * CS : 0) + (blk >= 0 ? mdl : 0);
@@ -897,8 +969,13 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
         double p0 = wsum(q.j0 * a), p1 = wsum(q.j1 * a), p2 = wsum(q.j2 * a);
         if (ob) { p0 += dot6(q.Jo, af); p1 += dot6(q.Jo + 6, af); p2 += dot6(q.Jo + 12, af); }
         double as_ = 0.0;
-        if (sl >= 0) as_ = FR ? S.ae[sl] - dot6(S.Be + 6 * sl, af) * S.einvm[sl] : S.ae[sl];
-        double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
+        if (sl >= 0) {
+          if (FR) {
+            const SGT_LDSP double* Bs_ = BeL + 6 * sl;
+            as_ = aeL[sl] - (Bs_[0] * af[0] + Bs_[1] * af[1] + Bs_[2] * af[2] + Bs_[3] * af[3] + Bs_[4] * af[4] + Bs_[5] * af[5]) * einvmL[sl];
+          } else as_ = aeL[sl];
+        }
+        double f[3] = {cfL[3 * ci], cfL[3 * ci + 1], cfL[3 * ci + 2]}, df[3];
         const double res[3] = {q.B[0] + q.Js[0] * as_ + p0 + q.R * f[0], q.B[1] + q.Js[1] * as_ + p1 + q.R * f[1], q.B[2] + q.Js[2] * as_ + p2 + q.R * f[2]};
         const double ch = contact_block_update(q.A, res, f, con_mu, df);
         if (act) {
@@ -906,8 +983,8 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
           a += q.w0 * df[0] + q.w1 * df[1] + q.w2 * df[2];
           const double dge = sl >= 0 ? q.Js[0] * df[0] + q.Js[1] * df[1] + q.Js[2] * df[2] : 0.0;
           if (lane == 0) {
-            S.cf[3 * ci] = f[0]; S.cf[3 * ci + 1] = f[1]; S.cf[3 * ci + 2] = f[2];
-            if (sl >= 0) S.ae[sl] += q.invm * dge;
+            cfL[3 * ci] = f[0]; cfL[3 * ci + 1] = f[1]; cfL[3 * ci + 2] = f[2];
+            if (sl >= 0) aeL[sl] += q.invm * dge;
           }
           if (ob) {   // the push on the body: g_f += J_o' df; a_f += S^-1 J_o' df + C_sl dg_e
             double dg[6], da[6];
@@ -916,11 +993,12 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
             mat6vec(da, Si, dg);
             double Cs[6] = {0, 0, 0, 0, 0, 0};   // C_sl = -S^-1 B_sl / D_sl: the neighbour-row models keep it, the others recompute it (free_fix_rows)
             if (sl >= 0) {
-              if (NB) { for (int k = 0; k < 6; k++) Cs[k] = S.Ce[6 * sl + k]; }
+              if (NB) { for (int k = 0; k < 6; k++) Cs[k] = CeL[6 * sl + k]; }
               else {
-                double Bs[6];
-                mat6vec(Bs, Si, S.Be + 6 * sl);
-                const double im = S.einvm[sl];
+                double Bs[6], Bv[6];
+                for (int k = 0; k < 6; k++) Bv[k] = BeL[6 * sl + k];
+                mat6vec(Bs, Si, Bv);
+                const double im = einvmL[sl];
                 for (int k = 0; k < 6; k++) Cs[k] = -Bs[k] * im;
               }
             }
@@ -939,10 +1017,10 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
           update(rb, j + 1 < ncon);
         }
       }
-      if (dofl) S.aF[lane] = a;
+      if (dofl) aFL[lane] = a;
       if (FR && lane == 0) {
 #pragma unroll
-        for (int q = 0; q < 6; q++) { S.of[OF_AF + q] = af[q]; S.of[OF_GF + q] = gf[q]; }
+        for (int q = 0; q < 6; q++) { ofL[OF_AF + q] = af[q]; ofL[OF_GF + q] = gf[q]; }
       }
       SGT_SYNC();
     }
@@ -2099,18 +2177,40 @@ static SGT_STAGE_ATTR void tree_stage(SGT_STAGE_PARAMS) {
       const int ncc = ncon < S.ncache ? ncon : S.ncache;
       SGT_PAR(i, ncc * SGT_CSC) S.csc[i] = cscal(i / SGT_CSC)[i % SGT_CSC];
     }
-    // Contacts of different chains commute exactly unless they share a slider; mj_solPGS's order within a chain is kept by that
-    // chain's stream.  One lane per chain then sweeps its own contacts (a serial list is the fallback, decided here per substep).
+    // THE CONTACTS' LEVEL SCHEDULE (r05).  Two contacts commute exactly unless they share a dof: the same chain, or the same slider
+    // (two fingers on one capsule).  Level(i) = 1 + the highest level of an EARLIER contact that shares a dof with i: contacts of one level are
+    // mutually independent, and every pair that does not commute keeps mj_solPGS's order -- the levels in sequence ARE the
+    // sequential sweep.  A level holds at most one contact per chain: the sweep runs it on the chains' lane groups side by side.
+    // (Until r04 a slider under two fingers sent the WHOLE list to the one-after-the-other fallback: the four-finger scene at
+    // the squeeze -- 13 contacts, always a shared capsule somewhere -- ran 13 serial updates per sweep with two barriers each, 55 % of
+    // a substep; its levels: 4 - 5.)  Table S.hit_pair[level][chain] = contact id or -1 (the pair walk's hit list is done with); a
+    // contact with two chain blocks, without one, or on a free object still makes the list serial, as does a table overflow.
     SGT_PAR(ci, ncon) {
-      const int c = S.con_chain[ci];
-      bool serial = c == -2;
-      if (c >= 0) {
-        const int sl = (int)cscal(ci)[CS_SL];
-        if (sl >= 0)
-          for (int cj = 0; cj < ncon; cj++)
-            if (S.con_chain[cj] >= 0 && S.con_chain[cj] != c && (int)cscal(cj)[CS_SL] == sl) serial = true;
+      if (S.con_chain[ci] == -2) S.icnt[IC_SERIAL] = 1;
+      S.hit_sorted[ci] = (int)cscal(ci)[CS_SL];      // (staged for the one lane that builds the schedule: a word of LDS instead of a trip to the work space per contact)
+    }
+    SGT_PAR(i, SGT_MAXHIT) S.hit_pair[i] = -1;
+    SGT_PAR(e, N) S.hit_off[e] = 0;                  // last level + 1 of slider e (N <= SGT_MAXHIT: four elements a lane)
+    SGT_PAR(c, K) S.hit_sorted[SGT_MAXCON + c] = 0;  // ... of chain c
+    SGT_SYNC();
+    SGT_ONE {
+      int nlev = 0;
+      if (S.icnt[IC_SERIAL] == 0) {
+        const int cap = SGT_MAXHIT / K;
+        for (int ci = 0; ci < ncon; ci++) {
+          const int c = S.con_chain[ci];
+          if (c < 0) continue;
+          const int sl = S.hit_sorted[ci];
+          int L = S.hit_sorted[SGT_MAXCON + c];
+          if (sl >= 0 && S.hit_off[sl] > L) L = S.hit_off[sl];
+          if (L >= cap) { S.icnt[IC_SERIAL] = 1; break; }
+          S.hit_pair[L * K + c] = ci;
+          S.hit_sorted[SGT_MAXCON + c] = L + 1;
+          if (sl >= 0) S.hit_off[sl] = L + 1;
+          nlev = nlev > L + 1 ? nlev : L + 1;
+        }
       }
-      if (serial) S.icnt[IC_SERIAL] = 1;
+      S.icnt[IC_NLEV] = nlev;
     }
     SGT_SYNC();
     const bool serial_contacts = S.icnt[IC_SERIAL] != 0;
@@ -2118,19 +2218,6 @@ static SGT_STAGE_ATTR void tree_stage(SGT_STAGE_PARAMS) {
     // the serial list's wave-synchronous pass reads a contact's chains from LDS (S.hit_cnt: the narrowphase counts are done with)
     if (serial_contacts) {
       SGT_PAR(ci, ncon) S.hit_cnt[ci] = (((int)cscal(ci)[CS_C1] + 1) & 0xff) | ((((int)cscal(ci)[CS_C2] + 1) & 0xff) << 8);
-      SGT_SYNC();
-    }
-    // the streams' contact lists for the sweep's lane groups: the contact ids ordered by chain (mj_solPGS's order within a chain) in
-    // S.hit_pair[0 .. ), the chains' offsets behind them (the pair walk's hit list is done with: rank + narrowphase read it last)
-    if (!serial_contacts) {
-      SGT_PAR(c, K + 1) {
-        int off = 0;
-        for (int ci = 0; ci < ncon; ci++) off += (S.con_chain[ci] >= 0 && S.con_chain[ci] < c) ? 1 : 0;
-        S.hit_pair[SGT_MAXCON + c] = off;
-        if (c < K)
-          for (int ci = 0; ci < ncon; ci++)
-            if (S.con_chain[ci] == c) S.hit_pair[off++] = ci;
-      }
       SGT_SYNC();
     }
 #endif
