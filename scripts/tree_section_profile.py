@@ -54,8 +54,9 @@ def main():
                 print("   %-36s %9.0f  %5.1f %%" % (name, v[k], 100 * v[k] / v.sum()))
             x = np.array(buf[40:48], dtype=np.float64)
             if x[1] or x[5]:
-                print("   contact streams: %.2f update slots per pass (the longest stream of the wavefront), %.0f cycles inside the 3 x 3 block update per slot; "
-                      "chain limit rows: %.2f row slots per pass" % (x[0] / max(x[1], 1), x[2] / max(x[3], 1), x[4] / max(x[5], 1)))
+                print("   contact levels: %.2f update slots per pass of the lane groups; chain limit rows: %.2f row slots per pass" % (x[0] / max(x[1], 1), x[4] / max(x[5], 1)))
+                if x[3]:
+                    print("   one update slot: %.0f cycles to the residual (record's loads, row sums, LDS words), %.0f in the 3 x 3 block update, %.0f in the pushes and stores" % (x[2] / x[3], x[6] / x[3], x[7] / x[3]))
 
 
 if __name__ == "__main__":

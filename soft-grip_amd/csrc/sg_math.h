@@ -703,6 +703,102 @@ SG_HD double contact_block_update(const double* A, const double* res, double* f,
   df[0] = reject ? 0.0 : d0; df[1] = reject ? 0.0 : d1; df[2] = reject ? 0.0 : d2;
   return reject ? 0.0 : change;
 }
+// ---- the same block update with the contact's constants PRECOMPUTED (tree pipeline, r05; the rows pipeline's solver has worked this way
+// since r03, sg_rows.hip): Pe = {P11, P12, P22, e1, e2, cs, sn} -- the inverse of the friction-scaled 2 x 2 block S (0 when it is
+// singular) and S's eigen-decomposition S = Q diag(e1, e2) Q', Q = [[cs, sn], [-sn, cs]], built once per contact and substep
+// (contact_block_constants).  Same iterates, same stopping rules and the same results as contact_block_update to round-off (mju_QCQP2's
+// Newton iteration in S's eigen-coordinates: DESIGN.md 4.5) -- but one division on the common path instead of three and no square root,
+// which is what a wavefront alone on its SIMD pays for: every instruction of this dependent chain costs its full latency.
+SG_HD void contact_block_constants(const double* A, const double* mu, double* Pe) {
+  const double S11 = A[3] * mu[0] * mu[0], S22 = A[5] * mu[1] * mu[1], S12 = A[4] * mu[0] * mu[1];
+  const double det = S11 * S22 - S12 * S12, di = det < 1e-10 ? 0.0 : 1.0 / det;
+  Pe[0] = S22 * di; Pe[1] = -S12 * di; Pe[2] = S11 * di;
+  double ecs = 1.0, esn = 0.0, ee1 = S11, ee2 = S22;
+  if (fabs(S12) > 1e-300) {   // one Jacobi rotation
+    const double tau = (S22 - S11) / (2.0 * S12), tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+    ecs = 1.0 / sqrt(1.0 + tt * tt); esn = tt * ecs;
+    ee1 = S11 - tt * S12; ee2 = S22 + tt * S12;
+  }
+  Pe[3] = ee1; Pe[4] = ee2; Pe[5] = ecs; Pe[6] = esn;
+}
+SG_HD double sg_rsqrt(double q) {   // 1 / sqrt(q), q > 0
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(q);
+  y = y * (1.5 - 0.5 * q * y * y);
+  return y * (1.5 - 0.5 * q * y * y);
+#else
+  return 1.0 / sqrt(q);
+#endif
+}
+SG_HD double contact_block_update_pre(const double* A, const double* Pe, const double* res, double* f, const double* mu, double* df) {
+  const double o0 = f[0], o1 = f[1], o2 = f[2];
+  const double A00 = A[0], A01 = A[1], A02 = A[2], A11 = A[3], A12 = A[4], A22 = A[5];
+  const double P11 = Pe[0], P12 = Pe[1], P22 = Pe[2];
+  const double w0 = A00 * o0 + A01 * o1 + A02 * o2, w1 = A01 * o0 + A11 * o1 + A12 * o2, w2 = A02 * o0 + A12 * o1 + A22 * o2;   // A f
+  // ---- normal (f0 ~ 0) or ray update ----
+  double g0;
+  {
+    const double denom = o0 * w0 + o1 * w1 + o2 * w2, num = o0 * res[0] + o1 * res[1] + o2 * res[2];
+    double x = denom >= SG_MINVAL ? sg_div(-num, denom) : 0.0;
+    x = (o0 + x * o0 < 0) ? -1.0 : x;
+    g0 = o0 + x * o0;
+  }
+  if (o0 < SG_MINVAL) {  // uncommon: no normal force yet
+    g0 = o0 - sg_div(res[0], A00);
+    g0 = g0 < 0 ? 0.0 : g0;
+  }
+  // ---- friction rows with the normal force fixed: min 1/2 v'Ac v + v'bc  s.t. |v/mu| <= g0 (mju_QCQP2) ----
+  const bool nofric = g0 < SG_MINVAL;
+  const double b1 = nofric ? 0.0 : ((res[1] - w1) + A01 * g0) * mu[0], b2 = nofric ? 0.0 : ((res[2] - w2) + A02 * g0) * mu[1];
+  const double u1 = -(P11 * b1 + P12 * b2), u2 = -(P12 * b1 + P22 * b2);   // 0 when the friction block is singular
+  const double val = (u1 * u1 + u2 * u2) - g0 * g0;
+  double v1 = u1 * mu[0], v2 = u2 * mu[1];
+  if (!(val < 1e-10) && !nofric) {  // uncommon: outside the cone -- Newton on the multiplier, in S's eigen-coordinates
+    const double e1 = Pe[3], e2 = Pe[4], qcs = Pe[5], qsn = Pe[6];
+    const double c1 = qcs * b1 - qsn * b2, c2 = qsn * b1 + qcs * b2;
+    const double C1h = 0.5 * c1 * c1, C2h = 0.5 * c2 * c2, R2h = 0.5 * g0 * g0;
+    double la = 0.0;
+    bool run;
+    {
+      const double deriv = -2.0 * (P11 * u1 * u1 + 2.0 * P12 * u1 * u2 + P22 * u2 * u2), delta = sg_div(-val, deriv);
+      run = !(delta < 1e-10);
+      la = run ? delta : 0.0;
+    }
+    const bool ever = run;
+    double x1 = e1, x2 = e2;
+    if (run) {
+      for (int it = 1; it < 20; it++) {
+        x1 = e1 + la; x2 = e2 + la;
+        const double y1 = x1 * x1, y2 = x2 * x2, ah = C1h * y2, bh = C2h * y1, yy = y1 * y2;
+        const double Nh = fma(-R2h, yy, ah + bh);            // val det^2 / 2
+        const double Dh = fma(ah, x2, bh * x1);              // w' adj w / 2
+        const double xx = x1 * x2;                           // det
+        const double delta = sg_div_fast(Nh * xx, Dh + Dh);  // a Newton step: its last bits are absorbed by the next evaluation
+        if (xx < 1e-10 || Nh < 0.5e-10 * yy || delta < 1e-10) break;
+        la += delta;
+      }
+    }
+    const double det = x1 * x2;
+    const double t1e = -c1 * x2, t2e = -c2 * x1;   // last evaluation, back in the contact's coordinates: v = Q (-c1 / x1, -c2 / x2) = (t1, t2) / det
+    const double t1 = qcs * t1e + qsn * t2e, t2 = qcs * t2e - qsn * t1e;
+    const bool sing = ever && det < 1e-10;
+    const double q1 = ever ? t1 : u1, q2 = ever ? t2 : u2, qdet = ever ? det : 1.0;
+    const bool active = la != 0.0 && !sing;
+    // v = q / qdet, rescaled onto the cone when the constraint is active: |(v1 / mu0, v2 / mu1)| = g0 (the division by qdet cancels)
+    const double qq = fmax(SG_MINVAL, active ? q1 * q1 + q2 * q2 : qdet * qdet);
+    const double y = sg_rsqrt(qq);
+    const double sc = sing ? 0.0 : (active ? g0 * y : y);
+    v1 = q1 * mu[0] * sc; v2 = q2 * mu[1] * sc;
+  }
+  const double g1 = v1, g2 = v2;
+  const double n0 = A00 * g0 + A01 * g1 + A02 * g2, n1 = A01 * g0 + A11 * g1 + A12 * g2, n2 = A02 * g0 + A12 * g1 + A22 * g2;   // A f_new
+  const double d0 = g0 - o0, d1 = g1 - o1, d2 = g2 - o2;
+  const double change = d0 * (0.5 * (n0 - w0) + res[0]) + d1 * (0.5 * (n1 - w1) + res[1]) + d2 * (0.5 * (n2 - w2) + res[2]);
+  const bool reject = change > 1e-10;  // the update must not increase the cost
+  f[0] = reject ? o0 : g0; f[1] = reject ? o1 : g1; f[2] = reject ? o2 : g2;
+  df[0] = reject ? 0.0 : d0; df[1] = reject ? 0.0 : d1; df[2] = reject ? 0.0 : d2;
+  return reject ? 0.0 : change;
+}
 SG_HD double contact_update(Contact& c, const double* aF, double as_, const double* mu, double* df) {
   double res[3];
 #pragma unroll

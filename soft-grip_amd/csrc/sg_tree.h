@@ -88,7 +88,8 @@ SG_HD long long cws_row_doubles(int CS) { return 12LL * CS + SGT_CSC; }   // 2 b
 // scalar part of a contact record
 enum { CS_A = 0, CS_B = 6, CS_F0 = 9, CS_R = 12, CS_INVM = 13, CS_JS = 14, CS_SL = 17, CS_C1 = 18, CS_N1 = 19, CS_C2 = 20, CS_N2 = 21,
        CS_ROWS = 22, CS_TOUCH = 23, CS_OBJ = 24 /* the contact touches the free object */, CS_JO = 25 /* [3][6]: its rows on the object's free dofs, body frame */,
-       CS_TMP = 43 /* [12]: between the phases of the rows' build: J v, J a_smooth, J a_warm, body invweights, blocks, distance */ };
+       CS_TMP = 43 /* [12]: between the phases of the rows' build: J v, J a_smooth, J a_warm, body invweights, blocks, distance */,
+       CS_PE = 43 /* [7], once the rows are built (the temporaries are done with): the friction block's inverse and eigen-decomposition, contact_block_constants */ };
 // the free object's block in LDS (S.of[..]); body frame unless said otherwise
 enum { OF_P = 0, OF_Q = 3, OF_R = 7, OF_VW = 16 /* world */, OF_VL = 19, OF_WL = 22 /* (v, w) contiguous */, OF_WARM = 25, OF_ASM = 31, OF_AF = 37, OF_GF = 43, OF_SINV = 49,
        OF_CEN = 85 /* world */, OF_GL = 88, OF_CTEN = 91, OF_BIAS = 97, OF_X = 103, OF_Y = 109, OF_WB = 115 /* OF_WARM: dof coordinates (world translations), kept
@@ -260,6 +261,11 @@ SG_HD size_t gws_doubles(const SgTreeDev& T, int N, int has_free, int nnb) {   /
 #define SGT_STRIDE 64
 #define SGT_PAR(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
 #define SGT_ONE if (threadIdx.x == 0)
+#if defined(SGT_X_ROWS1LANE)
+#define SGT_ROW_LANES if (threadIdx.x == 0)
+#else
+#define SGT_ROW_LANES if (threadIdx.x < 8)   // free_fix_rows: the free body's serial joint-fix rows on eight lanes
+#endif
 #define SGT_SYNC() __syncthreads()
 // cross-lane moves without LDS: DPP on the two halves of a double (row_ror:n = 0x120 + n, rotation inside a row of 16 lanes)
 template <int CTRL>
@@ -303,6 +309,7 @@ __device__ __forceinline__ int lds_inc(int* p) { return atomicAdd(p, 1); }
 #define SGT_PAR(i, n) for (int i = 0; i < (n); i++)
 #endif
 #define SGT_ONE if (true)
+#define SGT_ROW_LANES if (true)
 #define SGT_SYNC() ((void)0)
 inline double wsum(double x) { return x; }
 inline double wmax(double x) { return x; }
@@ -419,6 +426,54 @@ SG_HD void mat6vec(double* r, const double* M, const double* v) {
 // register allocation of its own.  The next row's 19 words are loaded before this row's dependent arithmetic.
 static SGT_NOINLINE double free_fix_rows(const SGT_LDSP double* frow, const SGT_LDSP double* Be, const SGT_LDSP double* einvm, const SGT_LDSP double* Sinv,
                                          SGT_LDSP double* ffix, SGT_LDSP double* ae, SGT_LDSP double* af, int N) {
+#if SGT_DEVICE && !defined(SGT_X_ROWS1LANE)
+  // EIGHT LANES (r05; the caller enters with lanes 0 .. 7): lane q < 6 owns component q of the body's acceleration a_f, of B_e and of
+  // C_e = -S^-1 B_e / D_e.  A row on one lane cost ~66 instructions -- 6 for B_e . a_f, 36 for C_e (recomputed per row since r04: the
+  // array would not fit the LDS share of four workgroups per CU), 6 for a_f += C_e df -- and a wavefront alone on its SIMD pays ~7
+  // cycles for each, whatever it is and however few lanes it feeds: 500 cycles a row, 40 % of a free-ball substep.  Here the dot product
+  // is one multiply and an 8-lane DPP sum, C_e six multiply-adds per lane (row q of S^-1 in registers), the push one: ~40 instructions.
+  // The scalar part of a row (residual, force, cost) runs on all eight lanes alike.  The next row's words are read one row ahead.
+  const int q = (int)threadIdx.x & 7;
+  const bool own = q < 6;
+  const int qq = own ? q : 0;
+  double afq = own ? af[qq] : 0.0, imp = 0;
+  double Sq[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) Sq[k] = Sinv[6 * qq + k];
+  double nr[4], nB[6], nBq = Be[qq], nf = ffix[0], na = ae[0], ni = einvm[0];
+#pragma unroll
+  for (int k = 0; k < 4; k++) nr[k] = frow[k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) nB[k] = Be[k];
+  for (int e = 0; e < N; e++) {
+    double r4[4], B6[6];
+    const double Bq = nBq, f = nf, ael = na, invm = ni;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r4[k] = nr[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) B6[k] = nB[k];
+    {  // (the row behind the last one is read too: the arrays are followed by other words of the LDS block, and the values are dropped)
+      const int en = e + 1;
+#pragma unroll
+      for (int k = 0; k < 4; k++) nr[k] = frow[4 * en + k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) nB[k] = Be[6 * en + k];
+      nBq = Be[6 * en + qq]; nf = ffix[en]; na = ae[en]; ni = einvm[en];
+    }
+    double dot = own ? Bq * afq : 0.0;          // B_e . a_f over the six owner lanes (lanes 6, 7 add nothing)
+    dot += dpp64<0xB1>(dot);                    // quad_perm [1,0,3,2]
+    dot += dpp64<0x4E>(dot);                    // quad_perm [2,3,0,1]
+    dot += dpp64<0x141>(dot);                   // row_half_mirror: the other quad of the eight
+    double fn = f;
+    imp -= scalar_update_rcp(fn, r4[0], ael - dot * invm, r4[1], r4[2], r4[3], false);
+    const double dfl = fn - f;
+    const double Cq = -(((Sq[0] * B6[0] + Sq[1] * B6[1]) + (Sq[2] * B6[2] + Sq[3] * B6[3])) + (Sq[4] * B6[4] + Sq[5] * B6[5])) * invm;
+    afq += Cq * dfl;                            // (lanes 6, 7 carry a dummy: never stored)
+    if (q == 0) { ffix[e] = fn; ae[e] = ael + invm * dfl; }
+  }
+  if (own) af[qq] = afq;
+  return imp;
+#else
   // C_e = -S^-1 B_e / D_e is RECOMPUTED per row (r04: 36 multiply-adds that do not depend on the previous row -- they run in the shadow
   // of its dependent chain) instead of read from a [N][6] array: without that array and the rows' copy of 1 / D the free ball's
   // LDS block is 37.8 KB instead of 50 -- four workgroups per CU instead of three.  Same expressions as the rows' build (tree_stage).
@@ -458,6 +513,7 @@ static SGT_NOINLINE double free_fix_rows(const SGT_LDSP double* frow, const SGT_
   }
   for (int q = 0; q < 6; q++) af[q] = af6[q];
   return imp;
+#endif
 }
 // The same with the composite's neighbour equalities: the equality BLOCKS [fix_e, e's neighbour rows (partner p: J = +1 on e, -1 on p)] in
 // mj_solPGS's order.  A neighbour row moves two sliders and, through both, the body: a_f += (C_e - C_p) df.  (The neighbour rows' words
@@ -602,9 +658,10 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
         S.red[0] = free_eq_blocks((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.Ce, (const SGT_LDSP double*)S.einvm, (SGT_LDSP double*)S.ffix,
                                   (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N, A.nbtab, S.nbf, S.nbb, S.nbR, S.nbA, S.nbI);
       }
-      if (!NB) SGT_ONE {
-        S.red[0] = free_fix_rows((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.einvm, (const SGT_LDSP double*)(S.of + OF_SINV),
-                                 (SGT_LDSP double*)S.ffix, (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N);
+      if (!NB) SGT_ROW_LANES {   // (device: lanes 0 .. 7, the six components of the body's acceleration a lane each)
+        const double r_ = free_fix_rows((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.einvm, (const SGT_LDSP double*)(S.of + OF_SINV),
+                                        (SGT_LDSP double*)S.ffix, (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N);
+        SGT_ONE { S.red[0] = r_; }
       }
       SGT_SYNC();
       imp_uni += S.red[0];
@@ -793,7 +850,7 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
         // a contact as the sweep needs it: J and W rows, word l (j, w) and word l + 16 (k, x), and the scalars of its record -- all from the
         // work space (one address space: the loads of the NEXT contact, requested before this one's update, stay in flight across it;
         // through a pointer that may be LDS or global every use waited for every load issued before it)
-        struct CRec { double j0, j1, j2, k0, k1, k2, w0, w1, w2, x0, x1, x2, A[6], B[3], R, invm, Js[3], slf; int ci; };
+        struct CRec { double j0, j1, j2, k0, k1, k2, w0, w1, w2, x0, x1, x2, A[6], Pe[7], B[3], R, invm, Js[3], slf; int ci; };
         auto load_rec = [&](CRec& q, int ci) {
           const double* J = crow(ci);
           const double* W = J + 3 * CS;
@@ -807,6 +864,8 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
 #pragma unroll
           for (int k = 0; k < 3; k++) { q.B[k] = sc[CS_B + k]; q.Js[k] = sc[CS_JS + k]; }
           q.R = sc[CS_R]; q.invm = sc[CS_INVM]; q.slf = sc[CS_SL];
+#pragma unroll
+          for (int k = 0; k < 7; k++) q.Pe[k] = sc[CS_PE + k];
         };
         if (nslot > 0) {
 #if defined(SG_SECTION_PROF)
@@ -819,19 +878,28 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
           auto contact_of = [&](int sl_) { const int c = chain_of(sl_); return (sl_ < nslot && c < K) ? lvl[(sl_ / nb) * K + c] : -1; };
           int cc = grp < K ? grp : 0;
           double a0 = lo_w ? aFL[cc * CS + l] : 0.0, a1 = hi_w ? aFL[cc * CS + l + 16] : 0.0;   // (0 on a lane without a word: its J a terms vanish)
+#if defined(SG_SECTION_PROF)
+          long long tpa = 0, tpb = 0, tpc = 0, tpn = 0;   // cycles of an update's three parts (registers; added up once per pass, below)
+#define SGT_TP(x) const long long x = clock64()
+#else
+#define SGT_TP(x) ((void)0)
+#endif
           auto update = [&](const CRec& q, const bool act) {
+            SGT_TP(t0_);
             const int ci = q.ci, sl = (int)q.slf;
             const double p0 = rowsum16(q.j0 * a0 + q.k0 * a1), p1 = rowsum16(q.j1 * a0 + q.k1 * a1), p2 = rowsum16(q.j2 * a0 + q.k2 * a1);
             const double as_ = sl >= 0 ? aeL[sl] : 0.0;
             double f[3] = {cfL[3 * ci], cfL[3 * ci + 1], cfL[3 * ci + 2]}, df[3];
             const double res[3] = {q.B[0] + q.Js[0] * as_ + p0 + q.R * f[0], q.B[1] + q.Js[1] * as_ + p1 + q.R * f[1], q.B[2] + q.Js[2] * as_ + p2 + q.R * f[2]};
 #if defined(SG_SECTION_PROF)
-            const long long tq0 = clock64();
+            asm volatile("" :: "v"(res[0]), "v"(res[1]), "v"(res[2]));
 #endif
-            const double ch = contact_block_update(q.A, res, f, con_mu, df);
+            SGT_TP(t1_);
+            const double ch = contact_block_update_pre(q.A, q.Pe, res, f, con_mu, df);
 #if defined(SG_SECTION_PROF)
-            if (threadIdx.x == 0) { atomicAdd(&A.secprof[42], (unsigned long long)(clock64() - tq0)); atomicAdd(&A.secprof[43], 1ull); }   // cycles inside the 3 x 3 block update
+            asm volatile("" :: "v"(df[0]), "v"(df[1]), "v"(df[2]), "v"(ch));
 #endif
+            SGT_TP(t2_);
             if (act) {
               if (lo_w) a0 += q.w0 * df[0] + q.w1 * df[1] + q.w2 * df[2];
               if (hi_w) a1 += q.x0 * df[0] + q.x1 * df[1] + q.x2 * df[2];
@@ -841,6 +909,10 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
                 if (sl >= 0) aeL[sl] += q.invm * (q.Js[0] * df[0] + q.Js[1] * df[1] + q.Js[2] * df[2]);
               }
             }
+#if defined(SG_SECTION_PROF)
+            asm volatile("" :: "v"(a0), "v"(a1));
+            { const long long t3_ = clock64(); tpa += t1_ - t0_; tpb += t2_ - t1_; tpc += t3_ - t2_; tpn++; }
+#endif
           };
           // one slot: more than four chains -> the group's chain changes from slot to slot, its accelerations go through LDS
           auto slot = [&](const CRec& q, int sl_, int ci) {
@@ -870,6 +942,10 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
             if (lo_w) aFL[cc * CS + l] = a0;
             if (hi_w) aFL[cc * CS + l + 16] = a1;
           }
+#if defined(SG_SECTION_PROF)
+          if (threadIdx.x == 0) { atomicAdd(&A.secprof[42], (unsigned long long)tpa); atomicAdd(&A.secprof[43], (unsigned long long)tpn); atomicAdd(&A.secprof[46], (unsigned long long)tpb); atomicAdd(&A.secprof[47], (unsigned long long)tpc); }
+#endif
+#undef SGT_TP
         }
       }
 #else
@@ -898,7 +974,7 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
           double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
           const double res[3] = {sc[CS_B] + sc[CS_JS] * as_ + p0 + sc[CS_R] * f[0], sc[CS_B + 1] + sc[CS_JS + 1] * as_ + p1 + sc[CS_R] * f[1],
                                  sc[CS_B + 2] + sc[CS_JS + 2] * as_ + p2 + sc[CS_R] * f[2]};
-          imp_par -= contact_block_update(sc + CS_A, res, f, con_mu, df);
+          imp_par -= contact_block_update_pre(sc + CS_A, sc + CS_PE, res, f, con_mu, df);
           double an[CHD];
 #pragma unroll
           for (int k = 0; k < CHD; k++) an[k] = aFc[k] + (w0[k] * df[0] + w1[k] * df[1] + w2[k] * df[2]);
@@ -941,7 +1017,7 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
 #pragma unroll
         for (int q = 0; q < 36; q++) Si[q] = ofL[OF_SINV + q];
       }
-      struct SRec { double j0, j1, j2, w0, w1, w2, A[6], B[3], R, invm, Js[3], slf, rowsf, objf, Jo[18]; int ci; };
+      struct SRec { double j0, j1, j2, w0, w1, w2, A[6], Pe[7], B[3], R, invm, Js[3], slf, rowsf, objf, Jo[18]; int ci; };
       auto load_srec = [&](SRec& q, int ci) {
         const double* J = crow(ci);
         const double* sc = J + 12 * CS;
@@ -958,6 +1034,8 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
 #pragma unroll
         for (int k = 0; k < 3; k++) { q.B[k] = sc[CS_B + k]; q.Js[k] = sc[CS_JS + k]; }
         q.R = sc[CS_R]; q.invm = sc[CS_INVM]; q.slf = sc[CS_SL]; q.rowsf = sc[CS_ROWS]; q.objf = sc[CS_OBJ];
+#pragma unroll
+        for (int k = 0; k < 7; k++) q.Pe[k] = sc[CS_PE + k];
         if (FR) {
 #pragma unroll
           for (int k = 0; k < 18; k++) q.Jo[k] = sc[CS_JO + k];
@@ -977,7 +1055,7 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
         }
         double f[3] = {cfL[3 * ci], cfL[3 * ci + 1], cfL[3 * ci + 2]}, df[3];
         const double res[3] = {q.B[0] + q.Js[0] * as_ + p0 + q.R * f[0], q.B[1] + q.Js[1] * as_ + p1 + q.R * f[1], q.B[2] + q.Js[2] * as_ + p2 + q.R * f[2]};
-        const double ch = contact_block_update(q.A, res, f, con_mu, df);
+        const double ch = contact_block_update_pre(q.A, q.Pe, res, f, con_mu, df);
         if (act) {
           imp_uni -= ch;
           a += q.w0 * df[0] + q.w1 * df[1] + q.w2 * df[2];
@@ -1046,7 +1124,7 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
       double f[3] = {S.cf[3 * ci], S.cf[3 * ci + 1], S.cf[3 * ci + 2]}, df[3];
       const double res[3] = {sc[CS_B] + sc[CS_JS] * as_ + p0 + sc[CS_R] * f[0], sc[CS_B + 1] + sc[CS_JS + 1] * as_ + p1 + sc[CS_R] * f[1],
                              sc[CS_B + 2] + sc[CS_JS + 2] * as_ + p2 + sc[CS_R] * f[2]};
-      imp_uni -= contact_block_update(sc + CS_A, res, f, H.con_mu, df);
+      imp_uni -= contact_block_update_pre(sc + CS_A, sc + CS_PE, res, f, con_mu, df);
       SGT_SYNC();   // every lane has read the old forces and accelerations
       const int n1c = c1 >= 0 ? CS : 0, n2c = c2 >= 0 ? CS : 0;
       SGT_PAR(i, n1c + n2c) {
@@ -2167,6 +2245,12 @@ static SGT_STAGE_ATTR void tree_stage(SGT_STAGE_PARAMS) {
       for (int k = 0; k < 3; k++) { sc[CS_B + k] = bb[k]; sc[CS_F0 + k] = rows ? f[k] : 0.0; S.cf[3 * ci + k] = rows ? f[k] : 0.0; }
       sc[CS_R] = R;
       sc[CS_ROWS] = rows ? 1.0 : 0.0;
+      {
+        const double mu2[2] = {H.con_mu[0], H.con_mu[1]};
+        double pe[7];
+        contact_block_constants(Am, mu2, pe);
+        for (int k = 0; k < 7; k++) sc[CS_PE + k] = pe[k];   // (every temporary of this record has been read above)
+      }
       // the contact's stream in the sweep: its one chain; -1 = no rows; -2 = not exactly one chain block (both fingers, or a slider
       // against a static geom): such a list is swept serially
       S.con_chain[ci] = !rows ? -1 : ((nblk == 1 && !onfree) ? ch[0] : -2);   // (a free object couples every contact on it: serial list)

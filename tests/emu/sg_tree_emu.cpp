@@ -140,3 +140,40 @@ void temu_run(TreeEmu* E, int mode, int nsub) {
 }
 
 }  // extern "C"
+
+// ---- the two forms of the contact block update on random blocks (tests/test_tree_emu.py): the generic one (mju_QCQP2 as written,
+// the oracle's formula) and the one with precomputed constants that the tree sweep runs (sg_math.h contact_block_update_pre)
+extern "C" int temu_block_update_check(int n, unsigned seed, double* max_df, double* max_rel, int* n_slide, int* n_rejected) {
+  unsigned long long st = seed * 6364136223846793005ULL + 1442695040888963407ULL;
+  auto rnd = [&]() { st = st * 6364136223846793005ULL + 1442695040888963407ULL; return (double)((st >> 11) & ((1ULL << 53) - 1)) / (double)(1ULL << 53) * 2.0 - 1.0; };
+  int bad = 0;
+  *max_df = *max_rel = 0; *n_slide = *n_rejected = 0;
+  for (int t = 0; t < n; t++) {
+    double J[3][5], A[6], res[3], f0[3], mu[2] = {1.0, 1.0};
+    if (t % 3 == 1) { mu[0] = 0.7; mu[1] = 0.4; }
+    for (auto& r : J) for (double& x : r) x = rnd();
+    const double R = 0.02 + 0.5 * (rnd() + 1), scale = (t % 5 == 0) ? 1e-3 : 1.0;
+    int k = 0;
+    for (int i = 0; i < 3; i++)
+      for (int j = i; j < 3; j++) { double s = 0; for (int q = 0; q < 5; q++) s += J[i][q] * J[j][q]; A[k++] = scale * s + (i == j ? R : 0.0); }
+    const double fn = (t % 7 == 0) ? 0.0 : 2.0 * (rnd() + 1);   // some contacts without a normal force yet
+    f0[0] = fn; f0[1] = 0.6 * fn * rnd() * mu[0]; f0[2] = 0.6 * fn * rnd() * mu[1];
+    for (double& x : res) x = 3.0 * rnd();
+    double fa[3] = {f0[0], f0[1], f0[2]}, fb[3] = {f0[0], f0[1], f0[2]}, da[3], db[3], Pe[7];
+    const double ca = sgm::contact_block_update(A, res, fa, mu, da);
+    sgm::contact_block_constants(A, mu, Pe);
+    const double cb = sgm::contact_block_update_pre(A, Pe, res, fb, mu, db);
+    const double mag = 1.0 + fabs(fa[0]) + fabs(fa[1]) + fabs(fa[2]);
+    for (int i = 0; i < 3; i++) {
+      const double d = fabs(fa[i] - fb[i]);
+      if (d > *max_df) *max_df = d;
+      if (d / mag > *max_rel) *max_rel = d / mag;
+      if (d > 1e-9 * mag) bad++;
+    }
+    if (fabs(ca - cb) > 1e-9 * (1 + fabs(ca))) bad++;
+    const double s2 = fa[1] * fa[1] / (mu[0] * mu[0]) + fa[2] * fa[2] / (mu[1] * mu[1]);
+    if (fa[0] > 0 && s2 > 0.999999 * fa[0] * fa[0]) (*n_slide)++;
+    if (da[0] == 0 && da[1] == 0 && da[2] == 0) (*n_rejected)++;
+  }
+  return bad;
+}

@@ -515,3 +515,17 @@ def test_checking_layout_gives_the_same_numbers(tmp_path):
         assert (plain.ncon, plain.nefc, plain.iters, plain.flags) == (sep.ncon, sep.nefc, sep.iters, sep.flags)
         np.testing.assert_array_equal(plain.sensordata, sep.sensordata)
         np.testing.assert_array_equal(plain.qpos, sep.qpos)
+
+
+def test_block_update_with_precomputed_constants_is_the_generic_update():
+    """sg_math.h contact_block_update_pre (what the tree sweep runs since r05: the friction block's inverse and eigen-decomposition built
+    once per contact, mju_QCQP2's Newton iteration in eigen-coordinates) against contact_block_update (the oracle's formula) on 200 000 random 3 x 3
+    blocks -- anisotropic friction, contacts without a normal force yet, nearly singular friction blocks: forces and cost change equal
+    to 1e-9 relative, a third of the updates ending ON the cone"""
+    import ctypes as C
+    L = C.CDLL(os.path.join(ROOT, "tests", "emu", "libsgtreeemu.so"))
+    L.temu_block_update_check.argtypes = [C.c_int, C.c_uint] + [C.POINTER(C.c_double)] * 2 + [C.POINTER(C.c_int)] * 2
+    mdf, mrel, ns, nr = C.c_double(), C.c_double(), C.c_int(), C.c_int()
+    bad = L.temu_block_update_check(200000, 7, C.byref(mdf), C.byref(mrel), C.byref(ns), C.byref(nr))
+    assert bad == 0 and mrel.value < 1e-9, (bad, mdf.value, mrel.value)
+    assert ns.value > 20000 and nr.value < 150000, (ns.value, nr.value)
