@@ -441,7 +441,6 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
             cpos[r][0] = EL(SGE_GX, e) + ax[0] * dq; cpos[r][1] = EL(SGE_GY, e) + ax[1] * dq; cpos[r][2] = EL(SGE_GZ, e) + ax[2] * dq;
             if (!(qe[r] > EL(SGE_QLO, e) && qe[r] < EL(SGE_QHI, e))) unsupported = 1;
             Sm.ve[e] = ve[r]; Sm.asme[e] = asme[r]; Sm.we[e] = we[r];
-            Sm.owner[0][e] = 0; Sm.owner[1][e] = 0;
             *(unsigned int*)&Sm.eslot[e][0] = 0u;
             Sm.as[e] = qe[r];  // scratch until recompute_a: the dense narrowphase below reads other lanes' slider positions
           }
@@ -546,7 +545,6 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
             nsc[cc] += __popcll(m1) + __popcll(m2);
             if (nsc[cc] > 32 * CPL) { nsc[cc] = 32 * CPL; overflow = 1; }
           }
-          if (n > 0 && !is_center) Sm.owner[c][e] = 1;
 #pragma unroll
           for (int bb = 0; bb < SG_MAXCH * SG_CG; bb++)
             if (__ballot(n > 0 && b == bb)) touch |= 1 << bb;
@@ -629,7 +627,7 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
 #pragma unroll
           for (int r = 0; r < R; r++) {
             const int e = r * 64 + lane;
-            if (e < N) { *(unsigned int*)&Sm.eslot[e][0] = 0u; Sm.owner[0][e] = 0; Sm.owner[1][e] = 0; }
+            if (e < N) *(unsigned int*)&Sm.eslot[e][0] = 0u;
           }
           __syncthreads();
         }
@@ -638,7 +636,9 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
 #pragma unroll
       for (int r = 0; r < R; r++) {
         int e = r * 64 + lane;
-        if (e < N && Sm.owner[0][e] && Sm.owner[1][e]) shared_slider = 1;
+        // (a slider under both fingers: both chains hold a contact slot of this element -- eslot[e][2 c .. 2 c + 1], SG_CG = 2 boxes a chain)
+        static_assert(SG_MAXCH == 2 && SG_CG == 2, "the shared-slider test reads an element's four slot bytes as two halves");
+        if (e < N && ((const unsigned short*)&Sm.eslot[e][0])[0] != 0 && ((const unsigned short*)&Sm.eslot[e][0])[1] != 0) shared_slider = 1;
       }
       shared_slider = __ballot(shared_slider) != 0;
 
@@ -795,10 +795,16 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
       constexpr int ND = NB ? 3 : 0;  // neighbour rows per element (loops over d vanish without them)
       int nbe2[R][3], nbid[R][3];
       double nbc0[R][3];  // f (R f / 2 + b)
+      // the rows' warmstart forces: in registers on the lane that builds them, and in the work space (W.nbf, where the solver takes them
+      // from) for the one cross-lane use -- an element gathering the rows that have it as SECOND joint.  Until r04 an LDS array by
+      // row id (6 KB for the ball): without it the kernel's LDS block is 23 KB instead of 29 (ball) / 20 instead of 25 (cylinder):
+      // 7 / 8 workgroups per CU instead of 5 / 6, the 4096 wavefronts in 2.3 / 2 rounds instead of 3.2 / 2.7
+      [[maybe_unused]] double nbff[R][3];
+      [[maybe_unused]] double* const gnbf = W.nbf + (size_t)env * 3 * N;
 #pragma unroll
       for (int r = 0; r < R; r++)
 #pragma unroll
-        for (int d = 0; d < 3; d++) { nbe2[r][d] = -1; nbid[r][d] = -1; nbc0[r][d] = 0; }
+        for (int d = 0; d < 3; d++) { nbe2[r][d] = -1; nbid[r][d] = -1; nbc0[r][d] = 0; nbff[r][d] = 0; }
       if constexpr (NB) {
         // The solver's step factors c = (1/m) / (A + R) of the block [fix_e, e's neighbour rows] (A = 1/m for the fix row, 2/m for a
         // neighbour row: equal masses, sg_plan_build) go out in the SOLVER's order: four consecutive doubles at the place of the
@@ -824,7 +830,7 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
                 const double aref = -H.eqj_B * (ve[r] - Sm.ve[e2]) - H.eqj_K * imp * pos;
                 const double bb = (asme[r] - Sm.asme[e2]) - aref, ff = -((we[r] - Sm.we[e2]) - aref) / Rr;
                 nbe2[r][d] = e2; nbid[r][d] = id; nbc0[r][d] = ff * (0.5 * Rr * ff + bb);
-                Sm.nbf[id] = ff;
+                nbff[r][d] = ff; gnbf[id] = ff;
                 W.nbb[(size_t)env * 3 * N + id] = bb; W.nbR[(size_t)env * 3 * N + id] = Rr;
                 if (wantc) c4[1 + d] = sg_div(im0, 2.0 * im0 + Rr);
               }
@@ -855,9 +861,12 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
             double fe = eqf[r] + coef[r] * tf;
             if constexpr (NB) {  // + its own neighbour rows (J = +1), - the rows that have it as second joint (J = -1), in row order per side
 #pragma unroll
-              for (int d = 0; d < 3; d++) if (nbid[r][d] >= 0) fe += Sm.nbf[nbid[r][d]];
+              for (int d = 0; d < 3; d++) if (nbid[r][d] >= 0) fe += nbff[r][d];
+              double fin[3];   // (the three loads go out together: one round trip to L2, behind the barrier that made the stores visible)
 #pragma unroll
-              for (int d = 0; d < 3; d++) { const int ii = nbtabc[(6 + d) * N + e]; if (ii >= 0) fe -= Sm.nbf[ii]; }
+              for (int d = 0; d < 3; d++) { const int ii = nbtabc[(6 + d) * N + e]; fin[d] = ii >= 0 ? gnbf[ii] : 0.0; }
+#pragma unroll
+              for (int d = 0; d < 3; d++) fe -= fin[d];
             }
             double as_ = invm[r] * fe;
 #pragma unroll
@@ -915,7 +924,7 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
             double ae = Sm.as[e]; cp += eqf[r] * (0.5 * (ae + eqR[r] * eqf[r]) + eqb[r]); tJap += coef[r] * ae;
 #pragma unroll
             for (int d = 0; d < ND; d++)
-              if (nbid[r][d] >= 0) cp += 0.5 * Sm.nbf[nbid[r][d]] * (ae - Sm.as[nbe2[r][d]]) + nbc0[r][d];
+              if (nbid[r][d] >= 0) cp += 0.5 * nbff[r][d] * (ae - Sm.as[nbe2[r][d]]) + nbc0[r][d];
           }
         }
         double tJa = wave_sum2(tJap);
@@ -957,7 +966,7 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
           for (int r = 0; r < R; r++) {
             eqf[r] = 0;
 #pragma unroll
-            for (int d = 0; d < ND; d++) if (nbid[r][d] >= 0) Sm.nbf[nbid[r][d]] = 0.0;
+            for (int d = 0; d < ND; d++) if (nbid[r][d] >= 0) { nbff[r][d] = 0.0; gnbf[nbid[r][d]] = 0.0; }
           }
           tf = 0;
           if (is_chain_lane) {
@@ -996,9 +1005,7 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
         if (e < N) {
           size_t o = (size_t)env * N + e;
           W.as[o] = Sm.as[e]; W.eqf[o] = eqf[r]; W.eqb[o] = eqb[r]; W.eqR[o] = eqR[r];
-#pragma unroll
-          for (int d = 0; d < ND; d++)
-            if (nbid[r][d] >= 0) W.nbf[(size_t)env * 3 * N + nbid[r][d]] = Sm.nbf[nbid[r][d]];
+          // (W.nbf holds the neighbour rows' forces already: written where they were built, zeroed with the rest when the warmstart lost)
         }
       }
       if (is_chain_lane) {

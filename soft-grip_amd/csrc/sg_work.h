@@ -114,11 +114,9 @@ struct Smem2 {
   double boxp[SG_MAXCH * SG_CG][3], boxm[SG_MAXCH * SG_CG][9];
   double ve[R * 64], asme[R * 64], we[R * 64], as[R * 64];
   StageRec2 stage[SG_MAXCH][32 * CPL];
-  unsigned char owner[SG_MAXCH][R * 64];              // [c][e] != 0: chain c has a contact on this element's slider (plain stores of 1)
   unsigned short pairs[SG_MAXCH * SG_CG * (R * 64 + 2)];  // broadphase survivors, (box << 12) | element, in contact order
   unsigned char eslot[R * 64][SG_MAXCH * SG_CG];          // per element and box: first contact slot (< 64) | (contact count << 6)
   double cval[SG_MAXCH][32 * CPL];                        // per contact slot: invm * Js' f (its push on the slider)
-  double nbf[NB ? 3 * R * 64 : 1];                        // neighbour equality rows: warmstart force, by row id
 };
 #define SG_PAIR_CENTER 0xFFF  // element code of the object's centre sphere
 
