@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 device_sync = None   # torch.cuda.synchronize (set in main)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-PROFILE_TAG = "r04"    # profiles/<tag>_<scene>_{hbm_traffic,sq_totals}.json: the committed rocprofv3 PMC passes of this workload
+PROFILE_TAG = "r05"    # profiles/<tag>_<scene>_{hbm_traffic,sq_totals}.json: the committed rocprofv3 PMC passes of this workload
 
 
 def algorithmic_bytes_per_env_step(nq, nv, na, nu, nsens):

@@ -57,7 +57,10 @@ def build(force=False, verbose=False, prof=False, count=False, legacy=False):
                     os.remove(os.path.join(_HERE, "libsoftgrip_%s.so" % name))
             shutil.rmtree(os.path.join(_HERE, "build"), ignore_errors=True)
     if count:
-        return _compile(os.path.join(_HERE, "libsoftgrip_count.so"), ["-DSG_SECTION_PROF", "-DSG_SECTION_COUNT"], verbose)
+        # (sg_phase.hip under the default machine scheduler: with iterative-ilp the compiler itself crashes in its register allocator on
+        #  this variant of sg_phase_kernel<4, ...> -- r05, ROCm 7.2.0 -- while sg_tree.hip under the DEFAULT scheduler ends in "Illegal
+        #  instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base"; the counting build's cycle stamps are not timings anyway)
+        return _compile(os.path.join(_HERE, "libsoftgrip_count.so"), ["-DSG_SECTION_PROF", "-DSG_SECTION_COUNT"], verbose, default_sched=("sg_phase.hip",))
     if prof:
         return _compile(os.path.join(_HERE, "libsoftgrip_prof.so"), ["-DSG_SECTION_PROF"], verbose)
     if legacy:
@@ -90,19 +93,20 @@ def _build_lock():
             fcntl.flock(f, fcntl.LOCK_UN)
 
 
-def _compile(out, extra, verbose, sources=SOURCES):
+def _compile(out, extra, verbose, sources=SOURCES, default_sched=()):
     with _build_lock():
-        return _compile_locked(out, extra, verbose, sources)
+        return _compile_locked(out, extra, verbose, sources, default_sched)
 
 
-def _compile_locked(out, extra, verbose, sources):
+def _compile_locked(out, extra, verbose, sources, default_sched):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    flags = FLAGS + extra + (["-Rpass-analysis=kernel-resource-usage"] if verbose else [])
-    objdir = os.path.join(_HERE, "build", hashlib.sha1(" ".join(FLAGS + extra).encode()).hexdigest()[:12])
+    flags_all = FLAGS + extra + (["-Rpass-analysis=kernel-resource-usage"] if verbose else [])
+    objdir = os.path.join(_HERE, "build", hashlib.sha1(" ".join(FLAGS + extra + list(default_sched)).encode()).hexdigest()[:12])
     os.makedirs(objdir, exist_ok=True)
     hdrs = _headers()
 
     def one(src):
+        flags = [f for f in flags_all if f not in ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")] if src in default_sched else flags_all
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         path = os.path.join(CSRC, src)
         if not verbose and not _stale(obj, [path] + hdrs):

@@ -871,11 +871,16 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
 #if defined(SG_SECTION_PROF)
           if (threadIdx.x == 0) { atomicAdd(&A.secprof[40], (unsigned long long)nslot); atomicAdd(&A.secprof[41], 1ull); }   // update slots per pass
 #endif
+          const bool one_batch = nb == 1;   // (K <= 4: a group keeps ITS chain's accelerations in registers over the whole pass)
           int ci_safe = 0;   // (level 0 holds a contact: what a group without one in a slot reads; nothing of it is applied)
           for (int c = K - 1; c >= 0; c--) { const int x = lvl[c]; ci_safe = x >= 0 ? x : ci_safe; }
-          const bool one_batch = nb == 1;   // (K <= 4: a group keeps ITS chain's accelerations in registers over the whole pass)
-          auto chain_of = [&](int sl_) { return 4 * (sl_ % nb) + grp; };
-          auto contact_of = [&](int sl_) { const int c = chain_of(sl_); return (sl_ < nslot && c < K) ? lvl[(sl_ / nb) * K + c] : -1; };
+          // (K <= 4, every reference scene: slot = level, the group's chain is fixed -- no divisions by the batch count in the loop)
+          auto chain_of = [&](int sl_) { return one_batch ? grp : 4 * (sl_ % nb) + grp; };
+          auto contact_of = [&](int sl_) {
+            if (one_batch) return (sl_ < nslot && grp < K) ? lvl[sl_ * K + grp] : -1;
+            const int c = chain_of(sl_);
+            return (sl_ < nslot && c < K) ? lvl[(sl_ / nb) * K + c] : -1;
+          };
           int cc = grp < K ? grp : 0;
           double a0 = lo_w ? aFL[cc * CS + l] : 0.0, a1 = hi_w ? aFL[cc * CS + l + 16] : 0.0;   // (0 on a lane without a word: its J a terms vanish)
 #if defined(SG_SECTION_PROF)
