@@ -62,7 +62,7 @@ def build(force=False, verbose=False, prof=False, count=False, legacy=False):
         #  instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base"; the counting build's cycle stamps are not timings anyway)
         return _compile(os.path.join(_HERE, "libsoftgrip_count.so"), ["-DSG_SECTION_PROF", "-DSG_SECTION_COUNT"], verbose, default_sched=("sg_phase.hip",))
     if prof:
-        return _compile(os.path.join(_HERE, "libsoftgrip_prof.so"), ["-DSG_SECTION_PROF"], verbose)
+        return _compile(os.path.join(_HERE, "libsoftgrip_prof.so"), ["-DSG_SECTION_PROF"], verbose, default_sched=("sg_phase.hip",))   # (as for --count, below)
     if legacy:
         if not force and not needs_build(LEGACY_LIB, SOURCES + LEGACY_SOURCES):
             return LEGACY_LIB
