@@ -60,6 +60,9 @@ using namespace sgm;
 #define SGT_LDS_HEADER 2   // doubles at the head of the env's LDS block (lds_carve)
 #define SGT_CSC 56       // scalar doubles of a contact record in the work space
 #define SGT_LROW 6       // doubles of a chain limit row: dof, sign, R, b, f, 1 / (A + R)
+#ifndef SGT_LROW_AHEAD
+#define SGT_LROW_AHEAD 4 // register sets of the sweep's chain-limit-row pass (lookahead + 1).  8 measured: four-finger 196.6 -> 193.0 k, free ball 51.7 -> 49.8 k (r05 t9)
+#endif
 
 struct TreeArgs {
   const SgPlanHeader* H;
@@ -770,17 +773,21 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
           if (hi_w) a1 += q.m1 * dfl;
           if (act && l == 0) { imp_par -= ch; rows[SGT_LROW * i + 4] = f; }
         };
-        LRec qa, qb, qc, qd;   // four register sets: a row's words are requested three rows ahead (M^-1 sits in the work space: ~1 us away)
-        if (nmax > 0) { load_row(qa, 0); load_row(qb, 1); load_row(qc, 2); }
-        for (int i = 0; i < nmax; i += 4) {
-          load_row(qd, i + 3);
-          update_row(qa, i);
-          load_row(qa, i + 4);
-          update_row(qb, i + 1);
-          load_row(qb, i + 5);
-          update_row(qc, i + 2);
-          load_row(qc, i + 6);
-          update_row(qd, i + 3);
+        // SGT_LROW_AHEAD register sets: a row's words and its row of M^-1 -- two dependent round trips away: the row's dof index from LDS, then
+        // the work space -- are requested SGT_LROW_AHEAD - 1 rows ahead.  Seven ahead instead of three measured SLOWER (r05): the wait is
+        // not the loads' latency
+        constexpr int AH = SGT_LROW_AHEAD;
+        LRec q[AH];
+        if (nmax > 0) {
+#pragma unroll
+          for (int k = 0; k < AH - 1; k++) load_row(q[k], k);
+        }
+        for (int i = 0; i < nmax; i += AH) {
+#pragma unroll
+          for (int k = 0; k < AH; k++) {
+            load_row(q[(k + AH - 1) % AH], i + k + AH - 1);
+            update_row(q[k], i + k);
+          }
         }
         if (c < K) {
           if (lo_w) aFL[cc * CS + l] = a0;

@@ -106,6 +106,18 @@ class ManEnv(Env):
                              "joint_ids / tendon_ids" % (path, self.model.nv, self.model.ntendon, min(self.joint_ids), max(self.joint_ids),
                                                          self.tendon_ids))
         self.nmodel = native.NativeModel(self.model)
+        if self.check_scene:
+            # the load-time check runs BEFORE the batch is made, on a batch of ONE env: the dry run uses the model's own stiffness, so
+            # every env of a batch would do exactly the same (r04 ran it on all n_envs and, for a scene that needs the implicit damper,
+            # allocated two full batches: a third of the three-scene quick start's wall time, profiles/r05a_dataset_end_to_end.txt)
+            try:
+                self._check_scene(path)
+            except SimulationError as err:
+                if want != "auto" or self.tendon_damper == "implicit":
+                    raise
+                print("NOTICE: %s\n        reloading it with tendon_damper=\"implicit\" (DESIGN.md D5)" % err)
+                self._load(path, "implicit")
+                return
         self.env = native.NativeBatch(self.nmodel, self.n_envs, self.device_index)
         dev = self.env.device
         self._sens = torch.zeros(self.n_envs, self.nmodel.nsensordata, dtype=torch.float64, device=dev)
@@ -125,14 +137,7 @@ class ManEnv(Env):
         # list per env, kept on the device as a bit mask (bit i = finger_names[i] not yet removed)
         self._fingers_left = torch.full((self.n_envs,), (1 << len(self._finger_bits_names)) - 1, dtype=torch.int32, device=dev)
         if self.check_scene:
-            try:
-                self._check_scene(path)
-            except SimulationError as err:
-                if want != "auto" or self.tendon_damper == "implicit":
-                    raise
-                print("NOTICE: %s\n        reloading it with tendon_damper=\"implicit\" (DESIGN.md D5)" % err)
-                self._load(path, "implicit")
-                return
+            self.env.reset(0, flags=self._flags)   # the state after mj_resetData (a fresh MjSim's), as the check on the whole batch used to leave it
         self._scenes[path] = {k: getattr(self, k) for k in self._SCENE_STATE}
         while len(self._scenes) > max(1, self.max_cached_scenes):      # least recently used first; never the scene just loaded
             self._scenes.pop(next(iter(self._scenes)))
@@ -151,12 +156,13 @@ class ManEnv(Env):
         and every reset starts there again -- the reference's `except MujocoException: self.reset()` (manenv.py:50-51) would
         loop forever."""
         import torch
-        flags = torch.zeros_like(self._flags)
-        bad = torch.zeros_like(self._flags)
-        self.env.reset(max(self.sim_start, 0), flags=flags)
+        probe = native.NativeBatch(self.nmodel, 1, self.device_index)      # (one env: see _load)
+        flags = torch.zeros(1, dtype=torch.int32, device=probe.device)
+        bad = torch.zeros_like(flags)
+        probe.reset(max(self.sim_start, 0), flags=flags)
         bad |= flags
         for _ in range(n_steps):
-            self.env.step(self.sim_step, flags=flags)
+            probe.step(self.sim_step, flags=flags)
             bad |= flags
         if bool((bad != 0).any()):
             names = {1: "BADQPOS", 2: "BADQVEL", 4: "BADQACC", 8: "CONTACTFULL", 16: "CNSTRFULL", 32: "UNSUPPORTED_PAIR"}
@@ -164,7 +170,6 @@ class ManEnv(Env):
             raise SimulationError("scene %s does not survive its own idle phase with the %s tendon damper (flags %s within %d env steps "
                                   "at ctrl = 0); no dataset can be generated from it this way (check_scene=False loads it anyway)"
                                   % (path, self.tendon_damper, "|".join(v for k, v in names.items() if f & k), n_steps))
-        self.env.reset(0, flags=flags)   # back to the state after mj_resetData
 
     def _chain_geom_bits(self):
         """bit index -> geom name for the moving finger boxes, in the kernels' order: (chain, body, geom) = geom id order (two boxes

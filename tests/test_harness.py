@@ -222,7 +222,7 @@ def test_labels_are_the_pre_episode_draw_after_a_mid_episode_failure(fake_native
         orig(self, n, sens, flags, touch)
         calls["n"] += 1
         if calls["n"] == 12 and flags is not None and not self.nmodel.model.opt_implicit_tendon_damping:
-            flags[1] = 32
+            flags[-1] = 32     # (the load-time check runs on a one-env probe batch since r05)
     monkeypatch.setattr(fake_native, "_advance", failing)
     with pytest.raises(manenv.SimulationError, match="explicit tendon damper .flags UNSUPPORTED_PAIR"):
         manenv.ManEnv(1, 7, [model_path("softbox")], is_vis=False, n_envs=2, tendon_damper="explicit")
@@ -303,7 +303,7 @@ def test_load_env_of_a_scene_seen_before_reuses_its_batch(fake_native, monkeypat
 
     def counting_init(self, nmodel, n_envs, device=0):
         nmodel.model_path = nmodel.model._path
-        made.append(os.path.basename(nmodel.model_path))
+        made.append((os.path.basename(nmodel.model_path), n_envs))
         real_init(self, nmodel, n_envs, device)
     monkeypatch.setattr(manenv, "load_model", logging_load)
     monkeypatch.setattr(fake_native, "__init__", counting_init)
@@ -313,7 +313,8 @@ def test_load_env_of_a_scene_seen_before_reuses_its_batch(fake_native, monkeypat
     env.load_env(1)
     assert env.tendon_damper == "implicit" and "reloading it" in capsys.readouterr().out
     n_loads, n_made = len(loads), len(made)
-    assert n_loads == 3 and made == ["softbox_fix.sgmodel", "softball_fix.sgmodel", "softball_fix.sgmodel"]   # box; ball explicit, then implicit
+    # box: the one-env probe of the load-time check, then the batch; ball: the probe under the explicit damper (fails), the probe and the batch under the implicit one
+    assert n_loads == 3 and made == [("softbox_fix.sgmodel", 1), ("softbox_fix.sgmodel", 2), ("softball_fix.sgmodel", 1), ("softball_fix.sgmodel", 1), ("softball_fix.sgmodel", 2)]
     for _ in range(3):                                 # the episode loop: box, ball, box, ball ...
         env.load_env(0)
         assert env.tendon_damper == "explicit" and env.model.opt_implicit_tendon_damping == 0
