@@ -730,6 +730,91 @@ SG_HD double sg_rsqrt(double q) {   // 1 / sqrt(q), q > 0
   return 1.0 / sqrt(q);
 #endif
 }
+// mju_QCQP2's Newton iteration on the multiplier, evaluations 1 .. 19, in the eigen-coordinates of the friction block (contact_block_update_pre
+// below) -- the loop BY HAND on the device: the rows pipeline's (sg_rows.hip update_row, where it is written out in place: moved behind this
+// function the compiler fused the products after it differently and the box scene lost 1.4 %), for the tree pipeline's block update (r05:
+// four-finger scene +0.5 %).  la: in / out; x1, x2: e_k + la of the last evaluation.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SG_SECTION_COUNT)
+#define SG_NEWTON_BY_HAND 1
+__device__ __forceinline__ void qcqp_newton_by_hand(const double e1, const double e2, const double C1h, const double C2h, const double R2h, double& la, double& x1, double& x2) {
+  // the loop by hand (the compiler's lowering of the divergent loop spends 14 of its 41 instructions per evaluation on exec-mask
+  // bookkeeping; a lone wavefront pays ~7 cycles for each, scalar or vector): 28 instructions per evaluation, two evaluations
+  // per trip.  Lanes leave by having their exec bit cleared; exec is restored at the end.  v_rcp_f64 (a transcendental-unit op) has two independent
+  // instructions between it and its first consumer.
+  double y1, y2, xx, ah, bh, yy, nh, dh, rc, nx, er, dl, ox1, ox2;  // ox1, ox2: early-clobber outputs (as read-write
+  unsigned long long sv, m0, m1;                                    // operands initialised with e1, e2 they were given e1's, e2's registers)
+  unsigned cnt;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "s_mov_b32 %[cnt], 19\n"      // evaluations 1 .. 19 (the fast path did evaluation 0): nine trips of two and one more
+      "1:\n\t"
+      "v_add_f64 %[x1], %[e1], %[la]\n\t"
+      "v_add_f64 %[x2], %[e2], %[la]\n\t"
+      "v_mul_f64 %[y1], %[x1], %[x1]\n\t"
+      "v_mul_f64 %[y2], %[x2], %[x2]\n\t"
+      "v_mul_f64 %[xx], %[x1], %[x2]\n\t"
+      "v_mul_f64 %[ah], %[C1h], %[y2]\n\t"
+      "v_mul_f64 %[bh], %[C2h], %[y1]\n\t"
+      "v_mul_f64 %[yy], %[y1], %[y2]\n\t"
+      "v_add_f64 %[nh], %[ah], %[bh]\n\t"
+      "v_mul_f64 %[dh], %[bh], %[x1]\n\t"
+      "v_fma_f64 %[nh], %[nR2h], %[yy], %[nh]\n\t"
+      "v_fma_f64 %[dh], %[ah], %[x2], %[dh]\n\t"
+      "v_cmp_gt_f64_e64 %[m0], %[tol], %[xx]\n\t"
+      "v_add_f64 %[dh], %[dh], %[dh]\n\t"
+      "v_mul_f64 %[yy], %[yy], %[tolh]\n\t"
+      "v_rcp_f64_e32 %[rc], %[dh]\n\t"
+      "v_mul_f64 %[nx], %[nh], %[xx]\n\t"
+      "v_cmp_lt_f64_e64 %[m1], %[nh], %[yy]\n\t"
+      "v_fma_f64 %[er], -%[dh], %[rc], 1.0\n\t"
+      "s_or_b64 %[m0], %[m0], %[m1]\n\t"
+      "v_fma_f64 %[rc], %[er], %[rc], %[rc]\n\t"
+      "v_mul_f64 %[dl], %[nx], %[rc]\n\t"
+      "v_cmp_gt_f64_e64 %[m1], %[tol], %[dl]\n\t"
+      "s_or_b64 %[m0], %[m0], %[m1]\n\t"
+      "s_andn2_b64 exec, exec, %[m0]\n\t"
+      "s_cbranch_execz 2f\n\t"
+      "v_add_f64 %[la], %[la], %[dl]\n\t"
+      "s_cmp_eq_u32 %[cnt], 1\n\t"
+      "s_cbranch_scc1 2f\n\t"
+      "v_add_f64 %[x1], %[e1], %[la]\n\t"
+      "v_add_f64 %[x2], %[e2], %[la]\n\t"
+      "v_mul_f64 %[y1], %[x1], %[x1]\n\t"
+      "v_mul_f64 %[y2], %[x2], %[x2]\n\t"
+      "v_mul_f64 %[xx], %[x1], %[x2]\n\t"
+      "v_mul_f64 %[ah], %[C1h], %[y2]\n\t"
+      "v_mul_f64 %[bh], %[C2h], %[y1]\n\t"
+      "v_mul_f64 %[yy], %[y1], %[y2]\n\t"
+      "v_add_f64 %[nh], %[ah], %[bh]\n\t"
+      "v_mul_f64 %[dh], %[bh], %[x1]\n\t"
+      "v_fma_f64 %[nh], %[nR2h], %[yy], %[nh]\n\t"
+      "v_fma_f64 %[dh], %[ah], %[x2], %[dh]\n\t"
+      "v_cmp_gt_f64_e64 %[m0], %[tol], %[xx]\n\t"
+      "v_add_f64 %[dh], %[dh], %[dh]\n\t"
+      "v_mul_f64 %[yy], %[yy], %[tolh]\n\t"
+      "v_rcp_f64_e32 %[rc], %[dh]\n\t"
+      "v_mul_f64 %[nx], %[nh], %[xx]\n\t"
+      "v_cmp_lt_f64_e64 %[m1], %[nh], %[yy]\n\t"
+      "v_fma_f64 %[er], -%[dh], %[rc], 1.0\n\t"
+      "s_or_b64 %[m0], %[m0], %[m1]\n\t"
+      "v_fma_f64 %[rc], %[er], %[rc], %[rc]\n\t"
+      "v_mul_f64 %[dl], %[nx], %[rc]\n\t"
+      "v_cmp_gt_f64_e64 %[m1], %[tol], %[dl]\n\t"
+      "s_or_b64 %[m0], %[m0], %[m1]\n\t"
+      "s_andn2_b64 exec, exec, %[m0]\n\t"
+      "v_add_f64 %[la], %[la], %[dl]\n\t"   // (with every lane masked off this adds nothing)
+      "s_sub_u32 %[cnt], %[cnt], 2\n\t"
+      "s_cbranch_execnz 1b\n"
+      "2:\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : [x1] "=&v"(ox1), [x2] "=&v"(ox2), [la] "+v"(la), [y1] "=&v"(y1), [y2] "=&v"(y2), [xx] "=&v"(xx), [ah] "=&v"(ah), [bh] "=&v"(bh),
+        [yy] "=&v"(yy), [nh] "=&v"(nh), [dh] "=&v"(dh), [rc] "=&v"(rc), [nx] "=&v"(nx), [er] "=&v"(er), [dl] "=&v"(dl),
+        [sv] "=&s"(sv), [m0] "=&s"(m0), [m1] "=&s"(m1), [cnt] "=&s"(cnt)
+      : [e1] "v"(e1), [e2] "v"(e2), [C1h] "v"(C1h), [C2h] "v"(C2h), [nR2h] "v"(-R2h), [tol] "s"(1e-10), [tolh] "s"(0.5e-10)
+      : "vcc", "scc");
+  x1 = ox1; x2 = ox2;
+}
+#endif
 SG_HD double contact_block_update_pre(const double* A, const double* Pe, const double* res, double* f, const double* mu, double* df) {
   const double o0 = f[0], o1 = f[1], o2 = f[2];
   const double A00 = A[0], A01 = A[1], A02 = A[2], A11 = A[3], A12 = A[4], A22 = A[5];
@@ -767,6 +852,9 @@ SG_HD double contact_block_update_pre(const double* A, const double* Pe, const d
     const bool ever = run;
     double x1 = e1, x2 = e2;
     if (run) {
+#ifdef SG_NEWTON_BY_HAND
+      qcqp_newton_by_hand(e1, e2, C1h, C2h, R2h, la, x1, x2);
+#else
       for (int it = 1; it < 20; it++) {
         x1 = e1 + la; x2 = e2 + la;
         const double y1 = x1 * x1, y2 = x2 * x2, ah = C1h * y2, bh = C2h * y1, yy = y1 * y2;
@@ -777,6 +865,7 @@ SG_HD double contact_block_update_pre(const double* A, const double* Pe, const d
         if (xx < 1e-10 || Nh < 0.5e-10 * yy || delta < 1e-10) break;
         la += delta;
       }
+#endif
     }
     const double det = x1 * x2;
     const double t1e = -c1 * x2, t2e = -c2 * x1;   // last evaluation, back in the contact's coordinates: v = Q (-c1 / x1, -c2 / x2) = (t1, t2) / det
