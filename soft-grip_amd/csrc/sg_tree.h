@@ -518,6 +518,112 @@ static SGT_NOINLINE double free_fix_rows(const SGT_LDSP double* frow, const SGT_
   return imp;
 #endif
 }
+#if SGT_DEVICE && !defined(SGT_X_ROWS8LANE) && !defined(SGT_X_ROWS1LANE)
+#define SGT_FIXROWS_BLOCKED 1
+// The free object's joint-fix rows IN BLOCKS (r05).  A row's update is affine in the body's acceleration a_f -- with u = B_e . a_f its force
+// step is d = alpha_e + beta_e u (alpha_e = -(b + a_e + R f) / (A + R) from the row's own state, beta_e = (1 / D_e) / (A + R)) and
+// a_f' = a_f + C_e d = (I + beta_e C_e B_e') a_f + alpha_e C_e -- and an equality row is never clamped or reverted (its step always lowers the
+// cost: scalar_update_rcp's test cannot fire), so the sweep over the N rows is a chain of N affine maps of a 6-vector.  One after the other
+// on eight lanes it was 500 cycles a row, 218 rows, 30 sweeps: 40 - 48 % of a free-ball substep (profiles/r05_tree_sections_freeball.txt).
+// Here lane b < 32 owns a BLOCK of L consecutive rows (L = ceil(N / 32), made odd: the lanes' LDS addresses then fall into different banks):
+//   1. every lane runs its block from a_f = 0 (-> c_b) and, beside it, the six unit vectors without the rows' alpha (-> M_b, 6 x 6):
+//      the block as ONE affine map a_f -> M_b a_f + c_b.  M_b is constant over a substep's sweeps, but 36 values per lane have nowhere to
+//      stay between two calls (the env's LDS block is full), so they are rebuilt: 78 instructions a row;
+//   2. the scan: a_f at the start of block b + 1 = M_b (a_f at the start of block b) + c_b, block after block, the running a_f in scalar
+//      registers (one matrix-vector product on every lane, lane b's result read back: ~57 instructions a block);
+//   3. every lane runs its block again from its true start, now as the serial code does -- residual, force, cost, the slider's local part.
+// ~3 300 instructions a sweep instead of 218 x 70.  Same mathematics as mj_solPGS's row-after-row sweep; the rounding differs (a block's
+// successors see M_b a + c_b, not the sum its own rows accumulate: relative 1e-16 per block), as it already did between the oracle's serial
+// dot product and the eight-lane tree sum.  Host builds (the emulation) keep the serial loop above.
+static SGT_NOINLINE double free_fix_rows_blocked(const SGT_LDSP double* frow, const SGT_LDSP double* Be, const SGT_LDSP double* einvm, const SGT_LDSP double* Sinv,
+                                                 SGT_LDSP double* ffix, SGT_LDSP double* ae, SGT_LDSP double* af, int N) {
+  const int lane = (int)threadIdx.x;
+  const int L = ((N + 31) >> 5) | 1, nblk = (N + L - 1) / L;      // (uniform)
+  const bool act = lane < nblk;
+  const int e0 = act ? lane * L : 0;
+  double Si[36];
+#pragma unroll
+  for (int k = 0; k < 36; k++) Si[k] = Sinv[k];
+  struct Row { double b, R, A, I, B[6], C[6], f, al, im, z; int e; };
+  auto load = [&](Row& w, int r) {
+    const int e = e0 + r;
+    const bool ok = act && e < N;
+    const int ec = ok ? e : 0;
+    w.e = ec; w.z = ok ? 1.0 : 0.0;
+    w.b = frow[4 * ec]; w.R = frow[4 * ec + 1]; w.A = frow[4 * ec + 2]; w.I = frow[4 * ec + 3];
+#pragma unroll
+    for (int k = 0; k < 6; k++) w.B[k] = Be[6 * ec + k];
+    w.f = ffix[ec]; w.al = ae[ec]; w.im = einvm[ec];
+  };
+  auto cvec = [&](Row& w) {   // C_e = -S^-1 B_e / D_e (same expressions as the rows' build and the serial loop)
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+      w.C[q] = -(((Si[6 * q] * w.B[0] + Si[6 * q + 1] * w.B[1]) + (Si[6 * q + 2] * w.B[2] + Si[6 * q + 3] * w.B[3])) + (Si[6 * q + 4] * w.B[4] + Si[6 * q + 5] * w.B[5])) * w.im;
+  };
+  // ---- 1. my block as an affine map
+  double c[6] = {0, 0, 0, 0, 0, 0}, M[36];
+#pragma unroll
+  for (int k = 0; k < 36; k++) M[k] = (k % 7 == 0) ? 1.0 : 0.0;
+  {
+    Row w, wn;
+    load(wn, 0);
+    for (int r = 0; r < L; r++) {
+      w = wn;
+      load(wn, r + 1 < L ? r + 1 : r);
+      cvec(w);
+      const double beta = w.z * w.I * w.im, alpha = -(w.z * w.I) * ((w.b + w.al) + w.R * w.f);
+      const double d = alpha + beta * dot6(w.B, c);
+#pragma unroll
+      for (int q = 0; q < 6; q++) c[q] += w.C[q] * d;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {   // column k of M
+        const double uk = beta * (((w.B[0] * M[k] + w.B[1] * M[6 + k]) + (w.B[2] * M[12 + k] + w.B[3] * M[18 + k])) + (w.B[4] * M[24 + k] + w.B[5] * M[30 + k]));
+#pragma unroll
+        for (int q = 0; q < 6; q++) M[6 * q + k] += w.C[q] * uk;
+      }
+    }
+  }
+  // ---- 2. the scan over the blocks: the running a_f is uniform (scalar registers), lane b keeps the value it had in front of block b
+  double au[6], ain[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) { au[q] = af[q]; ain[q] = au[q]; }
+  for (int b = 0; b < nblk; b++) {
+    double t[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+      t[q] = ((c[q] + M[6 * q] * au[0]) + (M[6 * q + 1] * au[1] + M[6 * q + 2] * au[2])) + ((M[6 * q + 3] * au[3] + M[6 * q + 4] * au[4]) + M[6 * q + 5] * au[5]);
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      au[q] = readlane64(t[q], b);
+      ain[q] = lane > b ? au[q] : ain[q];
+    }
+  }
+  // ---- 3. my block's rows from their true start, as the serial sweep runs them
+  double imp = 0;
+  {
+    Row w, wn;
+    load(wn, 0);
+    for (int r = 0; r < L; r++) {
+      w = wn;
+      load(wn, r + 1 < L ? r + 1 : r);
+      cvec(w);
+      const double Ja = w.al - dot6(w.B, ain) * w.im;
+      const double res = w.b + Ja + w.R * w.f, fn = w.f - res * w.I, d = w.z * (fn - w.f);
+      imp -= 0.5 * d * d * w.A + d * res;
+      if (w.z != 0.0) { ffix[w.e] = fn; ae[w.e] = w.al + w.im * d; }
+#pragma unroll
+      for (int q = 0; q < 6; q++) ain[q] += w.C[q] * d;
+    }
+  }
+  // the body's acceleration behind the last block
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    const double last = readlane64(ain[q], nblk - 1);
+    if (lane == 0) af[q] = last;
+  }
+  return imp;
+}
+#endif
 // The same with the composite's neighbour equalities: the equality BLOCKS [fix_e, e's neighbour rows (partner p: J = +1 on e, -1 on p)] in
 // mj_solPGS's order.  A neighbour row moves two sliders and, through both, the body: a_f += (C_e - C_p) df.  (The neighbour rows' words
 // sit in the work space: generic pointers.)
@@ -661,11 +767,19 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
         S.red[0] = free_eq_blocks((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.Ce, (const SGT_LDSP double*)S.einvm, (SGT_LDSP double*)S.ffix,
                                   (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N, A.nbtab, S.nbf, S.nbb, S.nbR, S.nbA, S.nbI);
       }
+#ifdef SGT_FIXROWS_BLOCKED
+      if (!NB) {   // (device: every lane a block of the rows, free_fix_rows_blocked; each lane's share of the cost change goes into the wavefront sum)
+        imp_par += free_fix_rows_blocked((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.einvm, (const SGT_LDSP double*)(S.of + OF_SINV),
+                                         (SGT_LDSP double*)S.ffix, (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N);
+        SGT_ONE { S.red[0] = 0.0; }
+      }
+#else
       if (!NB) SGT_ROW_LANES {   // (device: lanes 0 .. 7, the six components of the body's acceleration a lane each)
         const double r_ = free_fix_rows((const SGT_LDSP double*)S.frow, (const SGT_LDSP double*)S.Be, (const SGT_LDSP double*)S.einvm, (const SGT_LDSP double*)(S.of + OF_SINV),
                                         (SGT_LDSP double*)S.ffix, (SGT_LDSP double*)S.ae, (SGT_LDSP double*)(S.of + OF_AF), N);
         SGT_ONE { S.red[0] = r_; }
       }
+#endif
       SGT_SYNC();
       imp_uni += S.red[0];
       SGT_PAR(e, N) S_ae += S.ecoef[e] * S.ae[e];
