@@ -1136,13 +1136,29 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
       const SGT_LDSP double* const einvmL = (const SGT_LDSP double*)S.einvm;
       const SGT_LDSP double* const CeL = (const SGT_LDSP double*)S.Ce;
       double a = dofl ? aFL[lane] : 0.0;
-      double af[6] = {0, 0, 0, 0, 0, 0}, gf[6] = {0, 0, 0, 0, 0, 0}, Si[36];
+      // (r05) The body's push a_f += S^-1 w is spread over six lanes: lane q < 6 keeps ROW q of S^-1 and computes component q, six scalar
+      // reads hand the result to every lane.  All 36 words on every lane -- parked in accumulation registers and fetched back for each
+      // product -- were 108 instructions per contact, and the slider's share C_sl dg_e = -S^-1 B_sl dg_e / D_sl a second such product:
+      // now ONE product, S^-1 (J_o' df - B_sl dg_e / D_sl).  ~900 instructions per contact before, a wavefront alone on its SIMD pays ~7
+      // cycles for each.
+      double af[6] = {0, 0, 0, 0, 0, 0}, gf[6] = {0, 0, 0, 0, 0, 0}, Siq[6] = {0, 0, 0, 0, 0, 0};
       if (FR) {
+        const int qr = (lane & 7) < 6 ? (lane & 7) : 5;
 #pragma unroll
-        for (int q = 0; q < 6; q++) { af[q] = ofL[OF_AF + q]; gf[q] = ofL[OF_GF + q]; }
-#pragma unroll
-        for (int q = 0; q < 36; q++) Si[q] = ofL[OF_SINV + q];
+        for (int q = 0; q < 6; q++) { af[q] = ofL[OF_AF + q]; gf[q] = ofL[OF_GF + q]; Siq[q] = ofL[OF_SINV + 6 * qr + q]; }
       }
+      // J a: sums over the lanes that hold chain words, the first K CS of the wavefront -- 8 for a two-finger gripper: a butterfly inside
+      // every group of eight lanes (the three rows' sums side by side: each step's DPP moves wait two cycles for the add in front of them),
+      // then one scalar read per group in use (a loop over a scalar count: a branch the compiler cannot turn into "do all and select")
+      const int ngrp = __builtin_amdgcn_readfirstlane((K * CS + 7) >> 3);
+      auto chain_sums = [&](double& x0, double& x1, double& x2) {
+        { const double t0 = dpp64<0xB1>(x0), t1 = dpp64<0xB1>(x1), t2 = dpp64<0xB1>(x2); x0 += t0; x1 += t1; x2 += t2; }
+        { const double t0 = dpp64<0x4E>(x0), t1 = dpp64<0x4E>(x1), t2 = dpp64<0x4E>(x2); x0 += t0; x1 += t1; x2 += t2; }
+        { const double t0 = dpp64<0x141>(x0), t1 = dpp64<0x141>(x1), t2 = dpp64<0x141>(x2); x0 += t0; x1 += t1; x2 += t2; }
+        double s0 = readlane64(x0, 0), s1 = readlane64(x1, 0), s2 = readlane64(x2, 0);
+        for (int gq = 1; gq < ngrp; gq++) { s0 += readlane64(x0, 8 * gq); s1 += readlane64(x1, 8 * gq); s2 += readlane64(x2, 8 * gq); }
+        x0 = s0; x1 = s1; x2 = s2;
+      };
       struct SRec { double j0, j1, j2, w0, w1, w2, A[6], Pe[7], B[3], R, invm, Js[3], slf, rowsf, objf, Jo[18]; int ci; };
       auto load_srec = [&](SRec& q, int ci) {
         const double* J = crow(ci);
@@ -1168,9 +1184,11 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
         }
       };
       auto update = [&](const SRec& q, const bool have) {
-        const int ci = q.ci, sl = (int)q.slf;
-        const bool act = have && q.rowsf != 0.0, ob = FR && q.objf != 0.0;
-        double p0 = wsum(q.j0 * a), p1 = wsum(q.j1 * a), p2 = wsum(q.j2 * a);
+        // (the record's words are the same on every lane: as scalars, the branches on them are real branches, not masked regions)
+        const int ci = q.ci, sl = __builtin_amdgcn_readfirstlane((int)q.slf);
+        const bool act = have && __builtin_amdgcn_readfirstlane((int)(q.rowsf != 0.0)) != 0, ob = FR && __builtin_amdgcn_readfirstlane((int)(q.objf != 0.0)) != 0;
+        double p0 = q.j0 * a, p1 = q.j1 * a, p2 = q.j2 * a;
+        chain_sums(p0, p1, p2);
         if (ob) { p0 += dot6(q.Jo, af); p1 += dot6(q.Jo + 6, af); p2 += dot6(q.Jo + 12, af); }
         double as_ = 0.0;
         if (sl >= 0) {
@@ -1190,24 +1208,24 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
             cfL[3 * ci] = f[0]; cfL[3 * ci + 1] = f[1]; cfL[3 * ci + 2] = f[2];
             if (sl >= 0) aeL[sl] += q.invm * dge;
           }
-          if (ob) {   // the push on the body: g_f += J_o' df; a_f += S^-1 J_o' df + C_sl dg_e
-            double dg[6], da[6];
+          if (ob) {   // the push on the body: g_f += J_o' df; a_f += S^-1 J_o' df + C_sl dg_e, C_sl = -S^-1 B_sl / D_sl
+            double dg[6], w6[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) dg[k] = q.Jo[k] * df[0] + q.Jo[6 + k] * df[1] + q.Jo[12 + k] * df[2];
-            mat6vec(da, Si, dg);
-            double Cs[6] = {0, 0, 0, 0, 0, 0};   // C_sl = -S^-1 B_sl / D_sl: the neighbour-row models keep it, the others recompute it (free_fix_rows)
+            for (int k = 0; k < 6; k++) { dg[k] = q.Jo[k] * df[0] + q.Jo[6 + k] * df[1] + q.Jo[12 + k] * df[2]; w6[k] = dg[k]; }
+            double Cs[6] = {0, 0, 0, 0, 0, 0};   // the neighbour-row models keep C_sl (S.Ce); the others fold the slider's share into the one product
             if (sl >= 0) {
-              if (NB) { for (int k = 0; k < 6; k++) Cs[k] = CeL[6 * sl + k]; }
-              else {
-                double Bs[6], Bv[6];
-                for (int k = 0; k < 6; k++) Bv[k] = BeL[6 * sl + k];
-                mat6vec(Bs, Si, Bv);
-                const double im = einvmL[sl];
-                for (int k = 0; k < 6; k++) Cs[k] = -Bs[k] * im;
+              if (NB) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) Cs[k] = CeL[6 * sl + k];
+              } else {
+                const double sh = dge * einvmL[sl];
+#pragma unroll
+                for (int k = 0; k < 6; k++) w6[k] -= BeL[6 * sl + k] * sh;
               }
             }
+            const double daq = dot6(Siq, w6);   // lane q < 6: component q of S^-1 w
 #pragma unroll
-            for (int k = 0; k < 6; k++) { gf[k] += dg[k]; af[k] += da[k] + Cs[k] * dge; }
+            for (int k = 0; k < 6; k++) { gf[k] += dg[k]; af[k] += NB ? readlane64(daq, k) + Cs[k] * dge : readlane64(daq, k); }
           }
         }
       };
