@@ -584,19 +584,23 @@ static SGT_NOINLINE double free_fix_rows_blocked(const SGT_LDSP double* frow, co
     }
   }
   // ---- 2. the scan over the blocks: the running a_f is uniform (scalar registers), lane b keeps the value it had in front of block b
-  double au[6], ain[6];
+  // (lanes below b sit the step out: lane b's t is then final -- the a_f behind ITS block -- and block b + 1 starts from its left neighbour's t)
+  double au[6], ain[6], t[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-  for (int q = 0; q < 6; q++) { au[q] = af[q]; ain[q] = au[q]; }
+  for (int q = 0; q < 6; q++) au[q] = af[q];
   for (int b = 0; b < nblk; b++) {
-    double t[6];
+    if (lane >= b) {
 #pragma unroll
-    for (int q = 0; q < 6; q++)
-      t[q] = ((c[q] + M[6 * q] * au[0]) + (M[6 * q + 1] * au[1] + M[6 * q + 2] * au[2])) + ((M[6 * q + 3] * au[3] + M[6 * q + 4] * au[4]) + M[6 * q + 5] * au[5]);
-#pragma unroll
-    for (int q = 0; q < 6; q++) {
-      au[q] = readlane64(t[q], b);
-      ain[q] = lane > b ? au[q] : ain[q];
+      for (int q = 0; q < 6; q++)
+        t[q] = ((c[q] + M[6 * q] * au[0]) + (M[6 * q + 1] * au[1] + M[6 * q + 2] * au[2])) + ((M[6 * q + 3] * au[3] + M[6 * q + 4] * au[4]) + M[6 * q + 5] * au[5]);
     }
+#pragma unroll
+    for (int q = 0; q < 6; q++) au[q] = readlane64(t[q], b);
+  }
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    const double left = dpp64<0x138>(t[q]);   // wave_shr:1 -- lane l receives lane l - 1's word
+    ain[q] = lane == 0 ? af[q] : left;
   }
   // ---- 3. my block's rows from their true start, as the serial sweep runs them
   double imp = 0;
