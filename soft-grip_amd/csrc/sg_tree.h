@@ -535,7 +535,14 @@ static SGT_NOINLINE double free_fix_rows(const SGT_LDSP double* frow, const SGT_
 // ~3 300 instructions a sweep instead of 218 x 70.  Same mathematics as mj_solPGS's row-after-row sweep; the rounding differs (a block's
 // successors see M_b a + c_b, not the sum its own rows accumulate: relative 1e-16 per block), as it already did between the oracle's serial
 // dot product and the eight-lane tree sum.  Host builds (the emulation) keep the serial loop above.
-static SGT_NOINLINE double free_fix_rows_blocked(const SGT_LDSP double* frow, const SGT_LDSP double* Be, const SGT_LDSP double* einvm, const SGT_LDSP double* Sinv,
+// (INLINED into the sweep: as a called function -- 248 registers -- it saved 44 callee-saved registers to scratch memory on every call, 30
+//  calls a substep: the free ball's fabric traffic went from 13.2 to 27.5 GB per sg_step call, profiles/r05_freeball_fix_hbm_traffic.json)
+#if defined(SGT_X_BLOCKED_CALL)
+#define SGT_BLOCKED_ATTR SGT_NOINLINE
+#else
+#define SGT_BLOCKED_ATTR __device__ __forceinline__
+#endif
+static SGT_BLOCKED_ATTR double free_fix_rows_blocked(const SGT_LDSP double* frow, const SGT_LDSP double* Be, const SGT_LDSP double* einvm, const SGT_LDSP double* Sinv,
                                                  SGT_LDSP double* ffix, SGT_LDSP double* ae, SGT_LDSP double* af, int N) {
   const int lane = (int)threadIdx.x;
   const int L = ((N + 31) >> 5) | 1, nblk = (N + L - 1) / L;      // (uniform)

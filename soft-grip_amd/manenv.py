@@ -109,7 +109,7 @@ class ManEnv(Env):
         if self.check_scene:
             # the load-time check runs BEFORE the batch is made, on a batch of ONE env: the dry run uses the model's own stiffness, so
             # every env of a batch would do exactly the same (r04 ran it on all n_envs and, for a scene that needs the implicit damper,
-            # allocated two full batches: a third of the three-scene quick start's wall time, profiles/r05a_dataset_end_to_end.txt)
+            # allocated two full batches: a third of the three-scene quick start's wall time, profiles/r05_dataset_end_to_end.txt)
             try:
                 self._check_scene(path)
             except SimulationError as err:
