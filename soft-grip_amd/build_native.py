@@ -25,10 +25,18 @@ LEGACY_SOURCES = ["sg_legacy.hip"]   # r01's fused / split pipelines: test build
 # (profiles/r02_sched_strategy.txt; max-ilp, max-memory-clause and iterative-minreg are slower, iterative-maxocc gains 2.3 %);
 # results bit-identical
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+# sg_tree.hip -fno-optimize-sibling-calls (r05): the tree kernel is a driver that CALLS its stage functions and the sweep.  A called function
+# saves the callee-saved registers it uses -- 200 - 400 of them to scratch memory at every call, although the driver keeps nothing in them:
+# 2 300 scratch instructions per substep and env, ~0.6 MB, most of the tree scenes' fabric traffic.  LLVM drops those saves for a local function
+# whose callers are all known (TargetFrameLowering::determineCalleeSaves under IPRA, which the AMDGPU target enables) -- unless a call of it
+# carries the IR's `tail` marker, which the tail-call pass puts on nearly every call.  With the pass off for this file the saves are gone:
+# 10 678 -> 1 554 scratch instructions in the translation unit (scripts/scratch_audit.py, profiles/r05_tree_scratch_audit.txt).
+SOURCE_FLAGS = {"sg_tree.hip": ["-fno-optimize-sibling-calls"]}
 
 
 def _headers():
-    return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(_HERE, "..", "include", "*.h")) + [os.path.join(CSRC, "sg_kernels.hip")])
+    # (this file too: the flags are in it)
+    return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(_HERE, "..", "include", "*.h")) + [os.path.join(CSRC, "sg_kernels.hip"), os.path.abspath(__file__)])
 
 
 def _stale(target, deps):
@@ -105,12 +113,13 @@ def _compile(out, extra, verbose, sources=SOURCES, default_sched=()):
 def _compile_locked(out, extra, verbose, sources, default_sched):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     flags_all = FLAGS + extra + (["-Rpass-analysis=kernel-resource-usage"] if verbose else [])
-    objdir = os.path.join(_HERE, "build", hashlib.sha1(" ".join(FLAGS + extra + list(default_sched)).encode()).hexdigest()[:12])
+    objdir = os.path.join(_HERE, "build", _objdir_name(extra, default_sched))
     os.makedirs(objdir, exist_ok=True)
     hdrs = _headers()
 
     def one(src):
         flags = [f for f in flags_all if f not in ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")] if src in default_sched else flags_all
+        own = SOURCE_FLAGS.get(src, [])
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         path = os.path.join(CSRC, src)
         if not verbose and not _stale(obj, [path] + hdrs):
@@ -122,7 +131,7 @@ def _compile_locked(out, extra, verbose, sources, default_sched):
         try:
             tmp = os.path.join(tmpdir, os.path.basename(obj))
             hip = src.endswith(".hip")
-            res = subprocess.run([hipcc] + flags + (["-save-temps=obj"] if hip else []) + ["-c", "-o", tmp, path], capture_output=True, text=True)
+            res = subprocess.run([hipcc] + flags + own + (["-save-temps=obj"] if hip else []) + ["-c", "-o", tmp, path], capture_output=True, text=True)
             log = ""
             if res.returncode != 0 and flags is flags_all and _compiler_crashed(res.stderr):
                 # ROCm 7.2.0's register allocator segfaults on some variants of the big kernels under iterative-ilp (which variant changes with
@@ -133,7 +142,7 @@ def _compile_locked(out, extra, verbose, sources, default_sched):
                 for f in os.listdir(tmpdir):
                     os.remove(os.path.join(tmpdir, f))
                 flags = [f for f in flags_all if f not in ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")]
-                res = subprocess.run([hipcc] + flags + (["-save-temps=obj"] if hip else []) + ["-c", "-o", tmp, path], capture_output=True, text=True)
+                res = subprocess.run([hipcc] + flags + own + (["-save-temps=obj"] if hip else []) + ["-c", "-o", tmp, path], capture_output=True, text=True)
             if res.returncode != 0:
                 raise RuntimeError("hipcc failed on %s:\n%s" % (src, res.stderr[-4000:]))
             log += res.stderr
@@ -168,9 +177,14 @@ def _compile_locked(out, extra, verbose, sources, default_sched):
     return out
 
 
+def _objdir_name(extra=(), default_sched=()):
+    key = FLAGS + list(extra) + list(default_sched) + ["%s:%s" % (k, " ".join(v)) for k, v in sorted(SOURCE_FLAGS.items())]
+    return hashlib.sha1(" ".join(key).encode()).hexdigest()[:12]
+
+
 def device_asm_files(extra=()):
     """the device assembly kept by the last build of the given variant (flags beyond FLAGS), one file per .hip source"""
-    objdir = os.path.join(_HERE, "build", hashlib.sha1(" ".join(FLAGS + list(extra)).encode()).hexdigest()[:12])
+    objdir = os.path.join(_HERE, "build", _objdir_name(extra))
     return sorted(glob.glob(os.path.join(objdir, "*.device.s")))
 
 
