@@ -2499,25 +2499,37 @@ static SGT_STAGE_ATTR void tree_stage(SGT_STAGE_PARAMS) {
         S.aF[idx] = s;
       }
       SGT_SYNC();
-      for (int ci = 0; ci < ncon; ci++) {   // contacts add their pushes one after the other (a slider / chain may be shared)
-        const double* sc = cscr(ci);
-        if (sc[CS_ROWS] == 0.0) continue;
-        const double* f = S.cf + 3 * ci;
-        const int c1 = (int)sc[CS_C1], c2 = (int)sc[CS_C2], n1c = c1 >= 0 ? CS : 0, n2c = c2 >= 0 ? CS : 0;
-        SGT_PAR(i, n1c + n2c) {
-          const bool second = i >= n1c;
-          const int dl = second ? i - n1c : i;
-          const double* W = crow(ci) + (second ? 9 * CS : 3 * CS);
-          S.aF[(second ? c2 : c1) * CS + dl] += W[dl] * f[0] + W[CS + dl] * f[1] + W[2 * CS + dl] * f[2];
+      // The contacts add their pushes in the list's order (a slider or a chain may carry several).  Every chain word has its lane, which walks
+      // the list and adds what is its own -- the same sums in the same order as contact after contact between barriers (two per contact
+      // until r05: 4 % of a free-ball substep), without a barrier; the sliders' and the object's words go through one lane meanwhile.
+      SGT_PAR(idx, K * CS) {
+        const int c = idx / CS, dl = idx % CS;
+        double a = S.aF[idx];
+        for (int ci = 0; ci < ncon; ci++) {
+          const double* sc = cscr(ci);
+          if (sc[CS_ROWS] == 0.0) continue;
+          const int c1 = (int)sc[CS_C1], c2 = (int)sc[CS_C2];
+          if (c1 != c && c2 != c) continue;
+          const double* f = S.cf + 3 * ci;
+          const double* W1 = crow(ci) + 3 * CS;
+          const double* W2 = crow(ci) + 9 * CS;
+          if (c1 == c) a += W1[dl] * f[0] + W1[CS + dl] * f[1] + W1[2 * CS + dl] * f[2];
+          if (c2 == c) a += W2[dl] * f[0] + W2[CS + dl] * f[1] + W2[2 * CS + dl] * f[2];
         }
-        SGT_ONE {
+        S.aF[idx] = a;
+      }
+      SGT_ONE {
+        for (int ci = 0; ci < ncon; ci++) {
+          const double* sc = cscr(ci);
+          if (sc[CS_ROWS] == 0.0) continue;
+          const double* f = S.cf + 3 * ci;
           const int sl = (int)sc[CS_SL];
           if (sl >= 0) S.ae[sl] += sc[CS_INVM] * (sc[CS_JS] * f[0] + sc[CS_JS + 1] * f[1] + sc[CS_JS + 2] * f[2]);
           if (FR && sc[CS_OBJ] != 0.0)
             for (int q = 0; q < 6; q++) S.of[OF_GF + q] += sc[CS_JO + q] * f[0] + sc[CS_JO + 6 + q] * f[1] + sc[CS_JO + 12 + q] * f[2];
         }
-        SGT_SYNC();
       }
+      SGT_SYNC();
       if (FR) {   // S.ae holds the sliders' LOCAL part g_e / D_e; the body: a_f = S^-1 (g_f - sum_e B_e g_e / D_e)
         double red[6] = {0, 0, 0, 0, 0, 0}, rhs[6], af6[6];
         SGT_PAR(e, N)

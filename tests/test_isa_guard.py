@@ -69,3 +69,29 @@ def test_one_function_tree_kernel_is_flagged():
     f = isa_check.check_asm(os.path.join(ROOT, "tests", "data", "tree_mono_d03dd81_site.s"))
     assert len(f) == 1 and "sg_tree_kernelILi24" in f[0][0] and f[0][1] == ".LBB16_1313", isa_check.describe(f, "mono")
     assert [t for _, t in f[0][2]] == ["v_accvgpr_write_b32 a0, v6", "v_accvgpr_write_b32 a1, v7"]
+
+
+def test_tree_stage_functions_save_no_callee_saved_registers():
+    """the tree kernel's called functions (stages, sweeps) used to save the callee-saved registers they use to scratch memory at
+    every call -- 10 678 scratch instructions in the translation unit, ~0.6 MB per substep and env, more than half of the tree scenes' fabric
+    traffic.  LLVM's no-CSR optimisation removes them as long as no call of these functions carries the IR's `tail` marker
+    (build_native.SOURCE_FLAGS: -fno-optimize-sibling-calls for sg_tree.hip).  Held here on the assembly the product build kept: the whole
+    unit below 2 500 scratch instructions and every sweep function below 40 (they have 4 - 11), so a flag or compiler change that brings
+    the saves back fails the CPU suite instead of showing up as traffic."""
+    import re
+    from softgrip_amd import build_native
+    build_native.build()
+    tree = [f for f in build_native.device_asm_files() if os.path.basename(f) == "sg_tree.device.s"]
+    assert len(tree) == 1
+    total, per, cur = 0, {}, None
+    with open(tree[0]) as f:
+        for line in f:
+            m = re.match(r"^(_Z\w+):", line)
+            if m:
+                cur = m.group(1)
+            elif cur and line.lstrip().startswith("scratch_"):
+                total += 1
+                per[cur] = per.get(cur, 0) + 1
+    sweeps = {k: v for k, v in per.items() if "tree_sweep" in k}
+    assert total < 2500, total
+    assert all(v < 40 for v in sweeps.values()), sweeps
