@@ -339,12 +339,16 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
     // the solver's table words (sg_pgs_rows_kernel): lane 2 b + h of a 16-lane group holds, for the block e in slot b of the round,
     // x | y << 11 | (2 e + h) << 22: the byte offsets of two slider words, (x, y) = 8 (e, p0) for h = 0 and 8 (p1, p2) for h = 1, and the
     // lane's pair of row states in 16-byte units
-    std::vector<unsigned> tab(2 * sch.size());
-    for (size_t i = 0; i < tab.size(); i++) {
+    // (models that keep the step factors in LDS -- SG_ROWS_NB_MODE 1, the box scene -- get TWO words per lane and round instead:
+    //  x | y << 16 and the byte offset of the lane's pair of 32-byte records)
+    const bool two_words = SG_ROWS_NB_MODE(H.nelem, H.eq_rounds) == 1;
+    std::vector<unsigned> tab((two_words ? 4 : 2) * sch.size());
+    for (size_t i = 0; i < 2 * sch.size(); i++) {
       const SgEqSlot& sl = sch[i >> 1];
       const int h = (int)(i & 1);
       const unsigned x = h ? sl.p[1] : sl.e, y = h ? sl.p[2] : sl.p[0];
-      tab[i] = (8u * x) | ((8u * y) << 11) | ((2u * (unsigned)sl.e + (unsigned)h) << 22);
+      if (two_words) { tab[2 * i] = (8u * x) | ((8u * y) << 16); tab[2 * i + 1] = 64u * (unsigned)sl.e + 32u * (unsigned)h; }
+      else tab[i] = (8u * x) | ((8u * y) << 11) | ((2u * (unsigned)sl.e + (unsigned)h) << 22);
     }
     ALLOC(b->dtab, sizeof(unsigned) * tab.size());
     HIPCHK(hipMemcpy(b->dtab, tab.data(), sizeof(unsigned) * tab.size(), hipMemcpyHostToDevice));

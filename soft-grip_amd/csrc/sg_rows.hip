@@ -104,7 +104,11 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   double* const Ae = lds + (size_t)lec * NAr;
   double* const GS = lds + (size_t)EPW * NAr + (size_t)lec * GW;
   unsigned* const TAB = (unsigned*)(lds + (size_t)EPW * NAr + (size_t)EPW * GW);
-  double* const Lnb = lds + (size_t)EPW * NAr + (size_t)EPW * GW + (size_t)8 * (H.eq_rounds + 8);  // [72 + 2 EPW]
+  // (NB = 1, the box scene: TWO words per lane and round, (x | y << 16, record offset) -- halves and a plain word decode inside the address
+  //  additions; the packed word costs four more integer instructions per round: the 8 us per launch that r04 lost against r03 on one box,
+  //  profiles/r05_ab_rounds.txt.  NB = 2 keeps the packed word: its LDS block has no 2.5 KB to spare)
+  constexpr int TABW = CST ? 1 : 2;
+  double* const Lnb = lds + (size_t)EPW * NAr + (size_t)EPW * GW + (size_t)8 * TABW * (H.eq_rounds + 8);  // [72 + 2 EPW]
   double* Lzero = NB ? Lnb : lds + (size_t)(5 * EPW + 2) * NR;  // [0]: a word that stays 0 (reads of "no slider"), [1 + lane]: write sink
   double* const Lenv = Lnb + 72;  // NB: [e2] sum of the env's slider accelerations at the start, [EPW + e2] its final offset aoff
   double* const ASb = NB ? Ae : (double*)AF;  // slider acceleration of element j: ASb[ASS * j]
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
     }
   }
   if constexpr (NB) {  // the schedule (plus eight idle rounds: padding to a multiple of four and the look-ahead) as LDS offsets: lane 2 b + h of a group, block slot b
-    const int ntab = 16 * (H.eq_rounds + 8);   // a.tab: the same words, laid out by the host once per batch (sg_api.hip)
+    const int ntab = 16 * TABW * (H.eq_rounds + 8);   // a.tab: the same words, laid out by the host once per batch (sg_api.hip)
 #pragma unroll 4
     for (int i = lane; i < ntab; i += 64) TAB[i] = a.tab[i];
   }
@@ -274,7 +278,8 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         // (a quad per block) was 32 x 48, a block per lane 24 x 80.
         char* const Ab = (char*)Ae;
         char* const Gb = (char*)GS;
-        const unsigned* tp = TAB + g;
+        using TabW = std::conditional_t<CST, unsigned, uint2>;
+        const TabW* tp = (const TabW*)TAB + g;
         const double2* cp = cp0;   // my step factors (c of my two rows), round k: cp0[64 k]
         const int hh = g & 1;
         const double hm = hh ? 1.0 : 0.0, h0 = 1.0 - hm;
@@ -283,9 +288,10 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         const int nrounds = H.eq_rounds;
         struct Adr { double *px, *py; double2* rec; };   // lane 0: slider e itself / partner of row 1; lane 1: partners of rows 2, 3; my rows' states
         struct Off { double sA, wA, sB, wB, ga, gb; };   // what a round leaves for its off-chain part
-        auto adr_of = [&](const unsigned tt) {
+        auto adr_of = [&](const TabW tt) {
           Adr q;
-          q.px = (double*)(Ab + (tt & 0x7ffu)); q.py = (double*)(Ab + ((tt >> 11) & 0x7ffu)); q.rec = (double2*)(Gb + ((tt >> 22) << (CST ? 4 : 5)));
+          if constexpr (CST) { q.px = (double*)(Ab + (tt & 0x7ffu)); q.py = (double*)(Ab + ((tt >> 11) & 0x7ffu)); q.rec = (double2*)(Gb + ((tt >> 22) << 4)); }
+          else { q.px = (double*)(Ab + (tt.x & 0xffffu)); q.py = (double*)(Ab + (tt.x >> 16)); q.rec = (double2*)(Gb + tt.y); }
           return q;
         };
         // The CHAIN of a round -- slider reads -> two rows on lane 0 -> hand-over -> two rows on lane 1 -> hand-over -> slider writes, which
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         // ahead left ~150 cycles of every round waiting: 0.405 -> 0.448 ms per launch on the box scene).  The factors do not change
         // over a substep's sweeps, so the last trip of a sweep requests the first four rounds again -- they arrive during the contact
         // phase -- and the round count is padded to a multiple of four with idle rounds (table and stream end with eight).
-        unsigned tC = tp[0], tD = tp[16];
+        TabW tC = tp[0], tD = tp[16];
         Adr qA = adr_of(tC), qB = adr_of(tD);
         double2 gA, gB;
         ld_rec(qA, gA, c0); ld_rec(qB, gB, c1);   // (NB = 1: the LDS path keeps a set's factors in c0 / c1)

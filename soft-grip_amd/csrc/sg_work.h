@@ -174,7 +174,7 @@ struct SgPgsArgs {
 // step factors c sat beside g -- 16 bytes a row, 70 KB for the ball's 218 elements: two workgroups per CU, i.e. the 1024 wavefronts of
 // a 4096-env batch in TWO rounds.  They now stream from memory in round-major order, SgWork::cst: 38 KB, four per CU, one round.)
 #define SG_ROWS_NA_NB(N) (((N) + 2) & ~1)
-#define SG_ROWS_LDS_NB(EPW, N, ROUNDS, CST) ((size_t)(EPW) * SG_ROWS_NA_NB(N) + (size_t)((CST) ? 4 : 8) * (EPW) * ((N) + 1) + (size_t)8 * ((ROUNDS) + 8) + 72 + 2 * (EPW))
+#define SG_ROWS_LDS_NB(EPW, N, ROUNDS, CST) ((size_t)(EPW) * SG_ROWS_NA_NB(N) + (size_t)((CST) ? 4 : 8) * (EPW) * ((N) + 1) + (size_t)((CST) ? 8 : 16) * ((ROUNDS) + 8) + 72 + 2 * (EPW))
 // the step factors stay in LDS beside the states (NB = 1) while four workgroups of the solver still share a CU's 160 KB that way
 #define SG_ROWS_NB_MODE(N, ROUNDS) (sizeof(double) * SG_ROWS_LDS_NB(4, N, ROUNDS, 0) <= 40 * 1024 ? 1 : 2)
 // ---- launchers (defined next to their kernels) ----
