@@ -100,7 +100,8 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   // with c = (1/m) / (A + R) in the same order.  TAB (shared by the
   // wavefront's envs): the plan's block schedule as LDS offsets per lane of a 16-lane group: lane 2 b + h holds, for the block e
   // in slot b of the round, x | y << 11 | (2 e + h) << 22 with the sliders' byte offsets (x, y) = 8 (e, p0) for h = 0 and 8 (p1, p2)
-  // for h = 1, and 2 e + h the lane's pair of row states in 16-byte units (NB = 1: pairs of records, 32-byte units).
+  // for h = 1, and 2 e + h the lane's pair of row states in 16-byte units (NB = 2; NB = 1: two words, x | y << 16 and the byte offset of
+  // the lane's pair of 32-byte records -- TABW below).
   double* const Ae = lds + (size_t)lec * NAr;
   double* const GS = lds + (size_t)EPW * NAr + (size_t)lec * GW;
   unsigned* const TAB = (unsigned*)(lds + (size_t)EPW * NAr + (size_t)EPW * GW);
