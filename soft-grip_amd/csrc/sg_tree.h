@@ -545,6 +545,7 @@ static SGT_NOINLINE double free_fix_rows(const SGT_LDSP double* frow, const SGT_
 static SGT_BLOCKED_ATTR double free_fix_rows_blocked(const SGT_LDSP double* frow, const SGT_LDSP double* Be, const SGT_LDSP double* einvm, const SGT_LDSP double* Sinv,
                                                  SGT_LDSP double* ffix, SGT_LDSP double* ae, SGT_LDSP double* af, int N) {
   const int lane = (int)threadIdx.x;
+  if (N <= 0) return 0.0;   // (a free body without sliders: no rows, a_f stays; uniform)
   const int L = ((N + 31) >> 5) | 1, nblk = (N + L - 1) / L;      // (uniform)
   const bool act = lane < nblk;
   const int e0 = act ? lane * L : 0;
