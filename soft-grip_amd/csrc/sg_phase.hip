@@ -1046,8 +1046,14 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
   SG_TEND();
 }
 
+#ifndef SG_X_PHASE_OCC
+#define SG_X_PHASE_OCC 2
+#endif
+#ifndef SG_X_CPL
+#define SG_X_CPL 2
+#endif
 template <int R, int CPL, bool NB, bool GEN = false>
-__global__ __launch_bounds__(64, 2) void sg_phase_kernel(SgPhaseArgs a) {
+__global__ __launch_bounds__(64, SG_X_PHASE_OCC) void sg_phase_kernel(SgPhaseArgs a) {
   if constexpr (GEN) {
     // the general pass: a SMALL grid (SG_GEN_GRID blocks; the kernel needs scratch memory and every register, and an empty block of it
     // is not free: one block per env of the batch cost the default benchmark 5 %) whose blocks stride over the list -- normally empty --
@@ -1264,10 +1270,10 @@ hipError_t sg_launch_chain(const SgPhaseArgs& p, int nenv, hipStream_t s) {
 hipError_t sg_launch_phase(const SgPhaseArgs& p, int rounds, bool nb, bool genpass, int nenv, hipStream_t s) {
 #define SG_PHASE(r)                                                                                   \
   if (nb) {                                                                                           \
-    hipLaunchKernelGGL((sg_phase_kernel<r, 2, true>), dim3(nenv), dim3(64), 0, s, p);                 \
+    hipLaunchKernelGGL((sg_phase_kernel<r, SG_X_CPL, true>), dim3(nenv), dim3(64), 0, s, p);                 \
     if (genpass && p.do_begin) hipLaunchKernelGGL((sg_phase_kernel<r, 2, true, true>), dim3(nenv < SG_GEN_GRID ? nenv : SG_GEN_GRID), dim3(64), 0, s, p); \
   } else {                                                                                            \
-    hipLaunchKernelGGL((sg_phase_kernel<r, 2, false>), dim3(nenv), dim3(64), 0, s, p);                \
+    hipLaunchKernelGGL((sg_phase_kernel<r, SG_X_CPL, false>), dim3(nenv), dim3(64), 0, s, p);                \
     if (genpass && p.do_begin) hipLaunchKernelGGL((sg_phase_kernel<r, 2, false, true>), dim3(nenv < SG_GEN_GRID ? nenv : SG_GEN_GRID), dim3(64), 0, s, p); \
   }
   switch (rounds) {
