@@ -317,7 +317,9 @@ int sg_batch_create(const sg_model* m, int n_envs, int device, sg_batch** out) {
               walloc((void**)&b->w.nbR, sizeof(double) * n * (3 * N + 1)) &&
               walloc((void**)&b->w.cst, sizeof(double) * ((H.nnb > 0 && SG_ROWS_NB_MODE(H.nelem, H.eq_rounds) == 2) ? SG_CST_INDEX((n + 3) / 4, 0, 0, H.eq_rounds + 8) : 2)) &&
               walloc((void**)&b->w.gcon, sizeof(double) * n * SG_GEN_MAXCON * SG_GEN_W) && walloc((void**)&b->w.gen, sizeof(int) * n) &&
-              walloc((void**)&b->w.gen_count, sizeof(int) * 4) && walloc((void**)&b->w.gen_list, sizeof(int) * n);
+              walloc((void**)&b->w.gen_count, sizeof(int) * 4) && walloc((void**)&b->w.gen_list, sizeof(int) * n) &&
+              walloc((void**)&b->w.gpairs16, SG_PHASE_SLIM(m->rounds) ? sizeof(unsigned short) * n * SG_PAIRS_CAP(4) : 16) &&
+              walloc((void**)&b->w.gcval, SG_PHASE_SLIM(m->rounds) ? sizeof(double) * n * SG_MAXCH * 64 : 16);
     if (!ok) { sg_batch_destroy(b); return fail(SG_ERR_NOMEM, "hipMalloc (split-pipeline workspace)"); }
     const char* pm = getenv("SG_PIPELINE");
     b->pipeline = (pm && strcmp(pm, "tree") == 0 && m->has_tree) ? 3 : 2;

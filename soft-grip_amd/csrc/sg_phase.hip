@@ -281,6 +281,18 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
   const SG_CONSTAS SgChain& C = H.chain[half < nchain ? half : 0];
   ChainLds2& CS = Sm.cs[half];
   const SgWork& W = a.w;
+  // the pair list and the per-slot slider pushes: LDS, or -- four element rounds, SG_PHASE_SLIM -- the env's slices of the work space (written
+  // and read by this wavefront only, a workgroup barrier's fence between the two)
+  [[maybe_unused]] unsigned short* const gpairs_env = W.gpairs16 + (size_t)env * SG_PAIRS_CAP(R);   // (uniform: scalar registers)
+  [[maybe_unused]] double* const gcval_env = W.gcval + (size_t)env * SG_MAXCH * (32 * CPL);
+  auto pair_at = [&](int i) -> unsigned short& {
+    if constexpr (SG_PHASE_SLIM(R)) return gpairs_env[i];
+    else return Sm.pairs[i];
+  };
+  auto cval_at = [&](int cc, int i) -> double& {
+    if constexpr (SG_PHASE_SLIM(R)) return gcval_env[cc * (32 * CPL) + i];
+    else return Sm.cval[cc * (32 * CPL) + i];
+  };
 
   // status and pending are LOADED here and TESTED below, after the state loads have been issued: an early return on them would put
   // one memory round trip in front of every other load of the kernel (a wavefront lives ~30 us, a round trip costs 1 - 2)
@@ -466,7 +478,7 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
           if (H.has_center) {
             double dif[3] = {bp[0] - H.center_pos[0], bp[1] - H.center_pos[1], bp[2] - H.center_pos[2]}, bound = H.center_radius + rb + H.con_margin;
             if (dot3(dif, dif) <= bound * bound) {
-              if (lane == 0) Sm.pairs[np] = (unsigned short)((b << 12) | SG_PAIR_CENTER);
+              if (lane == 0) pair_at(np) = (unsigned short)((b << 12) | SG_PAIR_CENTER);
               np++;
             }
           }
@@ -490,7 +502,7 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
               }
             }
             const unsigned long long m = __ballot(near);
-            if (near) Sm.pairs[np + lanes_below2(m)] = (unsigned short)((b << 12) | e);
+            if (near) pair_at(np + lanes_below2(m)) = (unsigned short)((b << 12) | e);
             np += __popcll(m);
           }
         }
@@ -501,7 +513,7 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
 #pragma unroll 1
         for (int p0 = 0; p0 < np; p0 += 64) {
           const bool have = p0 + lane < np;
-          const int code = have ? (int)Sm.pairs[p0 + lane] : 0, b = code >> 12, e = code & 0xFFF, c = b / SG_CG, g = b % SG_CG;
+          const int code = have ? (int)pair_at(p0 + lane) : 0, b = code >> 12, e = code & 0xFFF, c = b / SG_CG, g = b % SG_CG;
           const bool is_center = have && e == SG_PAIR_CENTER;
           ConRec r0, r1;
           bool v0 = false, v1 = false;
@@ -676,7 +688,7 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
           contact_build(c, rec, Sm.K[half], nd, CS.Minv, CS.v, CS.qacc_smooth, CS.w, C.b_invw_tran[bi], sl, ax, ve_, as_, we_, im, bw, *a.H);
           csl_[k] = sl; cinvm[k] = c.invm;
           cjsf[k] = c.Js[0] * c.f[0] + c.Js[1] * c.f[1] + c.Js[2] * c.f[2];
-          Sm.cval[half][i] = c.invm * cjsf[k];
+          cval_at(half, i) = c.invm * cjsf[k];
           ccost0[k] = c.f[0] * (0.5 * c.R * c.f[0] + c.b[0]) + c.f[1] * (0.5 * c.R * c.f[1] + c.b[1]) + c.f[2] * (0.5 * c.R * c.f[2] + c.b[2]);
 #pragma unroll
           for (int d = 0; d < SG_CD; d++) cg[k][d] = c.Jf[0][d] * c.f[0] + c.Jf[1][d] * c.f[1] + c.Jf[2][d] * c.f[2];
@@ -872,8 +884,8 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
 #pragma unroll
             for (int cb = 0; cb < SG_MAXCH * SG_CG; cb++) {
               const int u = Sm.eslot[e][cb], i0 = u & 0x3F, nst = u >> 6;
-              if (nst >= 1) as_ += Sm.cval[cb / SG_CG][i0];
-              if (nst >= 2) as_ += Sm.cval[cb / SG_CG][i0 + 1];
+              if (nst >= 1) as_ += cval_at(cb / SG_CG, i0);
+              if (nst >= 2) as_ += cval_at(cb / SG_CG, i0 + 1);
             }
             if constexpr (GEN)
               if (ngen) as_ += GL.gas[e];   // general contact path: the pushes of the env's one contact list on this slider
@@ -980,7 +992,7 @@ __device__ __forceinline__ void sg_phase_env(const SgPhaseArgs& a, const int env
 #pragma unroll
             for (int d = 0; d < SG_CD; d++) cg[k][d] = 0;
             if (i < myn) {
-              Sm.cval[half][i] = 0.0;
+              cval_at(half, i) = 0.0;
               if (!a.rowlayout) {
               double* ro = W.crec + SG_REC_INDEX(i, env / SG_EPW, 0, 2 * (env % SG_EPW) + half, nwb);
 #pragma unroll

@@ -49,6 +49,11 @@ struct SgWork {          // device workspace of one batch (all pointers device m
   int* gen;              // [nenv]  number of general contacts of the pending substep (0: the env is on the fast path)
   int* gen_count;        // [1]  envs the main phase pass has put on gen_list in this substep (reset by sg_chain_kernel)
   int* gen_list;         // [nenv]
+  // models of four element rounds (193 .. 256 sliders: the ball): the phase kernel's pair list and per-slot slider pushes, which its smaller
+  // instantiations keep in LDS (Smem2): without them its block is 19.5 KB instead of 22.6 -- EIGHT workgroups per CU, the 4096 wavefronts in two rounds
+  // instead of three (a round is ~60 us whatever its size: profiles/r05s_phase_kernel_occupancy.txt)
+  unsigned short* gpairs16;  // [nenv][SG_MAXCH * SG_CG * (4 * 64 + 2)]   (2 entries otherwise)
+  double* gcval;             // [nenv][SG_MAXCH][64]                       (2 entries otherwise)
 };
 
 struct SgPhaseArgs {
@@ -107,6 +112,8 @@ struct ChainLds2 {  // what the phase kernel needs of a finger chain (imported f
   double lim_sign[SG_MAXLIM], lim_R[SG_MAXLIM], lim_b[SG_MAXLIM], lim_f[SG_MAXLIM];  // contiguous, in the hand-off record's order
 };
 
+#define SG_PHASE_SLIM(R) ((R) >= 4)   // the pair list and the slot pushes live in the work space (SgWork::gpairs16, gcval), not in LDS
+#define SG_PAIRS_CAP(R) (SG_MAXCH * SG_CG * ((R) * 64 + 2))
 template <int R, int CPL, bool NB>
 struct Smem2 {
   ChainKin K[SG_MAXCH];
@@ -114,9 +121,9 @@ struct Smem2 {
   double boxp[SG_MAXCH * SG_CG][3], boxm[SG_MAXCH * SG_CG][9];
   double ve[R * 64], asme[R * 64], we[R * 64], as[R * 64];
   StageRec2 stage[SG_MAXCH][32 * CPL];
-  unsigned short pairs[SG_MAXCH * SG_CG * (R * 64 + 2)];  // broadphase survivors, (box << 12) | element, in contact order
+  unsigned short pairs[SG_PHASE_SLIM(R) ? 4 : SG_PAIRS_CAP(R)];  // broadphase survivors, (box << 12) | element, in contact order
   unsigned char eslot[R * 64][SG_MAXCH * SG_CG];          // per element and box: first contact slot (< 64) | (contact count << 6)
-  double cval[SG_MAXCH][32 * CPL];                        // per contact slot: invm * Js' f (its push on the slider)
+  double cval[SG_PHASE_SLIM(R) ? 1 : SG_MAXCH * 32 * CPL];   // per contact slot [chain][32 CPL]: invm * Js' f (its push on the slider)
 };
 #define SG_PAIR_CENTER 0xFFF  // element code of the object's centre sphere
 
