@@ -107,6 +107,7 @@ struct Lds {
   double *einvm, *ecoef, *ecen, *Ifix, *Ilim;   // 1 / (m + armature), tendon coefficient, capsule centres [3][N], 1 / (A + R) of the fix / limit rows
   double *lrow, *seg, *chs, *cf, *red, *swc, *ctx;   // swc: the step's scalars for the sweep function (SWC_*); ctx: those the stage functions hand on (CTX_*)
   double *nbf, *nbb, *nbR, *nbI, *nbA;   // neighbour equality rows by slot d * N + e (the d-th row registered for element e): force, b, R, 1 / (A + R); free object: A + R
+  double *nbq, *fixq;   // grippers with neighbour rows (no free object): the rows' sweep constants PACKED for the pipelined equality rounds of tree_sweep -- nbq[4 k] = R, b, 1 / (A + R), 1 / m of the partner; fixq[4 e] = b, R, 1 / (A + R), 1 / m of the fix row
   double *frow;   // free object: the joint-fix rows' constants for the serial sweep, [N][5]: b, R, A + R, 1 / (A + R), 1 / D
   double *of, *Be, *Ce, *Afix;   // free object (plans with has_free): scalars (OF_*), B_e [N][6], C_e = -S^-1 B_e / D_e [N][6], the fix rows' diagonals A + R
   int *hit_pair, *hit_sorted, *hit_cnt, *hit_off, *con_src, *con_chain, *icnt;
@@ -173,6 +174,7 @@ SG_HD size_t lds_carve(Lds& L, double* base, const SgTreeDev& T, int N, int has_
   L.frow = take(has_free ? 4 * N : 0);
   L.nbf = takeg(nnb ? 3 * N : 0); L.nbb = takeg(nnb ? 3 * N : 0); L.nbR = takeg(nnb ? 3 * N : 0); L.nbI = takeg(nnb ? 3 * N : 0);
   L.nbA = takeg((nnb && has_free) ? 3 * N : 0);
+  L.nbq = takeg((nnb && !has_free) ? 12 * N : 0); L.fixq = takeg((nnb && !has_free) ? 4 * N : 0);
   if (gdoubles) *gdoubles = (size_t)(g - gbase);
   int* ip = (int*)p;
   L.hit_pair = ip; ip += SGT_MAXHIT;
@@ -744,6 +746,8 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
   const SGT_GLOBP double* const nbRG = (const SGT_GLOBP double*)S.nbR;
   const SGT_GLOBP double* const nbIG = (const SGT_GLOBP double*)S.nbI;
   SGT_GLOBP double* const nbfG = (SGT_GLOBP double*)S.nbf;
+  [[maybe_unused]] const SGT_GLOBP double* const nbqG = (const SGT_GLOBP double*)S.nbq;
+  [[maybe_unused]] const SGT_GLOBP double* const fixqG = (const SGT_GLOBP double*)S.fixq;
   const SGT_EINVM_AS double* const einvmNF = (const SGT_EINVM_AS double*)S.einvm;   // scenes WITHOUT a free object only (with one: LDS, lds_carve)
   (void)aeL; (void)aFL; (void)cfL; (void)ffixL; (void)flimL; (void)lrowL; (void)ofL; (void)BeL; (void)icntL; (void)hitpairL; (void)hitcntL; (void)MinvT;
   (void)bfixG; (void)RfixG; (void)IfixG; (void)nbbG; (void)nbRG; (void)nbIG; (void)nbfG; (void)einvmNF;
@@ -800,6 +804,97 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
       // equality BLOCKS [fix_e, e's neighbour rows] in the plan's list schedule: the blocks of a round share no slider (they
       // commute exactly), every block sits in a later round than the blocks it depends on -- the rounds in order ARE mj_solPGS's
       // sequential sweep (sg_plan.h); 64 blocks per round, a lane each
+#if SGT_DEVICE && !defined(SGT_X_EQSYNC)
+      // (r05s) The rounds PIPELINED: a round's table words (its slot) and its rows' constants and forces -- two dependent trips to the work
+      // space -- do not depend on the rounds before it, only the sliders' accelerations (LDS) do.  As written for the emulation below, every
+      // round paid both trips and then a barrier that drains the rows' force stores: ~2.5 us a round, 55 us a sweep, three quarters of a
+      // substep of the four-finger gripper's default model.  Here a round's constants are requested two rounds ahead and its slot five (three
+      // register sets), and nothing in the loop waits at a barrier: the wavefront's LDS instructions execute in order, so a lane's read of a
+      // slider sees the write another lane made a round earlier.  Same rows, same order, same arithmetic: same bits.
+      {
+        const int lane = (int)threadIdx.x;
+        const int nr = H.eq_rounds;
+        struct ERec { int e, pe[3]; double invm, Rf, bf, If, ipm[3], R[3], b[3], I[3], f[3]; };
+        auto load_rec = [&](ERec& q, const SgEqSlot slot) {
+          q.e = slot.e;
+          const int e = slot.e < N ? slot.e : 0;
+          // (the rows' constants packed by the build stage, S.fixq / S.nbq: one 32-byte record per row -- two loads behind ONE address
+          //  instead of four or five words from as many arrays behind as many 64-bit address computations)
+          {
+            const SGT_GLOBP double2* const fq = (const SGT_GLOBP double2*)(fixqG + 4 * e);
+            const double2 u = fq[0], w = fq[1];
+            q.bf = u.x; q.Rf = u.y; q.If = w.x; q.invm = w.y;
+          }
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            const int pe = slot.e < N ? slot.p[d] : N;
+            const int k = d * N + e;
+            q.pe[d] = pe;
+            const SGT_GLOBP double2* const nq = (const SGT_GLOBP double2*)(nbqG + 4 * k);   // (row k's words exist whether the block has the row or not)
+            const double2 u = nq[0], w = nq[1];
+            q.R[d] = u.x; q.b[d] = u.y; q.I[d] = w.x; q.ipm[d] = w.y;
+            q.f[d] = nbfG[k];
+          }
+        };
+        // A block straight through: the slider's and its partners' accelerations are read TOGETHER at the top (one LDS latency, not four in
+        // a row behind each other's stores), the four rows run in registers, the stores follow.  A row the block does not have is a no-op
+        // by its record (R = b = 1 / (A + R) = 1 / m_p = f = 0: the step is exactly 0) on the block's own slider as stand-in partner, so no
+        // lane branches inside a block; the own slider's store comes last.
+        auto run = [&](const ERec& q) {
+          const int e = q.e;
+          if (e < N) {
+            const double invm = q.invm;
+            const int pc0 = q.pe[0] < N ? q.pe[0] : e, pc1 = q.pe[1] < N ? q.pe[1] : e, pc2 = q.pe[2] < N ? q.pe[2] : e;
+            double ae_ = aeL[e], f0 = ffixL[e];
+            const double ap0 = aeL[pc0], ap1 = aeL[pc1], ap2 = aeL[pc2];
+            double old = f0;
+            imp_par -= scalar_update_rcp(f0, q.bf, ae_, q.Rf, invm + q.Rf, q.If, false);
+            ae_ += invm * (f0 - old);
+            double f1 = q.f[0];
+            old = f1;
+            imp_par -= scalar_update_rcp(f1, q.b[0], ae_ - ap0, q.R[0], invm + q.ipm[0] + q.R[0], q.I[0], false);
+            const double d1 = f1 - old;
+            ae_ += invm * d1;
+            double f2 = q.f[1];
+            old = f2;
+            imp_par -= scalar_update_rcp(f2, q.b[1], ae_ - ap1, q.R[1], invm + q.ipm[1] + q.R[1], q.I[1], false);
+            const double d2 = f2 - old;
+            ae_ += invm * d2;
+            double f3 = q.f[2];
+            old = f3;
+            imp_par -= scalar_update_rcp(f3, q.b[2], ae_ - ap2, q.R[2], invm + q.ipm[2] + q.R[2], q.I[2], false);
+            const double d3 = f3 - old;
+            ae_ += invm * d3;
+            ffixL[e] = f0;
+            nbfG[e] = f1; nbfG[N + e] = f2; nbfG[2 * N + e] = f3;
+            aeL[pc0] = ap0 - q.ipm[0] * d1;
+            aeL[pc1] = ap1 - q.ipm[1] * d2;
+            aeL[pc2] = ap2 - q.ipm[2] * d3;
+            aeL[e] = ae_;
+          }
+        };
+        if (nr > 0) {
+          // three register sets: a round's record is requested TWO rounds before it runs, its slot three rounds before that
+          auto slot_of = [&](int r) { return sched[(r < nr ? r : 0) * 64 + lane]; };   // (past the end: round 0's words, read and not used)
+          ERec q0, q1, q2;
+          SgEqSlot t0 = slot_of(0), t1 = slot_of(1), t2 = slot_of(2);
+          load_rec(q0, t0); load_rec(q1, t1);
+          t0 = slot_of(3); t1 = slot_of(4);
+          for (int r = 0; r < nr; r += 3) {
+            load_rec(q2, t2); t2 = slot_of(r + 5);
+            run(q0);
+            __builtin_amdgcn_wave_barrier();
+            load_rec(q0, t0); t0 = slot_of(r + 6);
+            if (r + 1 < nr) run(q1);
+            __builtin_amdgcn_wave_barrier();
+            load_rec(q1, t1); t1 = slot_of(r + 7);
+            if (r + 2 < nr) run(q2);
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+        SGT_SYNC();
+      }
+#else
       for (int r = 0; r < H.eq_rounds; r++) {
         SGT_PAR(sl, 64) {
           const SgEqSlot slot = sched[r * 64 + sl];
@@ -828,6 +923,7 @@ static SGT_NOINLINE void tree_sweep(const SGT_CONST SgPlanHeader* Hp, const SGT_
         }
         SGT_SYNC();
       }
+#endif
       SGT_PAR_SLOT(e, t, N) S_ae += kco[t] * aeL[e];
       S_ae = wsum(S_ae);
     } else {
@@ -2131,6 +2227,7 @@ static SGT_STAGE_ATTR void tree_stage(SGT_STAGE_PARAMS) {
         fr4[0] = S.bfix[e]; fr4[1] = R; fr4[2] = Aee + R; fr4[3] = 1.0 / (Aee + R);
       }
       S.Ifix[e] = 1.0 / (Aee + R);
+      if (!FR && H.nnb > 0) { double* const fq = S.fixq + 4 * e; fq[0] = S.bfix[e]; fq[1] = R; fq[2] = S.Ifix[e]; fq[3] = invm; }
       tj_pos += co * S.qe[e]; tj_vel += co * S.ve[e]; tj_asm += co * S.asme[e]; tj_warm += co * S.we[e]; tj_A += co * co * invm;
       // (d) limit rows of the slider: slot 0 lower side, slot 1 upper side (MuJoCo's order)
       for (int sd = 0; sd < 2; sd++) {
@@ -2197,6 +2294,7 @@ static SGT_STAGE_ATTR void tree_stage(SGT_STAGE_PARAMS) {
           I = 1.0 / (Arow + R);
         }
         S.nbR[k] = R; S.nbb[k] = b; S.nbf[k] = f; S.nbI[k] = I;
+        if (!FR) { double* const nq = S.nbq + 4 * k; nq[0] = R; nq[1] = b; nq[2] = I; nq[3] = pe >= 0 ? S.einvm[pe] : 0.0; }
       }
     }
     // (c) limit rows of the chain dofs, one lane per chain: compact list in dof order, lower side first
