@@ -75,20 +75,10 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
   // which of the wavefront's envs have a substep pending: read ONCE, all EPW words together (uniform addresses: scalar loads).  The staging
   // loops and the epilogue used to re-read the word per env behind a branch -- EPW dependent memory round trips in a row, twice per launch
   unsigned pendmask = 0;
-  {
-    // (the EPW words are LOADED first, unconditionally, and tested afterwards: written as `env2 < nenv && pending[env2]` the compiler made each
-    //  load wait behind the branch of the one before it -- four scalar-load round trips in a row at the top of every launch, r05s)
-    int pw[EPW];
 #pragma unroll
-    for (int e2 = 0; e2 < EPW; e2++) {
-      const int env2 = blockIdx.x * EPW + e2;
-      pw[e2] = W.pending[env2 < a.nenv ? env2 : 0];
-    }
-#pragma unroll
-    for (int e2 = 0; e2 < EPW; e2++) {
-      const int env2 = blockIdx.x * EPW + e2;
-      pendmask |= (env2 < a.nenv && pw[e2] != 0) ? 1u << e2 : 0u;
-    }
+  for (int e2 = 0; e2 < EPW; e2++) {
+    const int env2 = blockIdx.x * EPW + e2;
+    pendmask |= (env2 < a.nenv && W.pending[env2 < a.nenv ? env2 : 0] != 0) ? 1u << e2 : 0u;
   }
   const bool valid = in_wave && ((pendmask >> lec) & 1u) != 0;
   if (pendmask == 0) return;
@@ -155,42 +145,18 @@ __global__ __launch_bounds__(64) void sg_pgs_rows_kernel(SgPgsArgs a) {
         }
         if (j < NR) { AF2[j] = af; BR2[j] = br; RI2[j] = ri; }
       }
-    }
-  }
-  if constexpr (NB != 0) {
-    // (r05s) the envs' slider accelerations: ALL loads first (unconditional, from a clamped address, the value selected afterwards), then the
-    // LDS stores and the four sums side by side.  Env by env -- load behind a branch, wait, store, six dependent shuffle steps, next env -- the
-    // four memory round trips and the four reductions ran one after the other: ~6 us at the top of every launch
-    constexpr int NT = (NA + 63) / 64;
-    double avv[EPW][NT];
-#pragma unroll
-    for (int e2 = 0; e2 < EPW; e2++) {
-      const int env2 = blockIdx.x * EPW + e2, envc = env2 < a.nenv ? env2 : 0;
-#pragma unroll
-      for (int t = 0; t < NT; t++) {
-        const int j = 64 * t + lane;
-        avv[e2][t] = W.as[(size_t)envc * N + (j < N ? j : 0)];
-      }
-    }
-    double ssum[EPW];
-#pragma unroll
-    for (int e2 = 0; e2 < EPW; e2++) {
-      const bool v2 = ((pendmask >> e2) & 1u) != 0;  // uniform
+    } else {
       double* const A2 = lds + (size_t)e2 * NAr;
-      ssum[e2] = 0.0;
+      double ssum = 0.0;
 #pragma unroll
-      for (int t = 0; t < NT; t++) {
-        const int j = 64 * t + lane;
-        const double av = (v2 && j < N) ? avv[e2][t] : 0.0;
+      for (int j0 = 0; j0 < NA; j0 += 64) {
+        const int j = j0 + lane;
+        const double av = (v2 && j < N) ? W.as[(size_t)env2 * N + j] : 0.0;
         if (j < NAr) A2[j] = av;
-        ssum[e2] += av;
+        ssum += av;
       }
-    }
-#pragma unroll
-    for (int e2 = 0; e2 < EPW; e2++) ssum[e2] = wave_sum2(ssum[e2]);
-    if (lane == 0) {
-#pragma unroll
-      for (int e2 = 0; e2 < EPW; e2++) { Lenv[e2] = ssum[e2]; Lenv[EPW + e2] = 0.0; }
+      ssum = wave_sum2(ssum);
+      if (lane == 0) { Lenv[e2] = ssum; Lenv[EPW + e2] = 0.0; }
     }
   }
   if constexpr (NB) {
