@@ -1228,6 +1228,63 @@ def test_general_contact_path_on_the_gpu(tmp_path, kind, neighbors):
 
 
 @pytest.mark.parametrize("neighbors", [False, True])
+def test_general_contact_path_on_a_four_round_model(tmp_path, neighbors):
+    """r05s: the phase kernel of models with 193 .. 256 sliders (four element rounds: `sg_phase_kernel<4, ...>`) keeps its pair list and per-slot
+    slider pushes in the work space instead of LDS (SG_PHASE_SLIM) -- in the general pass (`<4, ..., GEN = true>`) too, which no
+    reference scene runs.  The "rest" scene (the object on the ground plane: every env on the general path in every substep) with a 6 x 9 x 6
+    shell (212 sliders), 4 envs, 90 env steps through idle and closing, re-seated on the oracle per step: sensors, contact / row / sweep
+    counts and touch bits at every step, no flag."""
+    import torch
+    from oracle import oracle as O
+    from softgrip_amd import native
+    from test_emu_vs_oracle import general_path_scene, special_contacts
+    path = general_path_scene("rest", tmp_path / "rest212.xml")
+    x = open(path).read()
+    assert 'count="3 4 3" spacing="0.2"' in x
+    open(path, "w").write(x.replace('count="3 4 3" spacing="0.2"', 'count="6 9 6" spacing="0.08"'))
+    m = sg.Model.from_blob(native.compile_mjcf_native(path, composite_neighbors=neighbors))
+    assert m.nv - 8 == 212
+    jids, tids = list(range(8, m.nv)), [0]
+    ks = [640.0, 300.0, 1400.0, 950.0]
+    b = native.NativeBatch(native.NativeModel(m), len(ks), 0)
+    b.set_stiffness(np.asarray(ks), jids, tids)
+    sens, flags, touch = _bufs(b, len(ks))
+    om = O.OracleModel(m.to_blob())
+    sims = [O.OracleSim(om) for _ in ks]
+    for s, k in zip(sims, ks):
+        s.jnt_stiffness[jids] = k
+        s.tendon_stiffness[tids] = k
+        s.reset(); s.forward(); s.step()
+    b.reset(1, sens=sens, flags=flags, touch=touch)
+    ctrl = np.zeros(2)
+    special = fast = 0
+    bit_of = _touch_bit_of_geom(m)
+    T = lambda a: torch.tensor(np.stack(a), dtype=torch.float64, device=b.device).contiguous()  # noqa: E731
+    for t, c in enumerate(episode_schedule()[:90]):
+        if c is not None:
+            ctrl[:] = c
+            b.set_ctrl_broadcast(ctrl)
+            for s in sims:
+                s.ctrl[:] = c
+        b.step(7, sens=sens, flags=flags, touch=touch)
+        for s in sims:
+            for _ in range(7):
+                assert s.step() == 0
+        assert int(flags.abs().sum()) == 0, (t, flags.cpu().tolist())
+        assert np.abs(sens.cpu().numpy() - np.stack([s.sensordata for s in sims])).max() < TOL_SENSOR, t
+        st = b.solver_stats()
+        assert st["ncon"].cpu().tolist() == [s.ncon for s in sims] and st["iters"].cpu().tolist() == [s.solver_iter for s in sims], t
+        assert st["nefc"].cpu().tolist() == [s.nefc for s in sims], t
+        assert touch.cpu().tolist() == [_expected_touch(m, s.contacts(), bit_of) for s in sims], t
+        sp = sum(special_contacts(m, s.contacts(), "rest") for s in sims)
+        special += sp
+        fast += sum(s.ncon for s in sims) - sp
+        b.set_state(qpos=T([s.qpos for s in sims]), qvel=T([s.qvel for s in sims]), act=T([s.act for s in sims]),
+                    qacc_warmstart=T([s.qacc_warmstart for s in sims]))
+    assert special > 1000 and fast > 100, (special, fast)   # plane - capsule contacts throughout, finger contacts once the hand closes
+
+
+@pytest.mark.parametrize("neighbors", [False, True])
 def test_general_contact_path_takes_the_whole_batch(tmp_path, neighbors):
     """VERDICT r03 3(d) / ADVICE r03: the general contact path used to take 256 envs per substep and flag the rest (which 256: the order
     of arrival).  The "rest" scene -- the object resting on the ground plane, so EVERY env is on that path in EVERY substep -- at 1 500
