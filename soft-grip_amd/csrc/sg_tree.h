@@ -2623,6 +2623,37 @@ static SGT_STAGE_ATTR void tree_stage(SGT_STAGE_PARAMS) {
         }
         S.aF[idx] = a;
       }
+#if SGT_DEVICE && !defined(SGT_X_WSSERIAL)
+      // (r05s) the sliders' and the free body's words: every contact's TERMS on a lane of their own (its record's loads side by side with the
+      // other contacts'), then the sums in the list's order by scalar reads of the lanes -- the same terms added in the same order as the
+      // one-lane walk below, which paid a record's round trip to the work space per contact: ~1.5 us each, 3 % of a free-ball substep
+      if (ncon <= 64) {
+        const int lane = (int)threadIdx.x, cl = lane < ncon ? lane : 0;
+        const double* sc = cscr(cl);
+        const bool rows = lane < ncon && sc[CS_ROWS] != 0.0;
+        const double* f = S.cf + 3 * cl;
+        const double f0 = f[0], f1 = f[1], f2 = f[2];
+        const int sl = rows ? (int)sc[CS_SL] : -1;
+        const double ts = sl >= 0 ? sc[CS_INVM] * (sc[CS_JS] * f0 + sc[CS_JS + 1] * f1 + sc[CS_JS + 2] * f2) : 0.0;
+        const int ob = (FR && rows && sc[CS_OBJ] != 0.0) ? 1 : 0;
+        double tq[6] = {0, 0, 0, 0, 0, 0};
+        if (FR && ob)
+          for (int q = 0; q < 6; q++) tq[q] = sc[CS_JO + q] * f0 + sc[CS_JO + 6 + q] * f1 + sc[CS_JO + 12 + q] * f2;
+        double gf[6] = {0, 0, 0, 0, 0, 0};
+        if (FR)
+          for (int q = 0; q < 6; q++) gf[q] = S.of[OF_GF + q];
+        for (int c = 0; c < ncon; c++) {   // (uniform)
+          const int slc = __builtin_amdgcn_readlane(sl, c);
+          if (slc >= 0) {
+            const double t = readlane64(ts, c);
+            SGT_ONE { S.ae[slc] += t; }
+          }
+          if (FR && __builtin_amdgcn_readlane(ob, c))
+            for (int q = 0; q < 6; q++) gf[q] += readlane64(tq[q], c);
+        }
+        if (FR) SGT_ONE { for (int q = 0; q < 6; q++) S.of[OF_GF + q] = gf[q]; }
+      } else
+#endif
       SGT_ONE {
         for (int ci = 0; ci < ncon; ci++) {
           const double* sc = cscr(ci);
