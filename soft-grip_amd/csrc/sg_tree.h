@@ -2607,6 +2607,45 @@ static SGT_STAGE_ATTR void tree_stage(SGT_STAGE_PARAMS) {
       // The contacts add their pushes in the list's order (a slider or a chain may carry several).  Every chain word has its lane, which walks
       // the list and adds what is its own -- the same sums in the same order as contact after contact between barriers (two per contact
       // until r05: 4 % of a free-ball substep), without a barrier; the sliders' and the object's words go through one lane meanwhile.
+#if SGT_DEVICE && !defined(SGT_X_WSSERIAL)
+      // (r05s) when the chain words fit one wavefront (the free ball's two-finger gripper): a contact's chains come from the lane that holds
+      // its record (scalar reads: no trip to the work space per contact and lane), and the next contact's W words are requested while the
+      // current one's are added -- the same sums in the same order
+      if (ncon <= 64 && K * CS <= 64) {
+        const int lane = (int)threadIdx.x, cl = lane < ncon ? lane : 0;
+        const double* scl = cscr(cl);
+        const bool rows_l = lane < ncon && scl[CS_ROWS] != 0.0;
+        const int c1_l = rows_l ? (int)scl[CS_C1] : -1, c2_l = rows_l ? (int)scl[CS_C2] : -1;
+        const bool word = lane < K * CS;
+        const int c = word ? lane / CS : -2, dl = word ? lane % CS : 0;   // (-2: a lane without a word matches no chain)
+        double a = word ? S.aF[lane] : 0.0;
+        struct WR { double w0, w1, w2, w3, w4, w5; bool m1, m2; };
+        auto ldw = [&](WR& q, const int ci) {   // ci uniform
+          q.m1 = __builtin_amdgcn_readlane(c1_l, ci) == c; q.m2 = __builtin_amdgcn_readlane(c2_l, ci) == c;
+          const double* W1 = crow(ci) + 3 * CS + dl;
+          const double* W2 = crow(ci) + 9 * CS + dl;
+          q.w0 = q.w1 = q.w2 = q.w3 = q.w4 = q.w5 = 0.0;
+          if (q.m1) { q.w0 = W1[0]; q.w1 = W1[CS]; q.w2 = W1[2 * CS]; }
+          if (q.m2) { q.w3 = W2[0]; q.w4 = W2[CS]; q.w5 = W2[2 * CS]; }
+        };
+        auto acc = [&](const WR& q, const int ci) {
+          const double* f = S.cf + 3 * ci;
+          if (q.m1) a += q.w0 * f[0] + q.w1 * f[1] + q.w2 * f[2];
+          if (q.m2) a += q.w3 * f[0] + q.w4 * f[1] + q.w5 * f[2];
+        };
+        if (ncon > 0) {
+          WR qa, qb;
+          ldw(qa, 0);
+          for (int ci = 0; ci < ncon; ci += 2) {
+            ldw(qb, ci + 1 < ncon ? ci + 1 : 0);
+            acc(qa, ci);
+            ldw(qa, ci + 2 < ncon ? ci + 2 : 0);
+            if (ci + 1 < ncon) acc(qb, ci + 1);
+          }
+        }
+        if (word) S.aF[lane] = a;
+      } else
+#endif
       SGT_PAR(idx, K * CS) {
         const int c = idx / CS, dl = idx % CS;
         double a = S.aF[idx];
