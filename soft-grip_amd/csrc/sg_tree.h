@@ -2600,7 +2600,20 @@ static SGT_STAGE_ATTR void tree_stage(SGT_STAGE_PARAMS) {
         const int c = idx / CS, dl = idx % CS;
         const double* rows = S.lrow + SGT_LROW * 2 * T.c_dof0[c];
         double s = 0;
-        for (int i = 0; i < S.icnt[IC_NLIM0 + c]; i++) s += S.Minv[c * CS * CS + (int)rows[SGT_LROW * i] * CS + dl] * rows[SGT_LROW * i + 1] * rows[SGT_LROW * i + 4];
+        // (r05s: eight rows' words of M^-1 -- work space, behind the row's dof index from LDS -- requested together, then added in the rows'
+        //  order: row by row the loop paid a trip to the work space per row, 14 in a row for a finger of the four-finger gripper)
+        const int nl = S.icnt[IC_NLIM0 + c];
+        for (int i0 = 0; i0 < nl; i0 += 8) {
+          double mw[8];
+          for (int k = 0; k < 8; k++) {
+            const int ii = i0 + k < nl ? i0 + k : 0;   // (past the list: row 0's word, read and not used -- the dof index must be a valid one)
+            mw[k] = S.Minv[c * CS * CS + (int)rows[SGT_LROW * ii] * CS + dl];
+          }
+          for (int k = 0; k < 8; k++) {
+            const int i = i0 + k;
+            if (i < nl) s += mw[k] * rows[SGT_LROW * i + 1] * rows[SGT_LROW * i + 4];
+          }
+        }
         S.aF[idx] = s;
       }
       SGT_SYNC();
