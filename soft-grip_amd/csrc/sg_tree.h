@@ -2621,17 +2621,19 @@ static SGT_STAGE_ATTR void tree_stage(SGT_STAGE_PARAMS) {
       // the list and adds what is its own -- the same sums in the same order as contact after contact between barriers (two per contact
       // until r05: 4 % of a free-ball substep), without a barrier; the sliders' and the object's words go through one lane meanwhile.
 #if SGT_DEVICE && !defined(SGT_X_WSSERIAL)
-      // (r05s) when the chain words fit one wavefront (the free ball's two-finger gripper): a contact's chains come from the lane that holds
+      // (r05s) a list of at most 64 contacts: a contact's chains come from the lane that holds
       // its record (scalar reads: no trip to the work space per contact and lane), and the next contact's W words are requested while the
       // current one's are added -- the same sums in the same order
-      if (ncon <= 64 && K * CS <= 64) {
+      if (ncon <= 64) {
         const int lane = (int)threadIdx.x, cl = lane < ncon ? lane : 0;
         const double* scl = cscr(cl);
         const bool rows_l = lane < ncon && scl[CS_ROWS] != 0.0;
         const int c1_l = rows_l ? (int)scl[CS_C1] : -1, c2_l = rows_l ? (int)scl[CS_C2] : -1;
-        const bool word = lane < K * CS;
-        const int c = word ? lane / CS : -2, dl = word ? lane % CS : 0;   // (-2: a lane without a word matches no chain)
-        double a = word ? S.aF[lane] : 0.0;
+        for (int w0 = 0; w0 < K * CS; w0 += 64) {   // (the four-finger gripper's 80 chain words: two passes)
+        const int wi = w0 + lane;
+        const bool word = wi < K * CS;
+        const int c = word ? wi / CS : -2, dl = word ? wi % CS : 0;   // (-2: a lane without a word matches no chain)
+        double a = word ? S.aF[wi] : 0.0;
         struct WR { double w0, w1, w2, w3, w4, w5; bool m1, m2; };
         auto ldw = [&](WR& q, const int ci) {   // ci uniform
           q.m1 = __builtin_amdgcn_readlane(c1_l, ci) == c; q.m2 = __builtin_amdgcn_readlane(c2_l, ci) == c;
@@ -2656,7 +2658,8 @@ static SGT_STAGE_ATTR void tree_stage(SGT_STAGE_PARAMS) {
             if (ci + 1 < ncon) acc(qb, ci + 1);
           }
         }
-        if (word) S.aF[lane] = a;
+        if (word) S.aF[wi] = a;
+        }
       } else
 #endif
       SGT_PAR(idx, K * CS) {
