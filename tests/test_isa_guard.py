@@ -95,3 +95,29 @@ def test_tree_stage_functions_save_no_callee_saved_registers():
     sweeps = {k: v for k, v in per.items() if "tree_sweep" in k}
     assert total < 2500, total
     assert all(v < 40 for v in sweeps.values()), sweeps
+
+
+def test_phase_kernel_lds_blocks_fit_eight_workgroups_per_cu():
+    """a launch of the phase kernel is ROUNDS of wavefronts x one wavefront's life, so a workgroup per CU less is a whole
+    round more -- the ball's instantiation (four element rounds) at 22.6 KB of LDS ran seven per CU and its 4096 wavefronts in three rounds
+    instead of two until its pair list and slot pushes moved to the work space (SG_PHASE_SLIM).  Held here on the assembly the product
+    build kept: every instantiation of sg_phase_kernel asks for at most 160 KB / 8 of LDS and for at most 256 registers (two wavefronts per
+    SIMD = eight workgroups per CU), so an array added to Smem2 fails the CPU suite instead of showing up as a third round."""
+    import re
+    from softgrip_amd import build_native
+    build_native.build()
+    phase = [f for f in build_native.device_asm_files() if os.path.basename(f) == "sg_phase.device.s"]
+    assert len(phase) == 1
+    text = open(phase[0]).read()
+    seen = {}
+    for block in text.split("  - .agpr_count:")[1:]:           # one metadata entry per kernel
+        name = re.search(r"\.name:\s+(\S+)", block)
+        lds = re.search(r"\.group_segment_fixed_size:\s+(\d+)", block)
+        vg = re.search(r"\.vgpr_count:\s+(\d+)", block)
+        if name and lds and vg and "sg_phase_kernel" in name.group(1):
+            seen[name.group(1)] = (int(lds.group(1)), int(vg.group(1)))
+    assert len(seen) >= 16, sorted(seen)                        # four element rounds x (neighbour rows or not) x (main pass, general pass)
+    for k, (lds, vg) in seen.items():
+        assert lds <= 160 * 1024 // 8, (k, lds)
+        assert vg <= 256, (k, vg)
+    assert any("ILi4E" in k for k in seen)                      # the four-round instantiations are among them
